@@ -1,0 +1,216 @@
+"""CPU oracle for the TransFusion cross-fusion hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  The product path (``transfusion_amd``) never routes through this file and
+fails loudly when the HIP library is missing.
+
+It is a restatement -- explicit arithmetic in plain PyTorch CPU ops (no
+``nn.TransformerEncoder``, no ``nn.MultiheadAttention``, no ``F.fold``) -- of
+the reference algorithm; every function cites the reference file:line it
+follows (paths relative to the reference checkout).  The arithmetic that lives
+in the reference's third-party dependency torch==1.9.1 (requirements.txt:239)
+is restated from the reference's own vendored copy of it,
+``modeling/cross_fusion/ego_fusion/torch18_adapters.py``.
+
+Parity pin: the reference holds NO golden vectors or known-answer tests for
+this path.  The oracle is therefore pinned against outputs
+of the reference itself, imported in the build container, and committed as
+fixtures under ``tests/golden/`` by ``tests/golden/make_golden.py``
+(``tests/test_oracle_golden.py`` checks them on CPU).
+
+All functions are differentiable torch code, so oracle gradients come from
+autograd over the restated forward.  Dropout is expressed through explicit
+keep-masks (``masks`` dict) so that a device RNG stream can be replayed here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+LN_EPS = 1e-5  # torch18_adapters.py:63 (layer_norm_eps default)
+
+
+# ----------------------------------------------------------------------------
+# token plumbing
+# ----------------------------------------------------------------------------
+def sin1d_table(no_embeds: int, dim: int) -> torch.Tensor:
+    """modeling/cross_fusion/utils.py:267-273 (get_sin1d_embed) -> [1, n, dim]."""
+    position = torch.arange(no_embeds).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2) * (-math.log(10000.0) / dim))
+    pe = torch.zeros(no_embeds, dim)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0)
+
+
+def patch_embed(feat: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d(k=s=p, bias=False) + patchify_image(.,1,1) as one GEMM.
+
+    cross_f_box_wrapper.py:266-274 (conv), :183-185; utils.py:35-39.
+    feat [B,C,H,W], weight [d,C,ph,pw] -> tokens [B, H'*W', d] (h outer, w inner).
+    """
+    B, C, H, W = feat.shape
+    d, _, ph, pw = weight.shape
+    Hp, Wp = H // ph, W // pw
+    x = feat[:, :, : Hp * ph, : Wp * pw].reshape(B, C, Hp, ph, Wp, pw)
+    x = x.permute(0, 2, 4, 1, 3, 5).reshape(B, Hp * Wp, C * ph * pw)  # K order = (c, i, j)
+    return x @ weight.reshape(d, C * ph * pw).t()
+
+
+def regroup(tokens: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, init_h: int, init_w: int,
+            ph: int, pw: int, keep_mask: Optional[torch.Tensor] = None, p_drop: float = 0.0) -> torch.Tensor:
+    """RegroupPatchesLayerBox.forward with identity activation / norm.
+
+    utils.py:114-119 (dropout -> linear) and :42-46 (transpose + F.fold with
+    kernel == stride, a pure permutation; the border not covered by whole
+    patches stays zero).  tokens [B,Nv,d], weight [ph*pw*C, d] -> [B,C,init_h,init_w].
+    """
+    if keep_mask is not None:
+        tokens = tokens * keep_mask / (1.0 - p_drop)
+    y = tokens @ weight.t() + bias  # [B, Nv, C*ph*pw], column order (c, i, j) as F.fold expects
+    B, Nv, CK = y.shape
+    C = CK // (ph * pw)
+    Hp, Wp = init_h // ph, init_w // pw
+    assert Hp * Wp == Nv, (Hp, Wp, Nv)
+    y = y.reshape(B, Hp, Wp, C, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(B, C, Hp * ph, Wp * pw)
+    out = y.new_zeros(B, C, init_h, init_w)
+    out[:, :, : Hp * ph, : Wp * pw] = y
+    return out
+
+
+def local_visual_mask(h: int, w: int, k: int) -> torch.Tensor:
+    """utils.py:14-30 (get_visual_token_mask "local_k"): [h*w, h*w], 1 = blocked.
+
+    Row i = query token (r, c); the clamped (2k+1)^2 window around it is 0.
+    """
+    mask = torch.ones(h * w, h, w)
+    for i in range(h * w):
+        c0, r0 = i % w, i // w
+        for j1 in range(-k, k + 1):
+            for j2 in range(-k, k + 1):
+                c = max(0, min(c0 + j1, w - 1))
+                r = max(0, min(r0 + j2, h - 1))
+                mask[i, r, c] = 0
+    return mask.flatten(1)
+
+
+# ----------------------------------------------------------------------------
+# transformer arithmetic
+# ----------------------------------------------------------------------------
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.LayerNorm over the last dim, biased variance, eps 1e-5 (torch18_adapters.py:80-81)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    """Exact erf GELU (activ_f: gelu, cross_fusion_config_sym_ego_res50.yml:39)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def _drop(x, masks, key, p):
+    if masks is None or key not in masks or p == 0.0:
+        return x
+    return x * masks[key].to(x.dtype) / (1.0 - p)
+
+
+def mha(x: torch.Tensor, in_w, in_b, out_w, out_b, num_heads: int,
+        key_padding_mask: Optional[torch.Tensor], attn_mask: Optional[torch.Tensor] = None,
+        masks: Optional[Dict[str, torch.Tensor]] = None, prefix: str = "", p: float = 0.0) -> torch.Tensor:
+    """Self-attention of one encoder layer.
+
+    torch18_adapters.py:647-700 (_in_projection_packed: one [3d,d] linear, chunked
+    q|k|v), :530-540 (reshape to heads), :578-597 (key padding -> -inf additive
+    mask, OR-ed with a bool attn_mask), :788-799 (q/sqrt(hd) . k^T + mask ->
+    softmax -> dropout -> . v), :606-608 (merge heads, out_proj).
+    x [B,S,d]; key_padding_mask [B,S] bool True = ignore; attn_mask [S,S] bool True = blocked.
+    """
+    B, S, d = x.shape
+    hd = d // num_heads
+    qkv = x @ in_w.t() + in_b
+    q, k, v = qkv.split(d, dim=-1)
+
+    def heads(t):
+        return t.reshape(B, S, num_heads, hd).permute(0, 2, 1, 3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    scores = (q / math.sqrt(hd)) @ k.transpose(-2, -1)  # [B,h,S,S]
+    neg = torch.zeros(B, 1, S, S, dtype=x.dtype)
+    if key_padding_mask is not None:
+        neg = neg.masked_fill(key_padding_mask.view(B, 1, 1, S), float("-inf"))
+    if attn_mask is not None:
+        neg = neg.masked_fill(attn_mask.view(1, 1, S, S), float("-inf"))
+    scores = scores + neg
+    m = scores.max(dim=-1, keepdim=True).values
+    e = torch.exp(scores - m)
+    prob = e / e.sum(dim=-1, keepdim=True)
+    prob = _drop(prob, masks, prefix + "attn", p)
+    o = (prob @ v).permute(0, 2, 1, 3).reshape(B, S, d)
+    return o @ out_w.t() + out_b
+
+
+def encoder_layer(x, sd: Dict[str, torch.Tensor], pre: str, num_heads: int, key_padding_mask, attn_mask=None,
+                  masks=None, p: float = 0.0):
+    """Post-norm TransformerEncoderLayer, torch18_adapters.py:108-113.
+
+    src = norm1(src + dropout1(attn)); src = norm2(src + dropout2(W2 . dropout(gelu(W1 . src)))).
+    """
+    a = mha(x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"],
+            sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"], num_heads,
+            key_padding_mask, attn_mask, masks, pre, p)
+    x = layer_norm(x + _drop(a, masks, pre + "dropout1", p), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+    hdn = gelu(x @ sd[pre + "linear1.weight"].t() + sd[pre + "linear1.bias"])
+    hdn = _drop(hdn, masks, pre + "dropout", p)
+    y = hdn @ sd[pre + "linear2.weight"].t() + sd[pre + "linear2.bias"]
+    return layer_norm(x + _drop(y, masks, pre + "dropout2", p), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+
+
+def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch.Tensor,
+                    lang_pad_mask: Optional[torch.Tensor], num_heads: int, num_layers: int,
+                    vis_tokens_mask: Optional[torch.Tensor] = None, final_norm: bool = True,
+                    masks: Optional[Dict[str, torch.Tensor]] = None, token_dropout: float = 0.0,
+                    patch_dropout: float = 0.0):
+    """CrossTransformerModuleBox.forward, cross_f_box_layers.py:69-108.
+
+    sd uses the reference's state_dict names.  x [B,Nv,d],
+    lang [B,Nl,d], lang_pad_mask [B,Nl] bool True = ignore.
+    Returns (vis [B,Nv,d], lang [B,Nl,d]).  Every row is computed (train-mode /
+    torch-1.9 semantics); modern torch's eval fast path zeroes padded rows, so
+    parity on language rows is asserted only where the mask is False.
+    """
+    B, Nv, d = x.shape
+    Nl = lang.shape[1]
+    pe = sd["pos_embedding_layer.pos_embedding"]
+    x = x + pe[:, :Nv]                                   # utils.py:209-214
+    x = x + sd["image_kind_embedding"]                   # :73
+    x = _drop(x, masks, "patch", patch_dropout)          # :74
+    lang = lang + sd["lang_kind_embedding"]              # :76
+    kpm = None
+    if lang_pad_mask is not None:                        # :80-82
+        kpm = torch.cat([torch.zeros(B, Nv, dtype=torch.bool), lang_pad_mask], dim=1)
+    attn_mask = None
+    if vis_tokens_mask is not None:                      # :87-95
+        S = Nv + Nl
+        attn_mask = torch.zeros(S, S, dtype=torch.bool)
+        attn_mask[:Nv, :Nv] = vis_tokens_mask.to(torch.bool)
+    h = torch.cat([x, lang], dim=1)                      # :86
+    for j in range(num_layers):                          # :97
+        h = encoder_layer(h, sd, f"t_encoder.layers.{j}.", num_heads, kpm, attn_mask, masks, token_dropout)
+    vis = h[:, :Nv]
+    if final_norm:                                       # :104-107
+        vis = layer_norm(vis, sd["final_norm_layer.weight"], sd["final_norm_layer.bias"])
+    return vis, h[:, Nv:]
+
+
+def fusion_level_forward(feat: torch.Tensor, conv_w: torch.Tensor, enc_sd, lang, lang_pad_mask, num_heads, num_layers,
+                         reg_w, reg_b, ph: int, pw: int, vis_tokens_mask=None):
+    """One iteration of the per-FPN-level loop, cross_f_box_wrapper.py:177-212 (eval / p=0)."""
+    H, W = feat.shape[2:]
+    tok = patch_embed(feat, conv_w)
+    vis, lang_out = encoder_forward(enc_sd, tok, lang, lang_pad_mask, num_heads, num_layers, vis_tokens_mask)
+    # F.fold needs Nv == (H//ph)*(W//pw); the zero border comes from init_h/init_w = live H, W (:180-181)
+    return regroup(vis, reg_w, reg_b, H, W, ph, pw), lang_out

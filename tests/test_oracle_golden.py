@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (oracle/fusion_oracle.py) against fixtures produced by the
+reference itself (tests/golden/make_golden.py).  fp32 tolerance: 2e-5 abs on O(1) values."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import (ENCODER_CASES, LEVEL_CASES, make_encoder_inputs, make_encoder_params)
+from oracle import fusion_oracle as O
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False))
+
+
+def _sd(params, d):
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+    return sd
+
+
+def _close(a, b, tol=TOL, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), f"{what}: max abs err {err}"
+
+
+@pytest.mark.parametrize("name", [n for n, c in ENCODER_CASES.items() if not c.get("big")])
+def test_encoder_small_cases(golden_dir, name):
+    cfg = ENCODER_CASES[name]
+    g = _load(golden_dir, name)
+    params = {k[6:]: v for k, v in g.items() if k.startswith("param/")}
+    # the committed inputs equal what the seeded generator makes (so GPU tests may regenerate them)
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    assert np.array_equal(x, g["in_x"]) and np.array_equal(lang, g["in_lang"])
+    regen = make_encoder_params(cfg["seed"], cfg["d"], cfg["L"])
+    assert all(np.array_equal(regen[k], params[k]) for k in params)
+
+    sd = _sd(params, cfg["d"])
+    tx = torch.from_numpy(x).requires_grad_(True)
+    tl = torch.from_numpy(lang).requires_grad_(True)
+    tm = None if mask is None else torch.from_numpy(mask)
+    vm = torch.from_numpy(g["in_vis_tokens_mask"]) if "in_vis_tokens_mask" in g else None
+    vis, lo = O.encoder_forward(sd, tx, tl, tm, cfg["h"], cfg["L"], vis_tokens_mask=vm)
+    _close(vis, g["train_vis"], what="train_vis")
+    _close(lo, g["train_lang"], what="train_lang")
+    # eval fast path: visual rows equal, language rows equal where not padded (padded rows are zeros there)
+    _close(vis, g["eval_vis"], what="eval_vis")
+    valid = np.ones(lang.shape[:2], bool) if mask is None else ~mask
+    _close(lo.detach().numpy()[valid], g["eval_lang"][valid], what="eval_lang[valid]")
+    if mask is not None and mask.any() and vm is None:
+        # nested-tensor fast path (not taken when a src mask is given) zeroes the padded rows
+        assert np.all(g["eval_lang"][mask] == 0)
+
+    loss = (vis * torch.from_numpy(gv)).sum() + (lo * torch.from_numpy(gl)).sum()
+    loss.backward()
+    _close(tx.grad, g["grad_x"], what="grad_x")
+    _close(tl.grad, g["grad_lang"], what="grad_lang")
+    for k, v in g.items():
+        if k.startswith("gradp/"):
+            _close(sd[k[6:]].grad, v, tol=5e-5, what=k)
+    assert sd["heatmap_token"].grad is None
+    assert "gradp/heatmap_token" not in g
+
+
+def test_encoder_d768_subsampled(golden_dir):
+    cfg = ENCODER_CASES["enc_d768"]
+    g = _load(golden_dir, "enc_d768")
+    params = make_encoder_params(cfg["seed"], cfg["d"], cfg["L"])
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    sd = _sd(params, cfg["d"])
+    tx = torch.from_numpy(x).requires_grad_(True)
+    tl = torch.from_numpy(lang).requires_grad_(True)
+    vis, lo = O.encoder_forward(sd, tx, tl, torch.from_numpy(mask), cfg["h"], cfg["L"])
+    _close(vis[:, ::14], g["train_vis_rows"], what="vis rows")
+    _close(lo[:, ::8], g["train_lang_rows"], what="lang rows")
+    assert abs(vis.double().sum().item() - g["train_vis_sum"]) < 2e-2
+    ((vis * torch.from_numpy(gv)).sum() + (lo * torch.from_numpy(gl)).sum()).backward()
+    _close(tx.grad[:, ::14], g["grad_x_rows"], tol=5e-5, what="grad_x rows")
+    for k, v in g.items():
+        if k.startswith("gradp_head/"):
+            _close(sd[k[11:]].grad.reshape(-1)[:256], v, tol=1e-4, what=k)
+
+
+@pytest.mark.parametrize("name", list(LEVEL_CASES))
+def test_level_cases(golden_dir, name):
+    cfg = LEVEL_CASES[name]
+    g = _load(golden_dir, name)
+    params = {k[6:]: v for k, v in g.items() if k.startswith("param/")}
+    sd = _sd(params, cfg["d"])
+    feat = torch.from_numpy(g["in_feat"]).requires_grad_(True)
+    lang = torch.from_numpy(g["in_lang"]).requires_grad_(True)
+    conv_w = torch.from_numpy(g["conv_w"]).requires_grad_(True)
+    reg_w = torch.from_numpy(g["reg_w"]).requires_grad_(True)
+    reg_b = torch.from_numpy(g["reg_b"]).requires_grad_(True)
+    tok = O.patch_embed(feat, conv_w)
+    _close(tok, g["tokens"], what="tokens")
+    fused, lo = O.fusion_level_forward(feat, conv_w, sd, lang, torch.from_numpy(g["in_mask"]), cfg["h"], cfg["L"],
+                                       reg_w, reg_b, cfg["p"], cfg["p"])
+    _close(fused, g["fused"], what="fused")
+    _close(lo, g["lang_out"], what="lang_out")
+    ((fused * torch.from_numpy(g["cot_out"])).sum() + (lo * torch.from_numpy(g["cot_lang"])).sum()).backward()
+    _close(feat.grad, g["grad_feat"], tol=5e-5, what="grad_feat")
+    _close(lang.grad, g["grad_lang"], tol=5e-5, what="grad_lang")
+    _close(conv_w.grad, g["grad_conv_w"], tol=5e-5, what="grad_conv_w")
+    _close(reg_w.grad, g["grad_reg_w"], tol=5e-5, what="grad_reg_w")
+    _close(reg_b.grad, g["grad_reg_b"], tol=5e-5, what="grad_reg_b")
+    for k, v in g.items():
+        if k.startswith("gradp/"):
+            _close(sd[k[6:]].grad, v, tol=5e-5, what=k)
+
+
+def test_sin1d_and_local_mask(golden_dir):
+    g = _load(golden_dir, "sin1d_768")
+    pe = O.sin1d_table(8192, 768)
+    _close(pe[0, torch.from_numpy(g["idx"])], g["rows"], tol=1e-6, what="sin1d rows")
+    assert abs(pe.double().sum().item() - float(g["total"])) < 1e-2
+    m = _load(golden_dir, "local_mask_3x4_k1")["mask"]
+    assert np.array_equal(O.local_visual_mask(3, 4, 1).numpy(), m)
