@@ -1,0 +1,243 @@
+/* tfusion.h -- C ABI of libtfusion_hip.so: the MI355X (gfx950) kernels and encoder runtime behind the
+ * TransFusion cross-fusion block.
+ *
+ * The reference has no FFI seam: its boundary is the Python nn.Module contract of
+ *   modeling/cross_fusion/ego_fusion/cross_f_box_layers.py:13-108   (CrossTransformerModuleBox)
+ *   modeling/cross_fusion/ego_fusion/cross_f_box_wrapper.py:165-230 (CrossFusionBoxWrapper.forward)
+ * whose arithmetic lives in torch 1.9.1 (restated in .../ego_fusion/torch18_adapters.py).  The entry points below
+ * are what transfusion_amd's modules of the same names bind (via ctypes) underneath that contract; each entry
+ * cites the reference lines whose work it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); nothing here allocates or frees;
+ *   - tf_stream_t is a hipStream_t; every call only enqueues work on it (safe under graph capture);
+ *   - return 0 = ok, < 0 = argument error, > 0 = hipError_t; tf_last_error() gives a message (thread-local);
+ *   - entries are re-entrant and may be called from any thread (autograd backward thread included);
+ *   - bf16 tensors are row-major with a leading dimension in ELEMENTS that is a multiple of 8.
+ */
+#ifndef TFUSION_H_
+#define TFUSION_H_
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tf_stream_t;   /* hipStream_t */
+#define TF_ABI_VERSION 1
+#define TF_MAX_LAYERS 16
+
+enum TfEpilogue {
+  TF_EPI_NONE = 0,            // C = acc
+  TF_EPI_BIAS = 1,            // C = acc + bias
+  TF_EPI_BIAS_GELU_DROP = 2,  // C = U = acc + bias ; C2 = dropout(gelu(U))
+  TF_EPI_BIAS_DROP_RES = 3,   // C = R + dropout(acc + bias)
+  TF_EPI_ADD = 4,             // C = acc + R
+  TF_EPI_DGELU_DROP = 5       // C = acc * mask/(1-p) * gelu'(R)
+};
+
+typedef struct TfGemmArgs {
+  const void* A; int lda;     // [M,K] bf16
+  const void* W; int ldw;     // [N,K] bf16
+  void* C; int ldc;           // [M,N] bf16
+  const float* bias;          // [N] fp32 or null
+  const void* R; int ldr;     // [M,N] bf16 aux input (residual / pre-activation)
+  void* C2; int ldc2;         // second output (EPI_BIAS_GELU_DROP)
+  int M, N, K;
+  int epilogue;
+  unsigned drop_thr, drop_key; float drop_scale;   // drop_thr == 0 -> no dropout
+} TfGemmArgs;
+
+typedef struct TfWgradArgs {
+  const void* dY; int ldy;    // [M,N] bf16
+  const void* X; int ldx;     // [M,K] bf16
+  float* dW; int lddw;        // [n_src, k_src] fp32, accumulated with atomics
+  float* db;                  // [n_src] fp32 or null
+  const void* zeros;          // >= 256 B of zeros (reduction-tail source)
+  int M, N, K;                // padded extents of the bf16 operands
+  int rg, rgp, n_src;         // padded row n -> source row (n/rgp)*rg + n%rgp, valid iff n%rgp < rg
+  int cg, cgp, k_src;         // same for columns
+  int m_chunk;                // rows of M per block (0 = auto)
+} TfWgradArgs;
+
+
+typedef struct TfAttnArgs {
+  const void* qkv; int ld_qkv;   // [B*S, 3*H*HDP] bf16, column = (which*H + head)*HDP + e
+  void* out; int ld_out;         // [B*S, H*HDP] bf16
+  float* lse;                    // [B,H,S] fp32, log2 domain: m*scale*log2e + log2(l)
+  const uint8_t* key_mask;       // [B,S] 1 = ignore key, or null
+  int B, S, H, HDP;
+  float scale;                   // 1/sqrt(true head dim)
+  unsigned drop_thr, drop_key; float drop_scale;
+  // backward only
+  const void* dout; int ld_dout; // [B*S, H*HDP] bf16
+  void* dqkv; int ld_dqkv;       // [B*S, 3*H*HDP] bf16
+  float* delta;                  // [B,H,S] fp32 workspace: rowsum(dO . O)
+} TfAttnArgs;
+
+
+// ---- row-wise kernels (rowops.hip) ----
+// LayerNorm over the first d of ld columns; rows are addressed as (r / rows_per_group) * group_stride +
+// r % rows_per_group so the final LN can pick the visual rows of [B,S,*].
+typedef struct TfLnArgs {
+  const void* x; int ldx;        // bf16 in
+  void* y; int ldy; int y_is_f32;// bf16 (or fp32) out; pad columns [d, ldy) are zero-filled when bf16
+  const float* gamma; const float* beta;
+  float* mean; float* rstd;      // [rows] fp32 (may be null in inference)
+  int rows, d;
+  int rows_per_group, x_group_stride, y_group_stride;   // in rows
+  float eps;
+  // backward
+  const void* dy; int lddy; int dy_is_f32;
+  void* dx; int lddx;            // bf16 dz
+  void* dx_drop; int lddxd;      // optional second output: dz * mask/(1-p) (dropout that preceded the residual add)
+  unsigned drop_thr, drop_key; float drop_scale; int drop_ld;
+  float* dgamma; float* dbeta;   // fp32, atomically accumulated
+  const void* dres; int lddres;  // optional bf16 tensor added to dy before the backward (residual-path gradient)
+} TfLnArgs;
+
+typedef struct TfAssembleArgs {
+  const void* vis; int vis_is_f32; int ld_vis;   // [B,Nv,d]
+  const void* lang; int lang_is_f32; int ld_lang;// [B,Nl,d]
+  const float* pe;                               // [>=Nv, d] fp32
+  const float* kind_v; const float* kind_l;      // [d]
+  void* out; int ld_out;                         // [B,S,ld_out] bf16
+  int B, Nv, Nl, d;
+  unsigned drop_thr, drop_key; float drop_scale;
+  // backward
+  const void* dout; int ld_dout;                 // bf16
+  void* dvis; int dvis_is_f32; int ld_dvis;
+  void* dlang; int dlang_is_f32; int ld_dlang;
+  float* dkind_v; float* dkind_l;
+} TfAssembleArgs;
+
+// rowsum(dO . O) per (b, head, s)
+
+// fp32 [rows, cols] (param layout) -> bf16 padded/grouped shadow [rows_p, cols_p] and/or its transpose
+typedef struct TfPackArgs {
+  const float* src; int rows, cols;      // source (parameter layout)
+  void* dst; int ld_dst;                 // [rows_p, ld_dst] bf16 or null
+  void* dst_t; int ld_dst_t;             // [cols_p, ld_dst_t] bf16 (transpose) or null
+  int rows_p, cols_p;
+  int rg, rgp, cg, cgp;                  // group maps as in TfWgradArgs
+  int dst_is_f32;                        // biases keep fp32
+} TfPackArgs;
+
+// dst[map(r), 0:cols] = src[map(r), 0:cols] with dtype conversion; columns [cols, ld_dst) of a bf16 dst are zeroed.
+// src == null writes zeros.
+typedef struct TfCopyRowsArgs {
+  const void* src; int src_is_f32; int ld_src; int src_rpg, src_gstride;
+  void* dst; int dst_is_f32; int ld_dst; int dst_rpg, dst_gstride;
+  int rows, cols;
+} TfCopyRowsArgs;
+// key_mask[b, s] = s < Nv ? 0 : lang_pad_mask[b, s - Nv]
+
+
+// fused RAdam over a flat fp32 buffer (runner/metrics_losses/radam_optim.py:30-104 arithmetic)
+typedef struct TfRadamArgs {
+  float* p; const float* g; float* m; float* v; long long n;
+  float lr, beta1, beta2, eps, weight_decay;
+  float beta2_t;   // beta2^step
+  float bias1;     // 1 - beta1^step
+  float n_sma; float step_size; int rectified;   // host-computed schedule terms
+  float grad_scale;                               // multiplies g first (clip / loss-scale / 1/world)
+} TfRadamArgs;
+
+// patch <-> token permutations for K1 / K9
+typedef struct TfPatchArgs {
+  const void* feat; int feat_is_f32;     // [B,C,H,W]
+  void* cols; int ld_cols;               // [B*Hp*Wp, C*ph*pw (padded to ld_cols)] bf16
+  int B, C, H, W, ph, pw;
+} TfPatchArgs;
+
+
+/* ---- dropout key: every dropout site draws keep(i) = hash32(i, key) >= p * 2^32, key = f(seed, site) ---- */
+uint32_t tf_drop_key(uint64_t seed, uint32_t site);
+uint32_t tf_drop_threshold(float p);
+
+/* ---- library ---- */
+int tf_version(void);
+const char* tf_last_error(void);
+
+/* ---- per-op entries (thin validated wrappers over the kernels) ---------------------------------------------
+ * tf_gemm_fwd        nn.Linear / F.linear call sites: torch18_adapters.py:683-685 (QKV in-proj), :608 (out-proj),
+ *                    :111 (linear1, gelu, dropout, linear2) with the residual/dropout of :109,:112 fused as epilogues;
+ *                    also the dgrad GEMMs of their autograd backward (W^T shadows) and K1/K9's GEMMs
+ *                    (cross_f_box_wrapper.py:268-274 Conv2d k=s=p; cross_fusion/utils.py:116 RegroupPatchesLayerBox.linear)
+ * tf_gemm_wgrad      autograd weight/bias gradients of the same Linear layers
+ * tf_attn_fwd/bwd    torch18_adapters.py:756-799 (_scaled_dot_product_attention) + :578-597 (key-padding mask merge)
+ * tf_layernorm_*     norm1/norm2 (torch18_adapters.py:110,113) and final_norm_layer (cross_f_box_layers.py:59-60,107)
+ * tf_assemble_*      cross_f_box_layers.py:72-86 (pos-emb add utils.py:209-214, kind-emb adds, patch dropout, concat)
+ * tf_patchify_*      cross_fusion/utils.py:35-39 (patchify_image) fused with the im2col of the k=s=p Conv2d
+ * tf_regroup_*       cross_fusion/utils.py:42-46 (regroup_patches: transpose + F.fold, kernel == stride)
+ * tf_radam_step      runner/metrics_losses/radam_optim.py:30-104
+ */
+int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
+int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
+int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);
+int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* computes delta internally, then dQ, dK, dV */
+int tf_layernorm_fwd(const TfLnArgs* a, tf_stream_t s);
+int tf_layernorm_bwd(const TfLnArgs* a, tf_stream_t s);
+int tf_assemble_fwd(const TfAssembleArgs* a, tf_stream_t s);
+int tf_assemble_bwd(const TfAssembleArgs* a, tf_stream_t s);
+int tf_patchify_fwd(const TfPatchArgs* a, tf_stream_t s);                 /* feat -> token-major im2col rows */
+int tf_patchify_bwd(const TfPatchArgs* a, int out_is_f32, tf_stream_t s); /* d(cols) -> d(feat) */
+int tf_regroup_fwd(const TfPatchArgs* a, int out_is_f32, tf_stream_t s);  /* token rows -> [B,C,H,W], zero border */
+int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s);                  /* d(feat) -> d(token rows) */
+int tf_pack_weight(const TfPackArgs* a, tf_stream_t s);
+int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s);
+int tf_radam_step(const TfRadamArgs* a, tf_stream_t s);
+int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
+/* y = dropout(x) over a dense bf16 array of n (multiple of 8) elements; the same call is its backward (utils.py:115) */
+int tf_dropout_apply(const void* x, void* y, long long n, uint32_t key, uint32_t thr, float scale, tf_stream_t s);
+int tf_dropout_mask(uint8_t* out, long long n, uint32_t key, uint32_t thr, tf_stream_t s);   /* test hook */
+int tf_cast_f32_bf16(const float* src, void* dst, long long n, tf_stream_t s);
+int tf_cast_bf16_f32(const void* src, float* dst, long long n, tf_stream_t s);
+
+/* ---- whole-encoder runtime: one call = forward (or backward) of CrossTransformerModuleBox ------------------
+ * cross_f_box_layers.py:69-108.  The caller plans once (tf_encoder_plan), allocates `wpack` and `work` (both
+ * zero-initialised), and then calls fwd / bwd; parameter pointers are the reference's state_dict tensors
+ *  in fp32. */
+typedef struct TfLayerParams {
+  float *in_w, *in_b, *out_w, *out_b, *w1, *b1, *w2, *b2, *n1_w, *n1_b, *n2_w, *n2_b;
+} TfLayerParams;
+
+typedef struct TfEncoderPlan {
+  int hd, hdp, dp, ffp, ldq, S, M;
+  size_t wpack_bytes, work_bytes;
+} TfEncoderPlan;
+
+typedef struct TfEncoderDesc {
+  int B, Nv, Nl, d, H, L, ff;
+  int training;                 /* dropout on (p_token, p_patch) */
+  int final_norm;               /* final_norm == "ln" */
+  float p_token, p_patch;
+  uint64_t seed;                /* dropout stream for THIS forward; backward must pass the same value */
+  TfLayerParams p[TF_MAX_LAYERS];   /* parameters */
+  TfLayerParams g[TF_MAX_LAYERS];   /* gradients (fp32, accumulated into) */
+  float *kind_v, *kind_l, *fn_w, *fn_b;
+  float *g_kind_v, *g_kind_l, *g_fn_w, *g_fn_b;
+  const float* pe;              /* pos_embedding [>=Nv, d] fp32 */
+  void* wpack; void* work;
+  const void* vis; int vis_is_f32;          /* [B,Nv,d] */
+  const void* lang; int lang_is_f32;        /* [B,Nl,d] */
+  const uint8_t* lang_pad_mask;             /* [B,Nl] 1 = ignore, or null */
+  void* vis_out; int vis_out_is_f32;        /* [B,Nv,d] */
+  void* lang_out; int lang_out_is_f32;      /* [B,Nl,d] or null */
+  const void* d_vis_out; int d_vis_out_is_f32;
+  const void* d_lang_out; int d_lang_out_is_f32;   /* may be null (zero) */
+  void* d_vis; int d_vis_is_f32;            /* may be null */
+  void* d_lang; int d_lang_is_f32;          /* may be null */
+} TfEncoderDesc;
+
+int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);
+int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s);   /* fp32 parameters -> bf16 shadows in wpack */
+int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s);
+int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);
+/* test hook: copies an internal activation by name ("x<l>", "qkv<l>", "o<l>", "z1_<l>", "x1_<l>", "u<l>", "h<l>",
+ * "z2_<l>", "dqkv", ...) as fp32 [rows, cols] into dst; returns rows*cols (cols = padded width) or < 0 */
+long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* TFUSION_H_ */

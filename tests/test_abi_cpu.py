@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/tfusion.h declares,
+and the ctypes mirrors generated from the header have the sizes a C compiler gives them.  No compute calls."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from transfusion_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build_lib()
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    from transfusion_amd import _lib
+    assert len(_lib.FUNCTIONS) >= 28
+    for f in _lib.FUNCTIONS:
+        assert hasattr(lib, f), f
+    assert lib.tf_version() == _lib.CONSTS["TF_ABI_VERSION"]
+
+
+def test_struct_mirrors_match_c_layout(lib, tmp_path):
+    from transfusion_amd import _lib
+    names = sorted(_lib.STRUCTS)
+    src = tmp_path / "sz.c"
+    src.write_text('#include "tfusion.h"\n#include <stdio.h>\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        assert int(out[n]) == C.sizeof(_lib.STRUCTS[n]), n
+
+
+def test_plan_and_dropout_helpers_are_host_side(lib):
+    from transfusion_amd import _lib
+    plan = _lib.TfEncoderPlan()
+    assert lib.tf_encoder_plan(32, 196, 512, 768, 4, 4, 1536, C.byref(plan)) == 0
+    assert (plan.hd, plan.hdp, plan.dp, plan.ffp, plan.ldq, plan.S, plan.M) == (192, 192, 768, 1536, 2304, 708, 22656)
+    assert lib.tf_encoder_plan(2, 196, 128, 712, 4, 4, 1424, C.byref(plan)) == 0
+    assert (plan.hd, plan.hdp, plan.dp, plan.ffp) == (178, 192, 768, 1472)
+    assert lib.tf_encoder_plan(2, 196, 128, 770, 4, 4, 1424, C.byref(plan)) != 0     # d % H != 0
+    assert b"tf_encoder_plan" in lib.tf_last_error()
+    assert lib.tf_drop_threshold(0.0) == 0
+    assert abs(lib.tf_drop_threshold(0.15) / 2**32 - 0.15) < 1e-6
+    assert lib.tf_drop_key(42, 1) != lib.tf_drop_key(42, 2) != lib.tf_drop_key(43, 2)
+
+
+def test_no_cpu_fallback():
+    import torch
+    from transfusion_amd import _lib, ops
+    with pytest.raises(_lib.TfError):
+        ops.linear(torch.randn(4, 8), torch.randn(8, 8))

@@ -1,0 +1,292 @@
+"""Per-kernel parity, HIP (through the C ABI) vs the CPU oracle / explicit fp32 math on the SAME bf16-rounded
+inputs.  Tolerances are written next to each assert: bf16 outputs carry 2^-8 relative rounding."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 768), (1000, 2304, 768), (77, 8, 64)])
+def test_gemm_epilogues(dev, M, N, K):
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    R = bf(torch.randn(M, N, generator=g)).to(dev)
+    ref = A.float() @ W.float().t()
+    # EPI_NONE / BIAS
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, C, N, K, L.TF_EPI_NONE)
+    assert rel(C, ref) < 4e-3            # bf16 output rounding only (fp32 accumulate)
+    ops.gemm(A, W, C, N, K, L.TF_EPI_BIAS, bias=bias)
+    assert rel(C, ref + bias) < 4e-3
+    # ADD
+    ops.gemm(A, W, C, N, K, L.TF_EPI_ADD, R=R)
+    assert rel(C, bf(ref).float() + R.float()) < 4e-3
+    # BIAS_GELU_DROP without and with dropout
+    U = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    H = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, U, N, K, L.TF_EPI_BIAS_GELU_DROP, bias=bias, C2=H)
+    assert rel(U, ref + bias) < 4e-3
+    assert rel(H, gelu(U.float())) < 4e-3
+    p, seed, site = 0.15, 1234, 19
+    drop = ops.drop_params(p, seed, site)
+    ops.gemm(A, W, U, N, K, L.TF_EPI_BIAS_GELU_DROP, bias=bias, C2=H, drop=drop)
+    keep = ops.dropout_mask(M * N, p, seed, site, dev).view(M, N).float()   # index = row * ldc2 + col, ldc2 == N here
+    assert abs(keep.mean().item() - (1 - p)) < 0.02 or M * N < 5000
+    assert rel(H, gelu(U.float()) * keep / (1 - p)) < 4e-3
+    # BIAS_DROP_RES
+    ops.gemm(A, W, C, N, K, L.TF_EPI_BIAS_DROP_RES, bias=bias, R=R, drop=drop)
+    y = bf(ref + bias).float()
+    assert rel(C, R.float() + y * keep / (1 - p)) < 4e-3
+    # DGELU_DROP: C = acc * keep/(1-p) * gelu'(R)
+    ops.gemm(A, W, C, N, K, L.TF_EPI_DGELU_DROP, R=R, drop=drop)
+    assert rel(C, bf(ref).float() * keep / (1 - p) * gelu_grad(R.float())) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K,grouped", [(200, 136, 72, False), (708 * 2, 768, 768, False), (1000, 384, 128, True)])
+def test_wgrad(dev, M, N, K, grouped):
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(7)
+    dY = bf(torch.randn(M, N, generator=g)).to(dev)
+    X = bf(torch.randn(M, K, generator=g)).to(dev)
+    ref = dY.float().t() @ X.float()
+    refb = dY.float().sum(0)
+    if not grouped:
+        dW = torch.zeros(N, K, device=dev)
+        db = torch.zeros(N, device=dev)
+        ops.wgrad(dY, N, X, K, dW, db)
+        assert rel(dW, ref) < 1e-4          # fp32 accumulation of exact bf16 products, atomics order only
+        assert rel(db, refb) < 1e-4
+        # accumulation semantics: a second call adds
+        ops.wgrad(dY, N, X, K, dW, db, m_chunk=128)
+        assert rel(dW, 2 * ref) < 1e-4
+    else:
+        # padded row groups of 32 holding 18 valid rows each (head_dim 18 -> 32): N = 12 * 32
+        rg, rgp = 18, 32
+        n_src = (N // rgp) * rg
+        dW = torch.zeros(n_src, K, device=dev)
+        db = torch.zeros(n_src, device=dev)
+        ops.wgrad(dY, N, X, K, dW, db, rg=rg, rgp=rgp, n_src=n_src)
+        idx = torch.tensor([i for i in range(N) if i % rgp < rg])
+        assert rel(dW, ref[idx]) < 1e-4
+        assert rel(db, refb[idx]) < 1e-4
+
+
+def _attn_ref(qkv, B, S, H, hd, hdp, key_mask, keep=None, p=0.0):
+    """fp64 reference on the given (bf16-valued) packed qkv [B*S, 3*H*hdp]."""
+    x = qkv.double().cpu().view(B, S, 3, H, hdp)[..., :hd]
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if key_mask is not None:
+        s = s.masked_fill(key_mask.cpu().bool().view(B, 1, 1, S), float("-inf"))
+    P = torch.softmax(s, dim=-1)
+    Pd = P if keep is None else P * keep.double().cpu() / (1 - p)
+    o = (Pd @ v).permute(0, 2, 1, 3)       # [B,S,H,hd]
+    return o, P
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(2, 150, 2, 32), (1, 708, 4, 192), (2, 70, 4, 18), (1, 300, 2, 64), (1, 130, 1, 224)])
+def test_attention_fwd_bwd(dev, B, S, H, hd):
+    from transfusion_amd import _lib as L, ops
+    hdp = (hd + 31) // 32 * 32
+    g = torch.Generator().manual_seed(S + hd)
+    ldq = (3 * H * hdp + 63) // 64 * 64
+    qkv = torch.zeros(B * S, ldq)
+    view = qkv[:, : 3 * H * hdp].view(B * S, 3, H, hdp)
+    view[..., :hd] = torch.randn(B * S, 3, H, hd, generator=g)
+    qkv = bf(qkv).to(dev)
+    key_mask = torch.zeros(B, S, dtype=torch.uint8)
+    key_mask[0, S - S // 3:] = 1
+    key_mask = key_mask.to(dev)
+    ldo = (H * hdp + 63) // 64 * 64
+    out = torch.zeros(B * S, ldo, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B * H * S, device=dev)
+    for p in (0.0, 0.15):
+        seed, site = 99, 17
+        drop = ops.drop_params(p, seed, site)
+        a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=L.ptr(key_mask),
+                         B=B, S=S, H=H, HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2])
+        L.call("tf_attn_fwd", a, ops._stream())
+        keep = None
+        if p > 0:
+            keep = ops.dropout_mask(B * H * S * S, p, seed, site, dev).view(B, H, S, S)
+        o_ref, P = _attn_ref(qkv[:, : 3 * H * hdp], B, S, H, hd, hdp, key_mask, keep, p)
+        o_hip = out[:, : H * hdp].float().cpu().view(B, S, H, hdp)
+        assert rel(o_hip[..., :hd], o_ref) < 8e-3, f"fwd p={p}"          # bf16 P and bf16 output
+        assert o_hip[..., hd:].abs().max().item() == 0.0                # pad columns stay exactly zero
+        # LSE (log2 domain of the scaled scores)
+        x = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd]
+        s = (x[:, :, 0].permute(0, 2, 1, 3) @ x[:, :, 1].permute(0, 2, 3, 1)) / math.sqrt(hd)
+        s = s.masked_fill(key_mask.cpu().bool().view(B, 1, 1, S), float("-inf"))
+        lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+        assert (lse.cpu().view(B, H, S).double() - lse_ref).abs().max().item() < 2e-2
+
+        # ---- backward ----
+        do = torch.zeros(B * S, ldo)
+        do[:, : H * hdp].view(B * S, H, hdp)[..., :hd] = torch.randn(B * S, H, hd, generator=g)
+        do = bf(do).to(dev)
+        dqkv = torch.zeros(B * S, ldq, dtype=torch.bfloat16, device=dev)
+        delta = torch.empty(B * H * S, device=dev)
+        a.dout, a.ld_dout, a.dqkv, a.ld_dqkv, a.delta = L.ptr(do), ldo, L.ptr(dqkv), ldq, L.ptr(delta)
+        L.call("tf_attn_bwd", a, ops._stream())
+        xr = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd].clone().requires_grad_(True)
+        q, k, v = xr[:, :, 0].permute(0, 2, 1, 3), xr[:, :, 1].permute(0, 2, 1, 3), xr[:, :, 2].permute(0, 2, 1, 3)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        s = s.masked_fill(key_mask.cpu().bool().view(B, 1, 1, S), float("-inf"))
+        Pr = torch.softmax(s, -1)
+        if keep is not None:
+            Pr = Pr * keep.double().cpu() / (1 - p)
+        o = (Pr @ v).permute(0, 2, 1, 3)
+        o.backward(do[:, : H * hdp].double().cpu().view(B, S, H, hdp)[..., :hd])
+        g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)
+        for which, nm in enumerate("qkv"):
+            assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm} p={p}"
+        assert g_hip[..., hd:].abs().max().item() == 0.0
+
+
+def test_attention_online_softmax_rescale(dev):
+    """Forces the running-max update late in the key loop (a spike in the LAST key tile), which bounded
+    random data never exercises."""
+    from transfusion_amd import _lib as L, ops
+    B, S, H, hd = 1, 200, 1, 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(S, hd, generator=g)
+    k = torch.randn(S, hd, generator=g)
+    v = torch.randn(S, hd, generator=g)
+    k[S - 3] = 6.0 * q[10]          # a huge score for query 10 in the last tile
+    qkv = bf(torch.cat([q, k, v], dim=1)).to(dev)
+    out = torch.zeros(S, hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(S, device=dev)
+    a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=3 * hd, out=L.ptr(out), ld_out=hd, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hd,
+                     scale=1 / math.sqrt(hd), drop_thr=0, drop_key=0, drop_scale=1.0)
+    L.call("tf_attn_fwd", a, ops._stream())
+    o_ref, _ = _attn_ref(qkv, 1, S, 1, hd, hd, None)
+    assert rel(out.float().cpu().view(1, S, 1, hd), o_ref) < 8e-3
+    assert (out.float().cpu()[10] - o_ref[0, 10, 0].float()).abs().max() < 5e-2
+
+
+@pytest.mark.parametrize("rows,d,ld", [(37, 64, 64), (500, 768, 768), (64, 72, 128), (10, 712, 768)])
+def test_layernorm_fwd_bwd(dev, rows, d, ld):
+    from transfusion_amd import _lib as L, ops
+    from oracle import fusion_oracle as O
+    g = torch.Generator().manual_seed(rows)
+    x = torch.zeros(rows, ld)
+    x[:, :d] = torch.randn(rows, d, generator=g) * 2 + 0.5
+    xb = bf(x).to(dev)
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(d, generator=g)).to(dev)
+    y = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=dev)
+    mean = torch.empty(rows, device=dev)
+    rstd = torch.empty(rows, device=dev)
+    a = L.TfLnArgs(x=L.ptr(xb), ldx=ld, y=L.ptr(y), ldy=ld, y_is_f32=0, gamma=L.ptr(gamma), beta=L.ptr(beta), mean=L.ptr(mean),
+                   rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=1e-5)
+    L.call("tf_layernorm_fwd", a, ops._stream())
+    xr = xb.float().cpu()[:, :d].clone().requires_grad_(True)
+    gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br)
+    assert rel(y[:, :d], yr.detach()) < 4e-3
+    assert y[:, d:].float().abs().max().item() == 0.0 if ld > d else True
+    dy = bf(torch.randn(rows, ld, generator=g)).to(dev)
+    dx = torch.empty(rows, ld, dtype=torch.bfloat16, device=dev)
+    dg = torch.zeros(d, device=dev)
+    db = torch.zeros(d, device=dev)
+    a.dy, a.lddy, a.dy_is_f32, a.dx, a.lddx, a.dgamma, a.dbeta = L.ptr(dy), ld, 0, L.ptr(dx), ld, L.ptr(dg), L.ptr(db)
+    L.call("tf_layernorm_bwd", a, ops._stream())
+    yr.backward(dy.float().cpu()[:, :d])
+    assert rel(dx[:, :d], xr.grad) < 6e-3
+    assert rel(dg, gr.grad) < 1e-3 and rel(db, br.grad) < 1e-3
+
+
+def test_pack_and_patch_permutations(dev):
+    from transfusion_amd import ops
+    from oracle import fusion_oracle as O
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(72, 40, generator=g).to(dev)
+    sh, sht = ops.pack_weight(w, 72, 64, 64, 128)
+    assert torch.equal(sh[:, :40], bf(w)) and sh[:, 40:].abs().max() == 0
+    assert torch.equal(sht[:40, :72], bf(w).t()) and sht[40:].abs().max() == 0 and sht[:, 72:].abs().max() == 0
+    # im2col rows == the oracle's patch extraction; col2im == regroup fold with a zero border
+    feat = torch.randn(2, 8, 9, 10, generator=g).to(dev)
+    rows = ops.patchify(feat, 2, 2)
+    B, C, H, W, p = 2, 8, 9, 10, 2
+    x = feat.cpu()[:, :, : H // p * p, : W // p * p].reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * p * p)
+    assert torch.equal(rows.float().cpu(), bf(x).float())
+    img = ops.regroup(rows, H, W, p, p, out_dtype=torch.float32)
+    expect = torch.zeros(B, C, H, W)
+    expect[:, :, : H // p * p, : W // p * p] = bf(feat.cpu()[:, :, : H // p * p, : W // p * p]).float()
+    assert torch.equal(img.cpu(), expect)
+
+
+def test_linear_fn_fwd_bwd(dev):
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 50, 40, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(72, 40, generator=g) / 6).to(dev).requires_grad_(True)
+    b = torch.randn(72, generator=g).to(dev).requires_grad_(True)
+    y = ops.linear(x, w, b)
+    gy = torch.randn(3, 50, 72, generator=g).to(dev)
+    (y.float() * gy).sum().backward()
+    xr = bf(x.detach()).float().cpu().requires_grad_(True)
+    wr = bf(w.detach()).float().cpu().requires_grad_(True)
+    br = b.detach().cpu().clone().requires_grad_(True)
+    yr = xr @ wr.t() + br
+    (yr * gy.cpu()).sum().backward()
+    assert rel(y, yr.detach()) < 4e-3
+    assert rel(x.grad, xr.grad) < 1e-2 and rel(w.grad, wr.grad) < 1e-2 and rel(b.grad, br.grad) < 1e-2
+
+
+def test_radam_matches_reference_arithmetic(dev):
+    from transfusion_amd.optim import FusedRAdam
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(5000, generator=g)
+    p = p0.clone().to(dev)
+    opt = FusedRAdam([p], lr=1e-3, weight_decay=2e-4)
+    # straight restatement of runner/metrics_losses/radam_optim.py:55-100 in fp64
+    pr, m, v = p0.double(), torch.zeros(5000).double(), torch.zeros(5000).double()
+    b1, b2, eps, lr, wd = 0.9, 0.999, 1e-8, 1e-3, 2e-4
+    for step in range(1, 9):
+        grad = torch.randn(5000, generator=g)
+        p.grad = grad.clone().to(dev)
+        opt.step()
+        gd = grad.double()
+        v = v * b2 + (1 - b2) * gd * gd
+        m = m * b1 + (1 - b1) * gd
+        b2t = b2 ** step
+        nmax = 2 / (1 - b2) - 1
+        nsma = nmax - 2 * step * b2t / (1 - b2t)
+        if nsma >= 5:
+            ss = math.sqrt((1 - b2t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) / (1 - b1 ** step)
+            pr = pr - wd * lr * pr
+            pr = pr - ss * lr * m / (v.sqrt() + eps)
+    assert (p.cpu().double() - pr).abs().max().item() < 1e-5

@@ -1,0 +1,486 @@
+// Fused multi-head attention for the fusion block (K4 and its backward), bf16 MFMA on gfx950.
+//
+// Semantics (torch18_adapters.py:788-799 of the reference): P = softmax(q/sqrt(hd) . k^T + key_padding(-inf)),
+// Pd = dropout(P), O = Pd . v.  No [S,S] tensor ever reaches HBM: forward keeps an online softmax
+// and stores only LSE[b,h,s]; backward recomputes P from LSE.
+//
+// Orientation: the score tile is computed TRANSPOSED with v_mfma_f32_32x32x16_bf16, St[key][q] = K . Q^T,
+// so the query index lives on the lane (lane & 31) and keys live in the 16 accumulator registers: the
+// softmax row reduce is an in-register reduce plus ONE cross-half exchange, every per-row statistic
+// (max, sum, alpha, LSE, delta) is a per-lane scalar, and the accumulator tile is already the B operand
+// of the next product (O^T += V^T . Pt) with no LDS round trip (register 8s+j of the tile is row
+// 16s + 8(j>>2) + 4(lane>>5) + (j&3) of k-step s; the V^T operand is fetched in that k order with
+// ds_read_b64_tr_b16).  Backward uses the same trick three times (dQ^T += K^T . dSt ; dV^T += dO^T . Pd ;
+// dK^T += Q^T . dS) in two kernels so that no gradient needs cross-workgroup atomics:
+//   attn_bwd_dq  : query on the lane, loops over key tiles   -> dQ
+//   attn_bwd_dkv : key   on the lane, loops over query tiles -> dK, dV
+// LDS tiles are "dual use": row stride == 64 (mod 256) bytes and 16-B chunk ^= (row>>2)&3 make both the
+// row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16) bank-conflict free.
+#include "tf_common.h"
+#include "tf_kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int HDP> struct Geo {
+  static constexpr int CPR = HDP / 8;                                   // 16-B chunks per row
+  static constexpr int TSTR = ((2 * HDP - 64 + 255) / 256) * 256 + 64;  // row stride in bytes
+  static constexpr int KSTEPS = HDP / 16;
+  static constexpr int DBLK = HDP / 32;
+};
+
+__device__ __forceinline__ int tile_off(int row, int chunk, int tstr) { return row * tstr + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// cooperative global -> registers -> LDS tile copy (ROWS x HDP bf16), 256 threads
+template <int ROWS, int HDP> struct TileRegs {
+  static constexpr int TOTAL = ROWS * (HDP / 8);
+  static constexpr int PER = (TOTAL + 255) / 256;
+  u32x4 v[PER];
+  // row r of the tile comes from global row min(row0 + r, row_max) (clamped) or zeros when zero_fill && row0 + r > row_max
+  __device__ __forceinline__ void load(const u16* __restrict__ base, size_t ld, int row0, int row_max, bool zero_fill, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = i * 256 + tid;
+      if (TOTAL % 256 == 0 || id < TOTAL) {
+        const int r = id / (HDP / 8), c = id % (HDP / 8);
+        const int gr = row0 + r;
+        if (zero_fill && gr > row_max) v[i] = u32x4{0, 0, 0, 0};
+        else v[i] = *(const u32x4*)(base + (size_t)min(gr, row_max) * ld + c * 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = i * 256 + tid;
+      if (TOTAL % 256 == 0 || id < TOTAL) {
+        const int r = id / (HDP / 8), c = id % (HDP / 8);
+        *(u32x4*)(lds + tile_off(r, c, Geo<HDP>::TSTR)) = v[i];
+      }
+    }
+  }
+};
+
+// A-operand row fragment (32 rows x 16 k) of a dual-use tile: row = row0 + (lane&31), chunk 2*ks + (lane>>5)
+template <int HDP> __device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int row0, int ks, int lane) {
+  const int r = row0 + (lane & 31);
+  return *(const bf16x8*)(tile + tile_off(r, 2 * ks + (lane >> 5), Geo<HDP>::TSTR));
+}
+// A-operand TRANSPOSED fragment: A[i = column col0 + (lane&31)][k], where element j of lane-half h is tile row
+// krow0 + 8*(j>>2) + 4*h + (j&3)   (the k order of an accumulator tile used as B operand)
+template <int HDP> __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int krow0, int col0, int lane) {
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p = li & 3;
+  const int h = g >> 1, cb = g & 1;
+  const int r0 = krow0 + 4 * h + q4, r1 = r0 + 8;
+  const int ch = (col0 + cb * 16 + 4 * p) >> 3, o8 = (p & 1) * 8;   // 4p elements -> byte 8p -> chunk (p>>1), +8*(p&1)
+  const s16x4 a = lds_read_tr16(tile + tile_off(r0, ch, Geo<HDP>::TSTR) + o8);
+  const s16x4 b = lds_read_tr16(tile + tile_off(r1, ch, Geo<HDP>::TSTR) + o8);
+  return join_tr(a, b);
+}
+// registers 8s..8s+7 of a 32x32 accumulator -> bf16 B-operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (__bf16)x[8 * s + j];
+  return f;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// 64-bit validity mask of keys kv0 .. kv0+63 (bit = key may be attended)
+__device__ __forceinline__ unsigned long long key_bits(const uint8_t* __restrict__ km, int b, int S, int kv0, int lane) {
+  const int key = kv0 + lane;
+  bool ok = key < S;
+  if (ok && km != nullptr) ok = km[(size_t)b * S + key] == 0;
+  return __ballot(ok);
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kt = smem;
+  unsigned char* vt = smem + 64 * G::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int S = a.S;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const u16* __restrict__ qkv = (const u16*)a.qkv;
+  const size_t ld = a.ld_qkv;
+  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+
+  // Q^T B-operand fragments, resident in registers
+  bf16x8 qf[G::KSTEPS];
+  {
+    const int qr = min(q0 + (lane & 31), S - 1);
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ld + ks * 16 + 8 * h));
+  }
+  f32x16 o[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+  const int qrow = q0 + (lane & 31);
+  const unsigned drop_row = ((unsigned)bh * (unsigned)S + (unsigned)qrow) * (unsigned)S;
+
+  const int ntiles = (S + 63) / 64;
+  TileRegs<64, HDP> kr, vr;
+  kr.load(kbase, ld, 0, S - 1, false, tid);
+  vr.load(vbase, ld, 0, S - 1, false, tid);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();                       // previous tile fully consumed
+    kr.store(kt, tid);
+    vr.store(vt, tid);
+    __syncthreads();
+    if (t + 1 < ntiles) {                  // prefetch next tile into registers under the MFMA work
+      kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
+      vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
+    }
+    const unsigned long long vbits = key_bits(a.key_mask, b, S, kv0, lane) >> (4 * h);
+
+    // ---- St[key][q] = K . Q^T ----
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
+    }
+    // ---- online softmax (log2 domain) ----
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = (vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull;
+        const float s = ok ? st[kb][r] * sc : -INFINITY;
+        st[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = exp2f(st[kb][r] - m_new);
+        psum += p;
+        if (a.drop_thr) {
+          const unsigned key = (unsigned)(kv0 + kb * 32 + acc_row(r, h));
+          p = tf_keep(drop_row + key, a.drop_key, a.drop_thr) ? p : 0.f;
+        }
+        st[kb][r] = p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // ---- O^T[d][q] += V^T . Pt ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_frag(st[kb], s);
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d)
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(vt, kb * 32 + 16 * s, d * 32, lane), pf, o[d], 0, 0, 0);
+      }
+  }
+  // ---- epilogue ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
+  if (qrow < S) {
+    u16* orow = (u16*)a.out + ((size_t)b * S + qrow) * a.ld_out + (size_t)head * HDP;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 v;
+        v[0] = pack2bf(o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv);
+        v[1] = pack2bf(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+        *(u32x2*)(orow + d * 32 + 8 * g4 + 4 * h) = v;
+      }
+    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * S + qrow] = m_run + log2f(l_tot);
+  }
+}
+
+// ================================================================================================
+// backward, dQ: query on the lane, loop over key tiles
+//   St = K.Q^T -> P = exp2(St*sc - LSE);  dPt = V.dO^T;  dSt = P * (keep/(1-p) * dPt - delta)
+//   dQ^T[d][q] += K^T[d][key] . dSt[key][q];  dQ = scale * dQ^T^T
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kt = smem;
+  unsigned char* vt = smem + 64 * G::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int S = a.S;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t ld = a.ld_qkv;
+  const u16* qkv = (const u16*)a.qkv;
+  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+
+  const int qrow = q0 + (lane & 31);
+  const int qr = min(qrow, S - 1);
+  bf16x8 qf[G::KSTEPS], dof[G::KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < G::KSTEPS; ++ks) {
+    qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ld + ks * 16 + 8 * h));
+    dof[ks] = as_bf16x8(*(const u32x4*)(dobase + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
+  }
+  const float lse = a.lse[(size_t)bh * S + qr];
+  const float delta = a.delta[(size_t)bh * S + qr];
+  f32x16 dq[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+  const float sc = a.scale * LOG2E;
+  const unsigned drop_row = ((unsigned)bh * (unsigned)S + (unsigned)qrow) * (unsigned)S;
+
+  const int ntiles = (S + 63) / 64;
+  TileRegs<64, HDP> kr, vr;
+  kr.load(kbase, ld, 0, S - 1, false, tid);
+  vr.load(vbase, ld, 0, S - 1, false, tid);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();
+    kr.store(kt, tid);
+    vr.store(vt, tid);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
+      vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
+    }
+    const unsigned long long vbits = key_bits(a.key_mask, b, S, kv0, lane) >> (4 * h);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(vt, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = (vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull;
+        const float p = ok ? exp2f(st[r] * sc - lse) : 0.f;
+        float g = dp[r];
+        if (a.drop_thr) {
+          const unsigned key = (unsigned)(kv0 + kb * 32 + acc_row(r, h));
+          g = tf_keep(drop_row + key, a.drop_key, a.drop_thr) ? g * a.drop_scale : 0.f;
+        }
+        st[r] = p * (g - delta);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 dsf = acc_frag(st, s);
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d)
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane), dsf, dq[d], 0, 0, 0);
+      }
+    }
+  }
+  if (qrow < S) {
+    u16* orow = (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 v;
+        v[0] = pack2bf(dq[d][4 * g4] * a.scale, dq[d][4 * g4 + 1] * a.scale);
+        v[1] = pack2bf(dq[d][4 * g4 + 2] * a.scale, dq[d][4 * g4 + 3] * a.scale);
+        *(u32x2*)(orow + d * 32 + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
+// ================================================================================================
+// backward, dK / dV: key on the lane, loop over query tiles of 32
+//   S[q][key] = Q.K^T -> P ;  dP[q][key] = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
+//   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key] ; dK *= scale
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* qt = smem;
+  unsigned char* dot = smem + 32 * G::TSTR;
+  float* lse_s = (float*)(smem + 64 * G::TSTR);
+  float* del_s = lse_s + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int S = a.S;
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const size_t ld = a.ld_qkv;
+  const u16* qkv = (const u16*)a.qkv;
+  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+
+  const int key = key0 + (lane & 31);
+  const int kr_ = min(key, S - 1);
+  bool key_ok = key < S;
+  if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
+  // K^T / V^T B-operand fragments (B[k = hd][col = key]) resident in registers
+  bf16x8 kf[G::KSTEPS], vf[G::KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < G::KSTEPS; ++ks) {
+    kf[ks] = as_bf16x8(*(const u32x4*)(kbase + (size_t)kr_ * ld + ks * 16 + 8 * h));
+    vf[ks] = as_bf16x8(*(const u32x4*)(vbase + (size_t)kr_ * ld + ks * 16 + 8 * h));
+  }
+  f32x16 dk[G::DBLK], dv[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+  const float sc = a.scale * LOG2E;
+
+  const int ntiles = (S + 31) / 32;
+  TileRegs<32, HDP> qr, dr;
+  qr.load(qbase, ld, 0, S - 1, false, tid);
+  dr.load(dobase, a.ld_dout, 0, S - 1, true, tid);       // rows >= S contribute nothing
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = t * 32;
+    __syncthreads();
+    qr.store(qt, tid);
+    dr.store(dot, tid);
+    if (tid < 32) {
+      const int q = q0 + tid;
+      lse_s[tid] = q < S ? a.lse[(size_t)bh * S + q] : 1.0e30f;     // P = 0 for rows past the end
+      del_s[tid] = q < S ? a.delta[(size_t)bh * S + q] : 0.f;
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
+      dr.load(dobase, a.ld_dout, q0 + 32, S - 1, true, tid);
+    }
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(qt, 0, ks, lane), kf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(dot, 0, ks, lane), vf[ks], dp, 0, 0, 0);
+    }
+    // registers 4g..4g+3 are query rows 8g + 4h + (0..3): one 16-B LDS read per group for LSE and delta
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g4 + 4 * h);
+      const f32x4 d4 = *(const f32x4*)(del_s + 8 * g4 + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        const float p = key_ok ? exp2f(st[r] * sc - l4[i]) : 0.f;
+        float keep_scale = 1.f;
+        if (a.drop_thr) {
+          const unsigned q = (unsigned)(q0 + 8 * g4 + 4 * h + i);
+          const unsigned idx = ((unsigned)bh * (unsigned)S + q) * (unsigned)S + (unsigned)key;
+          keep_scale = tf_keep(idx, a.drop_key, a.drop_thr) ? a.drop_scale : 0.f;
+        }
+        st[r] = p * keep_scale;                         // Pd
+        dp[r] = p * (dp[r] * keep_scale - d4[i]);       // dS
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = acc_frag(st, s), dsf = acc_frag(dp, s);
+#pragma unroll
+      for (int d = 0; d < G::DBLK; ++d) {
+        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(dot, 16 * s, d * 32, lane), pf, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(qt, 16 * s, d * 32, lane), dsf, dk[d], 0, 0, 0);
+      }
+    }
+  }
+  if (key < S) {
+    u16* krow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
+    u16* vrow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 v;
+        v[0] = pack2bf(dk[d][4 * g4] * a.scale, dk[d][4 * g4 + 1] * a.scale);
+        v[1] = pack2bf(dk[d][4 * g4 + 2] * a.scale, dk[d][4 * g4 + 3] * a.scale);
+        *(u32x2*)(krow + d * 32 + 8 * g4 + 4 * h) = v;
+        v[0] = pack2bf(dv[d][4 * g4], dv[d][4 * g4 + 1]);
+        v[1] = pack2bf(dv[d][4 * g4 + 2], dv[d][4 * g4 + 3]);
+        *(u32x2*)(vrow + d * 32 + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
+template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
+  const size_t lds = 128 * Geo<HDP>::TSTR;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3((a->S + 127) / 128, a->B * a->H), dim3(256), lds, st, *a);
+  return (int)hipGetLastError();
+}
+template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
+  const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256;
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  dim3 grid((a->S + 127) / 128, a->B * a->H);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, grid, dim3(256), lds_kv, st, *a);
+  return (int)hipGetLastError();
+}
+
+int check(const TfAttnArgs* a) {
+  if (a->B <= 0 || a->S <= 0 || a->H <= 0) return 1;
+  if ((a->ld_qkv % 8) || (a->ld_out % 8)) return -2;
+  if ((long long)a->B * a->H * a->S * a->S >= (1ll << 32) && a->drop_thr) return -5;   // 32-bit dropout index space
+  return 0;
+}
+
+}  // namespace
+
+#define TF_ATTN_DISPATCH(FN)                     \
+  switch (a->HDP) {                              \
+    case 32: return FN<32>(a, st);               \
+    case 64: return FN<64>(a, st);               \
+    case 96: return FN<96>(a, st);               \
+    case 128: return FN<128>(a, st);             \
+    case 160: return FN<160>(a, st);             \
+    case 192: return FN<192>(a, st);             \
+    case 224: return FN<224>(a, st);             \
+    case 256: return FN<256>(a, st);             \
+    default: return -3;                          \
+  }
+
+extern "C" int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t st) {
+  const int c = check(a);
+  if (c) return c > 0 ? 0 : c;
+  TF_ATTN_DISPATCH(launch_fwd)
+}
+extern "C" int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t st) {
+  const int c = check(a);
+  if (c) return c > 0 ? 0 : c;
+  if ((a->ld_dout % 8) || (a->ld_dqkv % 8) || a->delta == nullptr || a->lse == nullptr) return -2;
+  TF_ATTN_DISPATCH(launch_bwd)
+}

@@ -1,0 +1,512 @@
+// HBM-bound row-wise kernels of the fusion block (gfx950): LayerNorm fwd/bwd, token assemble
+// fwd/bwd (positional + kind embeddings, patch dropout, concat), attention delta, parameter packing
+// (fp32 master -> bf16 padded shadows and their transposes), fused RAdam, im2col/col2im for K1/K9.
+// All bf16 traffic is 16 B per lane; one wave (64 lanes) owns one row so row statistics are a
+// wave-shuffle reduction with no LDS.
+#include "tf_common.h"
+#include "tf_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;   // 16-B chunks per lane per row  -> widths up to 64*4*8 = 2048
+
+__device__ __forceinline__ void load8_f32(const float* p, float (&f)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void store8_f32(float* p, const float (&f)[8]) {
+  *(f32x4*)p = f32x4{f[0], f[1], f[2], f[3]};
+  *(f32x4*)(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+}
+__device__ __forceinline__ void load8_any(const void* base, size_t off, int is_f32, float (&f)[8]) {
+  if (is_f32) load8_f32((const float*)base + off, f);
+  else unpack8(*(const u32x4*)((const u16*)base + off), f);
+}
+__device__ __forceinline__ void store8_any(void* base, size_t off, int is_f32, const float (&f)[8]) {
+  if (is_f32) store8_f32((float*)base + off, f);
+  else *(u32x4*)((u16*)base + off) = pack8(f);
+}
+__device__ __forceinline__ int map_row(int r, int rpg, int stride) { return (r / rpg) * stride + (r % rpg); }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta over the first d columns, fp32 statistics.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
+  const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
+  const u16* x = (const u16*)a.x + (size_t)xr * a.ldx;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < a.d) {
+      unpack8(*(const u32x4*)(x + c), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)a.d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < a.d) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[i][e] - mean; q += t * t; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)a.d + a.eps);
+  if (lane == 0 && a.mean != nullptr) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < a.d) {
+      float g[8], b[8], o[8];
+      load8_f32(a.gamma + c, g);
+      load8_f32(a.beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      store8_any(a.y, (size_t)yr * a.ldy + c, a.y_is_f32, o);
+    } else if (c < a.ldy && !a.y_is_f32) {
+      *(u32x4*)((u16*)a.y + (size_t)yr * a.ldy + c) = u32x4{0, 0, 0, 0};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  g = (dy [+ dres]) * gamma ; xhat = (x - mean) * rstd
+//   dx = rstd * (g - mean_d(g) - xhat * mean_d(g * xhat));  dgamma += dy * xhat;  dbeta += dy
+// optional second output dx_drop = dx * keep/(1-p)  (the dropout in front of the residual add).
+// Waves stride over rows keeping their dgamma/dbeta partials in registers; one LDS reduction per
+// block, then fp32 atomics (2*d per block).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
+  __shared__ float red[4][64 * MAXC * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[MAXC][8], db[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
+    const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    float xh[MAXC][8], g[MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < a.d) {
+        float xv[8], dy[8], gm[8];
+        unpack8(*(const u32x4*)((const u16*)a.x + (size_t)xr * a.ldx + c), xv);
+        load8_any(a.dy, (size_t)yr * a.lddy + c, a.dy_is_f32, dy);
+        if (a.dres != nullptr) {
+          float r[8];
+          unpack8(*(const u32x4*)((const u16*)a.dres + (size_t)xr * a.lddres + c), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dy[e] += r[e];
+        }
+        load8_f32(a.gamma + c, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xv[e] - mean) * rstd;
+          g[i][e] = dy[e] * gm[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          dg[i][e] += dy[e] * xh[i][e];
+          db[i][e] += dy[e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)a.d, c2 = wave_sum(s2) / (float)a.d;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < a.d) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
+        *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = pack8(o);
+        if (a.dx_drop != nullptr) {
+          if (a.drop_thr) {
+            const unsigned base = (unsigned)xr * (unsigned)a.drop_ld + (unsigned)c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = tf_keep(base + e, a.drop_key, a.drop_thr) ? o[e] * a.drop_scale : 0.f;
+          }
+          *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = pack8(o);
+        }
+      } else {
+        if (c < a.lddx) *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = u32x4{0, 0, 0, 0};
+        if (a.dx_drop != nullptr && c < a.lddxd) *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = u32x4{0, 0, 0, 0};
+      }
+    }
+  }
+  // block reduction of the column partials, two passes (gamma then beta) through one LDS array
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][(lane + 64 * i) * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
+    __syncthreads();
+    float* dst = pass == 0 ? a.dgamma : a.dbeta;
+    for (int c = threadIdx.x; c < a.d; c += 256) {
+      const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      atomicAdd(dst + c, t);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token assemble (K2): out[b, s] = s < Nv ? dropout(vis[b,s] + pe[s] + kind_v) : lang[b,s-Nv] + kind_l
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.Nv + a.Nl;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.B * S) return;
+  const int b = row / S, s = row - b * S;
+  u16* out = (u16*)a.out + (size_t)row * a.ld_out;
+  for (int c = lane * 8; c < a.ld_out; c += 512) {
+    if (c >= a.d) { *(u32x4*)(out + c) = u32x4{0, 0, 0, 0}; continue; }
+    float v[8], k[8];
+    if (s < a.Nv) {
+      float pe[8];
+      load8_any(a.vis, (size_t)(b * a.Nv + s) * a.ld_vis + c, a.vis_is_f32, v);
+      load8_f32(a.pe + (size_t)s * a.d + c, pe);
+      load8_f32(a.kind_v + c, k);
+      const unsigned base = (unsigned)row * (unsigned)a.ld_out + (unsigned)c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = v[e] + pe[e] + k[e];
+        if (a.drop_thr) t = tf_keep(base + e, a.drop_key, a.drop_thr) ? t * a.drop_scale : 0.f;
+        v[e] = t;
+      }
+    } else {
+      load8_any(a.lang, (size_t)(b * a.Nl + s - a.Nv) * a.ld_lang + c, a.lang_is_f32, v);
+      load8_f32(a.kind_l + c, k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += k[e];
+    }
+    *(u32x4*)(out + c) = pack8(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs a) {
+  __shared__ float red[4][64 * MAXC * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.Nv + a.Nl;
+  float kv[MAXC][8], kl[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kv[i][e] = 0.f; kl[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < a.B * S; row += gridDim.x * 4) {
+    const int b = row / S, s = row - b * S;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c >= a.d) continue;
+      float g[8];
+      unpack8(*(const u32x4*)((const u16*)a.dout + (size_t)row * a.ld_dout + c), g);
+      if (s < a.Nv) {
+        if (a.drop_thr) {
+          const unsigned base = (unsigned)row * (unsigned)a.ld_dout + (unsigned)c;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = tf_keep(base + e, a.drop_key, a.drop_thr) ? g[e] * a.drop_scale : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[i][e] += g[e];
+        if (a.dvis != nullptr) store8_any(a.dvis, (size_t)(b * a.Nv + s) * a.ld_dvis + c, a.dvis_is_f32, g);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kl[i][e] += g[e];
+        if (a.dlang != nullptr) store8_any(a.dlang, (size_t)(b * a.Nl + s - a.Nv) * a.ld_dlang + c, a.dlang_is_f32, g);
+      }
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][(lane + 64 * i) * 8 + e] = pass == 0 ? kv[i][e] : kl[i][e];
+    __syncthreads();
+    float* dst = pass == 0 ? a.dkind_v : a.dkind_l;
+    if (dst != nullptr)
+      for (int c = threadIdx.x; c < a.d; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
+  }
+}
+
+// delta[b,h,s] = sum_e dO[b,s,h,e] * O[b,s,h,e]; 8 lanes per (row, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const u16* __restrict__ o, int ldo, const u16* __restrict__ d_o,
+                                                         int lddo, float* __restrict__ delta, int B, int S, int H, int HDP) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long item = t >> 3;
+  const int sub = (int)(t & 7);
+  const bool ok = item < (long long)B * S * H;
+  float acc = 0.f;
+  int row = 0, head = 0;
+  if (ok) {
+    row = (int)(item / H); head = (int)(item % H);
+    for (int c = sub * 8; c < HDP; c += 64) {
+      float x[8], y[8];
+      unpack8(*(const u32x4*)(o + (size_t)row * ldo + head * HDP + c), x);
+      unpack8(*(const u32x4*)(d_o + (size_t)row * lddo + head * HDP + c), y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += x[e] * y[e];
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+  if (ok && sub == 0) { const int b = row / S, s = row - b * S; delta[((size_t)b * H + head) * S + s] = acc; }
+}
+
+// fp32 parameter [rows, cols] -> bf16 shadow (padded / head-grouped) and its transpose, via a 64x64 LDS tile
+__global__ __launch_bounds__(256) void pack_kernel(const TfPackArgs a) {
+  __shared__ u16 tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rl = i >> 6, cl = i & 63;
+    const int rp = r0 + rl, cp = c0 + cl;
+    float v = 0.f;
+    if (rp < a.rows_p && cp < a.cols_p) {
+      const int rgq = rp / a.rgp, rge = rp - rgq * a.rgp, cgq = cp / a.cgp, cge = cp - cgq * a.cgp;
+      const int rs = rgq * a.rg + rge, cs = cgq * a.cg + cge;
+      if (rge < a.rg && cge < a.cg && rs < a.rows && cs < a.cols) v = a.src[(size_t)rs * a.cols + cs];
+    }
+    if (a.dst_is_f32) {
+      if (rp < a.rows_p && cp < a.cols_p) ((float*)a.dst)[(size_t)rp * a.ld_dst + cp] = v;
+    } else {
+      tile[rl][cl] = f2bf(v);
+    }
+  }
+  if (a.dst_is_f32) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rl = i >> 6, cl = i & 63;
+    if (a.dst != nullptr && r0 + rl < a.rows_p && c0 + cl < a.cols_p)
+      ((u16*)a.dst)[(size_t)(r0 + rl) * a.ld_dst + c0 + cl] = tile[rl][cl];
+    // transposed: row index = column of the source
+    if (a.dst_t != nullptr && c0 + rl < a.cols_p && r0 + cl < a.rows_p)
+      ((u16*)a.dst_t)[(size_t)(c0 + rl) * a.ld_dst_t + r0 + cl] = tile[cl][rl];
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const TfCopyRowsArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const size_t sr = (size_t)map_row(row, a.src_rpg, a.src_gstride) * a.ld_src;
+  const size_t dr = (size_t)map_row(row, a.dst_rpg, a.dst_gstride) * a.ld_dst;
+  const int width = a.dst_is_f32 ? a.cols : a.ld_dst;
+  for (int c = lane * 8; c < width; c += 512) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (c < a.cols && a.src != nullptr) load8_any(a.src, sr + c, a.src_is_f32, v);
+    store8_any(a.dst, dr + c, a.dst_is_f32, v);
+  }
+}
+__global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restrict__ km, int B, int Nv, int Nl) {
+  const int S = Nv + Nl;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
+    const int b = i / S, s = i - b * S;
+    km[i] = (s < Nv || lm == nullptr) ? 0 : lm[b * Nl + s - Nv];
+  }
+}
+
+// y = keep(i) ? x * scale : 0 over a dense bf16 array (16 B per lane); its own backward
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restrict__ x, u16* __restrict__ y, long long n8, unsigned key,
+                                                            unsigned thr, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float f[8];
+    unpack8(*(const u32x4*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = tf_keep((unsigned)(i * 8 + e), key, thr) ? f[e] * scale : 0.f;
+    *(u32x4*)(y + i * 8) = pack8(f);
+  }
+}
+
+__global__ void dropout_mask_kernel(uint8_t* out, long long n, unsigned key, unsigned thr) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = tf_keep((unsigned)i, key, thr) ? 1 : 0;
+}
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, u16* __restrict__ d, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = f2bf(s[i]);
+}
+__global__ void cast_bf16_f32_kernel(const u16* __restrict__ s, float* __restrict__ d, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = bf2f(s[i]);
+}
+
+// RAdam (runner/metrics_losses/radam_optim.py:55-100): moments always updated; parameter update only
+// when the variance is rectifiable (N_sma >= 5) or in the SGD-degenerated mode.
+__global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    const float g = a.g[i] * a.grad_scale;
+    float v = a.v[i] * a.beta2 + (1.f - a.beta2) * g * g;
+    float m = a.m[i] * a.beta1 + (1.f - a.beta1) * g;
+    a.v[i] = v; a.m[i] = m;
+    if (a.rectified == 1) {
+      float p = a.p[i];
+      if (a.weight_decay != 0.f) p += -a.weight_decay * a.lr * p;
+      p += -a.step_size * a.lr * m / (sqrtf(v) + a.eps);
+      a.p[i] = p;
+    } else if (a.rectified == 2) {
+      float p = a.p[i];
+      if (a.weight_decay != 0.f) p += -a.weight_decay * a.lr * p;
+      p += -a.step_size * a.lr * m;
+      a.p[i] = p;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// K1 gather: cols[(b*Hp+hp)*Wp+wp][(c*ph+i)*pw+j] = feat[b][c][hp*ph+i][wp*pw+j]
+__global__ void im2col_kernel(const TfPatchArgs a) {
+  const int Hp = a.H / a.ph, Wp = a.W / a.pw, Kc = a.C * a.ph * a.pw;
+  const long long total = (long long)a.B * Hp * Wp * a.ld_cols;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(t % a.ld_cols);
+    const long long tok = t / a.ld_cols;
+    float v = 0.f;
+    if (k < Kc) {
+      const int j = k % a.pw, i = (k / a.pw) % a.ph, c = k / (a.pw * a.ph);
+      const int wp = (int)(tok % Wp), hp = (int)((tok / Wp) % Hp), b = (int)(tok / ((long long)Wp * Hp));
+      const size_t src = (((size_t)b * a.C + c) * a.H + hp * a.ph + i) * a.W + wp * a.pw + j;
+      v = a.feat_is_f32 ? ((const float*)a.feat)[src] : bf2f(((const u16*)a.feat)[src]);
+    }
+    ((u16*)a.cols)[t] = f2bf(v);
+  }
+}
+// K9 scatter (F.fold with kernel == stride): the inverse permutation; the uncovered border is zero
+__global__ void col2im_kernel(const TfPatchArgs a, int out_is_f32) {
+  const int Hp = a.H / a.ph, Wp = a.W / a.pw;
+  const long long total = (long long)a.B * a.C * a.H * a.W;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % a.W), y = (int)((t / a.W) % a.H), c = (int)((t / ((long long)a.W * a.H)) % a.C);
+    const int b = (int)(t / ((long long)a.W * a.H * a.C));
+    float v = 0.f;
+    if (y < Hp * a.ph && x < Wp * a.pw) {
+      const size_t tok = ((size_t)b * Hp + y / a.ph) * Wp + x / a.pw;
+      v = bf2f(((const u16*)a.cols)[tok * a.ld_cols + (c * a.ph + y % a.ph) * a.pw + x % a.pw]);
+    }
+    if (out_is_f32) ((float*)a.feat)[t] = v; else ((u16*)a.feat)[t] = f2bf(v);
+  }
+}
+
+inline int grid_for(long long n, int per_block, int cap = 2048) {
+  long long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
+  if (a->rows <= 0) return 0;
+  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ldx % 8) || (a->ldy % 8)) return -2;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
+  if (a->rows <= 0) return 0;
+  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(a->rows, 4 * 8, 1024)), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
+  const int rows = a->B * (a->Nv + a->Nl);
+  if (rows <= 0) return 0;
+  if ((a->d % 8) || (a->ld_out % 8) || (a->ld_vis % 8) || (a->ld_lang % 8)) return -2;
+  hipLaunchKernelGGL(assemble_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
+  const int rows = a->B * (a->Nv + a->Nl);
+  if (rows <= 0) return 0;
+  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(grid_for(rows, 4 * 8, 1024)), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int lddo, float* delta, int B, int S, int H,
+                                    int HDP, hipStream_t st) {
+  const long long threads = (long long)B * S * H * 8;
+  if (threads <= 0) return 0;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const u16*)o, ldo,
+                     (const u16*)d_o, lddo, delta, B, S, H, HDP);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_pack(const TfPackArgs* a, hipStream_t st) {
+  if (a->rows_p <= 0 || a->cols_p <= 0) return 0;
+  if (a->rg <= 0 || a->cg <= 0 || a->rgp < a->rg || a->cgp < a->cg) return -2;
+  hipLaunchKernelGGL(pack_kernel, dim3((a->cols_p + 63) / 64, (a->rows_p + 63) / 64), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
+  if (a->rows <= 0) return 0;
+  if ((a->cols % 8) || (a->ld_src % 8) || (a->ld_dst % 8)) return -2;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {
+  const int n = B * (Nv + Nl);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(key_mask_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, st, lm, km, B, Nv, Nl);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (n % 8) return -2;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const u16*)x, (u16*)y, n / 8, key, thr, scale);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, key, thr);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_cast_f32_bf16(const float* s, void* d, long long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, s, (u16*)d, n);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_cast_bf16_f32(const void* s, float* d, long long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const u16*)s, d, n);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
+  if (a->n <= 0) return 0;
+  hipLaunchKernelGGL(radam_kernel, dim3(grid_for(a->n, 256 * 4)), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8, 1024)), dim3(256), 0, st, x, n, out);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
+  const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t st) {
+  const long long total = (long long)a->B * a->C * a->H * a->W;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a, out_is_f32);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,412 @@
+// C-ABI layer of libtfusion_hip.so (see include/tfusion.h) and the native encoder runtime: the launch
+// sequence of one CrossTransformerModuleBox forward / backward, enqueued on the caller's stream with no
+// allocation, no synchronisation and no host-side state (graph-capturable, callable from any thread).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include "tf_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what) {
+  if (code > 0) snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", what, code, hipGetErrorString((hipError_t)code));
+  else snprintf(g_err, sizeof(g_err), "%s: invalid argument (code %d)", what, code);
+  return code;
+}
+#define TF_TRY(expr, what) do { const int rc__ = (expr); if (rc__ != 0) return fail(rc__, what); } while (0)
+
+inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr int BIG = 1 << 28;
+
+uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// ---- encoder memory layout ------------------------------------------------------------------------
+struct Dims {
+  int B, Nv, Nl, d, H, L, ff;
+  int S, M, hd, hdp, dp, ffp, nqkv, ldq;
+};
+bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o) {
+  if (B <= 0 || Nv < 0 || Nl < 0 || Nv + Nl <= 0 || d <= 0 || H <= 0 || L <= 0 || L > TF_MAX_LAYERS || ff <= 0) return false;
+  if (d % H != 0 || d % 8 != 0) return false;
+  o->B = B; o->Nv = Nv; o->Nl = Nl; o->d = d; o->H = H; o->L = L; o->ff = ff;
+  o->S = Nv + Nl; o->M = B * o->S;
+  o->hd = d / H;
+  o->hdp = (int)up(o->hd, 32);
+  if (o->hdp > 256) return false;
+  o->dp = (int)up((size_t)H * o->hdp, 64);
+  o->ffp = (int)up(ff, 64);
+  o->nqkv = 3 * H * o->hdp;
+  o->ldq = (int)up(o->nqkv, 64);
+  if (o->d > 2048) return false;
+  return true;
+}
+struct WOff {   // byte offsets inside wpack, per layer
+  size_t win, winT, wo, woT, w1, w1T, w2, w2T, bin, bo, b1, b2, stride;
+};
+WOff make_woff(const Dims& D) {
+  WOff w; size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += up(bytes, 256); return r; };
+  w.win = take((size_t)D.nqkv * D.dp * 2);   w.winT = take((size_t)D.dp * D.ldq * 2);
+  w.wo = take((size_t)D.dp * D.dp * 2);      w.woT = take((size_t)D.dp * D.dp * 2);
+  w.w1 = take((size_t)D.ffp * D.dp * 2);     w.w1T = take((size_t)D.dp * D.ffp * 2);
+  w.w2 = take((size_t)D.dp * D.ffp * 2);     w.w2T = take((size_t)D.ffp * D.dp * 2);
+  w.bin = take((size_t)D.ldq * 4); w.bo = take((size_t)D.dp * 4); w.b1 = take((size_t)D.ffp * 4); w.b2 = take((size_t)D.dp * 4);
+  w.stride = o;
+  return w;
+}
+struct AOff {   // byte offsets inside work
+  size_t keymask, zeros, x0, x_stride;            // X[l] = x0 + l * x_stride, l = 0..L
+  size_t layer0, layer_stride;                    // per-layer block
+  size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2;   // offsets inside a layer block
+  size_t meanf, rstdf;
+  size_t dxa, dxb, dz, dy, du, d_o, dqkv, delta;
+  size_t total;
+};
+AOff make_aoff(const Dims& D) {
+  AOff a; size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += up(bytes, 256); return r; };
+  const size_t md = (size_t)D.M * D.dp * 2, mf = (size_t)D.M * D.ffp * 2, mq = (size_t)D.M * D.ldq * 2;
+  const size_t st = (size_t)D.B * D.H * D.S * 4, mr = (size_t)D.M * 4;
+  a.zeros = take(256);
+  a.keymask = take((size_t)D.M);
+  a.x0 = o; a.x_stride = up(md, 256); o += a.x_stride * (D.L + 1);
+  a.layer0 = o;
+  {
+    size_t lo = 0;
+    auto ltake = [&](size_t bytes) { size_t r = lo; lo += up(bytes, 256); return r; };
+    a.qkv = ltake(mq); a.o = ltake(md); a.lse = ltake(st); a.z1 = ltake(md); a.mean1 = ltake(mr); a.rstd1 = ltake(mr);
+    a.x1 = ltake(md); a.u = ltake(mf); a.h = ltake(mf); a.z2 = ltake(md); a.mean2 = ltake(mr); a.rstd2 = ltake(mr);
+    a.layer_stride = lo;
+  }
+  o += a.layer_stride * D.L;
+  a.meanf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4); a.rstdf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4);
+  a.dxa = take(md); a.dxb = take(md); a.dz = take(md); a.dy = take(md); a.du = take(mf); a.d_o = take(md); a.dqkv = take(mq);
+  a.delta = take(st);
+  a.total = o;
+  return a;
+}
+
+struct Ctx {
+  Dims D; WOff W; AOff A;
+  const TfEncoderDesc* e;
+  unsigned char* wp; unsigned char* wk;
+  hipStream_t st;
+  void* X(int l) const { return wk + A.x0 + (size_t)l * A.x_stride; }
+  unsigned char* LB(int l) const { return wk + A.layer0 + (size_t)l * A.layer_stride; }
+  unsigned char* WB(int l) const { return wp + (size_t)l * W.stride; }
+};
+bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
+  if (e == nullptr || e->wpack == nullptr || e->work == nullptr) return false;
+  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D)) return false;
+  c->W = make_woff(c->D); c->A = make_aoff(c->D);
+  c->e = e; c->wp = (unsigned char*)e->wpack; c->wk = (unsigned char*)e->work; c->st = st;
+  return true;
+}
+
+struct Drop { unsigned thr, key; float scale; };
+Drop drop_for(const TfEncoderDesc* e, float p, unsigned site) {
+  Drop d{0u, 0u, 1.f};
+  if (e->training && p > 0.f) { d.thr = tf_drop_threshold(p); d.key = tf_drop_key(e->seed, site); d.scale = 1.f / (1.f - p); }
+  return d;
+}
+enum Site { SITE_PATCH = 0, SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4 };
+inline unsigned site_of(int layer, int which) { return 16u + (unsigned)layer * 8u + (unsigned)which; }
+
+int gemm(const Ctx& c, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias, const void* R, int ldr,
+         void* C2, int ldc2, int N, int K, int epi, Drop dr) {
+  TfGemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
+  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
+  return tf_launch_gemm_nt(&g, c.st);
+}
+int wgrad(const Ctx& c, const void* dY, int ldy, int N, const void* X, int ldx, int K, float* dW, int lddw, float* db, int rg, int rgp,
+          int n_src, int cg, int cgp, int k_src) {
+  TfWgradArgs w{};
+  w.dY = dY; w.ldy = ldy; w.X = X; w.ldx = ldx; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
+  w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
+  return tf_launch_wgrad_tn(&w, c.st);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int tf_version(void) { return TF_ABI_VERSION; }
+const char* tf_last_error(void) { return g_err; }
+
+uint32_t tf_drop_key(uint64_t seed, uint32_t site) { return (uint32_t)(splitmix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(site + 1))) >> 32); }
+uint32_t tf_drop_threshold(float p) {
+  if (!(p > 0.f)) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  if (t < 1.0) return 1u;
+  return (uint32_t)t;
+}
+
+#define TF_WRAP(name, call) do { if (a == nullptr) return fail(-1, name); TF_TRY(call, name); return 0; } while (0)
+int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_fwd", tf_launch_gemm_nt(a, (hipStream_t)s)); }
+int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_wgrad", tf_launch_wgrad_tn(a, (hipStream_t)s)); }
+int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s) { TF_WRAP("tf_attn_fwd", tf_launch_attn_fwd(a, (hipStream_t)s)); }
+int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s) {
+  if (a == nullptr) return fail(-1, "tf_attn_bwd");
+  TF_TRY(tf_launch_attn_delta(a->out, a->ld_out, a->dout, a->ld_dout, a->delta, a->B, a->S, a->H, a->HDP, (hipStream_t)s), "tf_attn_bwd(delta)");
+  TF_TRY(tf_launch_attn_bwd(a, (hipStream_t)s), "tf_attn_bwd");
+  return 0;
+}
+int tf_layernorm_fwd(const TfLnArgs* a, tf_stream_t s) { TF_WRAP("tf_layernorm_fwd", tf_launch_ln_fwd(a, (hipStream_t)s)); }
+int tf_layernorm_bwd(const TfLnArgs* a, tf_stream_t s) { TF_WRAP("tf_layernorm_bwd", tf_launch_ln_bwd(a, (hipStream_t)s)); }
+int tf_assemble_fwd(const TfAssembleArgs* a, tf_stream_t s) { TF_WRAP("tf_assemble_fwd", tf_launch_assemble_fwd(a, (hipStream_t)s)); }
+int tf_assemble_bwd(const TfAssembleArgs* a, tf_stream_t s) { TF_WRAP("tf_assemble_bwd", tf_launch_assemble_bwd(a, (hipStream_t)s)); }
+int tf_patchify_fwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_patchify_fwd", tf_launch_im2col(a, (hipStream_t)s)); }
+int tf_patchify_bwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_patchify_bwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
+int tf_regroup_fwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_regroup_fwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
+int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bwd", tf_launch_im2col(a, (hipStream_t)s)); }
+int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
+int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
+int tf_radam_step(const TfRadamArgs* a, tf_stream_t s) { TF_WRAP("tf_radam_step", tf_launch_radam(a, (hipStream_t)s)); }
+int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq(x, n, out, (hipStream_t)s), "tf_sumsq"); return 0; }
+int tf_dropout_mask(uint8_t* out, long long n, uint32_t key, uint32_t thr, tf_stream_t s) {
+  TF_TRY(tf_launch_dropout_mask(out, n, key, thr, (hipStream_t)s), "tf_dropout_mask"); return 0;
+}
+int tf_dropout_apply(const void* x, void* y, long long n, uint32_t key, uint32_t thr, float scale, tf_stream_t s) {
+  TF_TRY(tf_launch_dropout_apply(x, y, n, key, thr, scale, (hipStream_t)s), "tf_dropout_apply"); return 0;
+}
+int tf_cast_f32_bf16(const float* src, void* dst, long long n, tf_stream_t s) { TF_TRY(tf_launch_cast_f32_bf16(src, dst, n, (hipStream_t)s), "tf_cast_f32_bf16"); return 0; }
+int tf_cast_bf16_f32(const void* src, float* dst, long long n, tf_stream_t s) { TF_TRY(tf_launch_cast_bf16_f32(src, dst, n, (hipStream_t)s), "tf_cast_bf16_f32"); return 0; }
+
+// ---- encoder runtime --------------------------------------------------------------------------------
+int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out) {
+  Dims D;
+  if (out == nullptr || !make_dims(B, Nv, Nl, d, H, L, ff, &D)) return fail(-1, "tf_encoder_plan");
+  const WOff W = make_woff(D); const AOff A = make_aoff(D);
+  out->hd = D.hd; out->hdp = D.hdp; out->dp = D.dp; out->ffp = D.ffp; out->ldq = D.ldq; out->S = D.S; out->M = D.M;
+  out->wpack_bytes = W.stride * (size_t)D.L; out->work_bytes = A.total;
+  return 0;
+}
+
+int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s) {
+  Ctx c;
+  if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_pack");
+  const Dims& D = c.D;
+  for (int l = 0; l < D.L; ++l) {
+    unsigned char* w = c.WB(l);
+    const TfLayerParams& p = e->p[l];
+    auto pack = [&](const float* src, int rows, int cols, void* dst, int ld, void* dstT, int ldT, int rows_p, int cols_p, int rg, int rgp,
+                    int cg, int cgp, int f32) {
+      TfPackArgs a{};
+      a.src = src; a.rows = rows; a.cols = cols; a.dst = dst; a.ld_dst = ld; a.dst_t = dstT; a.ld_dst_t = ldT; a.rows_p = rows_p;
+      a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32;
+      return tf_launch_pack(&a, c.st);
+    };
+    TF_TRY(pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0), "pack in_w");
+    TF_TRY(pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0), "pack out_w");
+    TF_TRY(pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0), "pack w1");
+    TF_TRY(pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0), "pack w2");
+    TF_TRY(pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1), "pack in_b");
+    TF_TRY(pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1), "pack out_b");
+    TF_TRY(pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1), "pack b1");
+    TF_TRY(pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1), "pack b2");
+  }
+  return 0;
+}
+
+int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
+  Ctx c;
+  if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_fwd");
+  const Dims& D = c.D;
+  if (e->vis == nullptr || e->lang == nullptr || e->vis_out == nullptr || e->pe == nullptr) return fail(-1, "tf_encoder_fwd(null io)");
+  uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
+  TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
+  {
+    TfAssembleArgs a{};
+    a.vis = e->vis; a.vis_is_f32 = e->vis_is_f32; a.ld_vis = D.d; a.lang = e->lang; a.lang_is_f32 = e->lang_is_f32; a.ld_lang = D.d;
+    a.pe = e->pe; a.kind_v = e->kind_v; a.kind_l = e->kind_l; a.out = c.X(0); a.ld_out = D.dp; a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
+    const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
+    a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+    TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
+  }
+  const float scale = 1.0f / sqrtf((float)D.hd);
+  for (int l = 0; l < D.L; ++l) {
+    unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
+    const TfLayerParams& p = e->p[l];
+    const Drop none{0u, 0u, 1.f};
+    TF_TRY(gemm(c, c.X(l), D.dp, w + c.W.win, D.dp, b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin), nullptr, 0, nullptr, 0, D.nqkv, D.dp,
+                TF_EPI_BIAS, none), "gemm qkv");
+    {
+      TfAttnArgs a{};
+      a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
+      a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+      TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
+    }
+    TF_TRY(gemm(c, b + c.A.o, D.dp, w + c.W.wo, D.dp, b + c.A.z1, D.dp, (const float*)(w + c.W.bo), c.X(l), D.dp, nullptr, 0, D.dp, D.dp,
+                TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP1))), "gemm out_proj");
+    {
+      TfLnArgs n{};
+      n.x = b + c.A.z1; n.ldx = D.dp; n.y = b + c.A.x1; n.ldy = D.dp; n.y_is_f32 = 0; n.gamma = p.n1_w; n.beta = p.n1_b;
+      n.mean = (float*)(b + c.A.mean1); n.rstd = (float*)(b + c.A.rstd1); n.rows = D.M; n.d = D.d; n.rows_per_group = D.M;
+      n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln1_fwd");
+    }
+    TF_TRY(gemm(c, b + c.A.x1, D.dp, w + c.W.w1, D.dp, b + c.A.u, D.ffp, (const float*)(w + c.W.b1), nullptr, 0, b + c.A.h, D.ffp, D.ffp, D.dp,
+                TF_EPI_BIAS_GELU_DROP, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");
+    TF_TRY(gemm(c, b + c.A.h, D.ffp, w + c.W.w2, D.ffp, b + c.A.z2, D.dp, (const float*)(w + c.W.b2), b + c.A.x1, D.dp, nullptr, 0, D.dp, D.ffp,
+                TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down");
+    {
+      TfLnArgs n{};
+      n.x = b + c.A.z2; n.ldx = D.dp; n.y = c.X(l + 1); n.ldy = D.dp; n.y_is_f32 = 0; n.gamma = p.n2_w; n.beta = p.n2_b;
+      n.mean = (float*)(b + c.A.mean2); n.rstd = (float*)(b + c.A.rstd2); n.rows = D.M; n.d = D.d; n.rows_per_group = D.M;
+      n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln2_fwd");
+    }
+  }
+  // visual rows: final LayerNorm (cross_f_box_layers.py:104-107) or plain copy
+  if (D.Nv > 0) {
+    if (e->final_norm) {
+      TfLnArgs n{};
+      n.x = c.X(D.L); n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
+      n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
+      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
+      TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
+    } else {
+      TfCopyRowsArgs r{};
+      r.src = c.X(D.L); r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S;
+      r.dst = e->vis_out; r.dst_is_f32 = e->vis_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nv; r.dst_gstride = D.Nv; r.rows = D.B * D.Nv; r.cols = D.d;
+      TF_TRY(tf_launch_copy_rows(&r, c.st), "vis_copy");
+    }
+  }
+  if (e->lang_out != nullptr && D.Nl > 0) {
+    TfCopyRowsArgs r{};
+    r.src = (const unsigned char*)c.X(D.L) + (size_t)D.Nv * D.dp * 2; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nl; r.src_gstride = D.S;
+    r.dst = e->lang_out; r.dst_is_f32 = e->lang_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nl; r.dst_gstride = D.Nl; r.rows = D.B * D.Nl; r.cols = D.d;
+    TF_TRY(tf_launch_copy_rows(&r, c.st), "lang_copy");
+  }
+  return 0;
+}
+
+int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
+  Ctx c;
+  if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_bwd");
+  const Dims& D = c.D;
+  if (e->d_vis_out == nullptr && e->d_lang_out == nullptr) return fail(-1, "tf_encoder_bwd(no cotangent)");
+  unsigned char* dxa = c.wk + c.A.dxa; unsigned char* dxb = c.wk + c.A.dxb; unsigned char* dz = c.wk + c.A.dz; unsigned char* dy = c.wk + c.A.dy;
+  unsigned char* du = c.wk + c.A.du; unsigned char* d_o = c.wk + c.A.d_o; unsigned char* dqkv = c.wk + c.A.dqkv;
+  float* delta = (float*)(c.wk + c.A.delta);
+  const uint8_t* km = (const uint8_t*)(c.wk + c.A.keymask);
+  // ---- gradient w.r.t. the last layer's output X[L] -> dxa ----
+  if (D.Nv > 0) {
+    if (e->final_norm && e->d_vis_out != nullptr) {
+      TfLnArgs n{};
+      n.x = c.X(D.L); n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
+      n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
+      n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = dxa; n.lddx = D.dp; n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
+      TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
+    } else {
+      TfCopyRowsArgs r{};
+      r.src = e->d_vis_out; r.src_is_f32 = e->d_vis_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nv; r.src_gstride = D.Nv;
+      r.dst = dxa; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
+      TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
+    }
+  }
+  if (D.Nl > 0) {
+    TfCopyRowsArgs r{};
+    r.src = e->d_lang_out; r.src_is_f32 = e->d_lang_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nl; r.src_gstride = D.Nl;
+    r.dst = dxa + (size_t)D.Nv * D.dp * 2; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nl; r.dst_gstride = D.S; r.rows = D.B * D.Nl; r.cols = D.d;
+    TF_TRY(tf_launch_copy_rows(&r, c.st), "dlang_copy");
+  }
+  const float scale = 1.0f / sqrtf((float)D.hd);
+  const Drop none{0u, 0u, 1.f};
+  for (int l = D.L - 1; l >= 0; --l) {
+    unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
+    const TfLayerParams& p = e->p[l]; const TfLayerParams& g = e->g[l];
+    // ---- LN2 backward: dxa -> dz (= d z2), dy (= dropout2-masked) ----
+    const Drop d2 = drop_for(e, e->p_token, site_of(l, SITE_DROP2));
+    {
+      TfLnArgs n{};
+      n.x = b + c.A.z2; n.ldx = D.dp; n.gamma = p.n2_w; n.mean = (float*)(b + c.A.mean2); n.rstd = (float*)(b + c.A.rstd2);
+      n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      n.dy = dxa; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dz; n.lddx = D.dp; n.dgamma = g.n2_w; n.dbeta = g.n2_b;
+      if (d2.thr) { n.dx_drop = dy; n.lddxd = D.dp; n.drop_thr = d2.thr; n.drop_key = d2.key; n.drop_scale = d2.scale; n.drop_ld = D.dp; }
+      TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln2_bwd");
+    }
+    const unsigned char* dy2 = d2.thr ? dy : dz;
+    TF_TRY(wgrad(c, dy2, D.dp, D.dp, b + c.A.h, D.ffp, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
+    TF_TRY(gemm(c, dy2, D.dp, w + c.W.w2T, D.dp, du, D.ffp, nullptr, b + c.A.u, D.ffp, nullptr, 0, D.ffp, D.dp, TF_EPI_DGELU_DROP,
+                drop_for(e, e->p_token, site_of(l, SITE_FFN))), "dgrad ffn_down");
+    TF_TRY(wgrad(c, du, D.ffp, D.ffp, b + c.A.x1, D.dp, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
+    TF_TRY(gemm(c, du, D.ffp, w + c.W.w1T, D.ffp, dxb, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
+    // ---- LN1 backward: dxb -> dz (= d z1), dy (= dropout1-masked) ----
+    const Drop d1 = drop_for(e, e->p_token, site_of(l, SITE_DROP1));
+    {
+      TfLnArgs n{};
+      n.x = b + c.A.z1; n.ldx = D.dp; n.gamma = p.n1_w; n.mean = (float*)(b + c.A.mean1); n.rstd = (float*)(b + c.A.rstd1);
+      n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      n.dy = dxb; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dz; n.lddx = D.dp; n.dgamma = g.n1_w; n.dbeta = g.n1_b;
+      if (d1.thr) { n.dx_drop = dy; n.lddxd = D.dp; n.drop_thr = d1.thr; n.drop_key = d1.key; n.drop_scale = d1.scale; n.drop_ld = D.dp; }
+      TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln1_bwd");
+    }
+    const unsigned char* dy1 = d1.thr ? dy : dz;
+    TF_TRY(wgrad(c, dy1, D.dp, D.dp, b + c.A.o, D.dp, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
+    TF_TRY(gemm(c, dy1, D.dp, w + c.W.woT, D.dp, d_o, D.dp, nullptr, nullptr, 0, nullptr, 0, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
+    {
+      TfAttnArgs a{};
+      a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
+      a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+      a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
+      TF_TRY(tf_launch_attn_delta(a.out, a.ld_out, a.dout, a.ld_dout, delta, D.B, D.S, D.H, D.hdp, c.st), "attn_delta");
+      TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
+    }
+    TF_TRY(wgrad(c, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");
+    TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
+  }
+  {
+    TfAssembleArgs a{};
+    a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa; a.ld_dout = D.dp;
+    a.dvis = e->d_vis; a.dvis_is_f32 = e->d_vis_is_f32; a.ld_dvis = D.d; a.dlang = e->d_lang; a.dlang_is_f32 = e->d_lang_is_f32; a.ld_dlang = D.d;
+    a.dkind_v = e->g_kind_v; a.dkind_l = e->g_kind_l;
+    const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
+    a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+    TF_TRY(tf_launch_assemble_bwd(&a, c.st), "assemble_bwd");
+  }
+  return 0;
+}
+
+long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s) {
+  Ctx c;
+  if (name == nullptr || dst == nullptr || !make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_peek");
+  const Dims& D = c.D;
+  const void* src = nullptr; long long cols = 0;
+  int l = 0;
+  auto lb = [&](size_t off) { return (const void*)(c.LB(l) + off); };
+  if (sscanf(name, "qkv%d", &l) == 1) { src = lb(c.A.qkv); cols = D.ldq; }
+  else if (sscanf(name, "z1_%d", &l) == 1) { src = lb(c.A.z1); cols = D.dp; }
+  else if (sscanf(name, "x1_%d", &l) == 1) { src = lb(c.A.x1); cols = D.dp; }
+  else if (sscanf(name, "z2_%d", &l) == 1) { src = lb(c.A.z2); cols = D.dp; }
+  else if (sscanf(name, "x%d", &l) == 1) { if (l < 0 || l > D.L) return fail(-1, "peek"); src = c.X(l); cols = D.dp; l = 0; }
+  else if (sscanf(name, "o%d", &l) == 1) { src = lb(c.A.o); cols = D.dp; }
+  else if (sscanf(name, "u%d", &l) == 1) { src = lb(c.A.u); cols = D.ffp; }
+  else if (sscanf(name, "h%d", &l) == 1) { src = lb(c.A.h); cols = D.ffp; }
+  else if (strcmp(name, "dqkv") == 0) { src = c.wk + c.A.dqkv; cols = D.ldq; }
+  else if (strcmp(name, "dxa") == 0) { src = c.wk + c.A.dxa; cols = D.dp; }
+  else if (strcmp(name, "do") == 0) { src = c.wk + c.A.d_o; cols = D.dp; }
+  else return fail(-1, "tf_encoder_peek(name)");
+  if (l < 0 || l >= D.L) return fail(-1, "tf_encoder_peek(layer)");
+  const long long n = (long long)D.M * cols;
+  if (n > cap) return fail(-1, "tf_encoder_peek(cap)");
+  TF_TRY(tf_launch_cast_bf16_f32(src, dst, n, c.st), "peek cast");
+  return n;
+}
+
+}  // extern "C"

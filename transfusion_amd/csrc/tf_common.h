@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the cross-fusion hot path.
+// Wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short u16;
+
+#define TF_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define TF_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(u16 b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+// 8 bf16 packed in a u32x4 -> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+// ---- counter-based dropout RNG ----------------------------------------------------------------
+// keep(idx) is a pure function of (key, element index): forward and backward regenerate the same
+// mask from the element's logical index whatever the fragment layout.  murmur3 fmix32 of the index
+// xor-ed with a per-site key; an element is DROPPED when hash < thr, thr = p * 2^32.
+__device__ __forceinline__ unsigned tf_hash32(unsigned idx, unsigned key) {
+  unsigned h = idx * 0x9E3779B1u + key;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool tf_keep(unsigned idx, unsigned key, unsigned thr) { return tf_hash32(idx, key) >= thr; }
+
+// ---- exact (erf) GELU and its derivative -------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave reductions ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// transposed LDS read: lane i of each 16-lane group receives column i of a 4-row x 16-col block of
+// 16-bit elements; lane 4q+p of the group supplies the address of row q, columns 4p..4p+3.
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& a, const s16x4& b) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}

@@ -1,0 +1,33 @@
+// Internal launcher interface between the .hip translation units and the C-ABI layer (tf_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/tfusion.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream);
+int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
+int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t stream);
+int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t stream);
+int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t stream);
+int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t stream);
+int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t stream);
+int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t stream);
+int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int lddo, float* delta, int B, int S, int H, int HDP,
+                         hipStream_t stream);
+int tf_launch_pack(const TfPackArgs* a, hipStream_t stream);
+int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t stream);
+int tf_launch_key_mask(const uint8_t* lang_pad_mask, uint8_t* key_mask, int B, int Nv, int Nl, hipStream_t stream);
+int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t stream);
+int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t stream);
+int tf_launch_cast_f32_bf16(const float* src, void* dst, long long n, hipStream_t stream);
+int tf_launch_cast_bf16_f32(const void* src, float* dst, long long n, hipStream_t stream);
+int tf_launch_radam(const TfRadamArgs* a, hipStream_t stream);
+int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);
+int tf_launch_im2col(const TfPatchArgs* a, hipStream_t stream);       // feat -> cols
+int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t stream);  // cols -> feat (fold; border zero)
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,340 @@
+"""Fusion encoder -- host-side mirror of the reference's
+``modeling/cross_fusion/ego_fusion/cross_f_box_layers.py:13-108`` (CrossTransformerModuleBox):
+same constructor keywords, forward signature, return tuple, parameter / buffer names and error
+behaviour, so it drops into ``get_cross_box_encoder`` / reference checkpoints unchanged.
+
+The whole forward (pos-emb + kind-emb + patch dropout + concat, L post-norm encoder layers with fused
+attention, final LayerNorm) is ONE call into the native encoder runtime ``tf_encoder_fwd`` of
+libtfusion_hip.so, and the whole backward one call to ``tf_encoder_bwd``; PyTorch sees a single
+autograd node.  Compute dtype is bf16 (fp32 statistics / accumulation); parameters stay fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from transfusion_amd import _lib as L
+from transfusion_amd import ops
+
+# dropout site ids used by the runtime (tf_api.hip): patch = 0, layer l -> 16 + 8*l + {1 attn, 2 dropout1, 3 ffn, 4 dropout2}
+SITE_PATCH = 0
+
+
+def site_of(layer: int, which: int) -> int:
+    return 16 + 8 * layer + which
+
+
+class _OutProj(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d, d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _SelfAttnParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names and initialisation
+    (torch18_adapters.py:190-223: xavier_uniform in_proj_weight, zero biases)."""
+
+    def __init__(self, d, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _OutProj(d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.kaiming_uniform_(self.out_proj.weight, a=math.sqrt(5))
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter holder with nn.TransformerEncoderLayer's names (torch18_adapters.py:71-85)."""
+
+    def __init__(self, d, nhead, ff):
+        super().__init__()
+        self.self_attn = _SelfAttnParams(d, nhead)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1 = nn.LayerNorm(d, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d, eps=1e-5)
+
+
+class _EncoderStack(nn.Module):
+    """``nn.TransformerEncoder(layer, L)`` deep-copies one layer L times (cross_f_box_layers.py:58), so all
+    layers start from identical weights; reproduced here."""
+
+    def __init__(self, d, nhead, ff, num_layers):
+        super().__init__()
+        first = _EncoderLayerParams(d, nhead, ff)
+        layers = [first]
+        for _ in range(num_layers - 1):
+            nxt = _EncoderLayerParams(d, nhead, ff)
+            nxt.load_state_dict(first.state_dict())
+            layers.append(nxt)
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = num_layers
+
+
+_LAYER_FIELDS = (
+    ("in_w", "self_attn.in_proj_weight"), ("in_b", "self_attn.in_proj_bias"), ("out_w", "self_attn.out_proj.weight"),
+    ("out_b", "self_attn.out_proj.bias"), ("w1", "linear1.weight"), ("b1", "linear1.bias"), ("w2", "linear2.weight"),
+    ("b2", "linear2.bias"), ("n1_w", "norm1.weight"), ("n1_b", "norm1.bias"), ("n2_w", "norm2.weight"), ("n2_b", "norm2.bias"),
+)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, lang, pad_mask, *params):
+        desc, keep = mod._make_desc(x, lang, pad_mask)
+        B, Nv, d = x.shape
+        Nl = lang.shape[1]
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or lang.requires_grad or any(p.requires_grad for p in params))
+        out_dtype = x.dtype
+        vis_out = torch.empty(B, Nv, d, dtype=out_dtype, device=x.device)
+        lang_out = torch.empty(B, Nl, d, dtype=out_dtype, device=x.device)
+        desc.vis_out, desc.vis_out_is_f32 = L.ptr(vis_out), ops._is_f32(vis_out)
+        desc.lang_out, desc.lang_out_is_f32 = L.ptr(lang_out), ops._is_f32(lang_out)
+        st = ops._stream()
+        if mod._wpack_dirty():
+            L.call("tf_encoder_pack", desc, st)
+        L.call("tf_encoder_fwd", desc, st)
+        ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
+        ctx.io = (x.dtype, lang.dtype, x.requires_grad, lang.requires_grad)
+        ctx.nparams = len(params)
+        if not need_grad:
+            mod._release(keep)
+        return vis_out, lang_out
+
+    @staticmethod
+    def backward(ctx, g_vis, g_lang):
+        mod, desc, keep = ctx.mod, ctx.desc, ctx.keep
+        x_dtype, lang_dtype, x_rg, lang_rg = ctx.io
+        B, Nv, Nl, d = desc.B, desc.Nv, desc.Nl, desc.d
+        dev = keep["work"].device
+        g_vis = None if g_vis is None else g_vis.contiguous()
+        g_lang = None if g_lang is None else g_lang.contiguous()
+        if g_vis is None and g_lang is None:
+            mod._release(keep)
+            return (None,) * (4 + ctx.nparams)
+        desc.d_vis_out, desc.d_vis_out_is_f32 = L.ptr(g_vis), 0 if g_vis is None else ops._is_f32(g_vis)
+        desc.d_lang_out, desc.d_lang_out_is_f32 = L.ptr(g_lang), 0 if g_lang is None else ops._is_f32(g_lang)
+        d_vis = torch.empty(B, Nv, d, dtype=x_dtype, device=dev) if x_rg else None
+        d_lang = torch.empty(B, Nl, d, dtype=lang_dtype, device=dev) if lang_rg else None
+        desc.d_vis, desc.d_vis_is_f32 = L.ptr(d_vis), 0 if d_vis is None else ops._is_f32(d_vis)
+        desc.d_lang, desc.d_lang_is_f32 = L.ptr(d_lang), 0 if d_lang is None else ops._is_f32(d_lang)
+        grads, direct = mod._bind_grads(desc, dev)
+        L.call("tf_encoder_bwd", desc, ops._stream())
+        mod._release(keep)
+        if direct:
+            return (None, d_vis, d_lang, None) + (None,) * ctx.nparams
+        return (None, d_vis, d_lang, None) + tuple(grads)
+
+
+class CrossTransformerModuleBox(nn.Module):
+    def __init__(
+        self,
+        no_patches,
+        patch_dropout,
+        input_f_size,
+        pos_embedding_layer,
+        num_layers=2,
+        num_heads=4,
+        classif_token=False,
+        fforward_multiplier=2,
+        token_dropout=0.1,
+        back_to_img_fn="token",
+        activ_f="relu",
+        patch_norm=False,
+        final_norm=False,
+        lang_pos_embedding=None,
+    ):
+        super().__init__()
+        self.no_patches = no_patches
+        self.classif_token = classif_token
+        self.back_to_img_fn = back_to_img_fn
+        self.patch_norm = patch_norm
+        self.final_norm = final_norm
+        self.token_dim = input_f_size
+        self.pos_embedding_layer = pos_embedding_layer
+        self.image_kind_embedding = nn.Parameter(torch.randn(1, 1, self.token_dim))
+        self.lang_kind_embedding = nn.Parameter(torch.randn(1, 1, self.token_dim))
+        self.lang_pos_embedding = lang_pos_embedding
+        self.heatmap_token = nn.Parameter(torch.randn(1, 1, self.token_dim))     # never used by forward (as in the reference)
+        if self.classif_token:
+            self.class_token = nn.Parameter(torch.randn(1, 1, self.token_dim))
+        self.patch_dropout = patch_dropout
+        self.token_dropout = token_dropout
+        self.num_heads = num_heads
+        self.num_layers = num_layers
+        self.dim_feedforward = int(self.token_dim * fforward_multiplier)
+        self.register_buffer("padding_mask", torch.zeros(size=(1,), dtype=torch.bool))
+
+        if activ_f != "gelu":
+            raise NotImplementedError(f"activ_f={activ_f!r}: the HIP FFN epilogue implements exact GELU (the shipped configs' choice)")
+        if self.token_dim % num_heads or self.token_dim % 8:
+            raise ValueError(f"input_f_size={self.token_dim} must be divisible by num_heads={num_heads} and by 8")
+        if num_layers > L.TF_MAX_LAYERS:
+            raise ValueError(f"num_layers={num_layers} exceeds TF_MAX_LAYERS={L.TF_MAX_LAYERS}")
+        self.t_encoder = _EncoderStack(self.token_dim, num_heads, self.dim_feedforward, num_layers)
+        if self.final_norm == "ln":
+            self.final_norm_layer = nn.LayerNorm(self.token_dim)
+        elif self.final_norm == "bn":
+            raise ValueError("not implemented")
+        elif self.final_norm is False:
+            self.final_norm_layer = nn.Identity()
+        else:
+            raise ValueError("not implemented")
+
+        # runtime state (not part of state_dict)
+        self.accumulate_into_grad = False     # True: backward adds straight into p.grad (flat-buffer training loop)
+        self._wpack = None
+        self._wpack_versions = None
+        self._work_pool = {}
+        self._last_seed = 0
+
+    # ---- parameter plumbing ----------------------------------------------------------------------------
+    def _param_list(self):
+        ps = [self.image_kind_embedding, self.lang_kind_embedding]
+        for layer in self.t_encoder.layers:
+            sd = dict(layer.named_parameters())
+            ps += [sd[name] for _, name in _LAYER_FIELDS]
+        if self.final_norm == "ln":
+            ps += [self.final_norm_layer.weight, self.final_norm_layer.bias]
+        if isinstance(self.pos_embedding_layer.pos_embedding, nn.Parameter):
+            raise NotImplementedError("learned positional embeddings: only the sin1d buffer is wired into the assemble kernel")
+        return ps
+
+    def _wpack_dirty(self) -> bool:
+        vers = tuple((p.data_ptr(), p._version) for p in self._param_list())
+        if vers != self._wpack_versions:
+            self._wpack_versions = vers
+            return True
+        return False
+
+    def mark_weights_updated(self):
+        self._wpack_versions = None
+
+    def _get_work(self, key, plan, device):
+        pool = self._work_pool.setdefault(key, [])
+        for item in pool:
+            if not item["busy"]:
+                return item
+        if len(pool) >= 4:      # forwards without backward: drop the oldest instead of growing without bound
+            pool.pop(0)
+        item = {"work": torch.zeros(plan.work_bytes, dtype=torch.uint8, device=device), "busy": False}
+        pool.append(item)
+        return item
+
+    def _release(self, keep):
+        keep["busy"] = False
+
+    def _make_desc(self, x, lang, pad_mask):
+        ops._require_cuda(x, lang, pad_mask, self.image_kind_embedding)
+        B, Nv, d = x.shape
+        Nl = lang.shape[1]
+        if d != self.token_dim or lang.shape[2] != d or lang.shape[0] != B:
+            raise RuntimeError(f"token shapes {tuple(x.shape)} / {tuple(lang.shape)} do not match input_f_size={self.token_dim}")
+        if Nv > self.pos_embedding_layer.pos_embedding.shape[1]:
+            raise RuntimeError(f"{Nv} visual tokens exceed the positional table ({self.pos_embedding_layer.pos_embedding.shape[1]})")
+        for p in self._param_list():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.TfError("parameters must be contiguous fp32 (bf16 shadows are derived inside the runtime)")
+        lib = L.load()
+        plan = L.TfEncoderPlan()
+        L.check(lib.tf_encoder_plan(B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward, C.byref(plan)), "tf_encoder_plan")
+        if self._wpack is None or self._wpack.numel() != plan.wpack_bytes or self._wpack.device != x.device:
+            self._wpack = torch.zeros(plan.wpack_bytes, dtype=torch.uint8, device=x.device)
+            self._wpack_versions = None
+        keep = self._get_work((B, Nv, Nl), plan, x.device)
+        keep["busy"] = True
+        e = L.TfEncoderDesc()
+        e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward
+        e.training = 1 if self.training else 0
+        e.final_norm = 1 if self.final_norm == "ln" else 0
+        e.p_token, e.p_patch = float(self.token_dropout), float(self.patch_dropout)
+        self._last_seed = ops.next_seed() if self.training else 0
+        e.seed = self._last_seed
+        for j, layer in enumerate(self.t_encoder.layers):
+            sd = dict(layer.named_parameters())
+            for field, name in _LAYER_FIELDS:
+                setattr(e.p[j], field, sd[name].data_ptr())
+        e.kind_v, e.kind_l = self.image_kind_embedding.data_ptr(), self.lang_kind_embedding.data_ptr()
+        if e.final_norm:
+            e.fn_w, e.fn_b = self.final_norm_layer.weight.data_ptr(), self.final_norm_layer.bias.data_ptr()
+        pe = self.pos_embedding_layer.pos_embedding
+        if pe.dtype != torch.float32 or not pe.is_contiguous():
+            raise L.TfError("pos_embedding must be contiguous fp32")
+        e.pe = pe.data_ptr()
+        e.wpack, e.work = self._wpack.data_ptr(), keep["work"].data_ptr()
+        x = x.contiguous()
+        lang = lang.contiguous()
+        keep["inputs"] = (x, lang)
+        e.vis, e.vis_is_f32 = x.data_ptr(), ops._is_f32(x)
+        e.lang, e.lang_is_f32 = lang.data_ptr(), ops._is_f32(lang)
+        if pad_mask is not None:
+            if pad_mask.shape != (B, Nl):
+                raise RuntimeError(f"language_tokens_att_maks must be [B, Nl] = {(B, Nl)}, got {tuple(pad_mask.shape)}")
+            m8 = pad_mask.to(torch.uint8).contiguous()
+            keep["mask"] = m8
+            e.lang_pad_mask = m8.data_ptr()
+        return e, keep
+
+    def _bind_grads(self, desc, device):
+        """Point the runtime's gradient slots either at fresh zero buffers (returned through autograd) or,
+        with ``accumulate_into_grad``, straight at the preallocated ``p.grad`` tensors."""
+        params = self._param_list()
+        direct = self.accumulate_into_grad
+        grads = []
+        for p in params:
+            if direct:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                grads.append(p.grad)
+            else:
+                grads.append(torch.zeros_like(p, memory_format=torch.contiguous_format) if p.requires_grad else None)
+        scratch = None
+
+        def gp(t, ref):
+            nonlocal scratch
+            if t is not None:
+                return t.data_ptr()
+            if scratch is None or scratch.numel() < ref.numel():    # frozen parameter: gradient goes to a throw-away buffer
+                scratch = torch.zeros(max(ref.numel(), 1 << 16), dtype=torch.float32, device=device)
+            return scratch.data_ptr()
+
+        it = iter(zip(grads, params))
+        g, p = next(it); desc.g_kind_v = gp(g, p)
+        g, p = next(it); desc.g_kind_l = gp(g, p)
+        for j in range(self.num_layers):
+            for field, _ in _LAYER_FIELDS:
+                g, p = next(it)
+                setattr(desc.g[j], field, gp(g, p))
+        if desc.final_norm:
+            g, p = next(it); desc.g_fn_w = gp(g, p)
+            g, p = next(it); desc.g_fn_b = gp(g, p)
+        self._grad_keepalive = (grads, scratch)
+        return grads, direct
+
+    # ---- reference forward contract (cross_f_box_layers.py:69-108) --------------------------------------
+    def forward(self, x, language_tokens, language_tokens_att_maks, vis_tokens_mask=None):
+        if vis_tokens_mask is not None:
+            raise NotImplementedError("vis_mask_type local_k (dense [S,S] mask) is a 'next' row (SURVEY.md 8f-4); "
+                                      "the shipped configs use vis_mask_type: global")
+        if self.lang_pos_embedding:
+            raise NotImplementedError("lang_pos_embedding is not used by the shipped configs")
+        vis_tokens, lang_tokens = _EncoderFn.apply(self, x, language_tokens, language_tokens_att_maks, *self._param_list())
+        return vis_tokens, lang_tokens, None, None
+
+    def peek(self, desc_keep, name):
+        """Test hook: copy an internal activation of the last forward out of the workspace (fp32)."""
+        desc, keep = desc_keep
+        lib = L.load()
+        plan = L.TfEncoderPlan()
+        L.check(lib.tf_encoder_plan(desc.B, desc.Nv, desc.Nl, desc.d, desc.H, desc.L, desc.ff, C.byref(plan)), "plan")
+        cap = plan.M * max(plan.ldq, plan.ffp, plan.dp)
+        buf = torch.empty(cap, dtype=torch.float32, device=keep["work"].device)
+        n = lib.tf_encoder_peek(C.byref(desc), name.encode(), buf.data_ptr(), cap, ops._stream())
+        if n < 0:
+            L.check(int(n), "tf_encoder_peek")
+        return buf[:n].view(plan.M, -1)

@@ -1,0 +1,251 @@
+"""torch.autograd bindings over the C ABI (include/tfusion.h).  PyTorch only provides device memory,
+streams and the autograd graph here; every FLOP runs in libtfusion_hip.so.  All entries raise when
+given CPU tensors -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from transfusion_amd import _lib as L
+
+BIG = 1 << 28
+
+
+def _up(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.TfError("transfusion_amd kernels need device tensors on an MI355X (gfx950); there is no CPU fallback")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _is_f32(t) -> int:
+    if t.dtype == torch.float32:
+        return 1
+    if t.dtype == torch.bfloat16:
+        return 0
+    raise L.TfError(f"unsupported dtype {t.dtype}: fp32 or bf16 expected")
+
+
+def drop_params(p: float, seed: int, site: int):
+    lib = L.load()
+    if p <= 0.0:
+        return 0, 0, 1.0
+    return lib.tf_drop_threshold(p), lib.tf_drop_key(seed, site), 1.0 / (1.0 - p)
+
+
+_seed_counter = [0]
+
+
+def next_seed() -> int:
+    """A fresh dropout stream id per forward, derived from torch's seed so runs are reproducible."""
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------------
+# small helpers: padded bf16 copies
+# ------------------------------------------------------------------------------------------------------
+def to_bf16_padded(x2d: torch.Tensor, ld: int) -> torch.Tensor:
+    """[M, K] fp32/bf16 -> bf16 [M, ld] with zero pad columns (tf_copy_rows)."""
+    M, K = x2d.shape
+    if x2d.dtype == torch.bfloat16 and K == ld and x2d.is_contiguous():
+        return x2d
+    if K % 8:
+        raise L.TfError(f"feature width {K} must be a multiple of 8")
+    x2d = x2d.contiguous()
+    out = torch.empty(M, ld, dtype=torch.bfloat16, device=x2d.device)
+    a = L.TfCopyRowsArgs(src=L.ptr(x2d), src_is_f32=_is_f32(x2d), ld_src=K, src_rpg=max(M, 1), src_gstride=max(M, 1),
+                         dst=L.ptr(out), dst_is_f32=0, ld_dst=ld, dst_rpg=max(M, 1), dst_gstride=max(M, 1), rows=M, cols=K)
+    L.call("tf_copy_rows", a, _stream())
+    return out
+
+
+def from_padded(x2d: torch.Tensor, cols: int, dtype) -> torch.Tensor:
+    M, ld = x2d.shape
+    if cols == ld and dtype == x2d.dtype:
+        return x2d
+    out = torch.empty(M, cols, dtype=dtype, device=x2d.device)
+    a = L.TfCopyRowsArgs(src=L.ptr(x2d), src_is_f32=_is_f32(x2d), ld_src=ld, src_rpg=max(M, 1), src_gstride=max(M, 1),
+                         dst=L.ptr(out), dst_is_f32=_is_f32(out), ld_dst=cols, dst_rpg=max(M, 1), dst_gstride=max(M, 1), rows=M, cols=cols)
+    L.call("tf_copy_rows", a, _stream())
+    return out
+
+
+def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True):
+    """fp32 [N,K] parameter -> bf16 shadow [rows_p, ld] and transpose [cols_p, ld_t]."""
+    N, K = w.shape
+    w = w.detach().contiguous().float()
+    dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
+    dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
+    a = L.TfPackArgs(src=L.ptr(w), rows=N, cols=K, dst=L.ptr(dst), ld_dst=ld, dst_t=L.ptr(dst_t), ld_dst_t=ld_t,
+                     rows_p=rows_p, cols_p=cols_p, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG, dst_is_f32=0)
+    L.call("tf_pack_weight", a, _stream())
+    return dst, dst_t
+
+
+def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0)):
+    g = L.TfGemmArgs(A=L.ptr(A), lda=A.stride(0), W=L.ptr(W), ldw=W.stride(0), C=L.ptr(C_out), ldc=C_out.stride(0),
+                     bias=L.ptr(bias), R=L.ptr(R), ldr=0 if R is None else R.stride(0), C2=L.ptr(C2),
+                     ldc2=0 if C2 is None else C2.stride(0), M=A.shape[0], N=N, K=K,
+                     epilogue=L.TF_EPI_NONE if epilogue is None else epilogue,
+                     drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2])
+    L.call("tf_gemm_fwd", g, _stream())
+
+
+_zeros_cache = {}
+
+
+def _zeros256(device):
+    z = _zeros_cache.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zeros_cache[device] = z
+    return z
+
+
+def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0):
+    w = L.TfWgradArgs(dY=L.ptr(dY), ldy=dY.stride(0), X=L.ptr(X), ldx=X.stride(0), dW=L.ptr(dW), lddw=dW.stride(0), db=L.ptr(db),
+                      zeros=L.ptr(_zeros256(dY.device)), M=dY.shape[0], N=N, K=K, rg=rg, rgp=rgp,
+                      n_src=dW.shape[0] if n_src is None else n_src, cg=cg, cgp=cgp,
+                      k_src=dW.shape[1] if k_src is None else k_src, m_chunk=m_chunk)
+    L.call("tf_gemm_wgrad", w, _stream())
+
+
+# ------------------------------------------------------------------------------------------------------
+# K1 / K9 permutations
+# ------------------------------------------------------------------------------------------------------
+def _patch_args(feat, cols, B, Cc, H, W, ph, pw):
+    return L.TfPatchArgs(feat=L.ptr(feat), feat_is_f32=_is_f32(feat), cols=L.ptr(cols), ld_cols=cols.stride(0), B=B, C=Cc, H=H, W=W,
+                         ph=ph, pw=pw)
+
+
+class _PatchifyFn(torch.autograd.Function):
+    """feat [B,C,H,W] -> rows [B*Hp*Wp, ld] bf16 (column = (c*ph+i)*pw+j, zero padded to ld)."""
+
+    @staticmethod
+    def forward(ctx, feat, ph, pw, ld):
+        _require_cuda(feat)
+        feat = feat.contiguous()
+        B, Cc, H, W = feat.shape
+        Hp, Wp = H // ph, W // pw
+        cols = torch.empty(B * Hp * Wp, ld, dtype=torch.bfloat16, device=feat.device)
+        L.call("tf_patchify_fwd", _patch_args(feat, cols, B, Cc, H, W, ph, pw), _stream())
+        ctx.meta = (feat.shape, feat.dtype, ph, pw)
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype, ph, pw = ctx.meta
+        B, Cc, H, W = shape
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        dfeat = torch.empty(shape, dtype=dtype, device=g.device)
+        L.call("tf_patchify_bwd", _patch_args(dfeat, g, B, Cc, H, W, ph, pw), _stream(), _is_f32(dfeat))
+        return dfeat, None, None, None
+
+
+def patchify(image, patch_h, patch_w, ld=None):
+    B, Cc, H, W = image.shape
+    K = Cc * patch_h * patch_w
+    rows = _PatchifyFn.apply(image, patch_h, patch_w, K if ld is None else ld)
+    if ld is None:
+        return rows.view(B, (H // patch_h) * (W // patch_w), K)
+    return rows
+
+
+class _RegroupFn(torch.autograd.Function):
+    """rows [B*Nv, >= C*ph*pw] bf16 -> [B,C,H,W] (F.fold with kernel == stride; uncovered border zero)."""
+
+    @staticmethod
+    def forward(ctx, rows, B, Cc, H, W, ph, pw, out_dtype):
+        _require_cuda(rows)
+        if rows.dtype != torch.bfloat16:
+            rows = rows.to(torch.bfloat16)
+        rows = rows.contiguous()
+        out = torch.empty(B, Cc, H, W, dtype=out_dtype, device=rows.device)
+        L.call("tf_regroup_fwd", _patch_args(out, rows, B, Cc, H, W, ph, pw), _stream(), _is_f32(out))
+        ctx.meta = (rows.shape, B, Cc, H, W, ph, pw)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, B, Cc, H, W, ph, pw = ctx.meta
+        g = g.contiguous()
+        drows = torch.empty(shape, dtype=torch.bfloat16, device=g.device)
+        L.call("tf_regroup_bwd", _patch_args(g, drows, B, Cc, H, W, ph, pw), _stream())
+        return drows, None, None, None, None, None, None, None
+
+
+def regroup(patches, init_h, init_w, patch_h, patch_w, out_dtype=None):
+    B, Nv, CK = patches.shape
+    Cc = CK // (patch_h * patch_w)
+    if (init_h // patch_h) * (init_w // patch_w) != Nv:
+        raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {init_h}x{init_w} map with {patch_h}x{patch_w} patches")
+    return _RegroupFn.apply(patches.reshape(B * Nv, CK), B, Cc, init_h, init_w, patch_h, patch_w, out_dtype or patches.dtype)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Linear (K1's conv-as-GEMM and K9's back-projection)
+# ------------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, p_drop_in, seed):
+        _require_cuda(x2d, weight)
+        M, K = x2d.shape
+        N = weight.shape[0]
+        if N % 8 or K % 8:
+            raise L.TfError(f"linear: N={N}, K={K} must be multiples of 8")
+        Kp, Np = _up(K, 64), _up(N, 64)
+        xb = to_bf16_padded(x2d, Kp)
+        drop = drop_params(p_drop_in, seed, 7)
+        if drop[0]:
+            xd = torch.empty_like(xb)
+            L.check(L.load().tf_dropout_apply(L.ptr(xb), L.ptr(xd), xb.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
+            xb = xd
+        wsh, wsh_t = pack_weight(weight, N, Kp, Kp, Np)
+        y = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device) if Np != N else torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+        bf = None if bias is None else bias.detach().float().contiguous()
+        gemm(xb, wsh, y, N, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf)
+        ctx.save_for_backward(xb, wsh_t)
+        ctx.meta = (M, K, N, Kp, Np, x2d.dtype, drop, bias is not None, weight.shape)
+        return y[:, :N] if Np != N else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wsh_t = ctx.saved_tensors
+        M, K, N, Kp, Np, xdtype, drop, has_bias, wshape = ctx.meta
+        gyb = to_bf16_padded(gy.reshape(M, N), Np)
+        dx = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+        gemm(gyb, wsh_t, dx, Kp, Np, L.TF_EPI_NONE)
+        if drop[0]:
+            L.check(L.load().tf_dropout_apply(L.ptr(dx), L.ptr(dx), dx.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
+        dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
+        db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
+        wgrad(gyb, N, xb, Kp, dW.view(N, -1), db)
+        return from_padded(dx, K, xdtype), dW, db, None, None
+
+
+def linear(x, weight, bias=None, p_drop_in: float = 0.0):
+    """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N]."""
+    lead = x.shape[:-1]
+    w2 = weight.reshape(weight.shape[0], -1)
+    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0)
+    return y.reshape(*lead, weight.shape[0])
+
+
+def dropout_mask(n: int, p: float, seed: int, site: int, device) -> torch.Tensor:
+    """Test hook: the keep-mask a dropout site draws for element indices 0..n-1."""
+    thr, key, _ = drop_params(p, seed, site)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    L.check(L.load().tf_dropout_mask(L.ptr(out), n, key, thr, _stream()), "tf_dropout_mask")
+    return out
