@@ -144,7 +144,8 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
         o_ref, P = _attn_ref(qkv[:, : 3 * H * hdp], B, S, H, hd, hdp, key_mask, keep, p)
         o_hip = out[:, : H * hdp].float().cpu().view(B, S, H, hdp)
         assert rel(o_hip[..., :hd], o_ref) < 8e-3, f"fwd p={p}"          # bf16 P and bf16 output
-        assert o_hip[..., hd:].abs().max().item() == 0.0                # pad columns stay exactly zero
+        if hdp > hd:
+            assert o_hip[..., hd:].abs().max().item() == 0.0            # pad columns stay exactly zero
         # LSE (log2 domain of the scaled scores)
         x = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd]
         s = (x[:, :, 0].permute(0, 2, 1, 3) @ x[:, :, 1].permute(0, 2, 3, 1)) / math.sqrt(hd)
@@ -172,7 +173,8 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
         g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)
         for which, nm in enumerate("qkv"):
             assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm} p={p}"
-        assert g_hip[..., hd:].abs().max().item() == 0.0
+        if hdp > hd:
+            assert g_hip[..., hd:].abs().max().item() == 0.0
 
 
 def test_attention_online_softmax_rescale(dev):
@@ -216,7 +218,8 @@ def test_layernorm_fwd_bwd(dev, rows, d, ld):
     gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
     yr = O.layer_norm(xr, gr, br)
     assert rel(y[:, :d], yr.detach()) < 4e-3
-    assert y[:, d:].float().abs().max().item() == 0.0 if ld > d else True
+    if ld > d:
+        assert y[:, d:].float().abs().max().item() == 0.0
     dy = bf(torch.randn(rows, ld, generator=g)).to(dev)
     dx = torch.empty(rows, ld, dtype=torch.bfloat16, device=dev)
     dg = torch.zeros(d, device=dev)

@@ -1,0 +1,194 @@
+"""Fusion wrapper -- host-side mirror of the reference's
+``modeling/cross_fusion/ego_fusion/cross_f_box_wrapper.py:24-303`` (registry, CrossFusionBoxWrapper): same
+constructor, same ``forward(x, targets)`` flow over the FPN levels, same sub-module / parameter names
+(``cross_fusion_encoders.{i}``, ``patches_to_token.{i}.weight``, ``tokens_to_features.{i}.linear.*``).
+
+Per level (reference :177-212): K1 patch embedding = device im2col + MFMA GEMM (the Conv2d with k = s = p,
+bias=False, is exactly that GEMM), fused encoder, K9 back-projection GEMM + fold scatter.  The detector
+(``rcnn_model``) is whatever the caller supplies through the reference's own interface
+(get_dsampled_shapes / get_features_out_channels / forward_features / apply_fpn / apply_rpn_roi_on_features ...).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from transfusion_amd import ops
+from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+from transfusion_amd.modeling.cross_fusion.utils import (PositionalEmbeddingLayer, RegroupPatchesLayerBox,
+                                                          get_visual_token_mask)
+from transfusion_amd.modeling.narration_embeds.narr_pooling_layers import get_narr_pooling_layer
+
+MAX_NUM_PATCHES = 8192
+
+
+def get_cross_box_encoder(cross_type, class_token_only):
+    """reference :24-38.  Only the default joint-attention encoder is built."""
+    if cross_type == "cross_transformer":
+        if class_token_only:
+            raise NotImplementedError("narr_out_mode: embedding (CrossTransformerTokenModule) is broken in the reference "
+                                      "(cross_f_box_layers.py:143) and out of scope")
+        return CrossTransformerModuleBox
+    elif cross_type in ("space_time", "asymmetric"):
+        raise NotImplementedError(f"type: {cross_type} is not selected by the shipped configs (SURVEY.md 8f-4)")
+    else:
+        raise ValueError(f"{cross_type=} not implemented")
+
+
+class PatchToToken(nn.Module):
+    """``nn.Conv2d(C, d, kernel=stride=(ph, pw), bias=False)`` (reference :266-274) as a GEMM; the parameter keeps
+    the conv layout [d, C, ph, pw] and the name ``weight`` so reference checkpoints load."""
+
+    def __init__(self, in_channels, token_dim, patch_h, patch_w):
+        super().__init__()
+        holder = nn.Conv2d(in_channels, token_dim, kernel_size=(patch_h, patch_w), stride=(patch_h, patch_w), bias=False)
+        self.weight = nn.Parameter(holder.weight.detach().clone())      # same init family as the reference
+        self.patch_h, self.patch_w = patch_h, patch_w
+
+    def forward(self, feat):
+        """[B,C,H,W] -> tokens [B, H'*W', d] (already token-major: the reference's patchify_image(.,1,1) is fused)."""
+        B, Cc, H, W = feat.shape
+        K = Cc * self.patch_h * self.patch_w
+        rows = ops.patchify(feat, self.patch_h, self.patch_w, ld=(K + 63) // 64 * 64)
+        tok = ops.linear(rows[:, :K] if rows.shape[1] != K else rows, self.weight, None)
+        return tok.view(B, (H // self.patch_h) * (W // self.patch_w), -1)
+
+
+class CrossFusionBoxWrapper(nn.Module):
+    def __init__(self, rcnn_model, cross_layer_args, narr_embed_args, criterion=None):
+        super().__init__()
+        self.rcnn_model = rcnn_model
+        self.narr_embed_args = narr_embed_args
+        if "final_ln" in cross_layer_args["args"]:
+            w_ln = cross_layer_args["args"].pop("final_ln")
+            cross_layer_args["args"]["final_norm"] = "ln" if w_ln else False
+
+        self.cross_encoder_args = cross_layer_args
+        self.forward_language_f = self.cross_encoder_args.get("forward_language_f", False)
+        self.vis_mask_type = self.cross_encoder_args.get("vis_mask_type", "global")
+
+        self.dsampled_shapes = rcnn_model.get_dsampled_shapes()
+        self.in_rgb_channels = rcnn_model.get_features_out_channels()
+        self.fpn_features_idx = self.cross_encoder_args["fpn_features"][: len(self.dsampled_shapes)]
+        self.vis_input_key = "image"
+        self.token_dim = self.cross_encoder_args["args"]["input_f_size"]
+
+        self.narr_pooling_layer = get_narr_pooling_layer(narr_embed_args["text_pooling"])(
+            narr_embed_args, cross_layer_args["narr_out_mode"]
+        )
+
+        cross_fusion_encoders = self.setup_cross_fusion_encoders(self.cross_encoder_args)
+        patches_to_token = self.setup_patches_to_token()
+        tokens_to_features_layers = self.setup_token_to_features_layers()
+
+        self.cross_fusion_encoders = nn.ModuleList(cross_fusion_encoders)
+        self.patches_to_token = nn.ModuleList(patches_to_token)
+        self.tokens_to_features = nn.ModuleList(tokens_to_features_layers)
+
+        self.criterion = criterion
+        if criterion.get("lm", None):
+            raise NotImplementedError("criterion.lm > 0 (auxiliary language head, lm_layers.py) is a 'next' row (SURVEY.md 8f-3)")
+        self.lm_on = criterion.get("lm", False)
+        self.use_lm_f = self.cross_encoder_args["lm_args"].get("use_lm_f", False)
+        self.multi_lm = self.cross_encoder_args["lm_args"].get("multi", False) and self.lm_on and not self.use_lm_f
+
+    def setup_cross_fusion_encoders(self, cross_encoder_args):
+        cross_fusion_encoders = []
+        cross_encoder_clzz = get_cross_box_encoder(
+            cross_encoder_args["type"], class_token_only=cross_encoder_args["narr_out_mode"] == "embedding"
+        )
+        all_num_layers = cross_encoder_args["args"].pop("num_layers")
+        if not isinstance(all_num_layers, list):
+            all_num_layers = [all_num_layers] * len(self.dsampled_shapes)
+        for i in range(len(self.dsampled_shapes)):
+            pos_embedding_layer = PositionalEmbeddingLayer(cross_encoder_args["pos_embedding"], MAX_NUM_PATCHES, self.token_dim)
+            if cross_encoder_args.get("lang_pos_embedding", False):
+                raise NotImplementedError("lang_pos_embedding is not used by the shipped configs")
+            cross_fusion_encoders.append(
+                cross_encoder_clzz(no_patches=MAX_NUM_PATCHES, pos_embedding_layer=pos_embedding_layer, lang_pos_embedding=None,
+                                   num_layers=all_num_layers[i], **cross_encoder_args["args"])
+            )
+        return cross_fusion_encoders
+
+    def setup_token_to_features_layers(self):
+        tokens_to_features = []
+        for i, shape in enumerate(self.dsampled_shapes):
+            tokens_to_features.append(
+                RegroupPatchesLayerBox(self.token_dim, shape[0], shape[1], self.cross_encoder_args["patch_h"][i],
+                                       self.cross_encoder_args["patch_w"][i], self.in_rgb_channels[i],
+                                       self.cross_encoder_args["backproj_dropout"], self.cross_encoder_args.get("backproj_activ_f", None))
+            )
+        return tokens_to_features
+
+    def setup_patches_to_token(self):
+        patches_to_token = []
+        for i, _ in enumerate(self.dsampled_shapes):
+            patches_to_token.append(
+                self.setup_patch_to_token(self.cross_encoder_args["patch_norm"], None, self.token_dim, in_channels=self.in_rgb_channels[i],
+                                          patch_h=self.cross_encoder_args["patch_h"][i], patch_w=self.cross_encoder_args["patch_w"][i])
+            )
+        return patches_to_token
+
+    def setup_patch_to_token(self, patch_norm, patch_dim, token_dim, in_channels=None, patch_h=None, patch_w=None):
+        if in_channels is None:
+            raise NotImplementedError("flat nn.Linear patch projection is not used by the egonao path")
+        if patch_norm["visual"]:
+            raise NotImplementedError(f"patch_norm.visual={patch_norm['visual']!r}: the shipped configs use null")
+        return PatchToToken(in_channels, token_dim, patch_h, patch_w)
+
+    def forward(self, x, targets=None):
+        visual_data = x[self.vis_input_key]
+        features_dict = self.rcnn_model.forward_features(visual_data, targets)
+        if self.cross_encoder_args["narr_out_mode"] == "embedding":
+            raise NotImplementedError("narr_out_mode: embedding")
+        language_f, att_w, att_mask = self.narr_pooling_layer(x["language_f"], pad_mask=True)
+        if att_mask is None:
+            raise RuntimeError("the pooling layer returned no attention mask (IdentityLayer trap, narr_pooling_layers.py:409-414)")
+        pad_mask = ~(att_mask.type(torch.bool))     # HF mask (1 = token) -> torch convention (True = ignore), reference :196
+        fused_l_features = None
+        for i, key in enumerate(self.fpn_features_idx):
+            key = str(key)
+            feat = features_dict["features"][key]
+            self.tokens_to_features[i].init_h = feat.shape[2]
+            self.tokens_to_features[i].init_w = feat.shape[3]
+            vis_tokens = self.patches_to_token[i](feat)
+            hp, wp = feat.shape[2] // self.patches_to_token[i].patch_h, feat.shape[3] // self.patches_to_token[i].patch_w
+            vis_tokens_mask = get_visual_token_mask((hp, wp), self.vis_mask_type)
+            fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
+                vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
+            )
+            if self.forward_language_f:
+                if self.forward_language_f == "direct":
+                    language_f = fused_l_features
+                elif self.forward_language_f == "sum":
+                    language_f = language_f + fused_l_features
+                else:
+                    raise NotImplementedError()
+            features_dict["features"][key] = self.tokens_to_features[i](fused_features)
+
+        features_dict = self.rcnn_model.apply_fpn(features_dict)
+        if "hand_boxes" in x:
+            features_dict["hand_boxes"] = x["hand_boxes"]
+        if "hand_poses" in x:
+            features_dict["hand_poses"] = x["hand_poses"]
+        return self.rcnn_model.apply_rpn_roi_on_features(features_dict)
+
+    def call_model_epoch_triggers(self, epoch):
+        if epoch >= self.narr_embed_args["train_ep"] and self.narr_embed_args["train_ep"] != -1:
+            self.narr_pooling_layer.unfreeze_embeddings()
+        self.rcnn_model.call_model_epoch_triggers(epoch)
+
+    def dets_from_outs(self, outs, orig_img_shapes=None, targets=None, hand_poses=None, hand_boxes=None):
+        return self.rcnn_model.dets_from_outs(outs, orig_img_shapes, targets=targets, hand_poses=hand_poses, hand_boxes=hand_boxes)
+
+    def forward_w_dets(self, x, targets=None):
+        outs = self(x, targets)
+        original_image_shapes = [tuple(img.shape[1:]) for img in x["image"]]
+        return self.dets_from_outs(outs, orig_img_shapes=original_image_shapes, targets=targets, hand_poses=x.get("hand_poses"),
+                                   hand_boxes=x.get("hand_boxes"))
+
+    def postprocess_detections(self, detections, proposals, image_sizes, original_image_shapes):
+        return self.rcnn_model.postprocess_detections(detections, proposals, image_sizes, original_image_shapes)
+
+    def compute_rpn_loss(self, objectness, pred_bbox_deltas, labels, regression_targets):
+        return self.rcnn_model.compute_rpn_loss(objectness, pred_bbox_deltas, labels, regression_targets)

@@ -1,0 +1,69 @@
+"""Language-side pooling layers -- the registry of the reference's
+``modeling/narration_embeds/narr_pooling_layers.py:23-33`` with the one member that needs no third-party
+language model: a tensor-in pooling layer with the contract of ``SlowFastPooling``
+(modeling/narration_embeds/datasets/slowfast_features_dsets.py:207-240; selected by
+``narration_embeds.slowfast_f: True``, run_experiment.py:90-92).  It takes a list of [T, size] embedding tensors
+(precomputed narration / clip embeddings), applies ``out_mlp`` (Linear size -> out_mlp) on the MFMA GEMM,
+optional tanh, L2 normalisation over the token axis and ``out_dropout``, and returns
+``(tokens [B,T,d], None, hf_mask [B,T])`` with the HuggingFace mask convention (1 = real token).
+
+SBERT / GPT-2 / T5 layers wrap pretrained models that must be fetched by name: out of scope.
+Ragged inputs are right-padded and the mask marks the padding (the reference's ``torch.stack`` requires equal T).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from transfusion_amd import ops
+
+LEARNABLE_LM = {"sbert_finetune", "gpt2", "t5-wikihow", "slowfast"}
+
+
+class SlowFastPooling(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        cfg = args[0]
+        self.no_prev = cfg["strategy"]
+        out_mlp = cfg["out_mlp"]
+        self.size = cfg["size"]
+        self.out_dropout = nn.Dropout(cfg["out_dropout"])
+        self.use_out_tanh = cfg["out_tanh"]
+        self.out_mlp = nn.Linear(self.size, out_mlp) if out_mlp else None
+
+    def unfreeze_embeddings(self):
+        pass
+
+    def forward(self, tensor, *args, **kwargs):
+        lens = [t.shape[0] for t in tensor]
+        T = max(lens)
+        if min(lens) != T:
+            tensor = [F.pad(t, (0, 0, 0, T - t.shape[0])) for t in tensor]
+        tensor = torch.stack(tensor, dim=0)
+        att_mask = torch.ones(tensor.shape[:2], device=tensor.device)      # HF style: 1 = keep, 0 = cancelled
+        for b, n in enumerate(lens):
+            att_mask[b, n:] = 0
+        if self.out_mlp:
+            tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias).float()
+        if self.use_out_tanh:
+            tensor = torch.tanh(tensor)
+        if tensor.shape[1] > 1:
+            tensor = F.normalize(tensor, p=2, dim=1)
+        tensor = self.out_dropout(tensor)
+        return tensor, None, att_mask
+
+
+class IdentityLayer(torch.nn.Identity):
+    def forward(self, tensor, *args, **kwargs):
+        return tensor, None, None
+
+
+def get_narr_pooling_layer(typey):
+    if typey == "slowfast":
+        return SlowFastPooling
+    elif typey in ("sbert_finetune", "gpt2", "t5-wikihow"):
+        raise NotImplementedError(f"text_pooling={typey!r} wraps a pretrained language model fetched by name; out of scope "
+                                  "(feed precomputed embeddings with narration_embeds.slowfast_f: True)")
+    else:
+        return IdentityLayer
