@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train samples/s of the TransFusion fusion block on synthetic Ego4D-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+step  = forward + backward + gradient all-reduce (RCCL, N > 1) + global-norm clip + fused RAdam step of ONE
+        4-layer fusion encoder (CrossTransformerModuleBox: d=768, 4 heads, ff=1536, GELU, post-LN, final LN,
+        token dropout 0.15, patch dropout 0.1 -- cross_fusion_config_sym_ego_res50.yml) in training mode on a
+        batch of B=32 samples PER GPU, each 14x14=196 visual + 512 language tokens (right-padded to a random valid
+        length in [128, 512]), bf16 compute / fp32 master weights and statistics.  Weak scaling: B is per GPU.
+value = N * B / max-over-ranks step time.
+
+Also reported on the same JSON line: ``roofline`` for the dominant kernel (HIP-event timing of that kernel on the
+stream it runs on; algorithmic FLOPs from SURVEY.md 8(d)), a per-kernel table, and ``cpu_baseline`` (the CPU oracle
+-- a port of the reference arithmetic, oracle/fusion_oracle.py -- timed on this host's cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H, L, FF_MULT, NV, NL = 768, 4, 4, 2, 196, 512
+P_TOKEN, P_PATCH = 0.15, 0.1
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_encoder(device, d=D, h=H, layers=L, p_tok=P_TOKEN, p_patch=P_PATCH):
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    torch.manual_seed(42)                       # run.seed: 42 -- identical weights on every rank
+    pe = PositionalEmbeddingLayer("sin1d", 8192, d)
+    enc = CrossTransformerModuleBox(no_patches=8192, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=layers,
+                                    patch_dropout=p_patch, num_heads=h, fforward_multiplier=FF_MULT, token_dropout=p_tok,
+                                    back_to_img_fn="regroup", activ_f="gelu", final_norm="ln", input_f_size=d)
+    return enc.to(device)
+
+
+def make_batch(B, device, rank, d=D, nv=NV, nl=NL):
+    g = torch.Generator().manual_seed(42 + 1000 * rank)
+    x = torch.randn(B, nv, d, generator=g)
+    lang = torch.nn.functional.normalize(torch.randn(B, nl, d, generator=g), dim=-1)     # SBERT normalize: True
+    lens = torch.randint(nl // 4, nl + 1, (B,), generator=g)
+    pad = torch.arange(nl).view(1, -1) >= lens.view(-1, 1)                                # True = ignore
+    return x.to(device), lang.to(device), pad.to(device)
+
+
+def loss_fn(module, batch):
+    x, lang, pad = batch
+    vis, lo, _, _ = module(x, lang, pad)
+    valid = (~pad).unsqueeze(-1).to(lo.dtype)
+    return vis.float().pow(2).mean() + (lo.float().pow(2) * valid).sum() / (valid.sum() * lo.shape[-1])
+
+
+def flops_per_sample_layer(S, d):
+    return 16 * S * d * d + 4 * S * S * d       # forward, SURVEY.md 8(d)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def kernel_census(B, device, reps=20):
+    """Times every distinct kernel launch of one training step in isolation (HIP events on the launching stream)."""
+    from transfusion_amd import _lib as Lb, ops
+    S, M, d, ff, hd = NV + NL, B * (NV + NL), D, D * FF_MULT, D // H
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(device=device, dtype=bf)
+    X, Xf, W_qkv, W_o, W_1, W_2 = rnd(M, d), rnd(M, ff), rnd(3 * d, d) * 0.03, rnd(d, d) * 0.03, rnd(ff, d) * 0.03, rnd(d, ff) * 0.03
+    W_qkvT = rnd(d, 3 * d) * 0.03
+    QKV, Y, U, Hh = rnd(M, 3 * d), rnd(M, d), rnd(M, ff), torch.empty(M, ff, device=device, dtype=bf)
+    bias3, bias1, biasf = torch.zeros(3 * d, device=device), torch.zeros(d, device=device), torch.zeros(ff, device=device)
+    dW = torch.zeros(3 * d, d, device=device)
+    db = torch.zeros(3 * d, device=device)
+    O = torch.empty(M, d, device=device, dtype=bf)
+    lse = torch.empty(B * H * S, device=device)
+    delta = torch.empty(B * H * S, device=device)
+    dQKV = torch.empty(M, 3 * d, device=device, dtype=bf)
+    km = torch.zeros(B, S, dtype=torch.uint8, device=device)
+    km[:, S - 100:] = 1
+    drop = ops.drop_params(P_TOKEN, 1, 1)
+    att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * d, out=Lb.ptr(O), ld_out=d, lse=Lb.ptr(lse), key_mask=Lb.ptr(km), B=B, S=S, H=H, HDP=hd,
+                        scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], dout=Lb.ptr(Y), ld_dout=d,
+                        dqkv=Lb.ptr(dQKV), ld_dqkv=3 * d, delta=Lb.ptr(delta))
+    mean, rstd = torch.empty(M, device=device), torch.empty(M, device=device)
+    gam, bet, dgam, dbet = torch.ones(d, device=device), torch.zeros(d, device=device), torch.zeros(d, device=device), torch.zeros(d, device=device)
+    ln = Lb.TfLnArgs(x=Lb.ptr(X), ldx=d, y=Lb.ptr(O), ldy=d, y_is_f32=0, gamma=Lb.ptr(gam), beta=Lb.ptr(bet), mean=Lb.ptr(mean), rstd=Lb.ptr(rstd),
+                     rows=M, d=d, rows_per_group=M, x_group_stride=M, y_group_stride=M, eps=1e-5, dy=Lb.ptr(Y), lddy=d, dy_is_f32=0,
+                     dx=Lb.ptr(O), lddx=d, dx_drop=Lb.ptr(Y), lddxd=d, drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_ld=d,
+                     dgamma=Lb.ptr(dgam), dbeta=Lb.ptr(dbet))
+    E = Lb
+    GF = lambda m, n, k: 2.0 * m * n * k
+    st = ops._stream()
+    cases = [
+        # name, launches per layer-step, callable, algorithmic flops per launch, algorithmic HBM bytes per launch
+        ("gemm_qkv", 1, lambda: ops.gemm(X, W_qkv, QKV, 3 * d, d, E.TF_EPI_BIAS, bias=bias3), GF(M, 3 * d, d), 2 * (M * d + M * 3 * d)),
+        ("gemm_outproj+drop+res", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, d), 2 * 3 * M * d),
+        ("gemm_ffn_up+gelu+drop", 1, lambda: ops.gemm(X, W_1, U, ff, d, E.TF_EPI_BIAS_GELU_DROP, bias=biasf, C2=Hh, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("gemm_ffn_down+drop+res", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
+        ("dgrad_ffn_down+dgelu", 1, lambda: ops.gemm(X, W_1, Hh, ff, d, E.TF_EPI_DGELU_DROP, R=U, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("dgrad_ffn_up+add", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_ADD, R=Y), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
+        ("dgrad_outproj", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_NONE), GF(M, d, d), 2 * 2 * M * d),
+        ("dgrad_qkv+add", 1, lambda: ops.gemm(QKV, W_qkvT, O, d, 3 * d, E.TF_EPI_ADD, R=Y), GF(M, d, 3 * d), 2 * (M * 3 * d + 2 * M * d)),
+        ("wgrad_qkv", 1, lambda: ops.wgrad(QKV, 3 * d, X, d, dW, db), GF(M, 3 * d, d), 2 * (M * 3 * d + M * d)),
+        ("wgrad_d_d", 1, lambda: ops.wgrad(Y, d, X, d, dW[:d], db[:d]), GF(M, d, d), 2 * 2 * M * d),
+        ("wgrad_ffn", 2, lambda: ops.wgrad(U, ff, X, d, dW[:ff], db[:ff]), GF(M, ff, d), 2 * (M * ff + M * d)),
+        ("attn_fwd", 1, lambda: Lb.call("tf_attn_fwd", att, st), 4.0 * B * S * S * d, 2 * (M * 3 * d + M * d)),
+        ("attn_bwd(delta+dq+dkv)", 1, lambda: Lb.call("tf_attn_bwd", att, st), 8.0 * B * S * S * d, 2 * (2 * M * 3 * d + 2 * M * d)),
+        ("layernorm_fwd", 2, lambda: Lb.call("tf_layernorm_fwd", ln, st), 0.0, 2 * 2 * M * d),
+        ("layernorm_bwd", 2, lambda: Lb.call("tf_layernorm_bwd", ln, st), 0.0, 2 * 4 * M * d),
+    ]
+    out = []
+    for name, per_layer, fn, fl, by in cases:
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out.append(dict(kernel=name, us=round(us, 2), launches_per_step=per_layer * L, us_per_step=round(us * per_layer * L, 1),
+                        tflops=round(fl / us / 1e6, 1) if fl else None, gbs=round(by / us / 1e3, 1), flops=fl, bytes=by))
+    return out
+
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (a port of the reference arithmetic) timed on this host: forward + backward of the same
+    4-layer encoder with dropout masks drawn on the host (as the reference does), B=2 samples per step."""
+    from oracle import fusion_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))            # a one-GPU box owns a 16-core share of the host
+    torch.set_num_threads(nthreads)
+    B = 2
+    enc = make_encoder("cpu")
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "pos_embedding" not in k and "heatmap" not in k)
+          for k, v in enc.state_dict().items()}
+    x, lang, pad = make_batch(B, "cpu", 0)
+    S = NV + NL
+
+    def step():
+        masks = {"patch": (torch.rand(B, NV, D) >= P_PATCH).float()}
+        for l in range(L):
+            pre = f"t_encoder.layers.{l}."
+            masks[pre + "attn"] = (torch.rand(B, H, S, S) >= P_TOKEN).float()
+            masks[pre + "dropout1"] = (torch.rand(B, S, D) >= P_TOKEN).float()
+            masks[pre + "dropout"] = (torch.rand(B, S, D * FF_MULT) >= P_TOKEN).float()
+            masks[pre + "dropout2"] = (torch.rand(B, S, D) >= P_TOKEN).float()
+        for v in sd.values():
+            v.grad = None
+        vis, lo = O.encoder_forward(sd, x, lang, pad, H, L, masks=masks, token_dropout=P_TOKEN, patch_dropout=P_PATCH)
+        valid = (~pad).unsqueeze(-1).float()
+        loss = vis.pow(2).mean() + (lo.pow(2) * valid).sum() / (valid.sum() * D)
+        loss.backward()
+
+    t0 = time.perf_counter()
+    step()                                  # warm-up
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < 3 or (sum(times) + warm < seconds_budget and len(times) < 12):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return dict(value=round(B / best, 3), unit="samples/s", cores=nthreads, kind="port",
+                sample=f"oracle/fusion_oracle.py fwd+bwd, dropout on, B={B} x [{NV}+{NL}] tokens, d={D}, {L} layers, fp32, "
+                       f"best of {len(times)} steps after 1 warm-up ({best * 1e3:.0f} ms/step)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-census", action="store_true")
+    ap.add_argument("--grad-clip", type=float, default=1.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    enc = make_encoder(device)
+    enc.train()
+    trainer = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip)
+    batch = make_batch(args.batch, device, rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.step([batch], loss_fn)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step([batch], loss_fn)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    if not math.isfinite(final_loss):
+        raise SystemExit(f"non-finite loss {final_loss}")
+
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch / (elapsed / args.steps)
+    S = NV + NL
+    train_flops_step = 3 * L * flops_per_sample_layer(S, D) * args.batch          # per GPU
+    result = {
+        "metric": "train samples/sec, Ego4D NAO B=32 (14x14 vis + 512 txt tok), 1/2/4/8 GPU",
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"fusion-encoder train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
+                               f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding",
+                   "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}"},
+        "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "block_tflops_per_gpu": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
+        "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if world > 1 else 0.0,
+        "final_loss": round(final_loss, 5),
+    }
+    if rank == 0 and not args.no_census:
+        census = kernel_census(args.batch, device)
+        dom = max(census, key=lambda c: c["us_per_step"])
+        total = sum(c["us_per_step"] for c in census)
+        for c in sorted(census, key=lambda c: -c["us_per_step"]):
+            log(f"  {c['kernel']:28s} {c['us']:9.1f} us x{c['launches_per_step']:3d} = {c['us_per_step']:8.1f} us/step  "
+                f"{'' if c['tflops'] is None else str(c['tflops']) + ' TF/s':>12s}  {c['gbs']:8.1f} GB/s(alg)")
+        log(f"  census total {total:.0f} us/step vs measured step {ms * 1e3:.0f} us")
+        if dom["flops"]:
+            ach = dom["flops"] / dom["us"] / 1e6
+            result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_us": dom["us"],
+                                  "algorithmic_flops_per_launch": dom["flops"]}
+        else:
+            ach = dom["bytes"] / dom["us"] / 1e3
+            result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": dom["us"],
+                                  "algorithmic_bytes_per_launch": dom["bytes"]}
+        result["kernels"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,8 @@ typedef struct TfRadamArgs {
   float beta2_t;   // beta2^step
   float bias1;     // 1 - beta1^step
   float n_sma; float step_size; int rectified;   // host-computed schedule terms
-  float grad_scale;                               // multiplies g first (clip / loss-scale / 1/world)
+  float grad_scale;                               // multiplies g first (loss-scale / 1/world)
+  const float* sumsq; float clip;                 // optional device scalar sum(g^2): global-norm clip without a host sync
 } TfRadamArgs;
 
 // patch <-> token permutations for K1 / K9

@@ -350,8 +350,14 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ s, float* __restric
 // RAdam (runner/metrics_losses/radam_optim.py:55-100): moments always updated; parameter update only
 // when the variance is rectifiable (N_sma >= 5) or in the SGD-degenerated mode.
 __global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a) {
+  float gs = a.grad_scale;
+  if (a.sumsq != nullptr && a.clip > 0.f) {          // torch.nn.utils.clip_grad_norm_: coef = clip / (norm + 1e-6), clamped to 1
+    const float norm = sqrtf(*a.sumsq) * a.grad_scale;
+    const float coef = a.clip / (norm + 1e-6f);
+    if (coef < 1.f) gs *= coef;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
-    const float g = a.g[i] * a.grad_scale;
+    const float g = a.g[i] * gs;
     float v = a.v[i] * a.beta2 + (1.f - a.beta2) * g * g;
     float m = a.m[i] * a.beta1 + (1.f - a.beta1) * g;
     a.v[i] = v; a.m[i] = m;

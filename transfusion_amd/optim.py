@@ -62,7 +62,9 @@ class FusedRAdam:
                 if p.grad is not None:
                     L.check(lib.tf_sumsq(L.ptr(p.grad), p.grad.numel(), L.ptr(out), ops._stream()), "tf_sumsq")
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, sumsq: torch.Tensor = None, clip: float = 0.0):
+        """``sumsq`` (1-element device tensor holding sum(g^2) over ALL gradients) + ``clip`` > 0 apply torch's
+        clip_grad_norm_ coefficient on the device, with no host synchronisation."""
         self.step_count += 1
         st = ops._stream()
         for g in self.param_groups:
@@ -81,5 +83,6 @@ class FusedRAdam:
                 a = L.TfRadamArgs(p=L.ptr(p), g=L.ptr(p.grad), m=L.ptr(s["exp_avg"]), v=L.ptr(s["exp_avg_sq"]), n=p.numel(),
                                   lr=g["lr"], beta1=beta1, beta2=beta2, eps=g["eps"], weight_decay=g["weight_decay"],
                                   beta2_t=beta2 ** self.step_count, bias1=1 - beta1 ** self.step_count, n_sma=n_sma,
-                                  step_size=step_size, rectified=mode, grad_scale=grad_scale)
+                                  step_size=step_size, rectified=mode, grad_scale=grad_scale, sumsq=L.ptr(sumsq),
+                                  clip=float(clip))
                 L.call("tf_radam_step", a, st)

@@ -1,0 +1,113 @@
+"""Data-parallel training step for the fusion block: the counterpart of what PyTorch-Lightning's
+``strategy="ddp"`` + ``EgoNAOTrainer`` do around the model in the reference (run_experiment.py:437-454;
+ego_nao_trainer.py:259-380; optimiser groups abc_nao_trainer.py:179-201), reduced to the hot path:
+
+    forward -> backward (gradients land directly in ONE flat fp32 buffer) -> bucketed all-reduce of that
+    buffer over RCCL (torch.distributed backend "nccl") / gloo on CPU -> global-norm clip -> fused RAdam.
+
+One process per GPU.  Parameters never receiving a gradient (``heatmap_token``, frozen tensors) are excluded
+statically, which replaces Lightning's ``find_unused_parameters=True``.
+Gradient accumulation (``accumulate_grad_batches``) reduces only on the last micro-batch.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class FlatParams:
+    """Re-homes a module's trainable parameters (and their gradients) as views into two flat fp32 buffers."""
+
+    def __init__(self, module: nn.Module, exclude: Iterable[str] = ("heatmap_token",)):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and not any(n.endswith(e) for e in exclude)]
+        if not named:
+            raise ValueError("no trainable parameters")
+        dev = named[0][1].device
+        total = 0
+        self.slices = []
+        for n, p in named:
+            size = (p.numel() + 63) // 64 * 64          # 256-B aligned starts
+            self.slices.append((n, p, total, p.numel()))
+            total += size
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for n, p, off, num in self.slices:
+            self.flat[off:off + num].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + num].view_as(p)
+            p.grad = self.grad[off:off + num].view_as(p)
+        self.names = [n for n, _, _, _ in self.slices]
+        self.numel = sum(num for _, _, _, num in self.slices)
+
+
+class DataParallelReducer:
+    """Sum all-reduce of the flat gradient buffer in a few large buckets (xGMI rings are per-link bound: fewer,
+    larger messages).  Works with any initialised torch.distributed backend; a no-op at world size 1."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_mb: float = 64.0, group=None):
+        self.grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        n = flat_grad.numel()
+        per = max(1, int(bucket_mb * (1 << 20) // 4))
+        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.bytes_per_step = n * 4
+
+    def all_reduce(self, async_op: bool = False):
+        if self.world == 1:
+            return []
+        handles = []
+        for s, e in self.buckets:
+            h = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                handles.append(h)
+        return handles
+
+
+class FusionTrainStep:
+    """One optimiser step over ``accumulate`` micro-batches for a module that writes into ``p.grad`` directly."""
+
+    def __init__(self, module: nn.Module, lr=1e-4, weight_decay=2e-4, grad_clip: Optional[float] = 1.0, accumulate: int = 1,
+                 bucket_mb: float = 64.0, optimizer_cls=None):
+        from transfusion_amd.optim import FusedRAdam
+        self.module = module
+        self.flat = FlatParams(module)
+        for m in module.modules():
+            if hasattr(m, "accumulate_into_grad"):
+                m.accumulate_into_grad = True
+        self.reducer = DataParallelReducer(self.flat.grad, bucket_mb)
+        self.world = self.reducer.world
+        self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
+        self.grad_clip = grad_clip
+        self.accumulate = accumulate
+        self._norm = torch.zeros(1, dtype=torch.float32, device=self.flat.flat.device)
+
+    def flat_param(self):
+        p = self.flat.flat
+        p.grad = self.flat.grad
+        return p
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def step(self, micro_batches: List, loss_fn):
+        """``loss_fn(module, batch) -> scalar``; returns the last loss (detached)."""
+        self.zero_grad()
+        loss = None
+        for mb in micro_batches:
+            loss = loss_fn(self.module, mb)
+            (loss / len(micro_batches)).backward()
+        self.reducer.all_reduce()
+        scale = 1.0 / self.world
+        if self.grad_clip:
+            self._norm.zero_()
+            self.opt.grad_sumsq(self._norm)                        # stays on the device: no host sync in the step
+            self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip)
+        else:
+            self.opt.step(grad_scale=scale)
+        for m in self.module.modules():
+            if hasattr(m, "mark_weights_updated"):
+                m.mark_weights_updated()
+        return loss.detach()
