@@ -1,0 +1,133 @@
+"""Wrapper-level parity (K1 -> K2..K8 -> K9 per FPN level, cross_f_box_wrapper.py:177-212) against the golden
+level fixtures produced by the reference pieces, driven through transfusion_amd's CrossFusionBoxWrapper with a
+stub detector that implements the reference's rcnn_model interface."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from cases import LEVEL_CASES
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class StubDetector(torch.nn.Module):
+    """Minimal rcnn_model: feature maps pass straight through (the detector is out of scope)."""
+
+    def __init__(self, shapes, channels):
+        super().__init__()
+        self.shapes, self.channels = shapes, channels
+        self.noun_classes, self.verb_classes = 88, 75
+
+    def get_dsampled_shapes(self):
+        return self.shapes
+
+    def get_features_out_channels(self):
+        return self.channels
+
+    def forward_features(self, images, targets=None):
+        return {"features": {str(i): f for i, f in enumerate(images)}}
+
+    def apply_fpn(self, fd):
+        return fd
+
+    def apply_rpn_roi_on_features(self, fd):
+        return fd
+
+    def call_model_epoch_triggers(self, epoch):
+        pass
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name", list(LEVEL_CASES))
+def test_level_golden_through_wrapper(golden_dir, name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    dev = torch.device("cuda:0")
+    cfg = LEVEL_CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    B, C, H, W, p, d = cfg["B"], cfg["C"], cfg["H"], cfg["W"], cfg["p"], cfg["d"]
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": [0], "replace_fpn_features": True, "patch_h": [p], "patch_w": [p], "backproj_dropout": 0.0})
+    fusion["args"].update({"num_layers": [cfg["L"]], "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0},
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    det = StubDetector([(H, W)], [C])
+    model = get_fusion_model(det, {}, run_cfg, None).to(dev).train()
+    enc_sd = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    model.cross_fusion_encoders[0].load_state_dict(enc_sd, strict=False)
+    model.patches_to_token[0].weight.data.copy_(torch.from_numpy(g["conv_w"]))
+    model.tokens_to_features[0].linear.weight.data.copy_(torch.from_numpy(g["reg_w"]))
+    model.tokens_to_features[0].linear.bias.data.copy_(torch.from_numpy(g["reg_b"]))
+    assert {"cross_fusion_encoders.0.t_encoder.layers.0.self_attn.in_proj_weight", "patches_to_token.0.weight",
+            "tokens_to_features.0.linear.weight", "tokens_to_features.0.linear.bias"} <= set(model.state_dict())
+
+    feat = torch.from_numpy(g["in_feat"]).to(dev).requires_grad_(True)
+    # F.normalize over the token axis is part of the pooling layer; feed embeddings that are already normalised per
+    # the golden (which bypasses pooling) by undoing it: use one token list per sample with the mask lengths
+    lang_full = torch.from_numpy(g["in_lang"])
+    lens = [int((~g["in_mask"][b]).sum()) for b in range(B)]
+
+    class PassThroughPooling(torch.nn.Module):           # golden fixtures start at language tokens (pooling is out of scope)
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, n in enumerate(lens):
+                m[b, n:] = 0
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    lang_dev = lang_full.to(dev).requires_grad_(True)
+    out = model({"image": [feat], "language_f": [lang_dev[b] for b in range(B)]})
+    fused = out["features"]["0"]
+    assert fused.shape == (B, C, H, W)
+    assert rel(fused, g["fused"]) < 1e-2                               # bf16 compute, tolerance 1e-2
+    if H % p:                                                          # F.fold leaves the uncovered border at exactly zero
+        assert fused[:, :, H // p * p:].abs().max().item() == 0.0
+    (fused * torch.from_numpy(g["cot_out"]).to(dev)).sum().backward()
+    # golden loss also had a language-output term; compare only gradients that do not depend on it: none do exactly, so
+    # recompute the expectation from the oracle instead
+    from oracle import fusion_oracle as O
+    sd = {k: v.clone().requires_grad_(True) for k, v in enc_sd.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+    fr = torch.from_numpy(g["in_feat"]).requires_grad_(True)
+    cw = torch.from_numpy(g["conv_w"]).requires_grad_(True)
+    rw = torch.from_numpy(g["reg_w"]).requires_grad_(True)
+    rb = torch.from_numpy(g["reg_b"]).requires_grad_(True)
+    f_ref, _ = O.fusion_level_forward(fr, cw, sd, lang_full, torch.from_numpy(g["in_mask"]), cfg["h"], cfg["L"], rw, rb, p, p)
+    (f_ref * torch.from_numpy(g["cot_out"])).sum().backward()
+    assert rel(feat.grad, fr.grad) < 3e-2
+    assert rel(model.patches_to_token[0].weight.grad, cw.grad) < 3e-2
+    assert rel(model.tokens_to_features[0].linear.weight.grad, rw.grad) < 3e-2
+    assert rel(model.tokens_to_features[0].linear.bias.grad, rb.grad) < 3e-2
+    assert rel(model.cross_fusion_encoders[0].t_encoder.layers[0].linear1.weight.grad, sd["t_encoder.layers.0.linear1.weight"].grad) < 3e-2
+
+
+def test_slowfast_pooling_contract():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd.modeling.narration_embeds.narr_pooling_layers import get_narr_pooling_layer
+    dev = torch.device("cuda:0")
+    layer = get_narr_pooling_layer("slowfast")({"strategy": "current", "out_mlp": 64, "size": 48, "out_dropout": 0.0, "out_tanh": False}, "tokens").to(dev)
+    g = torch.Generator().manual_seed(0)
+    toks = [torch.randn(9, 48, generator=g).to(dev), torch.randn(6, 48, generator=g).to(dev)]
+    y, att, mask = layer(toks, pad_mask=True)
+    assert y.shape == (2, 9, 64) and att is None and mask.shape == (2, 9)
+    assert mask[0].sum() == 9 and mask[1].sum() == 6
+    w, b = layer.out_mlp.weight.detach().cpu(), layer.out_mlp.bias.detach().cpu()
+    ref = torch.nn.functional.normalize(toks[0].cpu().to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t() + b, p=2, dim=0)
+    assert rel(y[0], ref) < 1e-2
