@@ -91,8 +91,9 @@ def kernel_census(B, device, reps=20):
     km = torch.zeros(B, S, dtype=torch.uint8, device=device)
     km[:, S - 100:] = 1
     drop = ops.drop_params(P_TOKEN, 1, 1)
+    dbits = ops.attn_dropmask(B, H, S, P_TOKEN, 1, 1, device)
     att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * d, out=Lb.ptr(O), ld_out=d, lse=Lb.ptr(lse), key_mask=Lb.ptr(km), B=B, S=S, H=H, HDP=hd,
-                        scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], dout=Lb.ptr(Y), ld_dout=d,
+                        scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=Lb.ptr(dbits), dout=Lb.ptr(Y), ld_dout=d,
                         dqkv=Lb.ptr(dQKV), ld_dqkv=3 * d, delta=Lb.ptr(delta))
     mean, rstd = torch.empty(M, device=device), torch.empty(M, device=device)
     gam, bet, dgam, dbet = torch.ones(d, device=device), torch.zeros(d, device=device), torch.zeros(d, device=device), torch.zeros(d, device=device)

@@ -68,6 +68,7 @@ typedef struct TfAttnArgs {
   int B, S, H, HDP;
   float scale;                   // 1/sqrt(true head dim)
   unsigned drop_thr, drop_key; float drop_scale;
+  const void* drop_bits;         // [B*H*S, ceil(S/64)] u64 keep-bitmask from tf_attn_dropmask (required when drop_thr != 0)
   // backward only
   const void* dout; int ld_dout; // [B*S, H*HDP] bf16
   void* dqkv; int ld_dqkv;       // [B*S, 3*H*HDP] bf16
@@ -153,7 +154,11 @@ typedef struct TfPatchArgs {
 
 /* ---- dropout key: every dropout site draws keep(i) = hash32(i, key) >= p * 2^32, key = f(seed, site) ---- */
 uint32_t tf_drop_key(uint64_t seed, uint32_t site);
-uint32_t tf_drop_threshold(float p);
+uint32_t tf_drop_threshold(float p);   /* 16-bit threshold: round(p * 65536) */
+float tf_drop_scale(float p);          /* 1 / (1 - threshold/65536): the exact inverse keep probability */
+/* bytes of the attention dropout bitmask for (B, H, S) */
+size_t tf_attn_dropmask_bytes(int B, int H, int S);
+int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr, tf_stream_t s);
 
 /* ---- library ---- */
 int tf_version(void);

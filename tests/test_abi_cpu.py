@@ -49,7 +49,8 @@ def test_plan_and_dropout_helpers_are_host_side(lib):
     assert lib.tf_encoder_plan(2, 196, 128, 770, 4, 4, 1424, C.byref(plan)) != 0     # d % H != 0
     assert b"tf_encoder_plan" in lib.tf_last_error()
     assert lib.tf_drop_threshold(0.0) == 0
-    assert abs(lib.tf_drop_threshold(0.15) / 2**32 - 0.15) < 1e-6
+    assert abs(lib.tf_drop_threshold(0.15) / 2**16 - 0.15) < 1e-5
+    assert abs(lib.tf_drop_scale(0.15) - 1 / 0.85) < 1e-4
     assert lib.tf_drop_key(42, 1) != lib.tf_drop_key(42, 2) != lib.tf_drop_key(43, 2)
 
 

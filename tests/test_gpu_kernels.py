@@ -135,13 +135,16 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
     for p in (0.0, 0.15):
         seed, site = 99, 17
         drop = ops.drop_params(p, seed, site)
+        bits = ops.attn_dropmask(B, H, S, p, seed, site, dev) if p > 0 else None
         a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=L.ptr(key_mask),
-                         B=B, S=S, H=H, HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2])
+                         B=B, S=S, H=H, HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
+                         drop_bits=L.ptr(bits))
         L.call("tf_attn_fwd", a, ops._stream())
         keep = None
         if p > 0:
             keep = ops.dropout_mask(B * H * S * S, p, seed, site, dev).view(B, H, S, S)
-        o_ref, P = _attn_ref(qkv[:, : 3 * H * hdp], B, S, H, hd, hdp, key_mask, keep, p)
+        p_eff = 1.0 - 1.0 / drop[2] if p > 0 else 0.0        # 16-bit threshold: the exact drop probability
+        o_ref, P = _attn_ref(qkv[:, : 3 * H * hdp], B, S, H, hd, hdp, key_mask, keep, p_eff)
         o_hip = out[:, : H * hdp].float().cpu().view(B, S, H, hdp)
         assert rel(o_hip[..., :hd], o_ref) < 8e-3, f"fwd p={p}"          # bf16 P and bf16 output
         if hdp > hd:
@@ -167,7 +170,7 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
         s = s.masked_fill(key_mask.cpu().bool().view(B, 1, 1, S), float("-inf"))
         Pr = torch.softmax(s, -1)
         if keep is not None:
-            Pr = Pr * keep.double().cpu() / (1 - p)
+            Pr = Pr * keep.double().cpu() / (1 - p_eff)
         o = (Pr @ v).permute(0, 2, 1, 3)
         o.backward(do[:, : H * hdp].double().cpu().view(B, S, H, hdp)[..., :hd])
         g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Runs individual hot kernels at the benchmark shape (for rocprofv3 --pmc / --kernel-trace passes and A/B timing).
+usage: python tools/kernel_bench.py [attn|wgrad|gemm|ln|all] [reps]"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from transfusion_amd import _lib as Lb, ops  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B, NV, NL, D, H = 32, 196, 512, 768, 4
+S, M, hd, ff = NV + NL, B * (NV + NL), D // H, 2 * D
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+g = torch.Generator().manual_seed(1)
+rnd = lambda *s: torch.randn(*s, generator=g).to(device=dev, dtype=bf)
+st = ops._stream()
+
+
+def timeit(name, fn, flops):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print(f"{name:28s} {us:9.1f} us  {flops / us / 1e6:8.1f} TF/s", flush=True)
+
+
+if which in ("attn", "all"):
+    QKV, Y = rnd(M, 3 * D), rnd(M, D)
+    O = torch.empty(M, D, device=dev, dtype=bf)
+    lse, delta = torch.empty(B * H * S, device=dev), torch.empty(B * H * S, device=dev)
+    dQKV = torch.empty(M, 3 * D, device=dev, dtype=bf)
+    km = torch.zeros(B, S, dtype=torch.uint8, device=dev)
+    km[:, S - 100:] = 1
+    for p in (0.15, 0.0):
+        drop = ops.drop_params(p, 1, 1)
+        dbits = ops.attn_dropmask(B, H, S, p, 1, 1, dev) if p > 0 else None
+        att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * D, out=Lb.ptr(O), ld_out=D, lse=Lb.ptr(lse), key_mask=Lb.ptr(km), B=B, S=S, H=H, HDP=hd,
+                            scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=Lb.ptr(dbits),
+                            dout=Lb.ptr(Y), ld_dout=D, dqkv=Lb.ptr(dQKV), ld_dqkv=3 * D, delta=Lb.ptr(delta))
+        timeit(f"attn_fwd p={p}", lambda: Lb.call("tf_attn_fwd", att, st), 4.0 * B * S * S * D)
+        timeit(f"attn_bwd p={p}", lambda: Lb.call("tf_attn_bwd", att, st), 8.0 * B * S * S * D)
+if which in ("wgrad", "all"):
+    X, dYq, dYf = rnd(M, D), rnd(M, 3 * D), rnd(M, ff)
+    dW, db = torch.zeros(3 * D, D, device=dev), torch.zeros(3 * D, device=dev)
+    timeit("wgrad_qkv", lambda: ops.wgrad(dYq, 3 * D, X, D, dW, db), 2.0 * M * 3 * D * D)
+    timeit("wgrad_ffn", lambda: ops.wgrad(dYf, ff, X, D, dW[:ff], db[:ff]), 2.0 * M * ff * D)
+    timeit("wgrad_d_d", lambda: ops.wgrad(X, D, X, D, dW[:D], db[:D]), 2.0 * M * D * D)
+if which in ("gemm", "all"):
+    X, Xf = rnd(M, D), rnd(M, ff)
+    Wq, Wo, W1, W2 = rnd(3 * D, D) * 0.03, rnd(D, D) * 0.03, rnd(ff, D) * 0.03, rnd(D, ff) * 0.03
+    QKV, O, U, Hh, Y = torch.empty(M, 3 * D, device=dev, dtype=bf), torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, ff, device=dev, dtype=bf), torch.empty(M, ff, device=dev, dtype=bf), rnd(M, D)
+    b3, b1, bff = torch.zeros(3 * D, device=dev), torch.zeros(D, device=dev), torch.zeros(ff, device=dev)
+    drop = ops.drop_params(0.15, 1, 2)
+    timeit("gemm_qkv (bias)", lambda: ops.gemm(X, Wq, QKV, 3 * D, D, Lb.TF_EPI_BIAS, bias=b3), 2.0 * M * 3 * D * D)
+    timeit("gemm_ffn_up (gelu+drop)", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_GELU_DROP, bias=bff, C2=Hh, drop=drop), 2.0 * M * ff * D)
+    timeit("gemm_ffn_down (drop+res)", lambda: ops.gemm(Xf, W2, O, D, ff, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * ff * D)
+    timeit("gemm_outproj (drop+res)", lambda: ops.gemm(X, Wo, O, D, D, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * D * D)
+    timeit("gemm_d_d (none)", lambda: ops.gemm(X, Wo, O, D, D, Lb.TF_EPI_NONE), 2.0 * M * D * D)

@@ -23,6 +23,9 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 4.0f;   // log2 domain: O/l are rescaled only when some row's max grew by > 2^4 (T13, exact math)
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32 (x <= ~4 here)
 
 template <int HDP> struct Geo {
   static constexpr int CPR = HDP / 8;                                   // 16-B chunks per row
@@ -100,7 +103,7 @@ __device__ __forceinline__ unsigned long long key_bits(const uint8_t* __restrict
 // forward
 // ================================================================================================
 template <int HDP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const TfAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kt = smem;
@@ -130,23 +133,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const TfAttnArgs a) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
-  const unsigned drop_row = ((unsigned)bh * (unsigned)S + (unsigned)qrow) * (unsigned)S;
+  const int SW = (S + 63) / 64;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
 
   const int ntiles = (S + 63) / 64;
-  TileRegs<64, HDP> kr, vr;
-  kr.load(kbase, ld, 0, S - 1, false, tid);
-  vr.load(vbase, ld, 0, S - 1, false, tid);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
-    __syncthreads();                       // previous tile fully consumed
-    kr.store(kt, tid);
-    vr.store(vt, tid);
-    __syncthreads();
-    if (t + 1 < ntiles) {                  // prefetch next tile into registers under the MFMA work
-      kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
-      vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
+    // No register prefetch: the kernel stays under 256 VGPRs so that TWO workgroups share a CU (2 waves per SIMD)
+    // and one's K/V staging overlaps the other's MFMA / softmax work.
+    {
+      TileRegs<64, HDP> kr;
+      kr.load(kbase, ld, kv0, S - 1, false, tid);
+      __syncthreads();                     // previous tile fully consumed
+      kr.store(kt, tid);
+      kr.load(vbase, ld, kv0, S - 1, false, tid);
+      kr.store(vt, tid);
     }
-    const unsigned long long vbits = key_bits(a.key_mask, b, S, kv0, lane) >> (4 * h);
+    __syncthreads();
+    const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
+    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long vbits = vall >> (4 * h);
 
     // ---- St[key][q] = K . Q^T ----
     f32x16 st[2];
@@ -158,39 +164,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const TfAttnArgs a) {
       for (int ks = 0; ks < G::KSTEPS; ++ks)
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
     }
-    // ---- online softmax (log2 domain) ----
-    float mx = NEG_BIG;
+    // ---- online softmax (log2 domain; raw scores stay unscaled, the scale rides in the FMA) ----
+    if (vall != ~0ull) {                   // wave-uniform: only tiles that contain padded / out-of-range keys pay for the select
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!((vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull)) st[kb][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = (vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull;
-        const float s = ok ? st[kb][r] * sc : -INFINITY;
-        st[kb][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+    const bool need = mx - m_run > RESCALE_THR;   // per ROW: a row's arithmetic never depends on its wave-mates
+    if (__any(need)) {                            // wave-uniform gate only; rows that keep their max multiply by exactly 1
+      const float m_new = need ? fmaxf(m_run, mx) : m_run;
+      const float alpha = need ? fast_exp2(m_run - m_new) : 1.0f;
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = exp2f(st[kb][r] - m_new);
+        const float p = fast_exp2(fmaf(st[kb][r], sc, -m_run));
         psum += p;
-        if (a.drop_thr) {
-          const unsigned key = (unsigned)(kv0 + kb * 32 + acc_row(r, h));
-          p = tf_keep(drop_row + key, a.drop_key, a.drop_thr) ? p : 0.f;
-        }
-        st[kb][r] = p;
+        st[kb][r] = ((dm >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull) ? p : 0.f;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    l_run += psum;
     // ---- O^T[d][q] += V^T . Pt ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -258,9 +266,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
   const float sc = a.scale * LOG2E;
-  const unsigned drop_row = ((unsigned)bh * (unsigned)S + (unsigned)qrow) * (unsigned)S;
+  const int SW = (S + 63) / 64;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
   const int ntiles = (S + 63) / 64;
+  // dQ needs Q, dO (B operands) and the dQ^T accumulator resident: > 256 registers, so this kernel runs one wave per
+  // SIMD with the full 512-entry file and prefetches the next K/V tile into registers under the MFMA work instead.
   TileRegs<64, HDP> kr, vr;
   kr.load(kbase, ld, 0, S - 1, false, tid);
   vr.load(vbase, ld, 0, S - 1, false, tid);
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
       vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
     }
+    const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
     const unsigned long long vbits = key_bits(a.key_mask, b, S, kv0, lane) >> (4 * h);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -287,13 +300,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool ok = (vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull;
-        const float p = ok ? exp2f(st[r] * sc - lse) : 0.f;
-        float g = dp[r];
-        if (a.drop_thr) {
-          const unsigned key = (unsigned)(kv0 + kb * 32 + acc_row(r, h));
-          g = tf_keep(drop_row + key, a.drop_key, a.drop_thr) ? g * a.drop_scale : 0.f;
-        }
+        const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
+        const float p = ((vbits >> bit) & 1ull) ? fast_exp2(fmaf(st[r], sc, -lse)) : 0.f;
+        const float g = ((dm >> bit) & 1ull) ? dp[r] * dscale : 0.f;
         st[r] = p * (g - delta);
       }
 #pragma unroll
@@ -380,6 +389,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
       dr.load(dobase, a.ld_dout, q0 + 32, S - 1, true, tid);
     }
+    // keep-bits of this wave's 32 keys for the 32 query rows of the tile: lane l holds row q0 + (l & 31)
+    unsigned dw = 0xffffffffu;
+    if (a.drop_thr) {
+      const int qq = q0 + (lane & 31);
+      dw = qq < S ? ((const unsigned*)a.drop_bits)[((size_t)bh * S + qq) * (2 * ((S + 63) / 64)) + (key0 >> 5)] : 0u;
+    }
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
@@ -396,12 +411,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * g4 + i;
-        const float p = key_ok ? exp2f(st[r] * sc - l4[i]) : 0.f;
+        const float p = key_ok ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;
         float keep_scale = 1.f;
         if (a.drop_thr) {
-          const unsigned q = (unsigned)(q0 + 8 * g4 + 4 * h + i);
-          const unsigned idx = ((unsigned)bh * (unsigned)S + q) * (unsigned)S + (unsigned)key;
-          keep_scale = tf_keep(idx, a.drop_key, a.drop_thr) ? a.drop_scale : 0.f;
+          const unsigned w = (unsigned)__shfl((int)dw, 8 * g4 + 4 * h + i, 64);     // row q0 + acc_row(r, h)
+          keep_scale = ((w >> (lane & 31)) & 1u) ? a.drop_scale : 0.f;
         }
         st[r] = p * keep_scale;                         // Pd
         dp[r] = p * (dp[r] * keep_scale - d4[i]);       // dS
@@ -455,6 +469,7 @@ int check(const TfAttnArgs* a) {
   if (a->B <= 0 || a->S <= 0 || a->H <= 0) return 1;
   if ((a->ld_qkv % 8) || (a->ld_out % 8)) return -2;
   if ((long long)a->B * a->H * a->S * a->S >= (1ll << 32) && a->drop_thr) return -5;   // 32-bit dropout index space
+  if (a->drop_thr && a->drop_bits == nullptr) return -6;
   return 0;
 }
 

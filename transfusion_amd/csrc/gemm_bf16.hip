@@ -126,24 +126,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
       unpack8(v, f);
       if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) {
         *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
-        const unsigned base = (unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn;
+        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float h = gelu_f(f[e]);
-          if (g.drop_thr) h = tf_keep(base + e, g.drop_key, g.drop_thr) ? h * g.drop_scale : 0.f;
-          f[e] = h;
-        }
+        for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? gelu_f(f[e]) * g.drop_scale : 0.f;
         *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
       } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
         float r[8];
         unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
-        const unsigned base = (unsigned)gm * (unsigned)g.ldc + (unsigned)gn;
+        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float y = f[e];
-          if (g.drop_thr) y = tf_keep(base + e, g.drop_key, g.drop_thr) ? y * g.drop_scale : 0.f;
-          f[e] = r[e] + y;
-        }
+        for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
         *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
       } else if constexpr (EPI == TF_EPI_ADD) {
         float r[8];
@@ -155,13 +147,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
         // dU = dH . mask/(1-p) . gelu'(U); R = U, dropout index space = that of H (ldr == ld of H)
         float u[8];
         unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), u);
-        const unsigned base = (unsigned)gm * (unsigned)g.ldr + (unsigned)gn;
+        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float d = f[e];
-          if (g.drop_thr) d = tf_keep(base + e, g.drop_key, g.drop_thr) ? d * g.drop_scale : 0.f;
-          f[e] = d * gelu_grad_f(u[e]);
-        }
+        for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * gelu_grad_f(u[e]) : 0.f;
         *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
       }
     }
@@ -215,7 +203,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; accb[i][r] = 0.f; }
   }
-  const bool do_bias = (g.db != nullptr) && (k0 == 0) && (wc == 0);
+  // Bias grad = column sums of dY = one extra MFMA of the dY fragment against a ones operand.  The duty is spread
+  // evenly: the 2*tiles_k waves that share this n-range (tiles_k k-tile blocks x 2 wave columns) each take every
+  // (2*tiles_k)-th 16-row step, so no block carries more than ~1/(2*tiles_k) extra MFMA work (a k0==0-only scheme
+  // made those blocks 1.5x longer and they set the kernel time).
+  const bool has_bias = g.db != nullptr;
+  const int bias_mod = 2 * tiles_k;
+  int bias_cnt = 2 * (blockIdx.x % tiles_k) + wc;              // counts down to this wave's next duty step
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -252,7 +246,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
           acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
-        if (do_bias) accb[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], ones, accb[nb], 0, 0, 0);
+      }
+      const bool my_turn = has_bias && bias_cnt == 0;             // wave-uniform
+      bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
+      if (my_turn) {
+        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], ones, accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], ones, accb[1], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
         if (nok && kp < g.K && ke < g.cg && ks < g.k_src)
           atomicAdd(g.dW + (size_t)ns * g.lddw + ks, acc[nb][kb][r]);
       }
-      if (do_bias && (lane & 31) == 0 && nok) atomicAdd(g.db + ns, accb[nb][r]);
+      if (has_bias && (lane & 31) == 0 && nok) atomicAdd(g.db + ns, accb[nb][r]);
     }
   }
 }
@@ -313,7 +312,9 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
   const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
   const int steps = (a.M + 63) / 64;
-  int splits = a.m_chunk > 0 ? (a.M + a.m_chunk - 1) / a.m_chunk : (1024 + tiles - 1) / tiles;
+  // Every split adds one full fp32 |dW| of atomic traffic (chip-wide ~1.3 TB/s), so use the FEWEST splits that
+  // still give one resident wave of blocks: 256 CUs x 2 blocks (64 KiB LDS each).
+  int splits = a.m_chunk > 0 ? (a.M + a.m_chunk - 1) / a.m_chunk : (512 / tiles);
   if (splits > steps) splits = steps;
   if (splits < 1) splits = 1;
   if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 64;

@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
         *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = pack8(o);
         if (a.dx_drop != nullptr) {
           if (a.drop_thr) {
-            const unsigned base = (unsigned)xr * (unsigned)a.drop_ld + (unsigned)c;
+            const unsigned km = tf_keep8((unsigned)xr * (unsigned)a.drop_ld + (unsigned)c, a.drop_key, a.drop_thr);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = tf_keep(base + e, a.drop_key, a.drop_thr) ? o[e] * a.drop_scale : 0.f;
+            for (int e = 0; e < 8; ++e) o[e] = ((km >> e) & 1u) ? o[e] * a.drop_scale : 0.f;
           }
           *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = pack8(o);
         }
@@ -183,13 +183,9 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
       load8_any(a.vis, (size_t)(b * a.Nv + s) * a.ld_vis + c, a.vis_is_f32, v);
       load8_f32(a.pe + (size_t)s * a.d + c, pe);
       load8_f32(a.kind_v + c, k);
-      const unsigned base = (unsigned)row * (unsigned)a.ld_out + (unsigned)c;
+      const unsigned km = a.drop_thr ? tf_keep8((unsigned)row * (unsigned)a.ld_out + (unsigned)c, a.drop_key, a.drop_thr) : 0xffu;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = v[e] + pe[e] + k[e];
-        if (a.drop_thr) t = tf_keep(base + e, a.drop_key, a.drop_thr) ? t * a.drop_scale : 0.f;
-        v[e] = t;
-      }
+      for (int e = 0; e < 8; ++e) v[e] = ((km >> e) & 1u) ? (v[e] + pe[e] + k[e]) * a.drop_scale : 0.f;
     } else {
       load8_any(a.lang, (size_t)(b * a.Nl + s - a.Nv) * a.ld_lang + c, a.lang_is_f32, v);
       load8_f32(a.kind_l + c, k);
@@ -219,9 +215,9 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
       unpack8(*(const u32x4*)((const u16*)a.dout + (size_t)row * a.ld_dout + c), g);
       if (s < a.Nv) {
         if (a.drop_thr) {
-          const unsigned base = (unsigned)row * (unsigned)a.ld_dout + (unsigned)c;
+          const unsigned km = tf_keep8((unsigned)row * (unsigned)a.ld_dout + (unsigned)c, a.drop_key, a.drop_thr);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] = tf_keep(base + e, a.drop_key, a.drop_thr) ? g[e] * a.drop_scale : 0.f;
+          for (int e = 0; e < 8; ++e) g[e] = ((km >> e) & 1u) ? g[e] * a.drop_scale : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) kv[i][e] += g[e];
@@ -270,10 +266,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const u16* __restrict__
   if (ok && sub == 0) { const int b = row / S, s = row - b * S; delta[((size_t)b * H + head) * S + s] = acc; }
 }
 
-// fp32 parameter [rows, cols] -> bf16 shadow (padded / head-grouped) and its transpose, via a 64x64 LDS tile
-__global__ __launch_bounds__(256) void pack_kernel(const TfPackArgs a) {
+// fp32 parameter [rows, cols] -> bf16 shadow (padded / head-grouped) and its transpose, via a 64x64 LDS tile.
+// Up to 8 tensors per launch (blockIdx.z): one launch re-packs a whole encoder layer.
+struct PackBatch { TfPackArgs a[8]; };
+__global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
   __shared__ u16 tile[64][66];
+  const TfPackArgs& a = pb.a[blockIdx.z];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= a.rows_p || c0 >= a.cols_p) return;        // block-uniform
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int rl = i >> 6, cl = i & 63;
     const int rp = r0 + rl, cp = c0 + cl;
@@ -330,10 +330,32 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restric
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float f[8];
     unpack8(*(const u32x4*)(x + i * 8), f);
+    const unsigned km = tf_keep8((unsigned)(i * 8), key, thr);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = tf_keep((unsigned)(i * 8 + e), key, thr) ? f[e] * scale : 0.f;
+    for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * scale : 0.f;
     *(u32x4*)(y + i * 8) = pack8(f);
   }
+}
+
+// Attention-probability dropout as a bitmask: bits[row][w] bit k = keep(element row*S + 32*w + k), row = (b*H+h)*S + q.
+// Generated once per layer and forward; read by attn_fwd / attn_bwd_dq / attn_bwd_dkv (2 VALU ops per element there).
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict__ bits, long long nrows, int S, int SW32, unsigned key,
+                                                            unsigned thr16) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nrows * SW32) return;
+  const long long row = t / SW32;
+  const int w = (int)(t - row * SW32);
+  const unsigned base = (unsigned)(row * S) + (unsigned)w * 32u;
+  unsigned m = 0, last_pair = 0xffffffffu, h = 0;
+#pragma unroll 4
+  for (int k = 0; k < 32; ++k) {
+    if (w * 32 + k >= S) break;
+    const unsigned idx = base + k, pair = idx >> 1;
+    if (pair != last_pair) { h = tf_hash32(pair, key); last_pair = pair; }
+    const unsigned b = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+    m |= (b >= thr16 ? 1u : 0u) << k;
+  }
+  bits[t] = m;
 }
 
 __global__ void dropout_mask_kernel(uint8_t* out, long long n, unsigned key, unsigned thr) {
@@ -455,11 +477,23 @@ extern "C" int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int
                      (const u16*)d_o, lddo, delta, B, S, H, HDP);
   return (int)hipGetLastError();
 }
+extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (n > 8) return -2;
+  PackBatch pb;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].rg <= 0 || a[i].cg <= 0 || a[i].rgp < a[i].rg || a[i].cgp < a[i].cg || a[i].rows_p <= 0 || a[i].cols_p <= 0) return -2;
+    pb.a[i] = a[i];
+    gx = max(gx, (a[i].cols_p + 63) / 64);
+    gy = max(gy, (a[i].rows_p + 63) / 64);
+  }
+  hipLaunchKernelGGL(pack_kernel, dim3(gx, gy, n), dim3(256), 0, st, pb);
+  return (int)hipGetLastError();
+}
 extern "C" int tf_launch_pack(const TfPackArgs* a, hipStream_t st) {
   if (a->rows_p <= 0 || a->cols_p <= 0) return 0;
-  if (a->rg <= 0 || a->cg <= 0 || a->rgp < a->rg || a->cgp < a->cg) return -2;
-  hipLaunchKernelGGL(pack_kernel, dim3((a->cols_p + 63) / 64, (a->rows_p + 63) / 64), dim3(256), 0, st, *a);
-  return (int)hipGetLastError();
+  return tf_launch_pack_batch(a, 1, st);
 }
 extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
@@ -477,6 +511,15 @@ extern "C" int tf_launch_dropout_apply(const void* x, void* y, long long n, unsi
   if (n <= 0) return 0;
   if (n % 8) return -2;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const u16*)x, (u16*)y, n / 8, key, thr, scale);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t st) {
+  const long long nrows = (long long)B * H * S;
+  const int SW32 = 2 * ((S + 63) / 64);
+  if (nrows <= 0) return 0;
+  if (nrows * S >= (1ll << 32)) return -5;
+  const long long n = nrows * SW32;
+  hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)bits, nrows, S, SW32, key, thr);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t st) {

@@ -65,7 +65,7 @@ WOff make_woff(const Dims& D) {
 struct AOff {   // byte offsets inside work
   size_t keymask, zeros, x0, x_stride;            // X[l] = x0 + l * x_stride, l = 0..L
   size_t layer0, layer_stride;                    // per-layer block
-  size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2;   // offsets inside a layer block
+  size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
   size_t dxa, dxb, dz, dy, du, d_o, dqkv, delta;
   size_t total;
@@ -84,6 +84,7 @@ AOff make_aoff(const Dims& D) {
     auto ltake = [&](size_t bytes) { size_t r = lo; lo += up(bytes, 256); return r; };
     a.qkv = ltake(mq); a.o = ltake(md); a.lse = ltake(st); a.z1 = ltake(md); a.mean1 = ltake(mr); a.rstd1 = ltake(mr);
     a.x1 = ltake(md); a.u = ltake(mf); a.h = ltake(mf); a.z2 = ltake(md); a.mean2 = ltake(mr); a.rstd2 = ltake(mr);
+    a.dbits = ltake(tf_attn_dropmask_bytes(D.B, D.H, D.S));
     a.layer_stride = lo;
   }
   o += a.layer_stride * D.L;
@@ -114,7 +115,7 @@ bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
 struct Drop { unsigned thr, key; float scale; };
 Drop drop_for(const TfEncoderDesc* e, float p, unsigned site) {
   Drop d{0u, 0u, 1.f};
-  if (e->training && p > 0.f) { d.thr = tf_drop_threshold(p); d.key = tf_drop_key(e->seed, site); d.scale = 1.f / (1.f - p); }
+  if (e->training && p > 0.f) { d.thr = tf_drop_threshold(p); d.key = tf_drop_key(e->seed, site); d.scale = tf_drop_scale(p); }
   return d;
 }
 enum Site { SITE_PATCH = 0, SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4 };
@@ -146,10 +147,20 @@ const char* tf_last_error(void) { return g_err; }
 uint32_t tf_drop_key(uint64_t seed, uint32_t site) { return (uint32_t)(splitmix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(site + 1))) >> 32); }
 uint32_t tf_drop_threshold(float p) {
   if (!(p > 0.f)) return 0u;
-  double t = (double)p * 4294967296.0;
-  if (t >= 4294967295.0) return 0xFFFFFFFFu;
+  double t = floor((double)p * 65536.0 + 0.5);
+  if (t >= 65535.0) return 65535u;
   if (t < 1.0) return 1u;
   return (uint32_t)t;
+}
+float tf_drop_scale(float p) {
+  const uint32_t t = tf_drop_threshold(p);
+  return t ? (float)(1.0 / (1.0 - (double)t / 65536.0)) : 1.0f;
+}
+size_t tf_attn_dropmask_bytes(int B, int H, int S) { return (size_t)B * H * S * ((S + 63) / 64) * 8; }
+int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr, tf_stream_t s) {
+  if (bits == nullptr) return fail(-1, "tf_attn_dropmask");
+  TF_TRY(tf_launch_attn_dropmask(bits, B, H, S, key, thr, (hipStream_t)s), "tf_attn_dropmask");
+  return 0;
 }
 
 #define TF_WRAP(name, call) do { if (a == nullptr) return fail(-1, name); TF_TRY(call, name); return 0; } while (0)
@@ -200,21 +211,24 @@ int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s) {
   for (int l = 0; l < D.L; ++l) {
     unsigned char* w = c.WB(l);
     const TfLayerParams& p = e->p[l];
+    TfPackArgs batch[8];
+    int nb = 0;
     auto pack = [&](const float* src, int rows, int cols, void* dst, int ld, void* dstT, int ldT, int rows_p, int cols_p, int rg, int rgp,
                     int cg, int cgp, int f32) {
       TfPackArgs a{};
       a.src = src; a.rows = rows; a.cols = cols; a.dst = dst; a.ld_dst = ld; a.dst_t = dstT; a.ld_dst_t = ldT; a.rows_p = rows_p;
       a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32;
-      return tf_launch_pack(&a, c.st);
+      batch[nb++] = a;
     };
-    TF_TRY(pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0), "pack in_w");
-    TF_TRY(pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0), "pack out_w");
-    TF_TRY(pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0), "pack w1");
-    TF_TRY(pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0), "pack w2");
-    TF_TRY(pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1), "pack in_b");
-    TF_TRY(pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1), "pack out_b");
-    TF_TRY(pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1), "pack b1");
-    TF_TRY(pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1), "pack b2");
+    pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0);
+    pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0);
+    pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0);
+    pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0);
+    pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1);
+    pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+    pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
+    pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+    TF_TRY(tf_launch_pack_batch(batch, nb, c.st), "pack layer");
   }
   return 0;
 }
@@ -246,7 +260,8 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
       a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
+      if (dr.thr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
     }
     TF_TRY(gemm(c, b + c.A.o, D.dp, w + c.W.wo, D.dp, b + c.A.z1, D.dp, (const float*)(w + c.W.bo), c.X(l), D.dp, nullptr, 0, D.dp, D.dp,
@@ -363,7 +378,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
       a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
       a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
       TF_TRY(tf_launch_attn_delta(a.out, a.ld_out, a.dout, a.ld_dout, delta, D.B, D.S, D.H, D.hdp, c.st), "attn_delta");
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");

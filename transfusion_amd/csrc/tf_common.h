@@ -37,22 +37,49 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 }
 
 // ---- counter-based dropout RNG ----------------------------------------------------------------
-// keep(idx) is a pure function of (key, element index): forward and backward regenerate the same
-// mask from the element's logical index whatever the fragment layout.  murmur3 fmix32 of the index
-// xor-ed with a per-site key; an element is DROPPED when hash < thr, thr = p * 2^32.
-__device__ __forceinline__ unsigned tf_hash32(unsigned idx, unsigned key) {
-  unsigned h = idx * 0x9E3779B1u + key;
+// keep(idx) is a pure function of (key, element index): forward and backward regenerate the same mask from
+// the element's logical index whatever the fragment layout, and tests can replay it (tf_dropout_mask).
+// One murmur3-fmix32 hash serves a PAIR of consecutive indices (its two 16-bit halves); element idx is DROPPED
+// when its half < thr16, thr16 = round(p * 65536).  (32-bit integer multiplies are quarter rate: hashing once
+// per pair, and not at all inside the attention kernels -- they read a precomputed bitmask -- keeps dropout off
+// the critical VALU path.)
+__device__ __forceinline__ unsigned tf_hash32(unsigned x, unsigned key) {
+  unsigned h = x * 0x9E3779B1u + key;
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ bool tf_keep(unsigned idx, unsigned key, unsigned thr) { return tf_hash32(idx, key) >= thr; }
+__device__ __forceinline__ bool tf_keep(unsigned idx, unsigned key, unsigned thr16) {
+  const unsigned h = tf_hash32(idx >> 1, key);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;
+}
+// keep bits of 8 consecutive elements starting at an EVEN index (4 hashes); bit e = element base + e
+__device__ __forceinline__ unsigned tf_keep8(unsigned base, unsigned key, unsigned thr16) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned h = tf_hash32((base >> 1) + i, key);
+    m |= ((h & 0xffffu) >= thr16 ? 1u : 0u) << (2 * i);
+    m |= ((h >> 16) >= thr16 ? 1u : 0u) << (2 * i + 1);
+  }
+  return m;
+}
 
 // ---- exact (erf) GELU and its derivative -------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output rounding of 2^-9): one v_rcp,
+// one v_exp and five FMAs instead of libm's branchy erff; GELU and GELU' share the same exponential,
+// exp(-(x/sqrt2)^2) = exp(-x^2/2).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  ex = __expf(-ax * ax);                                   // = exp(-x^2 / 2)
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float erf_abs = 1.0f - poly * ex;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float c, e; gelu_parts(x, c, e);
+  return c + x * 0.39894228040143268f * e;
 }
 
 // ---- wave reductions ----------------------------------------------------------------------------

@@ -39,7 +39,7 @@ def drop_params(p: float, seed: int, site: int):
     lib = L.load()
     if p <= 0.0:
         return 0, 0, 1.0
-    return lib.tf_drop_threshold(p), lib.tf_drop_key(seed, site), 1.0 / (1.0 - p)
+    return lib.tf_drop_threshold(p), lib.tf_drop_key(seed, site), lib.tf_drop_scale(p)
 
 
 _seed_counter = [0]
@@ -241,6 +241,15 @@ def linear(x, weight, bias=None, p_drop_in: float = 0.0):
     w2 = weight.reshape(weight.shape[0], -1)
     y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0)
     return y.reshape(*lead, weight.shape[0])
+
+
+def attn_dropmask(B: int, H: int, S: int, p: float, seed: int, site: int, device) -> torch.Tensor:
+    """Keep-bitmask of the attention-probability dropout site ([B*H*S, ceil(S/64)] u64, as int64 storage)."""
+    lib = L.load()
+    thr, key, _ = drop_params(p, seed, site)
+    bits = torch.empty(lib.tf_attn_dropmask_bytes(B, H, S) // 8, dtype=torch.int64, device=device)
+    L.check(lib.tf_attn_dropmask(L.ptr(bits), B, H, S, key, thr, _stream()), "tf_attn_dropmask")
+    return bits
 
 
 def dropout_mask(n: int, p: float, seed: int, site: int, device) -> torch.Tensor:
