@@ -35,7 +35,8 @@ def gelu_grad(x):
     return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 768), (1000, 2304, 768), (77, 8, 64)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 768), (1000, 2304, 768), (77, 8, 64),
+                                   (5000, 776, 192), (4100, 2304, 64), (22656, 768, 768)])   # the last three take the large-tile kernel
 def test_gemm_epilogues(dev, M, N, K):
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)

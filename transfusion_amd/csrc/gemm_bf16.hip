@@ -12,13 +12,14 @@
 // The product is computed transposed (D'[n][m] = W.X^T) so that each lane owns 4 consecutive output
 // columns; the tile is then passed through LDS once so that the epilogue (bias / GELU / dropout /
 // residual) works on 16-B row chunks and HBM sees full 256-B row segments.
+#include <cstdlib>
 #include "tf_common.h"
 #include "tf_kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
+constexpr int BN = 128;
+constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per 128-row x 64-deep operand tile (wgrad; the W operand at BK = 64)
 constexpr int CT_STRIDE = 272;                    // C-tile row stride in LDS (256 B + 16 B pad)
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
@@ -33,8 +34,59 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// MI = 16-row fragments per wave along M: the tile is (32*MI) x 128, i.e. 128 / 160 / 192 rows.  All three run two
+// workgroups per CU; the host picks MI per launch to minimise (rounds over 512 slots) x (tile height) -- at M = 22656
+// a 128-row tiling of an N = 768 GEMM needs 3 rounds (1062 tiles) where 160-row tiles need 2 (852).
+// elementwise epilogue of one 16-B chunk (8 consecutive columns of one output row) -- shared by both GEMM kernels
 template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __restrict__ C, u32x4 v, int gm, int gn) {
+  if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
+    *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;
+  } else {
+    float f[8];
+    unpack8(v, f);
+    if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) {
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? gelu_f(f[e]) * g.drop_scale : 0.f;
+      *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
+    } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
+      float r[8];
+      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+    } else if constexpr (EPI == TF_EPI_ADD) {
+      float r[8];
+      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+    } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
+      // dU = dH . mask/(1-p) . gelu'(U); R = U, dropout index space = that of H (ldr == ld of H)
+      float u[8];
+      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), u);
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * gelu_grad_f(u[e]) : 0.f;
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+    }
+  }
+}
+
+// chunk swizzle of a tile row: BK = 64 (128-B rows, 8 chunks): ^ (r>>1)&7 ; BK = 32 (64-B rows, 4 chunks; four rows
+// span one 256-B bank row): ^ g[(r>>2)&3], g = {0,2,3,1}.  Both make the 16 rows of a ds_read_b128 lane group hit 16 distinct slots.
+template <int BK> __device__ __forceinline__ int swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((0x78 >> ((r >> 1) & 6)) & 3); }
+
+template <int EPI, int MI, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
+  constexpr int BM = 32 * MI;
+  constexpr int ROWB = BK * 2;                                   // bytes per tile row (128 or 64)
+  constexpr int RPI = 1024 / ROWB;                               // rows per 1-KiB DMA instruction (8 or 16)
+  constexpr int CPR = ROWB / 16;                                 // 16-B chunks per row (8 or 4)
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = 128 * ROWB, BUF_BYTES = A_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,24 +98,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
   const u16* __restrict__ W = (const u16*)g.W;
 
   auto stage = [&](int buf, int kt) {
-    unsigned char* abase = smem + buf * (2 * TILE_BYTES);
-    unsigned char* bbase = abase + TILE_BYTES;
+    unsigned char* abase = smem + buf * BUF_BYTES;
+    unsigned char* bbase = abase + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int R0 = (i * 4 + wave) * 8;                   // 8 rows x 128 B per wave-instruction
-      const int r = R0 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);            // swizzle on the source chunk
-      const int gm = min(m0 + r, g.M - 1), gn = min(n0 + r, g.N - 1);
-      glds16(A + (size_t)gm * g.lda + kt * BK + c * 8, abase + R0 * 128);
-      glds16(W + (size_t)gn * g.ldw + kt * BK + c * 8, bbase + R0 * 128);
+    for (int i = 0; i < (BM / RPI + 3) / 4; ++i) {          // A tile: BM rows, RPI rows per 1-KiB wave-instruction
+      const int inst = i * 4 + wave;
+      if (inst < BM / RPI) {
+        const int R0 = inst * RPI;
+        const int r = R0 + lane / CPR;
+        const int c = (lane % CPR) ^ swz<BK>(r);            // swizzle on the source chunk
+        const int gm = min(m0 + r, g.M - 1);
+        glds16(A + (size_t)gm * g.lda + kt * BK + c * 8, abase + R0 * ROWB);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (128 / RPI + 3) / 4; ++i) {         // W tile: 128 rows
+      const int inst = i * 4 + wave;
+      if (inst < 128 / RPI) {
+        const int R0 = inst * RPI;
+        const int r = R0 + lane / CPR;
+        const int c = (lane % CPR) ^ swz<BK>(r);
+        const int gn = min(n0 + r, g.N - 1);
+        glds16(W + (size_t)gn * g.ldw + kt * BK + c * 8, bbase + R0 * ROWB);
+      }
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
   stage(0, 0);
@@ -72,28 +137,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const unsigned char* abase = smem + cur * (2 * TILE_BYTES);
-    const unsigned char* bbase = abase + TILE_BYTES;
+    const unsigned char* abase = smem + cur * BUF_BYTES;
+    const unsigned char* bbase = abase + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4], xf[4];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 wf[4], xf[MI];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rn = wc * 64 + i * 16 + frow;
-        wf[i] = *(const bf16x8*)(bbase + rn * 128 + (((ks * 4 + fch) ^ ((rn >> 1) & 7)) << 4));
-        const int rm = wr * 64 + i * 16 + frow;
-        xf[i] = *(const bf16x8*)(abase + rm * 128 + (((ks * 4 + fch) ^ ((rm >> 1) & 7)) << 4));
+        wf[i] = *(const bf16x8*)(bbase + rn * ROWB + (((ks * 4 + fch) ^ swz<BK>(rn)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rm = wr * (BM / 2) + i * 16 + frow;
+        xf[i] = *(const bf16x8*)(abase + rm * ROWB + (((ks * 4 + fch) ^ swz<BK>(rm)) << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [128][CT_STRIDE] ----
+  // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [BM][CT_STRIDE] ----
   unsigned char* ct = smem;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -101,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (g.bias != nullptr && n0 + nl < g.N) b = *(const f32x4*)(g.bias + n0 + nl);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int ml = wr * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ml = wr * (BM / 2) + mi * 16 + (lane & 15);
       u32x2 v;
       v[0] = pack2bf(acc[ni][mi][0] + b[0], acc[ni][mi][1] + b[1]);
       v[1] = pack2bf(acc[ni][mi][2] + b[2], acc[ni][mi][3] + b[3]);
@@ -113,46 +181,145 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
   // ---- phase 2: row-contiguous 16-B chunks, elementwise epilogue, coalesced stores ----
   u16* __restrict__ C = (u16*)g.C;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 2 * MI; ++i) {
     const int id = i * 256 + tid;
     const int row = id >> 4, c = id & 15;
     const int gm = m0 + row, gn = n0 + c * 8;
     if (gm >= g.M || gn >= g.N) continue;
     u32x4 v = *(const u32x4*)(ct + row * CT_STRIDE + c * 16);
-    if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;
-    } else {
-      float f[8];
-      unpack8(v, f);
-      if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) {
-        *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
-        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+    gemm_epilogue_chunk<EPI>(g, C, v, gm, gn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-tile variant for the big launches: (32*MF) x 256 output tile (MF = 8 / 9 / 10 -> 256 / 288 / 320 rows),
+// 512 threads = 8 waves as 2 (M) x 4 (N), each wave (16*MF) x 64, one workgroup per CU.  Twice the MFMA work per
+// staged byte of the 128-wide kernel (whose waves spend their issue slots on LDS-DMA), and:
+//   * K advances in 32-deep steps through a 4-SLOT LDS ring; the DMA of step i+3 is issued in phase i, right after the
+//     barrier that proves slot (i+3)%4 was fully read, so every transfer has three phases (~3.5k cycles) to land;
+//   * waits are COUNTED (s_waitcnt vmcnt(8): everything except the two youngest phases' transfers) and the barrier is a
+//     raw s_barrier -- never __syncthreads(), which would drain the in-flight transfers;
+//   * a slot is read one phase AFTER the wait + barrier that retire its transfers.
+// ------------------------------------------------------------------------------------------------
+constexpr int BIG_BN = 256, BIG_BK = 32, BIG_ROWB = 64;          // 64-B tile rows, 16 rows per 1-KiB DMA instruction
+constexpr int BIG_CT_STRIDE = 528;                               // C-tile row stride in LDS (512 B + 16 B pad)
+
+__device__ __forceinline__ void wait_vm_barrier8() { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_vm_barrier4() { asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int EPI, int MF>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g) {
+  constexpr int BM = 32 * MF;
+  constexpr int A_BYTES = BM * BIG_ROWB, W_BYTES = BIG_BN * BIG_ROWB, SLOT = A_BYTES + W_BYTES;
+  constexpr int NA = BM / 16, NW = BIG_BN / 16, NINST = NA + NW;   // DMA instructions per K-step (34 / 36 / 36)
+  constexpr int PER_WAVE = (NINST + 7) / 8;                        // <= 5
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BIG_BN;
+  const unsigned char* __restrict__ A = (const unsigned char*)g.A;
+  const unsigned char* __restrict__ W = (const unsigned char*)g.W;
+
+  // per-lane byte offsets of this wave's DMA sources (loop invariant); instruction j = i*8 + wave covers 16 rows x 64 B
+  size_t src_off[PER_WAVE];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? gelu_f(f[e]) * g.drop_scale : 0.f;
-        *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
-      } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
-        float r[8];
-        unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
-        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int j = min(i * 8 + wave, NINST - 1);               // surplus slots repeat the last transfer (same bytes, same place)
+    const bool isW = j >= NA;
+    const int r = (isW ? j - NA : j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz<32>(r);
+    const int grow = isW ? min(n0 + r, g.N - 1) : min(m0 + r, g.M - 1);
+    src_off[i] = ((size_t)grow * (isW ? g.ldw : g.lda) + c * 8) * 2;
+  }
+  auto stage = [&](int slot, int kstep) {
+    unsigned char* sl = smem + slot * SLOT;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
-        *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
-      } else if constexpr (EPI == TF_EPI_ADD) {
-        float r[8];
-        unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += r[e];
-        *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
-      } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
-        // dU = dH . mask/(1-p) . gelu'(U); R = U, dropout index space = that of H (ldr == ld of H)
-        float u[8];
-        unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), u);
-        const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * gelu_grad_f(u[e]) : 0.f;
-        *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
-      }
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int j = min(i * 8 + wave, NINST - 1);               // wave-uniform, branch-free (keeps the K loop one basic block)
+      const bool isW = j >= NA;
+      const unsigned char* base = (isW ? W : A) + (size_t)kstep * (BIG_BK * 2);
+      unsigned char* dst = sl + (isW ? A_BYTES + (j - NA) * 1024 : j * 1024);
+      glds16(base + src_off[i], dst);
     }
+  };
+
+  f32x4 acc[4][MF];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BIG_BK;
+  const int frow = lane & 15, fch = lane >> 4;
+  // fragment j sits 16 rows = 1024 B after fragment 0 with the SAME swizzle: one base register each plus immediates
+  const int rn0 = wc * 64 + frow, rm0 = wr * (BM / 2) + frow;
+  const int woff0 = A_BYTES + rn0 * BIG_ROWB + ((fch ^ swz<32>(rn0)) << 4);
+  const int xoff0 = rm0 * BIG_ROWB + ((fch ^ swz<32>(rm0)) << 4);
+  // prologue: steps 0, 1, 2 in flight (past the end the last step is re-fetched: the loop body is branch-free, and
+  // every phase always has exactly two younger steps' transfers in flight, so one counted wait fits all phases)
+  stage(0, 0);
+  stage(1, min(1, nk - 1));
+  stage(2, min(2, nk - 1));
+  for (int i = 0; i < nk; ++i) {
+    // retire step i's transfers (issued three phases ago) on every wave, then make them visible
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PER_WAVE) : "memory");
+    const unsigned char* slw = smem + (i & 3) * SLOT + woff0;
+    const unsigned char* slx = smem + (i & 3) * SLOT + xoff0;
+    bf16x8 wf[4], xf[MF];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(slw + j * 1024);
+#pragma unroll
+    for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(slx + j * 1024);
+    // (after the reads in program order: the compiler cannot tell the DMA's LDS destination from the slot being read)
+    stage((i + 3) & 3, min(i + 3, nk - 1));     // slot (i+3)&3 == (i-1)&3: every wave finished reading it before this barrier
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    // schedule: fragment reads first, then the step's DMA instructions spread one per 7 MFMAs, so that a wave's DMA
+    // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF - 7 * PER_WAVE, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers must land before LDS is reused
+
+  // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [BM][BIG_CT_STRIDE] ----
+  unsigned char* ct = smem;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int nl = wc * 64 + ni * 16 + (lane >> 4) * 4;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias != nullptr && n0 + nl < g.N) b = *(const f32x4*)(g.bias + n0 + nl);
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const int ml = wr * (BM / 2) + mi * 16 + (lane & 15);
+      u32x2 v;
+      v[0] = pack2bf(acc[ni][mi][0] + b[0], acc[ni][mi][1] + b[1]);
+      v[1] = pack2bf(acc[ni][mi][2] + b[2], acc[ni][mi][3] + b[3]);
+      *(u32x2*)(ct + ml * BIG_CT_STRIDE + nl * 2) = v;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: row-contiguous 16-B chunks (32 per row), elementwise epilogue, coalesced stores ----
+  u16* __restrict__ C = (u16*)g.C;
+#pragma unroll 2
+  for (int i = 0; i < 2 * MF; ++i) {
+    const int id = i * 512 + tid;
+    const int row = id >> 5, c = id & 31;
+    const int gm = m0 + row, gn = n0 + c * 8;
+    if (gm >= g.M || gn >= g.N) continue;
+    u32x4 v = *(const u32x4*)(ct + row * BIG_CT_STRIDE + c * 16);
+    gemm_epilogue_chunk<EPI>(g, C, v, gm, gn);
   }
 }
 
@@ -284,14 +451,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
 // ------------------------------------------------------------------------------------------------
-extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
-  if (a->M <= 0 || a->N <= 0) return 0;
-  if (a->K <= 0 || a->K % BK != 0 || a->N % 8 != 0) return -2;
-  if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
+namespace {
+template <int MI, int BK> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
+  constexpr int BM = 32 * MI;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  const size_t lds = 4 * TILE_BYTES;   // 64 KiB (>= the 34 KiB C tile)
+  size_t lds = 2 * (size_t)(BM + 128) * BK * 2;                    // BK 64: 64 / 72 / 80 KiB
+  if (lds < (size_t)BM * CT_STRIDE) lds = (size_t)BM * CT_STRIDE;  // never below the C tile of BM x 272 B
   dim3 grid(tiles), block(256);
-#define TF_GEMM_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, lds, stream, *a); break;
+#define TF_GEMM_CASE(E)                                                                                           \
+  case E: {                                                                                                       \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_kernel<E, MI, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_kernel<E, MI, BK>), grid, block, lds, stream, *a);                                \
+  } break;
   switch (a->epilogue) {
     TF_GEMM_CASE(TF_EPI_NONE)
     TF_GEMM_CASE(TF_EPI_BIAS)
@@ -303,6 +475,85 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   }
 #undef TF_GEMM_CASE
   return (int)hipGetLastError();
+}
+int num_cus();
+// tile-height choice: minimise rounds(over 2 workgroups x #CUs) x height; ties go to the smaller tile
+int pick_mi(int M, int N) {
+  const int slots = 2 * num_cus();
+  const int tn = (N + BN - 1) / BN;
+  int best = 4; long best_cost = -1;
+  for (int mi = 4; mi <= 6; ++mi) {
+    const long tiles = (long)((M + 32 * mi - 1) / (32 * mi)) * tn;
+    const long cost = ((tiles + slots - 1) / slots) * mi;
+    if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
+  }
+  return best;
+}
+}  // namespace
+
+namespace {
+template <int MF> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
+  constexpr int BM = 32 * MF;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BIG_BN - 1) / BIG_BN);
+  size_t lds = 4 * (size_t)(BM + BIG_BN) * BIG_ROWB;               // 4-slot ring
+  if (lds < (size_t)BM * BIG_CT_STRIDE) lds = (size_t)BM * BIG_CT_STRIDE;
+  dim3 grid(tiles), block(512);
+#define TF_GEMM_CASE(E)                                                                                           \
+  case E: {                                                                                                       \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF>), grid, block, lds, stream, *a);                                \
+  } break;
+  switch (a->epilogue) {
+    TF_GEMM_CASE(TF_EPI_NONE)
+    TF_GEMM_CASE(TF_EPI_BIAS)
+    TF_GEMM_CASE(TF_EPI_BIAS_GELU_DROP)
+    TF_GEMM_CASE(TF_EPI_BIAS_DROP_RES)
+    TF_GEMM_CASE(TF_EPI_ADD)
+    TF_GEMM_CASE(TF_EPI_DGELU_DROP)
+    default: return -4;
+  }
+#undef TF_GEMM_CASE
+  return (int)hipGetLastError();
+}
+int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+// large tile: rows 256 or 288, one workgroup per CU: minimise rounds x height
+int pick_mf(int M, int N) {
+  const int tn = (N + BIG_BN - 1) / BIG_BN, slots = num_cus();
+  int best = 8; long best_cost = -1;
+  for (int mf = 8; mf <= 9; ++mf) {
+    const long tiles = (long)((M + 32 * mf - 1) / (32 * mf)) * tn;
+    const long cost = ((tiles + slots - 1) / slots) * mf;
+    if (best_cost < 0 || cost < best_cost) { best = mf; best_cost = cost; }
+  }
+  return best;
+}
+}  // namespace
+
+extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
+  if (a->M <= 0 || a->N <= 0) return 0;
+  if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
+  if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
+  static const int bk32 = getenv("TF_GEMM_BK32") ? atoi(getenv("TF_GEMM_BK32")) : 0;    // experiment switches
+  static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
+  if (bk32) return launch_gemm_mi<4, 32>(a, stream);
+  if (big && a->M >= 2048 && a->N >= 256) {
+    return pick_mf(a->M, a->N) == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+  }
+  switch (pick_mi(a->M, a->N)) {
+    case 5: return launch_gemm_mi<5, 64>(a, stream);
+    case 6: return launch_gemm_mi<6, 64>(a, stream);
+    default: return launch_gemm_mi<4, 64>(a, stream);
+  }
 }
 
 extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int MAXC = 4;   // 16-B chunks per lane per row  -> widths up to 64*4*8 = 2048
+constexpr int MAXC_MAX = 4;   // 16-B chunks per lane per row  -> widths up to 64*4*8 = 2048 (kernels are templated on 1 / 2 / 4)
 
 __device__ __forceinline__ void load8_f32(const float* p, float (&f)[8]) {
   const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
@@ -32,6 +32,7 @@ __device__ __forceinline__ int map_row(int r, int rpg, int stride) { return (r /
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta over the first d columns, fp32 statistics.
 // ------------------------------------------------------------------------------------------------
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 // Waves stride over rows keeping their dgamma/dbeta partials in registers; one LDS reduction per
 // block, then fp32 atomics (2*d per block).
 // ------------------------------------------------------------------------------------------------
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
   __shared__ float red[4][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   }
 }
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs a) {
   __shared__ float red[4][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,14 +448,24 @@ inline int grid_for(long long n, int per_block, int cap = 2048) {
 
 extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
-  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ldx % 8) || (a->ldy % 8)) return -2;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
+  if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->ldy % 8)) return -2;
+  const dim3 grid((a->rows + 3) / 4);
+  const int width = max(a->d, a->y_is_f32 ? a->d : a->ldy);      // columns a lane set must cover (payload + zeroed pad)
+  if (width > 64 * MAXC_MAX * 8) return -2;
+  if (width <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, st, *a);
+  else if (width <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
-  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(a->rows, 4 * 8, 1024)), dim3(256), 0, st, *a);
+  if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
+  const dim3 grid(grid_for(a->rows, 4 * 4, 2048));
+  const int width = max(a->d, max(a->lddx, a->dx_drop != nullptr ? a->lddxd : 0));
+  if (width > 64 * MAXC_MAX * 8) return -2;
+  if (width <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
+  else if (width <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
@@ -465,8 +478,11 @@ extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
 extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   const int rows = a->B * (a->Nv + a->Nl);
   if (rows <= 0) return 0;
-  if (a->d > 64 * MAXC * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(grid_for(rows, 4 * 8, 1024)), dim3(256), 0, st, *a);
+  if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
+  const dim3 grid(grid_for(rows, 4 * 8, 1024));
+  if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
+  else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(assemble_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int lddo, float* delta, int B, int S, int H,
