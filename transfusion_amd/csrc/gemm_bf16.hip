@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int BN = 128;
+int num_cus();
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per 128-row x 64-deep operand tile (wgrad; the W operand at BK = 64)
 constexpr int CT_STRIDE = 272;                    // C-tile row stride in LDS (256 B + 16 B pad)
 
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
 // ones operand in the k-tile-0 blocks.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
+  // K (= rows of M) advances in 32-row steps through a 4-slot LDS ring (16 KiB per slot: dY [32][128] | X [32][128]);
+  // the DMA of step i+3 is issued in phase i, so a transfer has three phases to land (with one-step prefetch the loop
+  // ran at DMA latency: ~2500 cycles per 64 rows against ~500 cycles of MFMA).  Counted vmcnt + raw s_barrier.
+  constexpr int STEP = 32, SLOT = 2 * STEP * 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,24 +346,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
   const int m_begin = blockIdx.y * g.m_chunk;
   const int m_end = min(g.M, m_begin + g.m_chunk);
-  const int nsteps = (m_end - m_begin + 63) / 64;
-  const u16* __restrict__ dY = (const u16*)g.dY;
-  const u16* __restrict__ X = (const u16*)g.X;
-  const u16* __restrict__ Z = (const u16*)g.zeros;
+  const int nsteps = (m_end - m_begin + STEP - 1) / STEP;
+  const unsigned char* __restrict__ dY = (const unsigned char*)g.dY;
+  const unsigned char* __restrict__ X = (const unsigned char*)g.X;
+  const unsigned char* __restrict__ Z = (const unsigned char*)g.zeros;
 
-  auto stage = [&](int buf, int st) {
-    unsigned char* ybase = smem + buf * (2 * TILE_BYTES);
-    unsigned char* xbase = ybase + TILE_BYTES;
+  // one step = 32 rows x 256 B per operand = 8 wave-instructions per operand, 2 per wave: rows R0..R0+3, R0 = (i*4+wave)*4
+  const int lr = lane >> 4, lc = lane & 15;
+  auto stage = [&](int slot, int st) {
+    unsigned char* ybase = smem + slot * SLOT;
+    unsigned char* xbase = ybase + STEP * 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int R0 = (i * 4 + wave) * 4;                   // 4 rows x 256 B per wave-instruction
-      const int r = R0 + (lane >> 4);
-      const int c = (lane & 15) ^ ((r & 3) << 2);
-      const int gm = m_begin + st * 64 + r;
+    for (int i = 0; i < 2; ++i) {
+      const int R0 = (i * 4 + wave) * 4;
+      const int r = R0 + lr;
+      const int c = lc ^ ((r & 3) << 2);
+      const int gm = m_begin + st * STEP + r;
       const bool ok = gm < m_end;
       const int cn = min(n0 + c * 8, g.N - 8), ck = min(k0 + c * 8, g.K - 8);   // clamp: never stored
-      const u16* sy = ok ? dY + (size_t)gm * g.ldy + cn : Z + c * 8;
-      const u16* sx = ok ? X + (size_t)gm * g.ldx + ck : Z + c * 8;
+      const unsigned char* sy = ok ? dY + ((size_t)gm * g.ldy + cn) * 2 : Z + c * 16;
+      const unsigned char* sx = ok ? X + ((size_t)gm * g.ldx + ck) * 2 : Z + c * 16;
       glds16(sy, ybase + R0 * 256);
       glds16(sx, xbase + R0 * 256);
     }
@@ -372,8 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   }
   // Bias grad = column sums of dY = one extra MFMA of the dY fragment against a ones operand.  The duty is spread
   // evenly: the 2*tiles_k waves that share this n-range (tiles_k k-tile blocks x 2 wave columns) each take every
-  // (2*tiles_k)-th 16-row step, so no block carries more than ~1/(2*tiles_k) extra MFMA work (a k0==0-only scheme
-  // made those blocks 1.5x longer and they set the kernel time).
+  // (2*tiles_k)-th 16-row step, so no block carries more than ~1/(2*tiles_k) extra MFMA work.
   const bool has_bias = g.db != nullptr;
   const int bias_mod = 2 * tiles_k;
   int bias_cnt = 2 * (blockIdx.x % tiles_k) + wc;              // counts down to this wave's next duty step
@@ -384,45 +390,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   // tr-read lane geometry
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
   const int h = grp >> 1, cb = grp & 1;
+  const int sw = q << 2, o8 = (p & 1) * 8;
+  // per-lane offsets inside a slot for (ms, b): row0 = ms*16 + 8h + q (row1 = row0 + 4), chunk = w*8 + b*4 + cb*2 + (p>>1)
+  const int yoff = (8 * h + q) * 256 + (((wr * 8 + cb * 2 + (p >> 1)) ^ sw) << 4) + o8;
+  const int xoff = STEP * 256 + (8 * h + q) * 256 + (((wc * 8 + cb * 2 + (p >> 1)) ^ sw) << 4) + o8;
 
+  const unsigned lds_base = lds_addr_of(smem);
   if (nsteps > 0) {
     stage(0, 0);
-    __syncthreads();
+    stage(1, min(1, nsteps - 1));
+    stage(2, min(2, nsteps - 1));
   }
   for (int st = 0; st < nsteps; ++st) {
-    const int cur = st & 1;
-    if (st + 1 < nsteps) stage(cur ^ 1, st + 1);
-    const unsigned char* ybase = smem + cur * (2 * TILE_BYTES);
-    const unsigned char* xbase = ybase + TILE_BYTES;
+    // retire step st's transfers (issued three phases ago; 4 per wave per step), make them visible, recycle slot (st+3)&3
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    const unsigned sl = lds_base + (st & 3) * SLOT;
+    // 16 transposed reads of this step, issued from inline asm (see tf_common.h): ya/yb = dY columns b = 0 / 1, xa/xb = X
+    u64 y[2][2][2], x[2][2][2];                               // [ms][b][row half]
+#define TF_TR(ms, b)                                                                           \
+    y[ms][b][0] = tr_read_asm<(ms) * 4096 + 0>(sl + (yoff ^ ((b) * 64)));                      \
+    y[ms][b][1] = tr_read_asm<(ms) * 4096 + 1024>(sl + (yoff ^ ((b) * 64)));                   \
+    x[ms][b][0] = tr_read_asm<(ms) * 4096 + 0>(sl + (xoff ^ ((b) * 64)));                      \
+    x[ms][b][1] = tr_read_asm<(ms) * 4096 + 1024>(sl + (xoff ^ ((b) * 64)));
+    TF_TR(0, 0) TF_TR(0, 1) TF_TR(1, 0) TF_TR(1, 1)
+#undef TF_TR
+    // (after the reads: hipcc orders an LDS-DMA before any LATER LDS read with a vmcnt(0), it cannot tell the slots apart)
+    stage((st + 3) & 3, min(st + 3, nsteps - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(y[0][0][0]), "+v"(y[0][0][1]), "+v"(y[0][1][0]), "+v"(y[0][1][1]), "+v"(y[1][0][0]), "+v"(y[1][0][1]),
+                   "+v"(y[1][1][0]), "+v"(y[1][1][1]), "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][1][0]), "+v"(x[0][1][1]),
+                   "+v"(x[1][0][0]), "+v"(x[1][0][1]), "+v"(x[1][1][0]), "+v"(x[1][1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 af[2][2], bfr[2][2];
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      bf16x8 af[2], bfr[2];
+    for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int row0 = ms * 16 + 8 * h + q, row1 = row0 + 4;   // row&3 == q for both
-        const int chy = wr * 8 + b * 4 + cb * 2 + (p >> 1);
-        const int chx = wc * 8 + b * 4 + cb * 2 + (p >> 1);
-        const int sw = q << 2, o8 = (p & 1) * 8;
-        af[b] = join_tr(lds_read_tr16(ybase + row0 * 256 + ((chy ^ sw) << 4) + o8),
-                        lds_read_tr16(ybase + row1 * 256 + ((chy ^ sw) << 4) + o8));
-        bfr[b] = join_tr(lds_read_tr16(xbase + row0 * 256 + ((chx ^ sw) << 4) + o8),
-                         lds_read_tr16(xbase + row1 * 256 + ((chx ^ sw) << 4) + o8));
-      }
+      for (int b = 0; b < 2; ++b) { af[ms][b] = join_tr64(y[ms][b][0], y[ms][b][1]); bfr[ms][b] = join_tr64(x[ms][b][0], x[ms][b][1]); }
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][nb], bfr[ms][kb], acc[nb][kb], 0, 0, 0);
       }
       const bool my_turn = has_bias && bias_cnt == 0;             // wave-uniform
       bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
       if (my_turn) {
-        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], ones, accb[0], 0, 0, 0);
-        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], ones, accb[1], 0, 0, 0);
+        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][0], ones, accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][1], ones, accb[1], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the workgroup retires
 
   // ---- epilogue: fp32 atomics into the (unpadded) parameter-layout gradient ----
 #pragma unroll
@@ -562,13 +582,21 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8) || a.zeros == nullptr) return -2;
   if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
   const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
-  const int steps = (a.M + 63) / 64;
+  const int steps = (a.M + 31) / 32;
   // Every split adds one full fp32 |dW| of atomic traffic (chip-wide ~1.3 TB/s), so use the FEWEST splits that
   // still give one resident wave of blocks: 256 CUs x 2 blocks (64 KiB LDS each).
-  int splits = a.m_chunk > 0 ? (a.M + a.m_chunk - 1) / a.m_chunk : (512 / tiles);
+  static const int env_slots = getenv("TF_WGRAD_SLOTS") ? atoi(getenv("TF_WGRAD_SLOTS")) : 0;   // experiment switches
+  static const int env_splits = getenv("TF_WGRAD_SPLITS") ? atoi(getenv("TF_WGRAD_SPLITS")) : 0;
+  // Measured on MI355X (M = 22656): the best block count grows with the tile count -- 36 tiles: ~6 splits (216 blocks),
+  // 72: 5-6 (360-432), 108: 4 (432) -- i.e. about 200 + 2.15 * tiles blocks, never more than one resident wave.
+  int target = env_slots > 0 ? env_slots : (int)(200 + 2.15 * tiles);
+  if (target > 2 * num_cus()) target = 2 * num_cus();
+  int splits = a.m_chunk > 0 ? (a.M + a.m_chunk - 1) / a.m_chunk : (target + tiles / 2) / tiles;
+  while (a.m_chunk <= 0 && splits > 1 && splits * tiles > 2 * num_cus()) --splits;
+  if (env_splits > 0 && a.m_chunk <= 0) splits = env_splits;
   if (splits > steps) splits = steps;
   if (splits < 1) splits = 1;
-  if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 64;
+  if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 32;
   splits = (a.M + a.m_chunk - 1) / a.m_chunk;
   dim3 grid(tiles, splits), block(256);
   hipLaunchKernelGGL(wgrad_tn_kernel, grid, block, 4 * TILE_BYTES, stream, a);

@@ -100,6 +100,26 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
 }
 
+// ---- transposed LDS reads issued through inline asm ---------------------------------------------------------------
+// hipcc orders every LDS-DMA (global_load_lds) before any LATER ds_read_b64_tr_b16 *intrinsic* with s_waitcnt vmcnt(0)
+// (it cannot prove the slots differ), which drains a multi-slot DMA ring every phase.  Reads issued from inline asm are
+// invisible to that pass; the kernel then owns the ordering: tr_read_asm(...) x N, then tr_wait_asm<...>() naming every
+// destination (so no consumer or register copy can be scheduled above the wait) + sched_barrier(0).
+typedef unsigned long long u64;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF> __device__ __forceinline__ u64 tr_read_asm(unsigned addr) {
+  u64 d;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+  return d;
+}
+__device__ __forceinline__ bf16x8 join_tr64(u64 lo, u64 hi) {
+  typedef __attribute__((ext_vector_type(2))) u64 u64x2;
+  u64x2 v = {lo, hi};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ bf16x8 join_tr(const s16x4& a, const s16x4& b) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
