@@ -105,25 +105,25 @@ def kernel_census(B, device, reps=20):
     GF = lambda m, n, k: 2.0 * m * n * k
     st = ops._stream()
     cases = [
-        # name, launches per layer-step, callable, algorithmic flops per launch, algorithmic HBM bytes per launch
-        ("gemm_qkv", 1, lambda: ops.gemm(X, W_qkv, QKV, 3 * d, d, E.TF_EPI_BIAS, bias=bias3), GF(M, 3 * d, d), 2 * (M * d + M * 3 * d)),
-        ("gemm_outproj+drop+res", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, d), 2 * 3 * M * d),
-        ("gemm_ffn_up+gelu+drop", 1, lambda: ops.gemm(X, W_1, U, ff, d, E.TF_EPI_BIAS_GELU_DROP, bias=biasf, C2=Hh, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
-        ("gemm_ffn_down+drop+res", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
-        ("dgrad_ffn_down+dgelu", 1, lambda: ops.gemm(X, W_1, Hh, ff, d, E.TF_EPI_DGELU_DROP, R=U, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
-        ("dgrad_ffn_up+add", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_ADD, R=Y), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
-        ("dgrad_outproj", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_NONE), GF(M, d, d), 2 * 2 * M * d),
-        ("dgrad_qkv+add", 1, lambda: ops.gemm(QKV, W_qkvT, O, d, 3 * d, E.TF_EPI_ADD, R=Y), GF(M, d, 3 * d), 2 * (M * 3 * d + 2 * M * d)),
-        ("wgrad_qkv", 1, lambda: ops.wgrad(QKV, 3 * d, X, d, dW, db), GF(M, 3 * d, d), 2 * (M * 3 * d + M * d)),
-        ("wgrad_d_d", 1, lambda: ops.wgrad(Y, d, X, d, dW[:d], db[:d]), GF(M, d, d), 2 * 2 * M * d),
-        ("wgrad_ffn", 2, lambda: ops.wgrad(U, ff, X, d, dW[:ff], db[:ff]), GF(M, ff, d), 2 * (M * ff + M * d)),
-        ("attn_fwd", 1, lambda: Lb.call("tf_attn_fwd", att, st), 4.0 * B * S * S * d, 2 * (M * 3 * d + M * d)),
-        ("attn_bwd(delta+dq+dkv)", 1, lambda: Lb.call("tf_attn_bwd", att, st), 8.0 * B * S * S * d, 2 * (2 * M * 3 * d + 2 * M * d)),
-        ("layernorm_fwd", 2, lambda: Lb.call("tf_layernorm_fwd", ln, st), 0.0, 2 * 2 * M * d),
-        ("layernorm_bwd", 2, lambda: Lb.call("tf_layernorm_bwd", ln, st), 0.0, 2 * 4 * M * d),
+        # name, kernel symbol, launches per layer-step, callable, algorithmic flops per launch, algorithmic HBM bytes per launch
+        ("gemm_qkv", "gemm_nt<BIAS>", 1, lambda: ops.gemm(X, W_qkv, QKV, 3 * d, d, E.TF_EPI_BIAS, bias=bias3), GF(M, 3 * d, d), 2 * (M * d + M * 3 * d)),
+        ("gemm_outproj+drop+res", "gemm_nt<BIAS_DROP_RES>", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, d), 2 * 3 * M * d),
+        ("gemm_ffn_up+gelu+drop", "gemm_nt<BIAS_GELU_DROP>", 1, lambda: ops.gemm(X, W_1, U, ff, d, E.TF_EPI_BIAS_GELU_DROP, bias=biasf, C2=Hh, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("gemm_ffn_down+drop+res", "gemm_nt<BIAS_DROP_RES>", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
+        ("dgrad_ffn_down+dgelu", "gemm_nt<DGELU_DROP>", 1, lambda: ops.gemm(X, W_1, Hh, ff, d, E.TF_EPI_DGELU_DROP, R=U, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("dgrad_ffn_up+add", "gemm_nt<ADD>", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_ADD, R=Y), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
+        ("dgrad_outproj", "gemm_nt<NONE>", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_NONE), GF(M, d, d), 2 * 2 * M * d),
+        ("dgrad_qkv+add", "gemm_nt<ADD>", 1, lambda: ops.gemm(QKV, W_qkvT, O, d, 3 * d, E.TF_EPI_ADD, R=Y), GF(M, d, 3 * d), 2 * (M * 3 * d + 2 * M * d)),
+        ("wgrad_qkv", "wgrad_tn_kernel", 1, lambda: ops.wgrad(QKV, 3 * d, X, d, dW, db), GF(M, 3 * d, d), 2 * (M * 3 * d + M * d)),
+        ("wgrad_d_d", "wgrad_tn_kernel", 1, lambda: ops.wgrad(Y, d, X, d, dW[:d], db[:d]), GF(M, d, d), 2 * 2 * M * d),
+        ("wgrad_ffn", "wgrad_tn_kernel", 2, lambda: ops.wgrad(U, ff, X, d, dW[:ff], db[:ff]), GF(M, ff, d), 2 * (M * ff + M * d)),
+        ("attn_fwd", "attn_fwd_kernel<192>", 1, lambda: Lb.call("tf_attn_fwd", att, st), 4.0 * B * S * S * d, 2 * (M * 3 * d + M * d)),
+        ("attn_bwd(delta+dq+dkv)", "attn_bwd_dq+dkv_kernel<192>", 1, lambda: Lb.call("tf_attn_bwd", att, st), 8.0 * B * S * S * d, 2 * (2 * M * 3 * d + 2 * M * d)),
+        ("layernorm_fwd", "ln_fwd_kernel", 2, lambda: Lb.call("tf_layernorm_fwd", ln, st), 0.0, 2 * 2 * M * d),
+        ("layernorm_bwd", "ln_bwd_kernel", 2, lambda: Lb.call("tf_layernorm_bwd", ln, st), 0.0, 2 * 4 * M * d),
     ]
     out = []
-    for name, per_layer, fn, fl, by in cases:
+    for name, symbol, per_layer, fn, fl, by in cases:
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -133,7 +133,7 @@ def kernel_census(B, device, reps=20):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        out.append(dict(kernel=name, us=round(us, 2), launches_per_step=per_layer * L, us_per_step=round(us * per_layer * L, 1),
+        out.append(dict(kernel=name, symbol=symbol, us=round(us, 2), launches_per_step=per_layer * L, us_per_step=round(us * per_layer * L, 1),
                         tflops=round(fl / us / 1e6, 1) if fl else None, gbs=round(by / us / 1e3, 1), flops=fl, bytes=by))
     return out
 
@@ -257,22 +257,38 @@ def main():
     }
     if rank == 0 and not args.no_census:
         census = kernel_census(args.batch, device)
-        dom = max(census, key=lambda c: c["us_per_step"])
         total = sum(c["us_per_step"] for c in census)
         for c in sorted(census, key=lambda c: -c["us_per_step"]):
             log(f"  {c['kernel']:28s} {c['us']:9.1f} us x{c['launches_per_step']:3d} = {c['us_per_step']:8.1f} us/step  "
                 f"{'' if c['tflops'] is None else str(c['tflops']) + ' TF/s':>12s}  {c['gbs']:8.1f} GB/s(alg)")
         log(f"  census total {total:.0f} us/step vs measured step {ms * 1e3:.0f} us")
+        # aggregate by kernel symbol (what rocprofv3 --stats reports): the dominant kernel is the one with the largest time per step
+        by_sym = {}
+        for c in census:
+            a = by_sym.setdefault(c["symbol"], dict(us=0.0, launches=0, flops=0.0, bytes=0.0))
+            a["us"] += c["us"] * c["launches_per_step"]
+            a["launches"] += c["launches_per_step"]
+            a["flops"] += c["flops"] * c["launches_per_step"]
+            a["bytes"] += c["bytes"] * c["launches_per_step"]
+        sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
+        avg_us = dom["us"] / dom["launches"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")          # PMC-derived HBM bytes per launch, measured offline
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(sym, {}).get("hbm_bytes_per_launch")
         if dom["flops"]:
             ach = dom["flops"] / dom["us"] / 1e6
-            result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_us": dom["us"],
-                                  "algorithmic_flops_per_launch": dom["flops"]}
+            result["roofline"] = {"kernel": sym, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 1),
+                                  "launches_per_step": dom["launches"],
+                                  "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                                  "us_per_step": round(dom["us"], 1)}
         else:
             ach = dom["bytes"] / dom["us"] / 1e3
-            result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": dom["us"],
-                                  "algorithmic_bytes_per_launch": dom["bytes"]}
+            result["roofline"] = {"kernel": sym, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 1),
+                                  "launches_per_step": dom["launches"],
+                                  "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "us_per_step": round(dom["us"], 1)}
         result["kernels"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -67,3 +67,20 @@ if which in ("gemm", "all"):
     timeit("gemm_ffn_down (drop+res)", lambda: ops.gemm(Xf, W2, O, D, ff, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * ff * D)
     timeit("gemm_outproj (drop+res)", lambda: ops.gemm(X, Wo, O, D, D, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * D * D)
     timeit("gemm_d_d (none)", lambda: ops.gemm(X, Wo, O, D, D, Lb.TF_EPI_NONE), 2.0 * M * D * D)
+if which in ("epi",):
+    X = rnd(M, D)
+    W1 = rnd(ff, D) * 0.03
+    U, Hh = torch.empty(M, ff, device=dev, dtype=bf), torch.empty(M, ff, device=dev, dtype=bf)
+    bff = torch.zeros(ff, device=dev)
+    Y = rnd(M, ff)
+    d15, d0 = ops.drop_params(0.15, 1, 2), (0, 0, 1.0)
+    fl = 2.0 * M * ff * D
+    timeit("ffn_up BIAS only", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS, bias=bff), fl)
+    timeit("ffn_up NONE", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_NONE), fl)
+    timeit("ffn_up ADD (reads R)", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_ADD, R=Y), fl)
+    timeit("ffn_up GELU p=0", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_GELU_DROP, bias=bff, C2=Hh, drop=d0), fl)
+    timeit("ffn_up GELU p=.15", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_GELU_DROP, bias=bff, C2=Hh, drop=d15), fl)
+    timeit("ffn_up DROP_RES p=0", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_DROP_RES, bias=bff, R=Y, drop=d0), fl)
+    timeit("ffn_up DROP_RES p=.15", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_DROP_RES, bias=bff, R=Y, drop=d15), fl)
+    timeit("ffn_up DGELU p=0", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d0), fl)
+    timeit("ffn_up DGELU p=.15", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d15), fl)

@@ -99,6 +99,27 @@ __device__ __forceinline__ unsigned long long key_bits(const uint8_t* __restrict
   return __ballot(ok);
 }
 
+// One past the last key of sample b that may be attended (S when there is no mask).  Key tiles at or beyond it hold
+// only padding: every probability there is exactly 0, so skipping them leaves all results bit-identical.
+__device__ __forceinline__ int valid_key_limit(const uint8_t* __restrict__ km, int b, int S, int lane) {
+  if (km == nullptr) return S;
+  int limit = 0;
+  for (int k0 = 0; k0 < S; k0 += 64) {
+    const int key = k0 + lane;
+    const bool ok = key < S && km[(size_t)b * S + key] == 0;
+    const unsigned long long bits = __ballot(ok);
+    if (bits) limit = k0 + 64 - __builtin_clzll(bits);
+  }
+  return limit;
+}
+
+// (batch, head) pair of a workgroup.  xcd_remap hands each XCD a CONTIGUOUS range of logical ids (so the blocks of one
+// pair share an L2); the pairs themselves are dealt to the XCDs with stride 8, so that every XCD serves many different
+// batch samples and ragged padding lengths do not unbalance the chiplets.
+__device__ __forceinline__ int pair_of_group(int g, int npairs) {
+  return (npairs & 7) == 0 ? (g % (npairs >> 3)) * 8 + g / (npairs >> 3) : g;
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -109,9 +130,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
   unsigned char* kt = smem;
   unsigned char* vt = smem + 64 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  // 1-D grid, XCD-aware: all query blocks of one (batch, head) -- which share K and V -- run on the same XCD / L2
   const int S = a.S;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int q0 = (logical % nqb) * 128 + wave * 32;
   const u16* __restrict__ qkv = (const u16*)a.qkv;
   const size_t ld = a.ld_qkv;
   const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
@@ -136,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
   const int SW = (S + 63) / 64;
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
 
-  const int ntiles = (S + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
     // No register prefetch: the kernel stays under 256 VGPRs so that TWO workgroups share a CU (2 waves per SIMD)
@@ -240,9 +264,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   unsigned char* kt = smem;
   unsigned char* vt = smem + 64 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  // 1-D grid, XCD-aware: all query blocks of one (batch, head) -- which share K and V -- run on the same XCD / L2
   const int S = a.S;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
   const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
-  const int ntiles = (S + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   // dQ needs Q, dO (B operands) and the dQ^T accumulator resident: > 256 registers, so this kernel runs one wave per
   // SIMD with the full 512-entry file and prefetches the next K/V tile into registers under the MFMA work instead.
   TileRegs<64, HDP> kr, vr;
@@ -342,9 +369,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   float* lse_s = (float*)(smem + 64 * G::TSTR);
   float* del_s = lse_s + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
   const int S = a.S;
-  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int nkb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);          // key blocks of one (batch, head) share Q and dO: same XCD
+  const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int key0 = (logical % nkb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
   const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
@@ -370,7 +399,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
     for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
   const float sc = a.scale * LOG2E;
 
-  const int ntiles = (S + 31) / 32;
+  // a key block that holds only padding receives exactly-zero dK / dV: skip its query loop
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
   TileRegs<32, HDP> qr, dr;
   qr.load(qbase, ld, 0, S - 1, false, tid);
   dr.load(dobase, a.ld_dout, 0, S - 1, true, tid);       // rows >= S contribute nothing
@@ -452,14 +482,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 128 * Geo<HDP>::TSTR;
   hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3((a->S + 127) / 128, a->B * a->H), dim3(256), lds, st, *a);
+  hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3(((a->S + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256;
   hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
   hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-  dim3 grid((a->S + 127) / 128, a->B * a->H);
+  dim3 grid(((a->S + 127) / 128) * a->B * a->H);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, grid, dim3(256), lds_kv, st, *a);
   return (int)hipGetLastError();

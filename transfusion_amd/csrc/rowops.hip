@@ -401,7 +401,13 @@ __global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a) {
 }
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
   float s = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+  const long long n4 = n >> 2;                               // 16-B lanes over the aligned body, scalar tail
+  const f32x4* x4 = (const f32x4*)x;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
@@ -560,7 +566,8 @@ extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
 }
 extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8, 1024)), dim3(256), 0, st, x, n, out);
+  if (((size_t)x & 15) != 0) return -2;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, x, n, out);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {

@@ -16,6 +16,19 @@ typedef unsigned short u16;
 #define TF_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define TF_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// ---- XCD-aware workgroup order -------------------------------------------------------------------
+// Bijective remap: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each
+// XCD a contiguous range of logical tiles so that tiles sharing an A panel hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// MI = 16-row fragments per wave along M: the tile is (32*MI) x 128, i.e. 128 / 160 / 192 rows.  All three run two
+// workgroups per CU; the host picks MI per launch to minimise (rounds over 512 slots) x (tile height) -- at M = 22656
+// a 128-row tiling of an N = 768 GEMM needs 3 rounds (1062 tiles) where 160-row tiles need 2 (852).
+
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(u16 b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
