@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--grad-clip", type=float, default=1.0)
+    ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,16 +206,22 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal hooks (never set by the driver): several ranks on ONE device over gloo, to exercise the N > 1 code path
+    dev_index = int(os.environ.get("TF_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("TF_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from transfusion_amd.runner.trainer import FusionTrainStep
     enc = make_encoder(device)
     enc.train()
-    trainer = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip)
+    trainer = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap)
     batch = make_batch(args.batch, device, rank)
 
     def sync():
@@ -235,6 +242,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    if world > 1 and os.environ.get("TF_CHECK_SYNC"):
+        # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
+        mine = trainer.flat.flat.double().sum().reshape(1)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert lo.item() == hi.item(), (lo.item(), hi.item())
+        if rank == 0:
+            log(f"  parameter checksum identical on {world} ranks: {lo.item():.6f}; overlap={'on' if trainer.layerwise is not None else 'off'}")
     if not math.isfinite(final_loss):
         raise SystemExit(f"non-finite loss {final_loss}")
 

@@ -233,6 +233,11 @@ typedef struct TfEncoderDesc {
   const void* d_lang_out; int d_lang_out_is_f32;   /* may be null (zero) */
   void* d_vis; int d_vis_is_f32;            /* may be null */
   void* d_lang; int d_lang_is_f32;          /* may be null */
+  /* partial backward (gradient all-reduce overlap): process bwd_nlayers layers starting at layer bwd_hi and going DOWN;
+   * bwd_nlayers == 0 means the whole encoder.  The output-side part (final LayerNorm) runs with the chunk that contains
+   * layer L-1, the input-side part (token assemble) with the chunk that contains layer 0; chunks must be issued in
+   * descending order on one stream. */
+  int bwd_hi, bwd_nlayers;
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);

@@ -74,3 +74,30 @@ def test_single_process_reducer_is_noop():
     g = torch.ones(10)
     r = DataParallelReducer(g)
     assert r.world == 1 and r.all_reduce() == [] and torch.equal(g, torch.ones(10))
+
+
+def test_layerwise_ranges_cover_flat_buffer_once():
+    """The per-layer all-reduce slices (top layer + final norm first, layer 0 + kind embeddings last) tile the flat
+    gradient buffer exactly: nothing reduced twice, nothing forgotten."""
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    from transfusion_amd.runner.trainer import FlatParams, LayerwiseReducer
+    pe = PositionalEmbeddingLayer("sin1d", 64, 32)
+    enc = CrossTransformerModuleBox(no_patches=64, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=3, patch_dropout=0.1,
+                                    num_heads=2, fforward_multiplier=2, token_dropout=0.1, back_to_img_fn="regroup", activ_f="gelu",
+                                    final_norm="ln", input_f_size=32)
+    flat = FlatParams(enc)
+    red = LayerwiseReducer(flat)
+    assert red.num_layers == 3 and red.world == 1
+    spans = sorted(red.ranges.values())
+    assert spans[0][0] == 0 and spans[-1][1] == max(off + n for _, _, off, n in flat.slices)
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    # every parameter slice lies in exactly one range, final norm with the top layer, kind embeddings with layer 0
+    where = {}
+    for name, _, off, num in flat.slices:
+        hits = [l for l, (lo, hi) in red.ranges.items() if lo <= off and off + num <= hi]
+        assert len(hits) == 1, name
+        where[name] = hits[0]
+    assert where["final_norm_layer.weight"] == 2 and where["image_kind_embedding"] == 0
+    assert where["t_encoder.layers.1.linear1.weight"] == 1

@@ -186,3 +186,30 @@ def test_full_size_properties(dev):
     g_all, g_a, g_b = grads(slice(0, 32)), grads(slice(0, 16)), grads(slice(16, 32))
     for k in g_all:
         assert rel(g_all[k], g_a[k] + g_b[k]) < 2e-3, k
+
+
+def test_layerwise_backward_equals_single_call(dev):
+    """The per-layer backward (used to overlap the gradient all-reduce) produces the gradients of the single-call
+    backward; differences are fp32 atomic-add ordering only."""
+    cfg = dict(B=3, Nv=40, Nl=50, d=128, h=4, L=3, mask_lens=[50, 20, 33], seed=31)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+
+    def run(hook):
+        enc.zero_grad(set_to_none=True)
+        enc.layer_grad_hook = hook
+        xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+        ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+        v, l, _, _ = enc(xd, ld, torch.from_numpy(mask).to(dev))
+        ((v * torch.from_numpy(gv).to(dev)).sum() + (l * torch.from_numpy(gl).to(dev)).sum()).backward()
+        enc.layer_grad_hook = None
+        return xd.grad.clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+
+    order = []
+    gx1, g1 = run(None)
+    gx2, g2 = run(lambda m, layer: order.append(layer))
+    assert order == [2, 1, 0]
+    assert torch.equal(gx1, gx2)
+    for k in g1:
+        assert rel(g2[k], g1[k]) < 1e-5, k

@@ -318,8 +318,12 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   unsigned char* du = c.wk + c.A.du; unsigned char* d_o = c.wk + c.A.d_o; unsigned char* dqkv = c.wk + c.A.dqkv;
   float* delta = (float*)(c.wk + c.A.delta);
   const uint8_t* km = (const uint8_t*)(c.wk + c.A.keymask);
+  const int l_hi = e->bwd_nlayers > 0 ? e->bwd_hi : D.L - 1;
+  const int l_lo = e->bwd_nlayers > 0 ? e->bwd_hi - e->bwd_nlayers + 1 : 0;
+  if (l_hi >= D.L || l_lo < 0 || l_lo > l_hi) return fail(-1, "tf_encoder_bwd(layer range)");
+  const bool head = l_hi == D.L - 1, tail = l_lo == 0;
   // ---- gradient w.r.t. the last layer's output X[L] -> dxa ----
-  if (D.Nv > 0) {
+  if (head && D.Nv > 0) {
     if (e->final_norm && e->d_vis_out != nullptr) {
       TfLnArgs n{};
       n.x = c.X(D.L); n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
@@ -333,7 +337,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
     }
   }
-  if (D.Nl > 0) {
+  if (head && D.Nl > 0) {
     TfCopyRowsArgs r{};
     r.src = e->d_lang_out; r.src_is_f32 = e->d_lang_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nl; r.src_gstride = D.Nl;
     r.dst = dxa + (size_t)D.Nv * D.dp * 2; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nl; r.dst_gstride = D.S; r.rows = D.B * D.Nl; r.cols = D.d;
@@ -341,7 +345,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   }
   const float scale = 1.0f / sqrtf((float)D.hd);
   const Drop none{0u, 0u, 1.f};
-  for (int l = D.L - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= l_lo; --l) {
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l]; const TfLayerParams& g = e->g[l];
     // ---- LN2 backward: dxa -> dz (= d z2), dy (= dropout2-masked) ----
@@ -386,7 +390,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     TF_TRY(wgrad(c, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");
     TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
-  {
+  if (tail) {
     TfAssembleArgs a{};
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa; a.ld_dout = D.dp;
     a.dvis = e->d_vis; a.dvis_is_f32 = e->d_vis_is_f32; a.ld_dvis = D.d; a.dlang = e->d_lang; a.dlang_is_f32 = e->d_lang_is_f32; a.ld_dlang = D.d;

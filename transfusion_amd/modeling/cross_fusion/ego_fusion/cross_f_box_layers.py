@@ -124,7 +124,18 @@ class _EncoderFn(torch.autograd.Function):
         desc.d_vis, desc.d_vis_is_f32 = L.ptr(d_vis), 0 if d_vis is None else ops._is_f32(d_vis)
         desc.d_lang, desc.d_lang_is_f32 = L.ptr(d_lang), 0 if d_lang is None else ops._is_f32(d_lang)
         grads, direct = mod._bind_grads(desc, dev)
-        L.call("tf_encoder_bwd", desc, ops._stream())
+        hook = mod.layer_grad_hook
+        if hook is None:
+            L.call("tf_encoder_bwd", desc, ops._stream())
+        else:
+            # one runtime call per layer, top layer first; after each, the hook may start reducing that layer's gradients
+            # (data-parallel all-reduce overlapped with the rest of the backward)
+            st = ops._stream()
+            for layer in range(desc.L - 1, -1, -1):
+                desc.bwd_hi, desc.bwd_nlayers = layer, 1
+                L.call("tf_encoder_bwd", desc, st)
+                hook(mod, layer)
+            desc.bwd_nlayers = 0
         mod._release(keep)
         if direct:
             return (None, d_vis, d_lang, None) + (None,) * ctx.nparams
@@ -188,6 +199,7 @@ class CrossTransformerModuleBox(nn.Module):
 
         # runtime state (not part of state_dict)
         self.accumulate_into_grad = False     # True: backward adds straight into p.grad (flat-buffer training loop)
+        self.layer_grad_hook = None           # callable(module, layer): called as soon as that layer's gradients are enqueued
         self._wpack = None
         self._wpack_versions = None
         self._work_pool = {}

@@ -66,11 +66,54 @@ class DataParallelReducer:
         return handles
 
 
+class LayerwiseReducer:
+    """All-reduce that starts as soon as a layer's gradients exist: the encoder runtime is called once per layer
+    (top layer first) and after each call the contiguous slice of the flat gradient buffer that belongs to that layer
+    (plus final-norm with the top layer, kind embeddings with layer 0) is reduced asynchronously; torch's RCCL process
+    group orders the collective after the kernels already enqueued and runs it on its own stream, so it overlaps the
+    remaining backward.  ``finish()`` joins before the optimiser."""
+
+    def __init__(self, flat: FlatParams, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bytes_per_step = flat.grad.numel() * 4
+        self.handles = []
+        self.ranges = {}
+        ends = {}
+        for name, _, off, num in flat.slices:
+            m = [tok for tok in name.split(".")]
+            layer = int(m[m.index("layers") + 1]) if "layers" in m else None
+            key = layer if layer is not None else ("tail" if "final_norm" in name else "head")
+            lo, hi = ends.get(key, (off, off + num))
+            ends[key] = (min(lo, off), max(hi, off + num))
+        self.num_layers = 1 + max(k for k in ends if isinstance(k, int))
+        for layer in range(self.num_layers):
+            lo, hi = ends[layer]
+            if layer == self.num_layers - 1 and "tail" in ends:
+                lo, hi = min(lo, ends["tail"][0]), max(hi, ends["tail"][1])
+            if layer == 0 and "head" in ends:
+                lo, hi = min(lo, ends["head"][0]), max(hi, ends["head"][1])
+            self.ranges[layer] = (lo, hi)
+        covered = sorted(self.ranges.values())
+        assert covered[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), covered
+
+    def hook(self, module, layer):
+        if self.world == 1:
+            return
+        lo, hi = self.ranges[layer]
+        self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
 class FusionTrainStep:
     """One optimiser step over ``accumulate`` micro-batches for a module that writes into ``p.grad`` directly."""
 
     def __init__(self, module: nn.Module, lr=1e-4, weight_decay=2e-4, grad_clip: Optional[float] = 1.0, accumulate: int = 1,
-                 bucket_mb: float = 64.0, optimizer_cls=None):
+                 bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True):
         from transfusion_amd.optim import FusedRAdam
         self.module = module
         self.flat = FlatParams(module)
@@ -79,6 +122,11 @@ class FusionTrainStep:
                 m.accumulate_into_grad = True
         self.reducer = DataParallelReducer(self.flat.grad, bucket_mb)
         self.world = self.reducer.world
+        self.layerwise = None
+        encoders = [m for m in module.modules() if hasattr(m, "layer_grad_hook")]
+        if overlap and self.world > 1 and accumulate == 1 and len(encoders) == 1 and encoders[0] is module:
+            self.layerwise = LayerwiseReducer(self.flat)
+            module.layer_grad_hook = self.layerwise.hook
         self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
         self.accumulate = accumulate
@@ -99,7 +147,10 @@ class FusionTrainStep:
         for mb in micro_batches:
             loss = loss_fn(self.module, mb)
             (loss / len(micro_batches)).backward()
-        self.reducer.all_reduce()
+        if self.layerwise is not None:
+            self.layerwise.finish()
+        else:
+            self.reducer.all_reduce()
         scale = 1.0 / self.world
         if self.grad_clip:
             self._norm.zero_()
