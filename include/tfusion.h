@@ -180,7 +180,7 @@ const char* tf_last_error(void);
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);
-int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* computes delta internally, then dQ, dK, dV */
+int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* dQ (which also fills `delta`), then dK, dV */
 int tf_layernorm_fwd(const TfLnArgs* a, tf_stream_t s);
 int tf_layernorm_bwd(const TfLnArgs* a, tf_stream_t s);
 int tf_assemble_fwd(const TfAssembleArgs* a, tf_stream_t s);

@@ -84,3 +84,18 @@ if which in ("epi",):
     timeit("ffn_up DROP_RES p=.15", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_DROP_RES, bias=bff, R=Y, drop=d15), fl)
     timeit("ffn_up DGELU p=0", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d0), fl)
     timeit("ffn_up DGELU p=.15", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d15), fl)
+if which in ("ln",):
+    X, DY = rnd(M, D), rnd(M, D)
+    DX, DXD = torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, D, device=dev, dtype=bf)
+    mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+    gam, bet, dgam, dbet = torch.ones(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    drop = ops.drop_params(0.15, 1, 1)
+    ln = Lb.TfLnArgs(x=Lb.ptr(X), ldx=D, y=Lb.ptr(DX), ldy=D, y_is_f32=0, gamma=Lb.ptr(gam), beta=Lb.ptr(bet), mean=Lb.ptr(mean), rstd=Lb.ptr(rstd),
+                     rows=M, d=D, rows_per_group=M, x_group_stride=M, y_group_stride=M, eps=1e-5, dy=Lb.ptr(DY), lddy=D, dy_is_f32=0,
+                     dx=Lb.ptr(DX), lddx=D, dx_drop=Lb.ptr(DXD), lddxd=D, drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_ld=D,
+                     dgamma=Lb.ptr(dgam), dbeta=Lb.ptr(dbet))
+    timeit("ln_fwd  (GB/s as TF col)", lambda: Lb.call("tf_layernorm_fwd", ln, st), 2.0 * 2 * M * D * 1e3)
+    timeit("ln_bwd  (GB/s as TF col)", lambda: Lb.call("tf_layernorm_bwd", ln, st), 2.0 * 4 * M * D * 1e3)
+    g32 = torch.randn(18912000, device=dev)
+    acc = torch.zeros(1, device=dev)
+    timeit("sumsq 75.6MB (GB/s)", lambda: Lb.check(Lb.load().tf_sumsq(Lb.ptr(g32), g32.numel(), Lb.ptr(acc), st)), 4.0 * g32.numel() * 1e3)

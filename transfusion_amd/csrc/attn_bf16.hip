@@ -286,7 +286,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
     dof[ks] = as_bf16x8(*(const u32x4*)(dobase + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
   }
   const float lse = a.lse[(size_t)bh * S + qr];
-  const float delta = a.delta[(size_t)bh * S + qr];
+  // delta[q] = rowsum(dO . O): this wave already holds dO in B-operand layout (lane half h owns hd elements 16ks+8h..+7),
+  // so read O the same way, reduce in registers + one cross-half exchange, and publish it for the dK/dV kernel
+  float delta = 0.f;
+  {
+    const u16* orow = (const u16*)a.out + ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      float of[8], df[8];
+      unpack8(*(const u32x4*)(orow + ks * 16 + 8 * h), of);
+      unpack8(__builtin_bit_cast(u32x4, dof[ks]), df);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (h == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+  }
   f32x16 dq[G::DBLK];
 #pragma unroll
   for (int d = 0; d < G::DBLK; ++d)

@@ -408,8 +408,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+  // one atomic per BLOCK: adds to a single address serialise at ~90 per microsecond chip-wide
+  __shared__ float part[4];
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // K1 gather: cols[(b*Hp+hp)*Wp+wp][(c*ph+i)*pw+j] = feat[b][c][hp*ph+i][wp*pw+j]
@@ -466,7 +470,7 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
 extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
-  const dim3 grid(grid_for(a->rows, 4 * 4, 2048));
+  const dim3 grid(grid_for(a->rows, 4 * 4, 512));      // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
   const int width = max(a->d, max(a->lddx, a->dx_drop != nullptr ? a->lddxd : 0));
   if (width > 64 * MAXC_MAX * 8) return -2;
   if (width <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
@@ -485,7 +489,7 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   const int rows = a->B * (a->Nv + a->Nl);
   if (rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
-  const dim3 grid(grid_for(rows, 4 * 8, 1024));
+  const dim3 grid(grid_for(rows, 4 * 8, 512));
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(assemble_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
@@ -567,7 +571,7 @@ extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
 extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) {
   if (n <= 0) return 0;
   if (((size_t)x & 15) != 0) return -2;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, x, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16, 512)), dim3(256), 0, st, x, n, out);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {

@@ -169,7 +169,6 @@ int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_wgrad"
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s) { TF_WRAP("tf_attn_fwd", tf_launch_attn_fwd(a, (hipStream_t)s)); }
 int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s) {
   if (a == nullptr) return fail(-1, "tf_attn_bwd");
-  TF_TRY(tf_launch_attn_delta(a->out, a->ld_out, a->dout, a->ld_dout, a->delta, a->B, a->S, a->H, a->HDP, (hipStream_t)s), "tf_attn_bwd(delta)");
   TF_TRY(tf_launch_attn_bwd(a, (hipStream_t)s), "tf_attn_bwd");
   return 0;
 }
@@ -384,7 +383,6 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
       a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
-      TF_TRY(tf_launch_attn_delta(a.out, a.ld_out, a.dout, a.ld_dout, delta, D.B, D.S, D.H, D.hdp, c.st), "attn_delta");
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
     TF_TRY(wgrad(c, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");

@@ -52,13 +52,13 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 // ---- counter-based dropout RNG ----------------------------------------------------------------
 // keep(idx) is a pure function of (key, element index): forward and backward regenerate the same mask from
 // the element's logical index whatever the fragment layout, and tests can replay it (tf_dropout_mask).
-// One murmur3-fmix32 hash serves a PAIR of consecutive indices (its two 16-bit halves); element idx is DROPPED
+// One 32-bit mixing hash serves a PAIR of consecutive indices (its two 16-bit halves); element idx is DROPPED
 // when its half < thr16, thr16 = round(p * 65536).  (32-bit integer multiplies are quarter rate: hashing once
 // per pair, and not at all inside the attention kernels -- they read a precomputed bitmask -- keeps dropout off
 // the critical VALU path.)
 __device__ __forceinline__ unsigned tf_hash32(unsigned x, unsigned key) {
-  unsigned h = x * 0x9E3779B1u + key;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  unsigned h = x + key;                       // "lowbias32" finaliser: two (quarter-rate) multiplies, full avalanche
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
   return h;
 }
 __device__ __forceinline__ bool tf_keep(unsigned idx, unsigned key, unsigned thr16) {
