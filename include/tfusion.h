@@ -212,6 +212,19 @@ typedef struct TfEncoderPlan {
   size_t wpack_bytes, work_bytes;
 } TfEncoderPlan;
 
+/* Optional side stream for the weight-gradient GEMMs of tf_encoder_bwd.  The backward chain (LN bwd -> dgrad -> attention
+ * bwd -> dgrad ...) is strictly serial and every kernel in it has a fill and a drain phase in which CUs idle; the four
+ * wgrad GEMMs of a layer depend only on tensors the chain has already produced, so with a TfOverlap they are issued on
+ * `stream` (forked from / joined back into the caller's stream with the events) and fill those bubbles.  The caller
+ * still sees single-stream semantics: tf_encoder_bwd joins before it returns.  Create once per device, reuse for every call
+ * (calls that share one TfOverlap must be issued from one thread).  No reference counterpart (autograd engine detail). */
+typedef struct TfOverlap {
+  void* stream;                 /* hipStream_t, non-blocking */
+  void* ev[8];                  /* hipEvent_t: [0..3] fork (chain -> side), [4..7] done (side -> chain) per wgrad site */
+} TfOverlap;
+int tf_overlap_create(TfOverlap* o);
+int tf_overlap_destroy(TfOverlap* o);
+
 typedef struct TfEncoderDesc {
   int B, Nv, Nl, d, H, L, ff;
   int training;                 /* dropout on (p_token, p_patch) */
@@ -238,6 +251,7 @@ typedef struct TfEncoderDesc {
    * layer L-1, the input-side part (token assemble) with the chunk that contains layer 0; chunks must be issued in
    * descending order on one stream. */
   int bwd_hi, bwd_nlayers;
+  const TfOverlap* overlap;     /* null: everything on the caller's stream */
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);

@@ -213,3 +213,42 @@ def test_layerwise_backward_equals_single_call(dev):
     assert torch.equal(gx1, gx2)
     for k in g1:
         assert rel(g2[k], g1[k]) < 1e-5, k
+
+
+@pytest.mark.gpu
+def test_wgrad_side_stream_matches_single_stream(monkeypatch):
+    """tf_encoder_bwd with a TfOverlap (weight-gradient GEMMs on a side stream, fork/join by events) must produce the
+    same gradients as the single-stream schedule; repeated to give a missing dependency a chance to show."""
+    import torch
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    from transfusion_amd import ops
+
+    def run(overlap):
+        monkeypatch.setenv("TF_WGRAD_OVERLAP", "1" if overlap else "0")
+        torch.manual_seed(3)
+        ops._seed_counter[0] = 0                    # same dropout streams in both schedules
+        pe = PositionalEmbeddingLayer("sin1d", 8192, 256)
+        m = CrossTransformerModuleBox(8192, 0.1, 256, pe, num_layers=3, num_heads=4, fforward_multiplier=2, token_dropout=0.15,
+                                      activ_f="gelu", final_norm="ln").cuda().train()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(6, 49, 256, generator=g).cuda().requires_grad_()
+        lang = torch.randn(6, 77, 256, generator=g).cuda().requires_grad_()
+        pad = torch.zeros(6, 77, dtype=torch.bool)
+        pad[1, 60:] = True
+        pad[4, 30:] = True
+        outs = []
+        for _ in range(3):
+            m.zero_grad(set_to_none=True)
+            v, l_, _, _ = m(x, lang, pad.cuda(), None)
+            (v.float().square().mean() + l_.float().square().mean()).backward()
+            outs.append([p.grad.detach().float().cpu().clone() for p in m._param_list()] + [x.grad.cpu().clone(), lang.grad.cpu().clone()])
+            x.grad = None
+            lang.grad = None
+        return outs
+
+    a = run(False)
+    b = run(True)
+    for ga, gb in zip(a[-1], b[-1]):
+        scale = ga.abs().max().item() + 1e-12
+        assert (ga - gb).abs().max().item() <= 2e-3 * scale      # fp32 atomics: summation order differs between runs

@@ -99,3 +99,16 @@ if which in ("ln",):
     g32 = torch.randn(18912000, device=dev)
     acc = torch.zeros(1, device=dev)
     timeit("sumsq 75.6MB (GB/s)", lambda: Lb.check(Lb.load().tf_sumsq(Lb.ptr(g32), g32.numel(), Lb.ptr(acc), st)), 4.0 * g32.numel() * 1e3)
+if which in ("ksweep",):
+    # time(K) = fixed (launch + prologue + epilogue) + K * slope  ->  asymptotic MFMA rate of the K-loop and the per-tile fixed cost
+    for N in (768, 2304):
+        O = torch.empty(M, N, device=dev, dtype=bf)
+        for K in (256, 512, 768, 1536, 3072, 6144):
+            Xk, Wk = rnd(M, K), rnd(N, K) * 0.03
+            timeit(f"gemm N={N} K={K} (none)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_NONE), 2.0 * M * N * K)
+            if K == 1536:
+                b1 = torch.zeros(N, device=dev)
+                drop = ops.drop_params(0.15, 1, 2)
+                Y = rnd(M, N)
+                timeit(f"gemm N={N} K={K} (bias)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_BIAS, bias=b1), 2.0 * M * N * K)
+                timeit(f"gemm N={N} K={K} (drop+res)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * N * K)

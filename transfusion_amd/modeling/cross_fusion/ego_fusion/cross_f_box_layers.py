@@ -279,6 +279,7 @@ class CrossTransformerModuleBox(nn.Module):
             raise L.TfError("pos_embedding must be contiguous fp32")
         e.pe = pe.data_ptr()
         e.wpack, e.work = self._wpack.data_ptr(), keep["work"].data_ptr()
+        e.overlap = ops.wgrad_overlap(x.device)
         x = x.contiguous()
         lang = lang.contiguous()
         keep["inputs"] = (x, lang)

@@ -5,6 +5,7 @@ given CPU tensors -- there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -99,6 +100,24 @@ def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 
                      epilogue=L.TF_EPI_NONE if epilogue is None else epilogue,
                      drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2])
     L.call("tf_gemm_fwd", g, _stream())
+
+
+_overlap_cache = {}
+
+
+def wgrad_overlap(device):
+    """Address of this device's ``TfOverlap`` (side stream + events on which ``tf_encoder_bwd`` issues its weight-gradient
+    GEMMs), created on first use; ``TF_WGRAD_OVERLAP=0`` keeps everything on the caller's stream (A/B switch)."""
+    if os.environ.get("TF_WGRAD_OVERLAP", "1") == "0":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    o = _overlap_cache.get(idx)
+    if o is None:
+        o = L.TfOverlap()
+        with torch.cuda.device(idx):
+            L.check(L.load().tf_overlap_create(C.byref(o)), "tf_overlap_create")
+        _overlap_cache[idx] = o
+    return C.addressof(o)
 
 
 _zeros_cache = {}
