@@ -335,11 +335,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       f32x16 st, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      // One wave per SIMD: nothing hides an LDS round trip but this wave's own instruction order, so the fragment reads
+      // run AHEAD of the MFMAs that consume them (hipcc's default order was read -> lgkmcnt(0) -> MFMA, one read in
+      // flight, i.e. ~110 cycles per 32-cycle MFMA).  A deeper software pipeline across the two halves (MFMAs of one
+      // half under the softmax VALU of the other) was tried and spills at 512 registers -- see DESIGN.md.
+      bf16x8 kfr[G::KSTEPS], vfr[G::KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) { kfr[ks] = row_frag<HDP>(kt, kb * 32, ks, lane); vfr[ks] = row_frag<HDP>(vt, kb * 32, ks, lane); }
 #pragma unroll
       for (int ks = 0; ks < G::KSTEPS; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(vt, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dp, 0, 0, 0);
       }
+      {
+        constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : 8;
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+        for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+      }
+      // K^T fragments of the dQ product do not depend on the softmax: issue their reads before the VALU block
+      bf16x8 ktf[2][G::DBLK];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
@@ -351,8 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       for (int s = 0; s < 2; ++s) {
         const bf16x8 dsf = acc_frag(st, s);
 #pragma unroll
-        for (int d = 0; d < G::DBLK; ++d)
-          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane), dsf, dq[d], 0, 0, 0);
+        for (int d = 0; d < G::DBLK; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s][d], dsf, dq[d], 0, 0, 0);
       }
     }
   }
@@ -383,6 +402,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   unsigned char* dot = smem + 32 * G::TSTR;
   float* lse_s = (float*)(smem + 64 * G::TSTR);
   float* del_s = lse_s + 32;
+  unsigned* dw_s = (unsigned*)(del_s + 32);                       // [4 waves][32 query rows] keep-bit words of the wave's 32 keys
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int S = a.S;
   const int nkb = (S + 127) / 128;
@@ -413,67 +433,101 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
   const float sc = a.scale * LOG2E;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
   // a key block that holds only padding receives exactly-zero dK / dV: skip its query loop
   const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
   TileRegs<32, HDP> qr, dr;
-  qr.load(qbase, ld, 0, S - 1, false, tid);
-  dr.load(dobase, a.ld_dout, 0, S - 1, true, tid);       // rows >= S contribute nothing
+  // per-tile row scalars travel with the tile prefetch (one tile ahead, in registers): LSE / delta of row q0 + tid
+  // (threads 0..31) and the keep-bit word of (row q0 + (lane & 31), this wave's 32 keys).  Loaded inside the loop body
+  // they sat between the two barriers with their global latency fully exposed, once per tile.
+  const int dw_ld = 2 * ((S + 63) / 64);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  float lse_n = 1.0e30f, del_n = 0.f;
+  unsigned dw_n = 0xffffffffu;
+  auto prefetch_rows = [&](int q0n) {
+    if (tid < 32) {
+      const int q = q0n + tid;
+      lse_n = q < S ? a.lse[(size_t)bh * S + q] : 1.0e30f;         // P = 0 for rows past the end
+      del_n = q < S ? a.delta[(size_t)bh * S + q] : 0.f;
+    }
+    if (a.drop_thr) {
+      const int qq = q0n + (lane & 31);
+      dw_n = qq < S ? dbits[(size_t)qq * dw_ld] : 0u;
+    }
+  };
+  if (ntiles > 0) {
+    qr.load(qbase, ld, 0, S - 1, false, tid);
+    dr.load(dobase, a.ld_dout, 0, S - 1, true, tid);       // rows >= S contribute nothing
+    prefetch_rows(0);
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = t * 32;
     __syncthreads();
     qr.store(qt, tid);
     dr.store(dot, tid);
-    if (tid < 32) {
-      const int q = q0 + tid;
-      lse_s[tid] = q < S ? a.lse[(size_t)bh * S + q] : 1.0e30f;     // P = 0 for rows past the end
-      del_s[tid] = q < S ? a.delta[(size_t)bh * S + q] : 0.f;
-    }
+    if (tid < 32) { lse_s[tid] = lse_n; del_s[tid] = del_n; }
+    if (lane < 32) dw_s[wave * 32 + lane] = dw_n;
     __syncthreads();
     if (t + 1 < ntiles) {
       qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
       dr.load(dobase, a.ld_dout, q0 + 32, S - 1, true, tid);
-    }
-    // keep-bits of this wave's 32 keys for the 32 query rows of the tile: lane l holds row q0 + (l & 31)
-    unsigned dw = 0xffffffffu;
-    if (a.drop_thr) {
-      const int qq = q0 + (lane & 31);
-      dw = qq < S ? ((const unsigned*)a.drop_bits)[((size_t)bh * S + qq) * (2 * ((S + 63) / 64)) + (key0 >> 5)] : 0u;
+      prefetch_rows(q0 + 32);
     }
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+    // one wave per SIMD: fragment reads run ahead of their MFMAs (see the dQ kernel)
+    {
+      bf16x8 qfr[G::KSTEPS], dfr[G::KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(qt, 0, ks, lane), kf[ks], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(dot, 0, ks, lane), vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < G::KSTEPS; ++ks) { qfr[ks] = row_frag<HDP>(qt, 0, ks, lane); dfr[ks] = row_frag<HDP>(dot, 0, ks, lane); }
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[ks], vf[ks], dp, 0, 0, 0);
+      }
+      constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : 8;
+      __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+      for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
     }
-    // registers 4g..4g+3 are query rows 8g + 4h + (0..3): one 16-B LDS read per group for LSE and delta
+    // registers 4g..4g+3 are query rows 8g + 4h + (0..3): one 16-B LDS read per group for LSE, delta and the keep words
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g4 + 4 * h);
       const f32x4 d4 = *(const f32x4*)(del_s + 8 * g4 + 4 * h);
+      const u32x4 w4 = *(const u32x4*)(dw_s + wave * 32 + 8 * g4 + 4 * h);           // rows q0 + acc_row(4 g4 + i, h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * g4 + i;
         const float p = key_ok ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;
-        float keep_scale = 1.f;
-        if (a.drop_thr) {
-          const unsigned w = (unsigned)__shfl((int)dw, 8 * g4 + 4 * h + i, 64);     // row q0 + acc_row(r, h)
-          keep_scale = ((w >> (lane & 31)) & 1u) ? a.drop_scale : 0.f;
-        }
+        const float keep_scale = ((w4[i] >> (lane & 31)) & 1u) ? dscale : 0.f;
         st[r] = p * keep_scale;                         // Pd
         dp[r] = p * (dp[r] * keep_scale - d4[i]);       // dS
       }
     }
+    {
+      // dV^T += dO^T . Pd and dK^T += Q^T . dS: 4 DBLK transposed fragments (2 reads each), 4 fragments ahead of the MFMAs
+      constexpr int NF = 4 * G::DBLK, AH = 4;
+      const bf16x8 pf[2] = {acc_frag(st, 0), acc_frag(st, 1)}, dsf[2] = {acc_frag(dp, 0), acc_frag(dp, 1)};
+      bf16x8 tf[NF];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = acc_frag(st, s), dsf = acc_frag(dp, s);
-#pragma unroll
-      for (int d = 0; d < G::DBLK; ++d) {
-        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(dot, 16 * s, d * 32, lane), pf, dv[d], 0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(qt, 16 * s, d * 32, lane), dsf, dk[d], 0, 0, 0);
+      for (int i = 0; i < NF; ++i) {
+        const int s2 = i / (2 * G::DBLK), d = (i >> 1) % G::DBLK;
+        tf[i] = (i & 1) ? tr_frag<HDP>(qt, 16 * s2, d * 32, lane) : tr_frag<HDP>(dot, 16 * s2, d * 32, lane);
       }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int s2 = i / (2 * G::DBLK), d = (i >> 1) % G::DBLK;
+        if (i & 1) dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], dsf[s2], dk[d], 0, 0, 0);
+        else dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i], pf[s2], dv[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);
+#pragma unroll
+      for (int i = 0; i < NF - AH; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
     }
   }
   if (key < S) {
@@ -501,7 +555,7 @@ template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
-  const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256;
+  const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256 + 512;
   hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
   hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   dim3 grid(((a->S + 127) / 128) * a->B * a->H);
