@@ -103,13 +103,14 @@ __device__ __forceinline__ unsigned long long key_bits(const uint8_t* __restrict
 // only padding: every probability there is exactly 0, so skipping them leaves all results bit-identical.
 __device__ __forceinline__ int valid_key_limit(const uint8_t* __restrict__ km, int b, int S, int lane) {
   if (km == nullptr) return S;
+  // lane-strided scan with independent loads, then one wave max (a ballot per 64 keys made every load wait for the
+  // previous one: ~S/64 serial global round trips in the prologue of every workgroup)
+  const uint8_t* __restrict__ row = km + (size_t)b * S;
   int limit = 0;
-  for (int k0 = 0; k0 < S; k0 += 64) {
-    const int key = k0 + lane;
-    const bool ok = key < S && km[(size_t)b * S + key] == 0;
-    const unsigned long long bits = __ballot(ok);
-    if (bits) limit = k0 + 64 - __builtin_clzll(bits);
-  }
+#pragma unroll 4
+  for (int k = lane; k < S; k += 64) limit = row[k] == 0 ? k + 1 : limit;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) limit = max(limit, __shfl_xor(limit, o, 64));
   return limit;
 }
 
@@ -316,20 +317,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   // dQ needs Q, dO (B operands) and the dQ^T accumulator resident: > 256 registers, so this kernel runs one wave per
   // SIMD with the full 512-entry file and prefetches the next K/V tile into registers under the MFMA work instead.
   TileRegs<64, HDP> kr, vr;
-  kr.load(kbase, ld, 0, S - 1, false, tid);
-  vr.load(vbase, ld, 0, S - 1, false, tid);
+  // The keep-bit word and the key-validity byte of a tile travel with the tile prefetch, one tile ahead in registers:
+  // vmcnt retires in order, so loading them inside the body (after the 12 prefetch loads were issued) made their
+  // s_waitcnt a vmcnt(0) that exposed the whole prefetch latency in every tile.
+  // (RAW loaded values are carried: any arithmetic on them here would pull their wait up to this point)
+  const uint8_t* kmrow = a.key_mask ? a.key_mask + (size_t)b * S : nullptr;
+  unsigned long long dm_n = ~0ull;
+  uint8_t km_n = 0;
+  if (ntiles > 0) {
+    kr.load(kbase, ld, 0, S - 1, false, tid);
+    vr.load(vbase, ld, 0, S - 1, false, tid);
+    if (a.drop_thr) dm_n = drow[0];
+    if (kmrow) km_n = kmrow[min(lane, S - 1)];
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
     __syncthreads();
     kr.store(kt, tid);
     vr.store(vt, tid);
+    const unsigned long long dm = dm_n >> (4 * h);
+    const unsigned long long vbits = __ballot(kv0 + lane < S && km_n == 0) >> (4 * h);
     __syncthreads();
     if (t + 1 < ntiles) {
       kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
       vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
+      if (a.drop_thr) dm_n = drow[t + 1];
+      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, S - 1)];
     }
-    const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
-    const unsigned long long vbits = key_bits(a.key_mask, b, S, kv0, lane) >> (4 * h);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 st, dp;
@@ -339,14 +353,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       // run AHEAD of the MFMAs that consume them (hipcc's default order was read -> lgkmcnt(0) -> MFMA, one read in
       // flight, i.e. ~110 cycles per 32-cycle MFMA).  A deeper software pipeline across the two halves (MFMAs of one
       // half under the softmax VALU of the other) was tried and spills at 512 registers -- see DESIGN.md.
+      __builtin_amdgcn_sched_barrier(0);        // phases are separate scheduling regions: each group chain sees only its own reads / MFMAs
       bf16x8 kfr[G::KSTEPS], vfr[G::KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < G::KSTEPS; ++ks) { kfr[ks] = row_frag<HDP>(kt, kb * 32, ks, lane); vfr[ks] = row_frag<HDP>(vt, kb * 32, ks, lane); }
+      for (int ks = 0; ks < G::KSTEPS; ++ks) kfr[ks] = row_frag<HDP>(kt, kb * 32, ks, lane);
 #pragma unroll
-      for (int ks = 0; ks < G::KSTEPS; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dp, 0, 0, 0);
-      }
+      for (int ks = 0; ks < G::KSTEPS; ++ks) vfr[ks] = row_frag<HDP>(vt, kb * 32, ks, lane);
+      // (hipcc issues the St chain before the dPt chain whatever the source order: the reads follow that order)
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dp, 0, 0, 0);
       {
         constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : 8;
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
@@ -354,6 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
         for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
       // K^T fragments of the dQ product do not depend on the softmax: issue their reads before the VALU block
       bf16x8 ktf[2][G::DBLK];
 #pragma unroll
@@ -445,16 +463,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
   float lse_n = 1.0e30f, del_n = 0.f;
   unsigned dw_n = 0xffffffffu;
+  // (RAW loaded values are carried, from clamped addresses; the row-validity selects happen when they are stored to
+  // LDS one iteration later -- arithmetic on them here would pull their vmcnt wait up to this point)
   auto prefetch_rows = [&](int q0n) {
     if (tid < 32) {
-      const int q = q0n + tid;
-      lse_n = q < S ? a.lse[(size_t)bh * S + q] : 1.0e30f;         // P = 0 for rows past the end
-      del_n = q < S ? a.delta[(size_t)bh * S + q] : 0.f;
+      const int q = min(q0n + tid, S - 1);
+      lse_n = a.lse[(size_t)bh * S + q];
+      del_n = a.delta[(size_t)bh * S + q];
     }
-    if (a.drop_thr) {
-      const int qq = q0n + (lane & 31);
-      dw_n = qq < S ? dbits[(size_t)qq * dw_ld] : 0u;
-    }
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
   };
   if (ntiles > 0) {
     qr.load(qbase, ld, 0, S - 1, false, tid);
@@ -466,8 +483,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
     __syncthreads();
     qr.store(qt, tid);
     dr.store(dot, tid);
-    if (tid < 32) { lse_s[tid] = lse_n; del_s[tid] = del_n; }
-    if (lane < 32) dw_s[wave * 32 + lane] = dw_n;
+    if (tid < 32) {
+      const bool in = q0 + tid < S;
+      lse_s[tid] = in ? lse_n : 1.0e30f;                     // P = 0 for rows past the end
+      del_s[tid] = in ? del_n : 0.f;
+    }
+    if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < S) ? dw_n : 0u;
     __syncthreads();
     if (t + 1 < ntiles) {
       qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
@@ -512,6 +533,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       // dV^T += dO^T . Pd and dK^T += Q^T . dS: 4 DBLK transposed fragments (2 reads each), 4 fragments ahead of the MFMAs
       constexpr int NF = 4 * G::DBLK, AH = 4;
       const bf16x8 pf[2] = {acc_frag(st, 0), acc_frag(st, 1)}, dsf[2] = {acc_frag(dp, 0), acc_frag(dp, 1)};
+      __builtin_amdgcn_sched_barrier(0);        // own scheduling region: the groups below then only see these reads / MFMAs
       bf16x8 tf[NF];
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
