@@ -252,6 +252,9 @@ typedef struct TfEncoderDesc {
    * descending order on one stream. */
   int bwd_hi, bwd_nlayers;
   const TfOverlap* overlap;     /* null: everything on the caller's stream */
+  int repack;                   /* tf_encoder_fwd only: refresh the bf16 weight shadows first (what tf_encoder_pack does); with an
+                                 * overlap handle only layer 0 is packed on the caller's stream, layers >= 1 and the attention
+                                 * dropout masks are produced on the side stream while the chain already runs layer 0 */
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);

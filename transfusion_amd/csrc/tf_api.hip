@@ -249,32 +249,38 @@ int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncode
   return 0;
 }
 
+}  // extern "C"
+namespace {
+int pack_layer(const Ctx& c, int l, hipStream_t st) {
+  const Dims& D = c.D;
+  unsigned char* w = c.WB(l);
+  const TfLayerParams& p = c.e->p[l];
+  TfPackArgs batch[8];
+  int nb = 0;
+  auto pack = [&](const float* src, int rows, int cols, void* dst, int ld, void* dstT, int ldT, int rows_p, int cols_p, int rg, int rgp,
+                  int cg, int cgp, int f32) {
+    TfPackArgs a{};
+    a.src = src; a.rows = rows; a.cols = cols; a.dst = dst; a.ld_dst = ld; a.dst_t = dstT; a.ld_dst_t = ldT; a.rows_p = rows_p;
+    a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32;
+    batch[nb++] = a;
+  };
+  pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0);
+  pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0);
+  pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0);
+  pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0);
+  pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1);
+  pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+  pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
+  pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+  return tf_launch_pack_batch(batch, nb, st);
+}
+}  // namespace
+extern "C" {
+
 int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s) {
   Ctx c;
   if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_pack");
-  const Dims& D = c.D;
-  for (int l = 0; l < D.L; ++l) {
-    unsigned char* w = c.WB(l);
-    const TfLayerParams& p = e->p[l];
-    TfPackArgs batch[8];
-    int nb = 0;
-    auto pack = [&](const float* src, int rows, int cols, void* dst, int ld, void* dstT, int ldT, int rows_p, int cols_p, int rg, int rgp,
-                    int cg, int cgp, int f32) {
-      TfPackArgs a{};
-      a.src = src; a.rows = rows; a.cols = cols; a.dst = dst; a.ld_dst = ld; a.dst_t = dstT; a.ld_dst_t = ldT; a.rows_p = rows_p;
-      a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32;
-      batch[nb++] = a;
-    };
-    pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0);
-    pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0);
-    pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0);
-    pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0);
-    pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1);
-    pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-    pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
-    pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-    TF_TRY(tf_launch_pack_batch(batch, nb, c.st), "pack layer");
-  }
+  for (int l = 0; l < c.D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
   return 0;
 }
 
@@ -293,8 +299,31 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
   }
+  // ---- side stream: everything of this forward that does not depend on activations (see TfOverlap) ----
+  hipStream_t side = nullptr; hipEvent_t* ev = nullptr;
+  if (e->overlap != nullptr && e->overlap->stream != nullptr) { side = (hipStream_t)e->overlap->stream; ev = (hipEvent_t*)e->overlap->ev; }
+  auto evi = [](int l) { return l < 3 ? l : 3; };    // layers >= 3 share an event: their waits then cover every later record (correct, less overlap)
+  if (e->repack) TF_TRY(pack_layer(c, 0, c.st), "pack layer 0");
+  if (side != nullptr) {
+    TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
+    TF_TRY((int)hipStreamWaitEvent(side, ev[0], 0), "fwd fork");
+    for (int l = 0; l < D.L; ++l) {
+      const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
+      if (dr.thr) {
+        TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, side), "attn_dropmask");
+        TF_TRY((int)hipEventRecord(ev[4 + evi(l)], side), "mask event");
+      }
+      if (e->repack && l + 1 < D.L) {
+        TF_TRY(pack_layer(c, l + 1, side), "pack layer");
+        TF_TRY((int)hipEventRecord(ev[evi(l + 1)], side), "pack event");
+      }
+    }
+  } else if (e->repack) {
+    for (int l = 1; l < D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
+  }
   const float scale = 1.0f / sqrtf((float)D.hd);
   for (int l = 0; l < D.L; ++l) {
+    if (side != nullptr && e->repack && l >= 1) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(l)], 0), "pack wait");
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l];
     const Drop none{0u, 0u, 1.f};
@@ -306,7 +335,8 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
-      if (dr.thr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
+      if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
+      if (dr.thr && side != nullptr) TF_TRY((int)hipStreamWaitEvent(c.st, ev[4 + evi(l)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
     }
     TF_TRY(gemm(c, b + c.A.o, D.dp, w + c.W.wo, D.dp, b + c.A.z1, D.dp, (const float*)(w + c.W.bo), c.X(l), D.dp, nullptr, 0, D.dp, D.dp,

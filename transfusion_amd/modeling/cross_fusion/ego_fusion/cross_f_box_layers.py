@@ -96,9 +96,9 @@ class _EncoderFn(torch.autograd.Function):
         desc.vis_out, desc.vis_out_is_f32 = L.ptr(vis_out), ops._is_f32(vis_out)
         desc.lang_out, desc.lang_out_is_f32 = L.ptr(lang_out), ops._is_f32(lang_out)
         st = ops._stream()
-        if mod._wpack_dirty():
-            L.call("tf_encoder_pack", desc, st)
+        desc.repack = 1 if mod._wpack_dirty() else 0     # bf16 weight shadows are refreshed inside the forward call
         L.call("tf_encoder_fwd", desc, st)
+        desc.repack = 0
         ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
         ctx.io = (x.dtype, lang.dtype, x.requires_grad, lang.requires_grad)
         ctx.nparams = len(params)
