@@ -143,6 +143,36 @@ def kernel_census(B, device, reps=20):
 
 
 
+def traced_kernels(trainer, batch, nsteps):
+    """Per-kernel durations IN SITU: `nsteps` further training steps with the library's launch tracer on (a HIP event pair
+    around every kernel, on the stream it is launched on -- the side stream for the overlapped weight-gradient GEMMs).
+    Aggregated by kernel symbol, i.e. the rows of `rocprofv3 --kernel-trace --stats` for the same command."""
+    import ctypes
+    from transfusion_amd import _lib as Lb
+    lib = Lb.load()
+    Lb.check(lib.tf_trace_start(), "tf_trace_start")
+    for _ in range(nsteps):
+        trainer.step([batch], loss_fn)
+    cap = 1 << 14
+    recs = (Lb.TfTraceRecord * cap)()
+    n = lib.tf_trace_stop(ctypes.addressof(recs), cap)
+    if n < 0:
+        Lb.check(int(n), "tf_trace_stop")
+    by = {}
+    for i in range(min(n, cap)):
+        r = recs[i]
+        a = by.setdefault(r.name.decode(), dict(us=0.0, launches=0, flops=0.0, bytes=0.0, side=0))
+        a["us"] += r.us; a["launches"] += 1; a["flops"] += r.flops; a["bytes"] += r.bytes; a["side"] += r.side
+    rows = []
+    for name, a in by.items():
+        rows.append(dict(kernel=name, avg_us=round(a["us"] / a["launches"], 2), launches_per_step=round(a["launches"] / nsteps, 2),
+                         us_per_step=round(a["us"] / nsteps, 1), tflops=round(a["flops"] / a["us"] / 1e6, 1) if a["flops"] else None,
+                         gbs=round(a["bytes"] / a["us"] / 1e3, 1) if a["bytes"] else None, side_stream=a["side"] > 0,
+                         flops_per_launch=a["flops"] / a["launches"], bytes_per_launch=a["bytes"] / a["launches"]))
+    rows.sort(key=lambda r: -r["us_per_step"])
+    return rows
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle (a port of the reference arithmetic) timed on this host: forward + backward of the same
     4-layer encoder with dropout masks drawn on the host (as the reference does), B=2 samples per step."""
@@ -196,7 +226,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-census", action="store_true")
+    ap.add_argument("--no-census", action="store_true", help="skip the traced steps / kernel table / roofline object")
+    ap.add_argument("--trace-steps", type=int, default=5)
+    ap.add_argument("--isolated-census", action="store_true", help="also time every kernel alone (back-to-back launches of one kernel)")
     ap.add_argument("--grad-clip", type=float, default=1.0)
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     args = ap.parse_args()
@@ -276,40 +308,35 @@ def main():
         "final_loss": round(final_loss, 5),
     }
     if rank == 0 and not args.no_census:
-        census = kernel_census(args.batch, device)
-        total = sum(c["us_per_step"] for c in census)
-        for c in sorted(census, key=lambda c: -c["us_per_step"]):
-            log(f"  {c['kernel']:28s} {c['us']:9.1f} us x{c['launches_per_step']:3d} = {c['us_per_step']:8.1f} us/step  "
-                f"{'' if c['tflops'] is None else str(c['tflops']) + ' TF/s':>12s}  {c['gbs']:8.1f} GB/s(alg)")
-        log(f"  census total {total:.0f} us/step vs measured step {ms * 1e3:.0f} us")
-        # aggregate by kernel symbol (what rocprofv3 --stats reports): the dominant kernel is the one with the largest time per step
-        by_sym = {}
-        for c in census:
-            a = by_sym.setdefault(c["symbol"], dict(us=0.0, launches=0, flops=0.0, bytes=0.0))
-            a["us"] += c["us"] * c["launches_per_step"]
-            a["launches"] += c["launches_per_step"]
-            a["flops"] += c["flops"] * c["launches_per_step"]
-            a["bytes"] += c["bytes"] * c["launches_per_step"]
-        sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["us"])
-        avg_us = dom["us"] / dom["launches"]
+        # in-situ kernel table: traced steps run AFTER the timed region (two event records per launch would perturb it)
+        rows = traced_kernels(trainer, batch, args.trace_steps)
+        total = sum(r["us_per_step"] for r in rows)
+        for r in rows:
+            log(f"  {r['kernel']:34s} {r['avg_us']:9.1f} us x{r['launches_per_step']:6.1f} = {r['us_per_step']:8.1f} us/step  "
+                f"{'' if r['tflops'] is None else str(r['tflops']) + ' TF/s':>12s} {'' if r['gbs'] is None else str(r['gbs']) + ' GB/s':>12s}"
+                f"{'  [side stream]' if r['side_stream'] else ''}")
+        log(f"  sum of kernel durations {total:.0f} us/step (streams overlap) vs measured step {ms * 1e3:.0f} us")
+        dom = rows[0]                                            # the kernel symbol with the largest time per step
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")          # PMC-derived HBM bytes per launch, measured offline
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, measured offline
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(sym, {}).get("hbm_bytes_per_launch")
-        if dom["flops"]:
-            ach = dom["flops"] / dom["us"] / 1e6
-            result["roofline"] = {"kernel": sym, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 1),
-                                  "launches_per_step": dom["launches"],
-                                  "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-                                  "us_per_step": round(dom["us"], 1)}
+            traffic = json.load(open(tpath)).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+        if dom["tflops"] is not None:
+            result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                                  "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
+                                  "algorithmic_flops_per_launch": dom["flops_per_launch"], "us_per_step": dom["us_per_step"],
+                                  "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
         else:
-            ach = dom["bytes"] / dom["us"] / 1e3
-            result["roofline"] = {"kernel": sym, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 1),
-                                  "launches_per_step": dom["launches"],
-                                  "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "us_per_step": round(dom["us"], 1)}
-        result["kernels"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
+            result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round((dom["gbs"] or 0.0) / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_us": dom["avg_us"],
+                                  "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                                  "us_per_step": dom["us_per_step"],
+                                  "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
+        result["kernels"] = [{k: r[k] for k in ("kernel", "avg_us", "launches_per_step", "us_per_step", "tflops", "gbs", "side_stream")} for r in rows]
+        if args.isolated_census:
+            census = kernel_census(args.batch, device)
+            result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -265,6 +265,19 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);
  * "z2_<l>", "dqkv", ...) as fp32 [rows, cols] into dst; returns rows*cols (cols = padded width) or < 0 */
 long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s);
 
+/* ---- launch tracer (measurement only) ----
+ * Between tf_trace_start and tf_trace_stop every kernel launch of this library is bracketed by a HIP event pair on
+ * the stream it is launched on, so durations are the kernels' own, in situ (side-stream overlap included) -- the same
+ * quantity rocprofv3 --kernel-trace reports.  bench.py uses it for the `roofline` object.  Process-wide, one tracer. */
+typedef struct TfTraceRecord {
+  char name[56];                /* kernel symbol as rocprofv3 prints it (short form) */
+  float us;                     /* duration of this launch */
+  int side;                     /* 1: launched on a TfOverlap side stream */
+  double flops, bytes;          /* algorithmic work of this launch (SURVEY.md 8(d) accounting; 0 where not applicable) */
+} TfTraceRecord;
+int tf_trace_start(void);
+long long tf_trace_stop(TfTraceRecord* out, long long cap);   /* device sync; returns the number of launches recorded (<= cap are written) */
+
 #ifdef __cplusplus
 }
 #endif

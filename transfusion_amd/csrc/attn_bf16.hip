@@ -17,6 +17,7 @@
 // LDS tiles are "dual use": row stride == 64 (mod 256) bytes and 16-B chunk ^= (row>>2)&3 make both the
 // row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16) bank-conflict free.
 #include "tf_common.h"
+#include <cstdio>
 #include "tf_kernels.h"
 
 namespace {
@@ -572,17 +573,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 128 * Geo<HDP>::TSTR;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once;
+  char nm[56];
+  snprintf(nm, sizeof(nm), "attn_fwd_kernel<%d>", HDP);
+  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)a->S * a->S * HDP);
   hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3(((a->S + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256 + 512;
-  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  static const hipError_t once_q = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+  static const hipError_t once_kv = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  (void)once_q; (void)once_kv;
   dim3 grid(((a->S + 127) / 128) * a->B * a->H);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, grid, dim3(256), lds_kv, st, *a);
+  // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
+  const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;
+  char nm[56];
+  {
+    snprintf(nm, sizeof(nm), "attn_bwd_dq_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
+  }
+  {
+    snprintf(nm, sizeof(nm), "attn_bwd_dkv_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, grid, dim3(256), lds_kv, st, *a);
+  }
   return (int)hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 // residual) works on 16-B row chunks and HBM sees full 256-B row segments.
 #include <cstdlib>
 #include "tf_common.h"
+#include <cstdio>
 #include "tf_kernels.h"
 
 namespace {
@@ -560,10 +561,18 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
   static const int bk32 = getenv("TF_GEMM_BK32") ? atoi(getenv("TF_GEMM_BK32")) : 0;    // experiment switches
   static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
+  const double fl = 2.0 * a->M * a->N * a->K;
   if (bk32) return launch_gemm_mi<4, 32>(a, stream);
   if (big && a->M >= 2048 && a->N >= 256) {
-    return pick_mf(a->M, a->N) == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+    const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    char nm[56];
+    snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
+    TfTraceScope tr(nm, stream, fl);
+    return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
   }
+  char nm[56];
+  snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64>", a->epilogue, pick_mi(a->M, a->N));
+  TfTraceScope tr(nm, stream, fl);
   switch (pick_mi(a->M, a->N)) {
     case 5: return launch_gemm_mi<5, 64>(a, stream);
     case 6: return launch_gemm_mi<6, 64>(a, stream);
@@ -594,6 +603,7 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 32;
   splits = (a.M + a.m_chunk - 1) / a.m_chunk;
   dim3 grid(tiles * splits), block(256);
+  TfTraceScope tr("wgrad_tn_kernel", stream, 2.0 * a.M * a.N * a.K);
   hipLaunchKernelGGL(wgrad_tn_kernel, grid, block, 4 * TILE_BYTES, stream, a);
   return (int)hipGetLastError();
 }

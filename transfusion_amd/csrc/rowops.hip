@@ -86,9 +86,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 // Waves stride over rows keeping their dgamma/dbeta partials in registers; one LDS reduction per
 // block, then fp32 atomics (2*d per block).
 // ------------------------------------------------------------------------------------------------
-template <int MAXC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
-  __shared__ float red[4][64 * MAXC * 8];
+// LNB_WAVES waves per workgroup, one row per wave per pass: the kernel is a dependent load -> reduce -> store chain per
+// row, so its HBM rate is set by rows in flight (4-wave blocks at the 512-block cap ran 2 waves per SIMD: 3.2 TB/s)
+template <int MAXC, int LNB_WAVES>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a) {
+  __shared__ float red[LNB_WAVES][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[MAXC][8], db[MAXC][8];
 #pragma unroll
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
 
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < a.rows; row += gridDim.x * LNB_WAVES) {
     const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
     const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
     const float mean = a.mean[row], rstd = a.rstd[row];
@@ -159,8 +161,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TfLnArgs a) {
       for (int e = 0; e < 8; ++e) red[wave][(lane + 64 * i) * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
     __syncthreads();
     float* dst = pass == 0 ? a.dgamma : a.dbeta;
-    for (int c = threadIdx.x; c < a.d; c += 256) {
-      const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    for (int c = threadIdx.x; c < a.d; c += 64 * LNB_WAVES) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) t += red[w][c];
       atomicAdd(dst + c, t);
     }
     __syncthreads();
@@ -462,6 +466,7 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   const dim3 grid((a->rows + 3) / 4);
   const int width = max(a->d, a->y_is_f32 ? a->d : a->ldy);      // columns a lane set must cover (payload + zeroed pad)
   if (width > 64 * MAXC_MAX * 8) return -2;
+  TfTraceScope tr("ln_fwd_kernel", st, 0.0, 4.0 * a->rows * a->d);
   if (width <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (width <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, st, *a);
@@ -470,18 +475,23 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
 extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
-  const dim3 grid(grid_for(a->rows, 4 * 4, 512));      // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
   const int width = max(a->d, max(a->lddx, a->dx_drop != nullptr ? a->lddxd : 0));
   if (width > 64 * MAXC_MAX * 8) return -2;
-  if (width <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
-  else if (width <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
-  else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
+  static const int env_w = getenv("TF_LNB_WAVES") ? atoi(getenv("TF_LNB_WAVES")) : 8;     // experiment switch: 16 waves measured slower (39.9 vs 38.3 us)
+  const int nw = (width <= 1024 && env_w == 16) ? 16 : 8;   // 16 waves where the reduction array fits the 64 KiB static LDS
+  const dim3 grid(grid_for(a->rows, nw * 2, 512));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
+  TfTraceScope tr("ln_bwd_kernel", st, 0.0, (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
+  const dim3 block(64 * nw);
+  if (width <= 512) { if (nw == 16) hipLaunchKernelGGL((ln_bwd_kernel<1, 16>), grid, block, 0, st, *a); else hipLaunchKernelGGL((ln_bwd_kernel<1, 8>), grid, block, 0, st, *a); }
+  else if (width <= 1024) { if (nw == 16) hipLaunchKernelGGL((ln_bwd_kernel<2, 16>), grid, block, 0, st, *a); else hipLaunchKernelGGL((ln_bwd_kernel<2, 8>), grid, block, 0, st, *a); }
+  else hipLaunchKernelGGL((ln_bwd_kernel<4, 8>), grid, block, 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
   const int rows = a->B * (a->Nv + a->Nl);
   if (rows <= 0) return 0;
   if ((a->d % 8) || (a->ld_out % 8) || (a->ld_vis % 8) || (a->ld_lang % 8)) return -2;
+  TfTraceScope tr("assemble_fwd_kernel", st);
   hipLaunchKernelGGL(assemble_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
@@ -490,6 +500,7 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   if (rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
   const dim3 grid(grid_for(rows, 4 * 8, 512));
+  TfTraceScope tr("assemble_bwd_kernel", st, 0.0, 0.0);
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(assemble_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
@@ -499,6 +510,7 @@ extern "C" int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int
                                     int HDP, hipStream_t st) {
   const long long threads = (long long)B * S * H * 8;
   if (threads <= 0) return 0;
+  TfTraceScope tr("attn_delta_kernel", st);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const u16*)o, ldo,
                      (const u16*)d_o, lddo, delta, B, S, H, HDP);
   return (int)hipGetLastError();
@@ -514,6 +526,7 @@ extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) 
     gx = max(gx, (a[i].cols_p + 63) / 64);
     gy = max(gy, (a[i].rows_p + 63) / 64);
   }
+  TfTraceScope tr("pack_kernel", st);
   hipLaunchKernelGGL(pack_kernel, dim3(gx, gy, n), dim3(256), 0, st, pb);
   return (int)hipGetLastError();
 }
@@ -524,18 +537,21 @@ extern "C" int tf_launch_pack(const TfPackArgs* a, hipStream_t st) {
 extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
   if ((a->cols % 8) || (a->ld_src % 8) || (a->ld_dst % 8)) return -2;
+  TfTraceScope tr("copy_rows_kernel", st);
   hipLaunchKernelGGL(copy_rows_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {
   const int n = B * (Nv + Nl);
   if (n <= 0) return 0;
+  TfTraceScope tr("key_mask_kernel", st);
   hipLaunchKernelGGL(key_mask_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, st, lm, km, B, Nv, Nl);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t st) {
   if (n <= 0) return 0;
   if (n % 8) return -2;
+  TfTraceScope tr("dropout_apply_kernel", st);
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const u16*)x, (u16*)y, n / 8, key, thr, scale);
   return (int)hipGetLastError();
 }
@@ -545,44 +561,52 @@ extern "C" int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned
   if (nrows <= 0) return 0;
   if (nrows * S >= (1ll << 32)) return -5;
   const long long n = nrows * SW32;
+  TfTraceScope tr("attn_dropmask_kernel", st);
   hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)bits, nrows, S, SW32, key, thr);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t st) {
   if (n <= 0) return 0;
+  TfTraceScope tr("dropout_mask_kernel", st);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, n, key, thr);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_cast_f32_bf16(const float* s, void* d, long long n, hipStream_t st) {
   if (n <= 0) return 0;
+  TfTraceScope tr("cast_f32_bf16_kernel", st);
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, s, (u16*)d, n);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_cast_bf16_f32(const void* s, float* d, long long n, hipStream_t st) {
   if (n <= 0) return 0;
+  TfTraceScope tr("cast_bf16_f32_kernel", st);
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const u16*)s, d, n);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
   if (a->n <= 0) return 0;
+  TfTraceScope tr("radam_kernel", st);
   hipLaunchKernelGGL(radam_kernel, dim3(grid_for(a->n, 256 * 4)), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) {
   if (n <= 0) return 0;
   if (((size_t)x & 15) != 0) return -2;
+  TfTraceScope tr("sumsq_kernel", st);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16, 512)), dim3(256), 0, st, x, n, out);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
   if (total <= 0) return 0;
+  TfTraceScope tr("im2col_kernel", st);
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t st) {
   const long long total = (long long)a->B * a->C * a->H * a->W;
   if (total <= 0) return 0;
+  TfTraceScope tr("col2im_kernel", st);
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a, out_is_f32);
   return (int)hipGetLastError();
 }

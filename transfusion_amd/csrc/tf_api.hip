@@ -6,6 +6,8 @@
 #include <cstring>
 #include <cmath>
 #include "tf_kernels.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -17,6 +19,12 @@ int fail(int code, const char* what) {
   return code;
 }
 #define TF_TRY(expr, what) do { const int rc__ = (expr); if (rc__ != 0) return fail(rc__, what); } while (0)
+
+struct TraceRec { char name[56]; hipEvent_t e0, e1; hipStream_t st; double flops, bytes; };
+std::mutex g_trace_mu;
+bool g_trace_on = false;
+std::vector<TraceRec> g_trace;
+std::vector<hipStream_t> g_trace_sides;
 
 inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 constexpr int BIG = 1 << 28;
@@ -169,12 +177,42 @@ extern "C" {
 
 int tf_version(void) { return TF_ABI_VERSION; }
 
+int tf_trace_start(void) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  for (auto& r : g_trace) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_trace.clear();
+  g_trace_on = true;
+  return 0;
+}
+long long tf_trace_stop(TfTraceRecord* out, long long cap) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace_on = false;
+  TF_TRY((int)hipDeviceSynchronize(), "tf_trace_stop(sync)");
+  long long n = 0;
+  for (auto& r : g_trace) {
+    if (out != nullptr && n < cap) {
+      TfTraceRecord& o = out[n];
+      memset(&o, 0, sizeof(o));
+      strncpy(o.name, r.name, sizeof(o.name) - 1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+      o.us = ms * 1e3f; o.flops = r.flops; o.bytes = r.bytes;
+      for (hipStream_t sd : g_trace_sides) if (sd == r.st) o.side = 1;
+    }
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    ++n;
+  }
+  g_trace.clear();
+  return n;
+}
+
 int tf_overlap_create(TfOverlap* o) {
   if (o == nullptr) return fail(-1, "tf_overlap_create");
   memset(o, 0, sizeof(*o));
   hipStream_t st = nullptr;
   TF_TRY((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "tf_overlap_create(stream)");
   o->stream = st;
+  tf_trace_mark_side(st);
   for (int i = 0; i < 8; ++i) {
     hipEvent_t ev = nullptr;
     TF_TRY((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming), "tf_overlap_create(event)");
@@ -250,6 +288,27 @@ int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncode
 }
 
 }  // extern "C"
+TfTraceScope::TfTraceScope(const char* name, hipStream_t stream, double flops, double bytes) : idx(-1), st(stream) {
+  if (!g_trace_on) return;
+  TraceRec r{};
+  strncpy(r.name, name, sizeof(r.name) - 1);
+  r.st = stream; r.flops = flops; r.bytes = bytes;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, stream);
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.push_back(r);
+  idx = (long long)g_trace.size() - 1;
+}
+TfTraceScope::~TfTraceScope() {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  if (idx < (long long)g_trace.size()) (void)hipEventRecord(g_trace[idx].e1, st);
+}
+void tf_trace_mark_side(hipStream_t side) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  for (hipStream_t s : g_trace_sides) if (s == side) return;
+  g_trace_sides.push_back(side);
+}
 namespace {
 int pack_layer(const Ctx& c, int l, hipStream_t st) {
   const Dims& D = c.D;

@@ -33,3 +33,14 @@ int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t stream); 
 #ifdef __cplusplus
 }
 #endif
+
+#ifdef __cplusplus
+// Launch tracer hook (see tf_trace_start in tfusion.h): a scope object around one kernel launch.  Costs one predictable
+// branch when tracing is off.
+struct TfTraceScope {
+  long long idx; hipStream_t st;
+  TfTraceScope(const char* name, hipStream_t stream, double flops = 0.0, double bytes = 0.0);
+  ~TfTraceScope();
+};
+void tf_trace_mark_side(hipStream_t side);
+#endif
