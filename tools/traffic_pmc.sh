@@ -1,0 +1,35 @@
+#!/bin/bash
+# HBM bytes per launch of every kernel of a training step: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over
+# bench.py, bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section).
+# usage (on the GPU box): tools/traffic_pmc.sh  -> gpurun_out/traffic.json
+out=/root/repo/gpurun_out/pmc_traffic
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o t -- python /root/repo/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline > $out.$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out.$c.log; exit 1; }
+  echo "pass $c done"
+done
+python3 - $out <<'PY'
+import csv, sys, json, glob, collections, re
+out = sys.argv[1]
+acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+cnt = {c: collections.Counter() for c in ("FETCH_SIZE", "WRITE_SIZE")}
+for c in acc:
+    f = glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != c: continue
+        k = r["Kernel_Name"]
+        k = re.sub(r"^void ", "", k); k = k.replace("(anonymous namespace)::", ""); k = k.split("(")[0]
+        acc[c][k] += float(r["Counter_Value"]); cnt[c][k] += 1
+res = {}
+for k in acc["FETCH_SIZE"]:
+    n = cnt["FETCH_SIZE"][k]
+    if n == 0 or cnt["WRITE_SIZE"][k] == 0: continue
+    rd = 2.0 * acc["FETCH_SIZE"][k] / n * 1024; wr = acc["WRITE_SIZE"][k] / cnt["WRITE_SIZE"][k] * 1024
+    res[k] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr), "launches_sampled": n}
+res["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; bytes = (2*FETCH_SIZE + "
+               "WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B per 128-B request: MI355X_MICROARCH.md, HBM); mean over all launches of the symbol; "
+               "counter mode serialises the kernels, so side-stream overlap does not mix their traffic")
+json.dump(res, open("/root/repo/gpurun_out/traffic.json", "w"), indent=1)
+for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] if isinstance(kv[1], dict) else 0)):
+    if isinstance(v, dict) and ("kernel" in k or "Kernel" in k): print(f"{k:44s} {v['hbm_bytes_per_launch']/1e6:9.1f} MB  (rd {v['read_bytes']/1e6:8.1f} wr {v['write_bytes']/1e6:8.1f}) x{v['launches_sampled']}")
+PY
