@@ -102,6 +102,10 @@ def test_wgrad(dev, M, N, K, grouped):
         idx = torch.tensor([i for i in range(N) if i % rgp < rg])
         assert rel(dW, ref[idx]) < 1e-4
         assert rel(db, refb[idx]) < 1e-4
+        # caller-sized M-splits select the 256x128-tile kernel (the one the encoder runtime's side stream uses)
+        ops.wgrad(dY, N, X, K, dW, db, rg=rg, rgp=rgp, n_src=n_src, m_chunk=96)
+        assert rel(dW, 2 * ref[idx]) < 1e-4
+        assert rel(db, 2 * refb[idx]) < 1e-4
 
 
 def _attn_ref(qkv, B, S, H, hd, hdp, key_mask, keep=None, p=0.0):

@@ -462,6 +462,164 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, 256(n) x 128(k) tile: 4 waves (2x2) of 128x64 = 4x2 v_mfma_f32_32x32x16_bf16 per 16-row substep.
+// Why: with the 64x64 wave tile of wgrad_tn_kernel every MFMA needs two operand fragments = 1 KiB of LDS reads, i.e.
+// 128 B/clk per CU at MFMA peak -- exactly the LDS limit.  A 128x64 wave tile reads 6 fragments per 8 MFMAs (0.75 KiB
+// per MFMA).  Slot = dY [32][256] (512-B rows) | X [32][128] (256-B rows) = 24 KiB, 3-slot ring = 72 KiB -> two
+// workgroups per CU.  Same swizzle rule for both row widths: 16-B chunk ^= (row & 3) << 2 (bits 2-3 of the chunk index).
+// Bias grad: ONE extra accumulator for all four n-blocks -- D += SEL_nb . dYfrag_nb with SEL_nb[i][m] = (i >> 3 == nb),
+// so rows 8nb..8nb+7 of the 32x32 result (= accumulator registers 4nb..4nb+3) hold the column sums of n-block nb.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) {
+  constexpr int STEP = 32, YB = STEP * 512, XB = STEP * 256, SLOT = YB + XB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_k = (g.K + 127) / 128;
+  const int tiles = tiles_k * ((g.N + 255) / 256);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);       // an XCD owns a contiguous (split, tile) range, k-tile fastest
+  const int tile = logical % tiles, split = logical / tiles;
+  const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 128;
+  const int m_begin = split * g.m_chunk;
+  const int m_end = min(g.M, m_begin + g.m_chunk);
+  const int nsteps = (m_end - m_begin + STEP - 1) / STEP;
+  const unsigned char* __restrict__ dY = (const unsigned char*)g.dY;
+  const unsigned char* __restrict__ X = (const unsigned char*)g.X;
+  const unsigned char* __restrict__ Z = (const unsigned char*)g.zeros;
+
+  // one step = 16 KiB of dY (16 wave-instructions of 2 rows) + 8 KiB of X (8 of 4 rows): 6 per wave
+  auto stage = [&](int slot, int st) {
+    unsigned char* ybase = smem + slot * SLOT;
+    unsigned char* xbase = ybase + YB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = i * 4 + wave;
+      const int r = 2 * j + (lane >> 5);
+      const int c = (lane & 31) ^ ((r & 3) << 2);
+      const int gm = m_begin + st * STEP + r;
+      const int cn = min(n0 + c * 8, g.N - 8);                                   // clamp: never stored
+      const unsigned char* sy = gm < m_end ? dY + ((size_t)gm * g.ldy + cn) * 2 : Z + (c & 15) * 16;
+      glds16(sy, ybase + j * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = i * 4 + wave;
+      const int r = 4 * j + (lane >> 4);
+      const int c = (lane & 15) ^ ((r & 3) << 2);
+      const int gm = m_begin + st * STEP + r;
+      const int ck = min(k0 + c * 8, g.K - 8);
+      const unsigned char* sx = gm < m_end ? X + ((size_t)gm * g.ldx + ck) * 2 : Z + c * 16;
+      glds16(sx, xbase + j * 1024);
+    }
+  };
+
+  f32x16 acc[4][2], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+  }
+  const bool has_bias = g.db != nullptr;
+  const int bias_mod = 2 * tiles_k;                            // k-tile blocks x wave columns share one n-range: take turns
+  int bias_cnt = 2 * (tile % tiles_k) + wc;
+  bf16x8 sel[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sel[nb][e] = (((lane & 31) >> 3) == nb) ? (__bf16)1.0f : (__bf16)0.0f;
+
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int h = grp >> 1, cb = grp & 1;
+  const int sw = q << 2, o8 = (p & 1) * 8;
+  const int yoff = (8 * h + q) * 512 + (((wr * 16 + cb * 2 + (p >> 1)) ^ sw) << 4) + o8;        // n-block nb: ^ (nb * 64)
+  const int xoff = YB + (8 * h + q) * 256 + (((wc * 8 + cb * 2 + (p >> 1)) ^ sw) << 4) + o8;    // k-block kb: ^ (kb * 64)
+
+  const unsigned lds_base = lds_addr_of(smem);
+  if (nsteps > 0) {
+    stage(0, 0);
+    stage(1, min(1, nsteps - 1));
+  }
+  int slot = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    // retire step st's transfers (issued two phases ago; 6 per wave per step), make them visible, recycle slot (st+2)%3
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    const unsigned sl = lds_base + slot * SLOT;
+    u64 y0[4][2], x0[2][2], y1[4][2], x1[2][2];               // [block][row half] of substep 0 / 1
+#define TF_RD(Y, Xv, MS)                                                                                  \
+    Y[0][0] = tr_read_asm<(MS) * 8192>(sl + yoff);            Y[0][1] = tr_read_asm<(MS) * 8192 + 2048>(sl + yoff);            \
+    Xv[0][0] = tr_read_asm<(MS) * 4096>(sl + xoff);           Xv[0][1] = tr_read_asm<(MS) * 4096 + 1024>(sl + xoff);           \
+    Y[1][0] = tr_read_asm<(MS) * 8192>(sl + (yoff ^ 64));     Y[1][1] = tr_read_asm<(MS) * 8192 + 2048>(sl + (yoff ^ 64));     \
+    Xv[1][0] = tr_read_asm<(MS) * 4096>(sl + (xoff ^ 64));    Xv[1][1] = tr_read_asm<(MS) * 4096 + 1024>(sl + (xoff ^ 64));    \
+    Y[2][0] = tr_read_asm<(MS) * 8192>(sl + (yoff ^ 128));    Y[2][1] = tr_read_asm<(MS) * 8192 + 2048>(sl + (yoff ^ 128));    \
+    Y[3][0] = tr_read_asm<(MS) * 8192>(sl + (yoff ^ 192));    Y[3][1] = tr_read_asm<(MS) * 8192 + 2048>(sl + (yoff ^ 192));
+    TF_RD(y0, x0, 0)
+    TF_RD(y1, x1, 1)
+#undef TF_RD
+    // (after the reads: hipcc orders an LDS-DMA before any LATER LDS read with a vmcnt(0), it cannot tell the slots apart)
+    const int nslot = slot == 0 ? 2 : slot - 1;                // (st + 2) % 3 given slot = st % 3
+    stage(nslot, min(st + 2, nsteps - 1));
+    slot = slot == 2 ? 0 : slot + 1;
+    auto substep = [&](u64 (&Y)[4][2], u64 (&Xv)[2][2]) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) af[nb] = join_tr64(Y[nb][0], Y[nb][1]);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) bfr[kb] = join_tr64(Xv[kb][0], Xv[kb][1]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+      const bool my_turn = has_bias && bias_cnt == 0;          // wave-uniform
+      bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
+      if (my_turn) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[nb], af[nb], accb, 0, 0, 0);
+      }
+    };
+    // substep 0 may start when its 12 reads are back (the 12 of substep 1 still in flight)
+    asm volatile("s_waitcnt lgkmcnt(12)"
+                 : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(y0[1][0]), "+v"(y0[1][1]), "+v"(y0[2][0]), "+v"(y0[2][1]), "+v"(y0[3][0]),
+                   "+v"(y0[3][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    substep(y0, x0);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(y1[1][0]), "+v"(y1[1][1]), "+v"(y1[2][0]), "+v"(y1[2][1]), "+v"(y1[3][0]),
+                   "+v"(y1[3][1]), "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    substep(y1, x1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the workgroup retires
+
+  // ---- epilogue: fp32 atomics into the (unpadded) parameter-layout gradient ----
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int np = n0 + wr * 128 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int ng = np / g.rgp, ne = np - ng * g.rgp;
+      const int ns = ng * g.rg + ne;
+      const bool nok = (np < g.N) && (ne < g.rg) && (ns < g.n_src);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int kp = k0 + wc * 64 + kb * 32 + (lane & 31);
+        const int kg = kp / g.cgp, ke = kp - kg * g.cgp;
+        const int ks = kg * g.cg + ke;
+        if (nok && kp < g.K && ke < g.cg && ks < g.k_src) atomicAdd(g.dW + (size_t)ns * g.lddw + ks, acc[nb][kb][r]);
+      }
+    }
+    if (has_bias && lane < 32) {                                 // column sums of n-block nb: accumulator rows 8nb.. = register 4nb
+      const int np = n0 + wr * 128 + nb * 32 + lane;
+      const int ng = np / g.rgp, ne = np - ng * g.rgp;
+      const int ns = ng * g.rg + ne;
+      if (np < g.N && ne < g.rg && ns < g.n_src) atomicAdd(g.db + ns, accb[4 * nb]);
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -580,20 +738,36 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   }
 }
 
+namespace {
+// 1: 128x128 tile, 2: 256x128 tile.  Default: the caller that sizes the M-splits itself (the encoder runtime, whose wgrads
+// share the chip with the backward chain on a side stream) gets the 256x128 kernel -- same-box whole-step A/B 5056 -> 5150
+// samples/s; a wgrad that has the chip to itself needs more, smaller blocks to keep two workgroups on every CU (isolated:
+// qkv 121 us with 128x128 vs 161 us with 256x128) and keeps the 128x128 kernel.
+int wgrad_version(bool caller_sized) {
+  static const int v = getenv("TF_WGRAD_V") ? atoi(getenv("TF_WGRAD_V")) : 0;
+  return v ? v : (caller_sized ? 2 : 1);
+}
+}  // namespace
+// number of output tiles of the active wgrad kernel (the encoder runtime sizes its M-splits from it)
+extern "C" int tf_wgrad_tiles(int N, int K, int caller_sized) {
+  return wgrad_version(caller_sized != 0) == 2 ? ((N + 255) / 256) * ((K + 127) / 128) : ((N + 127) / 128) * ((K + 127) / 128);
+}
+
 extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   TfWgradArgs a = *a_in;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
   if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8) || a.zeros == nullptr) return -2;
   if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
-  const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
+  const int v2 = wgrad_version(a.m_chunk > 0) == 2;
+  const int tiles = tf_wgrad_tiles(a.N, a.K, a.m_chunk > 0);
   const int steps = (a.M + 31) / 32;
   // Every split adds one full fp32 |dW| of atomic traffic (chip-wide ~1.3 TB/s), so use the FEWEST splits that
-  // still give one resident wave of blocks: 256 CUs x 2 blocks (64 KiB LDS each).
+  // still give one resident wave of blocks: 256 CUs x 2 blocks.
   static const int env_slots = getenv("TF_WGRAD_SLOTS") ? atoi(getenv("TF_WGRAD_SLOTS")) : 0;   // experiment switches
   static const int env_splits = getenv("TF_WGRAD_SPLITS") ? atoi(getenv("TF_WGRAD_SPLITS")) : 0;
-  // Measured on MI355X (M = 22656): the best block count grows with the tile count -- 36 tiles: ~6 splits (216 blocks),
-  // 72: 5-6 (360-432), 108: 4 (432) -- i.e. about 200 + 2.15 * tiles blocks, never more than one resident wave.
-  int target = env_slots > 0 ? env_slots : (int)(200 + 2.15 * tiles);
+  // Measured on MI355X (M = 22656, 128x128 tiles): the best block count grows with the tile count -- 36 tiles: ~6 splits
+  // (216 blocks), 72: 5-6 (360-432), 108: 4 (432) -- i.e. about 200 + 2.15 * tiles blocks, never more than one resident wave.
+  int target = env_slots > 0 ? env_slots : (v2 ? 288 : (int)(200 + 2.15 * tiles));
   if (target > 2 * num_cus()) target = 2 * num_cus();
   int splits = a.m_chunk > 0 ? (a.M + a.m_chunk - 1) / a.m_chunk : (target + tiles / 2) / tiles;
   while (a.m_chunk <= 0 && splits > 1 && splits * tiles > 2 * num_cus()) --splits;
@@ -603,7 +777,14 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 32;
   splits = (a.M + a.m_chunk - 1) / a.m_chunk;
   dim3 grid(tiles * splits), block(256);
-  TfTraceScope tr("wgrad_tn_kernel", stream, 2.0 * a.M * a.N * a.K);
-  hipLaunchKernelGGL(wgrad_tn_kernel, grid, block, 4 * TILE_BYTES, stream, a);
+  TfTraceScope tr(v2 ? "wgrad_tn2_kernel" : "wgrad_tn_kernel", stream, 2.0 * a.M * a.N * a.K);
+  if (v2) {
+    constexpr int LDS2 = 3 * (32 * 512 + 32 * 256);
+    static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+    (void)once;
+    hipLaunchKernelGGL(wgrad_tn2_kernel, grid, block, LDS2, stream, a);
+  } else {
+    hipLaunchKernelGGL(wgrad_tn_kernel, grid, block, 4 * TILE_BYTES, stream, a);
+  }
   return (int)hipGetLastError();
 }

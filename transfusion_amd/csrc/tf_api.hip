@@ -3,6 +3,7 @@
 // allocation, no synchronisation and no host-side state (graph-capturable, callable from any thread).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include "tf_kernels.h"
@@ -156,8 +157,10 @@ int wgrad(const Ctx& c, Side& sd, int site, const void* dY, int ldy, int N, cons
   {
     // Overlapped with the chain the wgrad no longer has to fill the chip by itself: fewer, longer blocks mean fewer fp32
     // atomic flushes (measured on MI355X, whole step: ~288 blocks 4721 samples/s; 224: 4646; 352: 4663; 512: 4350).
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128), steps = (c.D.M + 31) / 32;
-    int splits = (288 + tiles / 2) / tiles;
+    // (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
+    const int tiles = tf_wgrad_tiles(N, K, 1), steps = (c.D.M + 31) / 32;
+    static const int ovl_target = getenv("TF_WGRAD_OVL_TARGET") ? atoi(getenv("TF_WGRAD_OVL_TARGET")) : 256;   // experiment switch
+    int splits = (ovl_target + tiles / 2) / tiles;
     if (splits < 1) splits = 1;
     if (splits > steps) splits = steps;
     w.m_chunk = ((steps + splits - 1) / splits) * 32;

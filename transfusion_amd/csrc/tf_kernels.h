@@ -8,6 +8,7 @@ extern "C" {
 #endif
 int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream);
 int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
+int tf_wgrad_tiles(int N, int K, int caller_sized);                // output tiles of the wgrad kernel that will run
 int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t stream);
