@@ -220,7 +220,7 @@ typedef struct TfEncoderPlan {
  * (calls that share one TfOverlap must be issued from one thread).  No reference counterpart (autograd engine detail). */
 typedef struct TfOverlap {
   void* stream;                 /* hipStream_t, non-blocking */
-  void* ev[8];                  /* hipEvent_t: [0..3] fork (chain -> side), [4..7] done (side -> chain) per wgrad site */
+  void* ev[8];                  /* hipEvent_t: [0..3] fork (chain -> side), [4..7] done (side -> chain); see tf_api.hip */
 } TfOverlap;
 int tf_overlap_create(TfOverlap* o);
 int tf_overlap_destroy(TfOverlap* o);

@@ -76,7 +76,7 @@ struct AOff {   // byte offsets inside work
   size_t layer0, layer_stride;                    // per-layer block
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
-  size_t dxa, dxb, dz, dy, du, d_o, dqkv, delta;
+  size_t dxa, dxb, dz, dy, dzb, dyb, du, d_o, dqkv, delta;
   size_t total;
 };
 AOff make_aoff(const Dims& D) {
@@ -98,7 +98,7 @@ AOff make_aoff(const Dims& D) {
   }
   o += a.layer_stride * D.L;
   a.meanf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4); a.rstdf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4);
-  a.dxa = take(md); a.dxb = take(md); a.dz = take(md); a.dy = take(md); a.du = take(mf); a.d_o = take(md); a.dqkv = take(mq);
+  a.dxa = take(md); a.dxb = take(md); a.dz = take(md); a.dy = take(md); a.dzb = take(md); a.dyb = take(md); a.du = take(mf); a.d_o = take(md); a.dqkv = take(mq);
   a.delta = take(st);
   a.total = o;
   return a;
@@ -137,18 +137,34 @@ int gemm(const Ctx& c, const void* A, int lda, const void* W, int ldw, void* C, 
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
   return tf_launch_gemm_nt(&g, c.st);
 }
-// wgrad sites of one layer (index into TfOverlap::ev): the tensors the side stream READS at each site are
-//   W2: dy/dz + h     W1: du + x1     WO: dy/dz + o     WIN: dqkv + x
-enum WSite { WS_W2 = 0, WS_W1 = 1, WS_WO = 2, WS_WIN = 3 };
-struct Side {                                  // fork / done bookkeeping of one tf_encoder_bwd call
-  hipStream_t st = nullptr; hipEvent_t* ev = nullptr; bool pending[4] = {false, false, false, false};
+// Side stream of one tf_encoder_bwd call.  An event record or wait on the chain is a barrier packet and costs ~5 us of
+// dispatch overlap (measured: 32 extra records per step = +170 us), so forks and guards are kept few -- but not at the
+// price of starting a wgrad late: forking {out_proj, in_proj} together after the attention backward measured SLOWER
+// (5264 vs 5337 samples/s), because it lengthens the un-overlapped tail after the last layer.  Per layer:
+//   fork A = {linear2, linear1} after the FFN-down dgrad     (reads dy/dz, h, du, x1)
+//   fork O = {out_proj}         after the LN1 backward       (reads dyb/dzb, o)
+//   fork I = {in_proj}          after the attention backward (reads dqkv, x)
+//   guard A at the top of the next layer, guard I (FIFO: covers O) before its LN1 backward.
+enum { EV_FORK_A = 0, EV_FORK_O = 1, EV_FORK_I = 2, EV_DONE_A = 4, EV_DONE_I = 5 };
+struct Side {
+  hipStream_t st = nullptr; hipEvent_t* ev = nullptr; bool pending[2] = {false, false};
 };
-// the chain is about to overwrite what `site`'s wgrad reads: wait for it (normally long finished)
-int guard(const Ctx& c, Side& sd, int site) {
-  if (sd.st != nullptr && sd.pending[site]) { sd.pending[site] = false; return (int)hipStreamWaitEvent(c.st, sd.ev[4 + site], 0); }
+int side_fork(const Ctx& c, Side& sd, int fork_ev) {            // what the chain has produced so far is visible to the side stream
+  if (sd.st == nullptr) return 0;
+  int rc = (int)hipEventRecord(sd.ev[fork_ev], c.st);
+  if (rc == 0) rc = (int)hipStreamWaitEvent(sd.st, sd.ev[fork_ev], 0);
+  return rc;
+}
+int side_done(Side& sd, int grp) {
+  if (sd.st == nullptr) return 0;
+  sd.pending[grp] = true;
+  return (int)hipEventRecord(sd.ev[EV_DONE_A + grp], sd.st);
+}
+int guard(const Ctx& c, Side& sd, int grp) {                    // the chain is about to overwrite what group `grp` reads
+  if (sd.st != nullptr && sd.pending[grp]) { sd.pending[grp] = false; return (int)hipStreamWaitEvent(c.st, sd.ev[EV_DONE_A + grp], 0); }
   return 0;
 }
-int wgrad(const Ctx& c, Side& sd, int site, const void* dY, int ldy, int N, const void* X, int ldx, int K, float* dW, int lddw, float* db,
+int wgrad(const Ctx& c, Side& sd, const void* dY, int ldy, int N, const void* X, int ldx, int K, float* dW, int lddw, float* db,
           int rg, int rgp, int n_src, int cg, int cgp, int k_src) {
   TfWgradArgs w{};
   w.dY = dY; w.ldy = ldy; w.X = X; w.ldx = ldx; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
@@ -156,8 +172,7 @@ int wgrad(const Ctx& c, Side& sd, int site, const void* dY, int ldy, int N, cons
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
   {
     // Overlapped with the chain the wgrad no longer has to fill the chip by itself: fewer, longer blocks mean fewer fp32
-    // atomic flushes (measured on MI355X, whole step: ~288 blocks 4721 samples/s; 224: 4646; 352: 4663; 512: 4350).
-    // (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
+    // atomic flushes (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
     const int tiles = tf_wgrad_tiles(N, K, 1), steps = (c.D.M + 31) / 32;
     static const int ovl_target = getenv("TF_WGRAD_OVL_TARGET") ? atoi(getenv("TF_WGRAD_OVL_TARGET")) : 256;   // experiment switch
     int splits = (ovl_target + tiles / 2) / tiles;
@@ -165,12 +180,7 @@ int wgrad(const Ctx& c, Side& sd, int site, const void* dY, int ldy, int N, cons
     if (splits > steps) splits = steps;
     w.m_chunk = ((steps + splits - 1) / splits) * 32;
   }
-  int rc = (int)hipEventRecord(sd.ev[site], c.st);                       // operands are complete on the chain ...
-  if (rc == 0) rc = (int)hipStreamWaitEvent(sd.st, sd.ev[site], 0);      // ... before the side stream reads them
-  if (rc == 0) rc = tf_launch_wgrad_tn(&w, sd.st);
-  if (rc == 0) rc = (int)hipEventRecord(sd.ev[4 + site], sd.st);
-  sd.pending[site] = true;
-  return rc;
+  return tf_launch_wgrad_tn(&w, sd.st);
 }
 
 }  // namespace
@@ -364,28 +374,27 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   // ---- side stream: everything of this forward that does not depend on activations (see TfOverlap) ----
   hipStream_t side = nullptr; hipEvent_t* ev = nullptr;
   if (e->overlap != nullptr && e->overlap->stream != nullptr) { side = (hipStream_t)e->overlap->stream; ev = (hipEvent_t*)e->overlap->ev; }
-  auto evi = [](int l) { return l < 3 ? l : 3; };    // layers >= 3 share an event: their waits then cover every later record (correct, less overlap)
+  // one event per layer on the side stream, recorded after that layer's re-pack AND dropout mask (FIFO: it covers both);
+  // layers >= 3 share an event: a wait on it then covers every later record too (correct, less overlap)
+  auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
+  bool side_work[TF_MAX_LAYERS] = {};
   if (e->repack) TF_TRY(pack_layer(c, 0, c.st), "pack layer 0");
   if (side != nullptr) {
     TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
     TF_TRY((int)hipStreamWaitEvent(side, ev[0], 0), "fwd fork");
     for (int l = 0; l < D.L; ++l) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      if (dr.thr) {
-        TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, side), "attn_dropmask");
-        TF_TRY((int)hipEventRecord(ev[4 + evi(l)], side), "mask event");
-      }
-      if (e->repack && l + 1 < D.L) {
-        TF_TRY(pack_layer(c, l + 1, side), "pack layer");
-        TF_TRY((int)hipEventRecord(ev[evi(l + 1)], side), "pack event");
-      }
+      if (e->repack && l >= 1) { TF_TRY(pack_layer(c, l, side), "pack layer"); side_work[l] = true; }
+      if (dr.thr) { TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
+      if (side_work[l]) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
     }
   } else if (e->repack) {
     for (int l = 1; l < D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
   }
   const float scale = 1.0f / sqrtf((float)D.hd);
   for (int l = 0; l < D.L; ++l) {
-    if (side != nullptr && e->repack && l >= 1) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(l)], 0), "pack wait");
+    // layer 0 needs only its mask (before the attention); later layers wait once, at the top, for pack + mask
+    if (side != nullptr && side_work[l] && l >= 1) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(l)], 0), "side wait");
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l];
     const Drop none{0u, 0u, 1.f};
@@ -398,7 +407,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
       if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
-      if (dr.thr && side != nullptr) TF_TRY((int)hipStreamWaitEvent(c.st, ev[4 + evi(l)], 0), "mask wait");
+      if (dr.thr && side != nullptr && l == 0) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(0)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
     }
     TF_TRY(gemm(c, b + c.A.o, D.dp, w + c.W.wo, D.dp, b + c.A.z1, D.dp, (const float*)(w + c.W.bo), c.X(l), D.dp, nullptr, 0, D.dp, D.dp,
@@ -484,40 +493,43 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   }
   const float scale = 1.0f / sqrtf((float)D.hd);
   const Drop none{0u, 0u, 1.f};
+  unsigned char* dzb = c.wk + c.A.dzb; unsigned char* dyb = c.wk + c.A.dyb;
   for (int l = l_hi; l >= l_lo; --l) {
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l]; const TfLayerParams& g = e->g[l];
     // ---- LN2 backward: dxa -> dz (= d z2), dy (= dropout2-masked) ----
     const Drop d2 = drop_for(e, e->p_token, site_of(l, SITE_DROP2));
+    TF_TRY(guard(c, sd, 0), "guard A");                      // previous layer's linear2 / linear1 wgrads read dy / dz / du
     {
       TfLnArgs n{};
       n.x = b + c.A.z2; n.ldx = D.dp; n.gamma = p.n2_w; n.mean = (float*)(b + c.A.mean2); n.rstd = (float*)(b + c.A.rstd2);
       n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
       n.dy = dxa; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dz; n.lddx = D.dp; n.dgamma = g.n2_w; n.dbeta = g.n2_b;
       if (d2.thr) { n.dx_drop = dy; n.lddxd = D.dp; n.drop_thr = d2.thr; n.drop_key = d2.key; n.drop_scale = d2.scale; n.drop_ld = D.dp; }
-      TF_TRY(guard(c, sd, WS_WO), "guard dy");                 // previous layer's out_proj wgrad read dy / dz
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln2_bwd");
     }
     const unsigned char* dy2 = d2.thr ? dy : dz;
-    TF_TRY(wgrad(c, sd, WS_W2, dy2, D.dp, D.dp, b + c.A.h, D.ffp, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
-    TF_TRY(guard(c, sd, WS_W1), "guard du");                   // previous layer's linear1 wgrad read du
     TF_TRY(gemm(c, dy2, D.dp, w + c.W.w2T, D.dp, du, D.ffp, nullptr, b + c.A.u, D.ffp, nullptr, 0, D.ffp, D.dp, TF_EPI_DGELU_DROP,
                 drop_for(e, e->p_token, site_of(l, SITE_FFN))), "dgrad ffn_down");
-    TF_TRY(wgrad(c, sd, WS_W1, du, D.ffp, D.ffp, b + c.A.x1, D.dp, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
+    TF_TRY(side_fork(c, sd, EV_FORK_A), "fork A");
+    TF_TRY(wgrad(c, sd, dy2, D.dp, D.dp, b + c.A.h, D.ffp, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
+    TF_TRY(wgrad(c, sd, du, D.ffp, D.ffp, b + c.A.x1, D.dp, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
+    TF_TRY(side_done(sd, 0), "done A");
     TF_TRY(gemm(c, du, D.ffp, w + c.W.w1T, D.ffp, dxb, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
-    // ---- LN1 backward: dxb -> dz (= d z1), dy (= dropout1-masked) ----
+    // ---- LN1 backward: dxb -> dzb (= d z1), dyb (= dropout1-masked) ----
     const Drop d1 = drop_for(e, e->p_token, site_of(l, SITE_DROP1));
+    TF_TRY(guard(c, sd, 1), "guard I");                      // previous layer's out_proj / in_proj wgrads read dyb / dzb / dqkv
     {
       TfLnArgs n{};
       n.x = b + c.A.z1; n.ldx = D.dp; n.gamma = p.n1_w; n.mean = (float*)(b + c.A.mean1); n.rstd = (float*)(b + c.A.rstd1);
       n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
-      n.dy = dxb; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dz; n.lddx = D.dp; n.dgamma = g.n1_w; n.dbeta = g.n1_b;
-      if (d1.thr) { n.dx_drop = dy; n.lddxd = D.dp; n.drop_thr = d1.thr; n.drop_key = d1.key; n.drop_scale = d1.scale; n.drop_ld = D.dp; }
-      TF_TRY(guard(c, sd, WS_W2), "guard dy");                 // this layer's linear2 wgrad read dy / dz
+      n.dy = dxb; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dzb; n.lddx = D.dp; n.dgamma = g.n1_w; n.dbeta = g.n1_b;
+      if (d1.thr) { n.dx_drop = dyb; n.lddxd = D.dp; n.drop_thr = d1.thr; n.drop_key = d1.key; n.drop_scale = d1.scale; n.drop_ld = D.dp; }
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln1_bwd");
     }
-    const unsigned char* dy1 = d1.thr ? dy : dz;
-    TF_TRY(wgrad(c, sd, WS_WO, dy1, D.dp, D.dp, b + c.A.o, D.dp, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
+    const unsigned char* dy1 = d1.thr ? dyb : dzb;
+    TF_TRY(side_fork(c, sd, EV_FORK_O), "fork O");
+    TF_TRY(wgrad(c, sd, dy1, D.dp, D.dp, b + c.A.o, D.dp, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
     TF_TRY(gemm(c, dy1, D.dp, w + c.W.woT, D.dp, d_o, D.dp, nullptr, nullptr, 0, nullptr, 0, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
     {
       TfAttnArgs a{};
@@ -526,11 +538,12 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
       a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
-      TF_TRY(guard(c, sd, WS_WIN), "guard dqkv");             // previous layer's in_proj wgrad read dqkv
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
-    TF_TRY(wgrad(c, sd, WS_WIN, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");
-    TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
+    TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
+    TF_TRY(wgrad(c, sd, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");
+    TF_TRY(side_done(sd, 1), "done I");
+    TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dzb, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
   if (tail) {
     TfAssembleArgs a{};
@@ -541,7 +554,9 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_bwd(&a, c.st), "assemble_bwd");
   }
-  for (int site = 0; site < 4; ++site) TF_TRY(guard(c, sd, site), "join");   // the caller sees one-stream semantics
+  // join: the side stream is FIFO, so its last recorded event covers everything before it -- one wait, not one per group
+  if (sd.pending[1]) { sd.pending[0] = false; TF_TRY(guard(c, sd, 1), "join"); }
+  TF_TRY(guard(c, sd, 0), "join");
   return 0;
 }
 
