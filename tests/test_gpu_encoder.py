@@ -252,3 +252,33 @@ def test_wgrad_side_stream_matches_single_stream(monkeypatch):
     for ga, gb in zip(a[-1], b[-1]):
         scale = ga.abs().max().item() + 1e-12
         assert (ga - gb).abs().max().item() <= 2e-3 * scale      # fp32 atomics: summation order differs between runs
+
+
+@pytest.mark.gpu
+def test_stress_shape_against_oracle(dev):
+    """BASELINE.json configs[3] (long-context stress): 28x28 visual grid + 1024 narration tokens, d = 1024, 4 heads, i.e.
+    head dim 256 -- the <256> instantiations of the attention kernels and S = 1808 (29 key tiles, ragged last tile).
+    B = 2 samples and 2 layers keep the CPU oracle to a few seconds; dropout off, training mode (every row computed)."""
+    from oracle import fusion_oracle as O
+    cfg = dict(B=2, Nv=784, Nl=1024, d=1024, h=4, L=2, mask_lens=[1024, 333], seed=11)
+    enc, params = build(cfg, dev)
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+    vis, lo, _, _ = enc(xd, ld, torch.from_numpy(mask).to(dev))
+    ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+    assert torch.isfinite(vis).all() and torch.isfinite(lo).all()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+    xr, lr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+    v_ref, l_ref = O.encoder_forward(sd, xr, lr, torch.from_numpy(mask), cfg["h"], cfg["L"])
+    ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+    valid = ~mask
+    assert rel(vis, v_ref.detach()) < FWD_TOL
+    assert rel(lo.detach().cpu()[valid], l_ref.detach()[valid]) < FWD_TOL
+    assert rel(xd.grad, xr.grad) < GRAD_TOL and rel(ld.grad, lr.grad) < GRAD_TOL
+    for k, p in enc.named_parameters():
+        if k in sd and sd[k].grad is not None:
+            assert rel(p.grad, sd[k].grad) < GRAD_TOL, k
