@@ -165,11 +165,13 @@ int guard(const Ctx& c, Side& sd, int grp) {                    // the chain is 
   return 0;
 }
 int wgrad(const Ctx& c, Side& sd, const void* dY, int ldy, int N, const void* X, int ldx, int K, float* dW, int lddw, float* db,
-          int rg, int rgp, int n_src, int cg, int cgp, int k_src) {
+          int rg, int rgp, int n_src, int cg, int cgp, int k_src, bool alone = false) {
   TfWgradArgs w{};
   w.dY = dY; w.ldy = ldy; w.X = X; w.ldx = ldx; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
+  static const int tail_alone = getenv("TF_WGRAD_TAIL_ALONE") ? atoi(getenv("TF_WGRAD_TAIL_ALONE")) : 1;   // experiment switch
+  if (alone && tail_alone) return tf_launch_wgrad_tn(&w, sd.st);   // the last wgrad of the backward has the chip to itself: stand-alone sizing
   {
     // Overlapped with the chain the wgrad no longer has to fill the chip by itself: fewer, longer blocks mean fewer fp32
     // atomic flushes (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
@@ -541,7 +543,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
     TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
-    TF_TRY(wgrad(c, sd, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d), "wgrad in_proj");
+    TF_TRY(wgrad(c, sd, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
     TF_TRY(side_done(sd, 1), "done I");
     TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dzb, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
