@@ -32,7 +32,10 @@ enum TfEpilogue {
   TF_EPI_BIAS_GELU_DROP = 2,  // C = U = acc + bias ; C2 = dropout(gelu(U))
   TF_EPI_BIAS_DROP_RES = 3,   // C = R + dropout(acc + bias)
   TF_EPI_ADD = 4,             // C = acc + R
-  TF_EPI_DGELU_DROP = 5       // C = acc * mask/(1-p) * gelu'(R)
+  TF_EPI_DGELU_DROP = 5,      // C = acc * mask/(1-p) * gelu'(R)
+  TF_EPI_BIAS_GELU_DROP_G = 6,// C = G = mask/(1-p) * gelu'(acc + bias) ; C2 = dropout(gelu(acc + bias)): the forward already holds erf
+                              //   and exp, so the activation derivative costs 3 more operations here instead of ~20 in the backward
+  TF_EPI_MUL = 7              // C = acc * R   (FFN-down dgrad against the stored G)
 };
 
 typedef struct TfGemmArgs {
@@ -261,7 +264,7 @@ int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncode
 int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s);   /* fp32 parameters -> bf16 shadows in wpack */
 int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s);
 int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);
-/* test hook: copies an internal activation by name ("x<l>", "qkv<l>", "o<l>", "z1_<l>", "x1_<l>", "u<l>", "h<l>",
+/* test hook: copies an internal activation by name ("x<l>", "qkv<l>", "o<l>", "z1_<l>", "x1_<l>", "u<l>" (holds G = d h / d u), "h<l>",
  * "z2_<l>", "dqkv", ...) as fp32 [rows, cols] into dst; returns rows*cols (cols = padded width) or < 0 */
 long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s);
 

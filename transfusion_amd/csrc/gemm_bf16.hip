@@ -42,6 +42,25 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? gelu_f(f[e]) * g.drop_scale : 0.f;
       *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
+    } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP_G) {
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+      float gd[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float cdf, ex;
+        gelu_parts(f[e], cdf, ex);
+        const float keep = ((km >> e) & 1u) ? g.drop_scale : 0.f;
+        gd[e] = keep * (cdf + f[e] * 0.39894228040143268f * ex);     // d dropout(gelu(u)) / du
+        f[e] = keep * (f[e] * cdf);
+      }
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(gd);
+      *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
+    } else if constexpr (EPI == TF_EPI_MUL) {
+      float r[8];
+      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= r[e];
+      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
       float r[8];
       unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
@@ -645,6 +664,8 @@ template <int MI, int BK> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t st
     TF_GEMM_CASE(TF_EPI_BIAS_DROP_RES)
     TF_GEMM_CASE(TF_EPI_ADD)
     TF_GEMM_CASE(TF_EPI_DGELU_DROP)
+    TF_GEMM_CASE(TF_EPI_BIAS_GELU_DROP_G)
+    TF_GEMM_CASE(TF_EPI_MUL)
     default: return -4;
   }
 #undef TF_GEMM_CASE
@@ -685,6 +706,8 @@ template <int MF> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
     TF_GEMM_CASE(TF_EPI_BIAS_DROP_RES)
     TF_GEMM_CASE(TF_EPI_ADD)
     TF_GEMM_CASE(TF_EPI_DGELU_DROP)
+    TF_GEMM_CASE(TF_EPI_BIAS_GELU_DROP_G)
+    TF_GEMM_CASE(TF_EPI_MUL)
     default: return -4;
   }
 #undef TF_GEMM_CASE

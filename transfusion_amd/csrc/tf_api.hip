@@ -422,7 +422,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln1_fwd");
     }
     TF_TRY(gemm(c, b + c.A.x1, D.dp, w + c.W.w1, D.dp, b + c.A.u, D.ffp, (const float*)(w + c.W.b1), nullptr, 0, b + c.A.h, D.ffp, D.ffp, D.dp,
-                TF_EPI_BIAS_GELU_DROP, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");
+                TF_EPI_BIAS_GELU_DROP_G, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");   // slot "u" holds G = d h / d u
     TF_TRY(gemm(c, b + c.A.h, D.ffp, w + c.W.w2, D.ffp, b + c.A.z2, D.dp, (const float*)(w + c.W.b2), b + c.A.x1, D.dp, nullptr, 0, D.dp, D.ffp,
                 TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down");
     {
@@ -511,8 +511,8 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln2_bwd");
     }
     const unsigned char* dy2 = d2.thr ? dy : dz;
-    TF_TRY(gemm(c, dy2, D.dp, w + c.W.w2T, D.dp, du, D.ffp, nullptr, b + c.A.u, D.ffp, nullptr, 0, D.ffp, D.dp, TF_EPI_DGELU_DROP,
-                drop_for(e, e->p_token, site_of(l, SITE_FFN))), "dgrad ffn_down");
+    TF_TRY(gemm(c, dy2, D.dp, w + c.W.w2T, D.dp, du, D.ffp, nullptr, b + c.A.u, D.ffp, nullptr, 0, D.ffp, D.dp, TF_EPI_MUL, none),
+           "dgrad ffn_down");                                 // dU = dH . G (G stored by the forward FFN-up epilogue)
     TF_TRY(side_fork(c, sd, EV_FORK_A), "fork A");
     TF_TRY(wgrad(c, sd, dy2, D.dp, D.dp, b + c.A.h, D.ffp, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
     TF_TRY(wgrad(c, sd, du, D.ffp, D.ffp, b + c.A.x1, D.dp, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
