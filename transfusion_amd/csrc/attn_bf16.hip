@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
     kr.store(kt, tid);
     vr.store(vt, tid);
     const unsigned long long dm = dm_n >> (4 * h);
-    const unsigned long long vbits = __ballot(kv0 + lane < S && km_n == 0) >> (4 * h);
+    const unsigned long long vall = __ballot(kv0 + lane < S && km_n == 0);
+    const unsigned long long vbits = vall >> (4 * h);
     __syncthreads();
     if (t + 1 < ntiles) {
       kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
@@ -379,12 +380,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int d = 0; d < G::DBLK; ++d) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
+      // dSt = P * (keep/(1-p) * dPt - delta); the key-validity select only exists on tiles that contain padded or
+      // out-of-range keys (wave-uniform branch: with right padding that is the last tile of a sample)
+      if (vall == ~0ull) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
-        const float p = ((vbits >> bit) & 1ull) ? fast_exp2(fmaf(st[r], sc, -lse)) : 0.f;
-        const float g = ((dm >> bit) & 1ull) ? dp[r] * dscale : 0.f;
-        st[r] = p * (g - delta);
+        for (int r = 0; r < 16; ++r) {
+          const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const float p = fast_exp2(fmaf(st[r], sc, -lse));
+          const float ks = ((dm >> bit) & 1ull) ? dscale : 0.f;
+          st[r] = p * fmaf(dp[r], ks, -delta);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const float p = ((vbits >> bit) & 1ull) ? fast_exp2(fmaf(st[r], sc, -lse)) : 0.f;
+          const float ks = ((dm >> bit) & 1ull) ? dscale : 0.f;
+          st[r] = p * fmaf(dp[r], ks, -delta);
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -524,10 +537,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * g4 + i;
-        const float p = key_ok ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;
+        const float p = key_ok ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;   // (a wave-uniform all-keys-valid branch here measured slower)
         const float keep_scale = ((w4[i] >> (lane & 31)) & 1u) ? dscale : 0.f;
-        st[r] = p * keep_scale;                         // Pd
-        dp[r] = p * (dp[r] * keep_scale - d4[i]);       // dS
+        st[r] = p * keep_scale;                           // Pd
+        dp[r] = p * fmaf(dp[r], keep_scale, -d4[i]);      // dS
       }
     }
     {
