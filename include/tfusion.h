@@ -72,6 +72,8 @@ typedef struct TfAttnArgs {
   float scale;                   // 1/sqrt(true head dim)
   unsigned drop_thr, drop_key; float drop_scale;
   const void* drop_bits;         // [B*H*S, ceil(S/64)] u64 keep-bitmask from tf_attn_dropmask (required when drop_thr != 0)
+  const void* block_bits;        // optional [S, ceil(S/64)] u64, bit k of row q = 1: query q does not attend key k (all batches and
+                                 //   heads) -- the bool attn_mask the reference builds from vis_tokens_mask, cross_f_box_layers.py:87-95
   // backward only
   const void* dout; int ld_dout; // [B*S, H*HDP] bf16
   void* dqkv; int ld_dqkv;       // [B*S, 3*H*HDP] bf16
@@ -243,6 +245,7 @@ typedef struct TfEncoderDesc {
   const void* vis; int vis_is_f32;          /* [B,Nv,d] */
   const void* lang; int lang_is_f32;        /* [B,Nl,d] */
   const uint8_t* lang_pad_mask;             /* [B,Nl] 1 = ignore, or null */
+  const void* attn_block_bits;              /* TfAttnArgs.block_bits for every layer (vis_mask_type "local_k"), or null */
   void* vis_out; int vis_out_is_f32;        /* [B,Nv,d] */
   void* lang_out; int lang_out_is_f32;      /* [B,Nl,d] or null */
   const void* d_vis_out; int d_vis_out_is_f32;

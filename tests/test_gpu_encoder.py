@@ -282,3 +282,29 @@ def test_stress_shape_against_oracle(dev):
     for k, p in enc.named_parameters():
         if k in sd and sd[k].grad is not None:
             assert rel(p.grad, sd[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.gpu
+def test_golden_local_mask(dev, golden_dir):
+    """vis_mask_type "local_1" on a 4x5 visual grid: fixture produced by the reference itself (tests/golden/make_golden.py),
+    here through the HIP path with the block-bit attention mask."""
+    cfg = ENCODER_CASES["enc_local1"]
+    g = dict(np.load(os.path.join(golden_dir, "enc_local1.npz")))
+    enc, params = build(cfg, dev)
+    enc.train()
+    x = torch.from_numpy(g["in_x"]).to(dev).requires_grad_(True)
+    lang = torch.from_numpy(g["in_lang"]).to(dev).requires_grad_(True)
+    mask = torch.from_numpy(g["in_mask"]).to(dev)
+    vmask = torch.from_numpy(g["in_vis_tokens_mask"])
+    vis, lo, _, _ = enc(x, lang, mask, vis_tokens_mask=vmask)
+    valid = ~g["in_mask"]
+    assert rel(vis, g["train_vis"]) < FWD_TOL
+    assert rel(lo.detach().cpu().numpy()[valid], g["train_lang"][valid]) < FWD_TOL
+    ((vis * torch.from_numpy(g["cot_vis"]).to(dev)).sum() + (lo * torch.from_numpy(g["cot_lang"]).to(dev)).sum()).backward()
+    assert rel(x.grad, g["grad_x"]) < GRAD_TOL and rel(lang.grad, g["grad_lang"]) < GRAD_TOL
+    for k, p in enc.named_parameters():
+        if "gradp/" + k in g:
+            assert rel(p.grad, g["gradp/" + k]) < GRAD_TOL, k
+    # the mask matters: without it the visual outputs differ
+    v0, _, _, _ = enc(x.detach(), lang.detach(), mask)
+    assert rel(v0, g["train_vis"]) > 5 * FWD_TOL

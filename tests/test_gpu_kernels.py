@@ -301,3 +301,64 @@ def test_radam_matches_reference_arithmetic(dev):
             pr = pr - wd * lr * pr
             pr = pr - ss * lr * m / (v.sqrt() + eps)
     assert (p.cpu().double() - pr).abs().max().item() < 1e-5
+
+
+def _pack_bits(m):
+    """bool [S, S] -> int64 [S, ceil(S/64)] little-endian bit words (the TfAttnArgs.block_bits layout)."""
+    S = m.shape[0]
+    SW = (S + 63) // 64
+    full = torch.zeros(S, SW * 64, dtype=torch.bool)
+    full[:, :S] = m
+    return (full.view(S, SW, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1).contiguous()
+
+
+@pytest.mark.parametrize("B,S,H,hd,p", [(2, 150, 2, 64, 0.0), (1, 333, 3, 18, 0.15)])
+def test_attention_block_mask(dev, B, S, H, hd, p):
+    """Boolean attn_mask (TfAttnArgs.block_bits, the reference's local_k visual mask mechanism): random blocked pairs on the
+    first two thirds of the sequence (every query keeps its own key), together with key padding and dropout."""
+    from transfusion_amd import _lib as L, ops
+    hdp = (hd + 31) // 32 * 32
+    g = torch.Generator().manual_seed(3 * S + hd)
+    ldq = (3 * H * hdp + 63) // 64 * 64
+    qkv = torch.zeros(B * S, ldq)
+    qkv[:, : 3 * H * hdp].view(B * S, 3, H, hdp)[..., :hd] = torch.randn(B * S, 3, H, hd, generator=g)
+    qkv = bf(qkv).to(dev)
+    nv = 2 * S // 3
+    blk = torch.zeros(S, S, dtype=torch.bool)
+    blk[:nv, :nv] = torch.rand(nv, nv, generator=g) < 0.6
+    blk[torch.arange(S), torch.arange(S)] = False
+    bits = _pack_bits(blk).to(dev)
+    key_mask = torch.zeros(B, S, dtype=torch.uint8)
+    key_mask[0, S - S // 5:] = 1
+    key_mask = key_mask.to(dev)
+    ldo = (H * hdp + 63) // 64 * 64
+    out = torch.zeros(B * S, ldo, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B * H * S, device=dev)
+    seed, site = 5, 9
+    drop = ops.drop_params(p, seed, site)
+    dbits = ops.attn_dropmask(B, H, S, p, seed, site, dev) if p > 0 else None
+    do = torch.zeros(B * S, ldo)
+    do[:, : H * hdp].view(B * S, H, hdp)[..., :hd] = torch.randn(B * S, H, hd, generator=g)
+    do = bf(do).to(dev)
+    dqkv = torch.zeros(B * S, ldq, dtype=torch.bfloat16, device=dev)
+    delta = torch.empty(B * H * S, device=dev)
+    a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=L.ptr(key_mask), B=B, S=S, H=H,
+                     HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=L.ptr(dbits),
+                     block_bits=L.ptr(bits), dout=L.ptr(do), ld_dout=ldo, dqkv=L.ptr(dqkv), ld_dqkv=ldq, delta=L.ptr(delta))
+    L.call("tf_attn_fwd", a, ops._stream())
+    L.call("tf_attn_bwd", a, ops._stream())
+    keep = ops.dropout_mask(B * H * S * S, p, seed, site, dev).view(B, H, S, S).double().cpu() if p > 0 else None
+    p_eff = 1.0 - 1.0 / drop[2] if p > 0 else 0.0
+    xr = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd].clone().requires_grad_(True)
+    q, k, v = xr[:, :, 0].permute(0, 2, 1, 3), xr[:, :, 1].permute(0, 2, 1, 3), xr[:, :, 2].permute(0, 2, 1, 3)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(key_mask.cpu().bool().view(B, 1, 1, S), float("-inf")).masked_fill(blk.view(1, 1, S, S), float("-inf"))
+    Pr = torch.softmax(s, -1)
+    if keep is not None:
+        Pr = Pr * keep / (1 - p_eff)
+    o = (Pr @ v).permute(0, 2, 1, 3)
+    o.backward(do[:, : H * hdp].double().cpu().view(B, S, H, hdp)[..., :hd])
+    assert rel(out[:, : H * hdp].float().cpu().view(B, S, H, hdp)[..., :hd], o.detach()) < 8e-3
+    g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)
+    for which, nm in enumerate("qkv"):
+        assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm}"

@@ -125,7 +125,7 @@ __device__ __forceinline__ int pair_of_group(int g, int npairs) {
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int HDP>
+template <int HDP, bool BLK>       // BLK: a block-bit matrix (TfAttnArgs.block_bits) is present
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
   const int qrow = q0 + (lane & 31);
   const int SW = (S + 63) / 64;
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
+  const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, S - 1) * SW : nullptr;
 
   const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   for (int t = 0; t < ntiles; ++t) {
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
     }
     __syncthreads();
     const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
+    // keys this lane's query may attend: not padded / out of range (wave-uniform ballot) and, with a block mask, not
+    // blocked for this query (per lane).  Without a block mask nothing per-lane is computed outside the rare masked tile.
     const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
-    const unsigned long long vbits = vall >> (4 * h);
+    const unsigned long long blk = BLK ? brow[t] : 0ull;
+    const bool masked_tile = vall != ~0ull || (BLK && __any(blk != 0ull));
+    const unsigned long long vbits = (vall & ~blk) >> (4 * h);
 
     // ---- St[key][q] = K . Q^T ----
     f32x16 st[2];
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
     }
     // ---- online softmax (log2 domain; raw scores stay unscaled, the scale rides in the FMA) ----
-    if (vall != ~0ull) {                   // wave-uniform: only tiles that contain padded / out-of-range keys pay for the select
+    if (masked_tile) {                     // wave-uniform: only tiles that contain padded / out-of-range / blocked keys pay for the select
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -323,12 +328,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   // s_waitcnt a vmcnt(0) that exposed the whole prefetch latency in every tile.
   // (RAW loaded values are carried: any arithmetic on them here would pull their wait up to this point)
   const uint8_t* kmrow = a.key_mask ? a.key_mask + (size_t)b * S : nullptr;
-  unsigned long long dm_n = ~0ull;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
+  unsigned long long dm_n = ~0ull, blk_n = 0ull;
   uint8_t km_n = 0;
   if (ntiles > 0) {
     kr.load(kbase, ld, 0, S - 1, false, tid);
     vr.load(vbase, ld, 0, S - 1, false, tid);
     if (a.drop_thr) dm_n = drow[0];
+    if (brow) blk_n = brow[0];
     if (kmrow) km_n = kmrow[min(lane, S - 1)];
   }
   for (int t = 0; t < ntiles; ++t) {
@@ -337,13 +344,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
     kr.store(kt, tid);
     vr.store(vt, tid);
     const unsigned long long dm = dm_n >> (4 * h);
-    const unsigned long long vall = __ballot(kv0 + lane < S && km_n == 0);
-    const unsigned long long vbits = vall >> (4 * h);
+    const unsigned long long vlane = __ballot(kv0 + lane < S && km_n == 0) & ~blk_n;     // per query: valid and not blocked
+    const bool all_valid = __all(vlane == ~0ull);
+    const unsigned long long vbits = vlane >> (4 * h);
     __syncthreads();
     if (t + 1 < ntiles) {
       kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
       vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
       if (a.drop_thr) dm_n = drow[t + 1];
+      if (brow) blk_n = brow[t + 1];
       if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, S - 1)];
     }
 #pragma unroll
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
         for (int d = 0; d < G::DBLK; ++d) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
       // dSt = P * (keep/(1-p) * dPt - delta); the key-validity select only exists on tiles that contain padded or
       // out-of-range keys (wave-uniform branch: with right padding that is the last tile of a sample)
-      if (vall == ~0ull) {
+      if (all_valid) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
 //   S[q][key] = Q.K^T -> P ;  dP[q][key] = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
 //   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key] ; dK *= scale
 // ================================================================================================
-template <int HDP>
+template <int HDP, bool BLK>       // BLK: a block-bit matrix (TfAttnArgs.block_bits) is present
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -435,6 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   float* lse_s = (float*)(smem + 64 * G::TSTR);
   float* del_s = lse_s + 32;
   unsigned* dw_s = (unsigned*)(del_s + 32);                       // [4 waves][32 query rows] keep-bit words of the wave's 32 keys
+  unsigned* bw_s = dw_s + 128;                                    // [4 waves][32 query rows] block-bit words (BLK only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int S = a.S;
   const int nkb = (S + 127) / 128;
@@ -475,8 +485,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   // they sat between the two barriers with their global latency fully exposed, once per tile.
   const int dw_ld = 2 * ((S + 63) / 64);
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
   float lse_n = 1.0e30f, del_n = 0.f;
-  unsigned dw_n = 0xffffffffu;
+  unsigned dw_n = 0xffffffffu, bw_n = 0u;
   // (RAW loaded values are carried, from clamped addresses; the row-validity selects happen when they are stored to
   // LDS one iteration later -- arithmetic on them here would pull their vmcnt wait up to this point)
   auto prefetch_rows = [&](int q0n) {
@@ -486,6 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       del_n = a.delta[(size_t)bh * S + q];
     }
     if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
   };
   if (ntiles > 0) {
     qr.load(qbase, ld, 0, S - 1, false, tid);
@@ -503,6 +515,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       del_s[tid] = in ? del_n : 0.f;
     }
     if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < S) ? dw_n : 0u;
+    if (BLK && lane < 32) bw_s[wave * 32 + lane] = bw_n;
     __syncthreads();
     if (t + 1 < ntiles) {
       qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
@@ -534,10 +547,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g4 + 4 * h);
       const f32x4 d4 = *(const f32x4*)(del_s + 8 * g4 + 4 * h);
       const u32x4 w4 = *(const u32x4*)(dw_s + wave * 32 + 8 * g4 + 4 * h);           // rows q0 + acc_row(4 g4 + i, h)
+      u32x4 b4 = {0u, 0u, 0u, 0u};
+      if (BLK) b4 = *(const u32x4*)(bw_s + wave * 32 + 8 * g4 + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * g4 + i;
-        const float p = key_ok ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;   // (a wave-uniform all-keys-valid branch here measured slower)
+        const bool att = BLK ? (key_ok && !((b4[i] >> (lane & 31)) & 1u)) : key_ok;     // this (query row, key) pair is attended
+        const float p = att ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;   // (a wave-uniform all-keys-valid branch here measured slower)
         const float keep_scale = ((w4[i] >> (lane & 31)) & 1u) ? dscale : 0.f;
         st[r] = p * keep_scale;                           // Pd
         dp[r] = p * fmaf(dp[r], keep_scale, -d4[i]);      // dS
@@ -586,19 +602,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 128 * Geo<HDP>::TSTR;
-  static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)once;
+  static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const hipError_t onceb = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once; (void)onceb;
   char nm[56];
   snprintf(nm, sizeof(nm), "attn_fwd_kernel<%d>", HDP);
   TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)a->S * a->S * HDP);
-  hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3(((a->S + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
+  const dim3 grid(((a->S + 127) / 128) * a->B * a->H);
+  if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HDP, true>), grid, dim3(256), lds, st, *a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<HDP, false>), grid, dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
-  const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256 + 512;
+  const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256 + 1024;
   static const hipError_t once_q = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-  static const hipError_t once_kv = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-  (void)once_q; (void)once_kv;
+  static const hipError_t once_kv = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  static const hipError_t once_kvb = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  (void)once_q; (void)once_kv; (void)once_kvb;
   dim3 grid(((a->S + 127) / 128) * a->B * a->H);
   // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
   const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;
@@ -611,7 +631,8 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, grid, dim3(256), lds_kv, st, *a);
+    if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, true>), grid, dim3(256), lds_kv, st, *a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, false>), grid, dim3(256), lds_kv, st, *a);
   }
   return (int)hipGetLastError();
 }

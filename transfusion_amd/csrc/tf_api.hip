@@ -407,7 +407,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
       a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
       if (dr.thr && side != nullptr && l == 0) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(0)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
@@ -538,7 +538,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
       a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits;
+      a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }

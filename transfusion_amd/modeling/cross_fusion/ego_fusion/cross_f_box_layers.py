@@ -279,6 +279,10 @@ class CrossTransformerModuleBox(nn.Module):
             raise L.TfError("pos_embedding must be contiguous fp32")
         e.pe = pe.data_ptr()
         e.wpack, e.work = self._wpack.data_ptr(), keep["work"].data_ptr()
+        bb = getattr(self, "_block_bits", None)
+        if bb is not None:
+            keep["block_bits"] = bb
+            e.attn_block_bits = bb.data_ptr()
         e.overlap = ops.wgrad_overlap(x.device)
         x = x.contiguous()
         lang = lang.contiguous()
@@ -331,13 +335,32 @@ class CrossTransformerModuleBox(nn.Module):
 
     # ---- reference forward contract (cross_f_box_layers.py:69-108) --------------------------------------
     def forward(self, x, language_tokens, language_tokens_att_maks, vis_tokens_mask=None):
-        if vis_tokens_mask is not None:
-            raise NotImplementedError("vis_mask_type local_k (dense [S,S] mask) is a 'next' row (SURVEY.md 8f-4); "
-                                      "the shipped configs use vis_mask_type: global")
         if self.lang_pos_embedding:
             raise NotImplementedError("lang_pos_embedding is not used by the shipped configs")
+        self._block_bits = None
+        if vis_tokens_mask is not None:
+            self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)
         vis_tokens, lang_tokens = _EncoderFn.apply(self, x, language_tokens, language_tokens_att_maks, *self._param_list())
         return vis_tokens, lang_tokens, None, None
+
+    def _pack_block_bits(self, vis_tokens_mask, Nv, Nl, device):
+        """vis_tokens_mask [Nv,Nv] (nonzero = blocked, reference utils.py:14-30) -> the [S, ceil(S/64)] u64 block-bit matrix of
+        the joint sequence: the reference pads it with zeros for the language rows / columns and casts to bool
+        (cross_f_box_layers.py:87-95), i.e. only visual-visual pairs can be blocked.  Cached per mask tensor."""
+        if tuple(vis_tokens_mask.shape) != (Nv, Nv):
+            raise RuntimeError(f"vis_tokens_mask must be [Nv, Nv] = {(Nv, Nv)}, got {tuple(vis_tokens_mask.shape)}")
+        key = (vis_tokens_mask.data_ptr(), vis_tokens_mask._version, Nv, Nl, str(device))
+        cache = getattr(self, "_block_bits_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        S = Nv + Nl
+        SW = (S + 63) // 64
+        full = torch.zeros(S, SW * 64, dtype=torch.bool)
+        full[:Nv, :Nv] = vis_tokens_mask.detach().to("cpu") != 0
+        words = (full.view(S, SW, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1)   # wraps mod 2^64: bit 63 is the sign
+        bits = words.contiguous().to(device)
+        self._block_bits_cache = (key, bits)
+        return bits
 
     def peek(self, desc_keep, name):
         """Test hook: copy an internal activation of the last forward out of the workspace (fp32)."""
