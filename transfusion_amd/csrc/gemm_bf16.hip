@@ -740,10 +740,8 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0) return 0;
   if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
-  static const int bk32 = getenv("TF_GEMM_BK32") ? atoi(getenv("TF_GEMM_BK32")) : 0;    // experiment switches
   static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
   const double fl = 2.0 * a->M * a->N * a->K;
-  if (bk32) return launch_gemm_mi<4, 32>(a, stream);
   if (big && a->M >= 2048 && a->N >= 256) {
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
     char nm[56];

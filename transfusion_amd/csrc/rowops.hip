@@ -250,29 +250,6 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
   }
 }
 
-// delta[b,h,s] = sum_e dO[b,s,h,e] * O[b,s,h,e]; 8 lanes per (row, head)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const u16* __restrict__ o, int ldo, const u16* __restrict__ d_o,
-                                                         int lddo, float* __restrict__ delta, int B, int S, int H, int HDP) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long item = t >> 3;
-  const int sub = (int)(t & 7);
-  const bool ok = item < (long long)B * S * H;
-  float acc = 0.f;
-  int row = 0, head = 0;
-  if (ok) {
-    row = (int)(item / H); head = (int)(item % H);
-    for (int c = sub * 8; c < HDP; c += 64) {
-      float x[8], y[8];
-      unpack8(*(const u32x4*)(o + (size_t)row * ldo + head * HDP + c), x);
-      unpack8(*(const u32x4*)(d_o + (size_t)row * lddo + head * HDP + c), y);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += x[e] * y[e];
-    }
-  }
-  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-  if (ok && sub == 0) { const int b = row / S, s = row - b * S; delta[((size_t)b * H + head) * S + s] = acc; }
-}
-
 // fp32 parameter [rows, cols] -> bf16 shadow (padded / head-grouped) and its transpose, via a 64x64 LDS tile.
 // Up to 8 tensors per launch (blockIdx.z): one launch re-packs a whole encoder layer.
 struct PackBatch { TfPackArgs a[8]; };
@@ -504,15 +481,6 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(assemble_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
-  return (int)hipGetLastError();
-}
-extern "C" int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int lddo, float* delta, int B, int S, int H,
-                                    int HDP, hipStream_t st) {
-  const long long threads = (long long)B * S * H * 8;
-  if (threads <= 0) return 0;
-  TfTraceScope tr("attn_delta_kernel", st);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const u16*)o, ldo,
-                     (const u16*)d_o, lddo, delta, B, S, H, HDP);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) {

@@ -15,8 +15,6 @@ int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t stream);
 int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t stream);
 int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t stream);
 int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t stream);
-int tf_launch_attn_delta(const void* o, int ldo, const void* d_o, int lddo, float* delta, int B, int S, int H, int HDP,
-                         hipStream_t stream);
 int tf_launch_pack(const TfPackArgs* a, hipStream_t stream);
 int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t stream);   // n <= 8 tensors, one launch
 int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t stream);
