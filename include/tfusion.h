@@ -226,9 +226,12 @@ typedef struct TfEncoderPlan {
 typedef struct TfOverlap {
   void* stream;                 /* hipStream_t, non-blocking */
   void* ev[8];                  /* hipEvent_t: [0..3] fork (chain -> side), [4..7] done (side -> chain); see tf_api.hip */
+  unsigned pending, reserved;   /* owned by the library: wgrad groups of a tf_encoder_bwd(defer_join) call not yet joined */
 } TfOverlap;
 int tf_overlap_create(TfOverlap* o);
 int tf_overlap_destroy(TfOverlap* o);
+/* makes stream s wait for everything the side stream has been given so far (after tf_encoder_bwd calls with defer_join) */
+int tf_overlap_join(TfOverlap* o, tf_stream_t s);
 
 typedef struct TfEncoderDesc {
   int B, Nv, Nl, d, H, L, ff;
@@ -257,7 +260,11 @@ typedef struct TfEncoderDesc {
    * layer L-1, the input-side part (token assemble) with the chunk that contains layer 0; chunks must be issued in
    * descending order on one stream. */
   int bwd_hi, bwd_nlayers;
-  const TfOverlap* overlap;     /* null: everything on the caller's stream */
+  TfOverlap* overlap;           /* null: everything on the caller's stream */
+  int defer_join;               /* tf_encoder_bwd with an overlap handle: return WITHOUT joining the side stream; its pending wgrads
+                                 * are recorded in the handle, guarded by the next tf_encoder_bwd call on the same handle and joined by
+                                 * tf_overlap_join (per-layer calls of the data-parallel reducer: the collective of a layer waits for
+                                 * the side stream's events on its own stream instead of stalling the backward chain) */
   int repack;                   /* tf_encoder_fwd only: refresh the bf16 weight shadows first (what tf_encoder_pack does); with an
                                  * overlap handle only layer 0 is packed on the caller's stream, layers >= 1 and the attention
                                  * dropout masks are produced on the side stream while the chain already runs layer 0 */

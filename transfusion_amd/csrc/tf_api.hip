@@ -235,6 +235,14 @@ int tf_overlap_create(TfOverlap* o) {
   }
   return 0;
 }
+int tf_overlap_join(TfOverlap* o, tf_stream_t s) {
+  if (o == nullptr) return fail(-1, "tf_overlap_join");
+  if (o->stream == nullptr || o->pending == 0u) return 0;
+  // FIFO side stream: the in_proj group's event is recorded after the linear2/linear1 group's of the same layer
+  TF_TRY((int)hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)o->ev[(o->pending & 2u) ? EV_DONE_I : EV_DONE_A], 0), "tf_overlap_join");
+  o->pending = 0u;
+  return 0;
+}
 int tf_overlap_destroy(TfOverlap* o) {
   if (o == nullptr) return fail(-1, "tf_overlap_destroy");
   for (int i = 0; i < 8; ++i) if (o->ev[i] != nullptr) { (void)hipEventDestroy((hipEvent_t)o->ev[i]); o->ev[i] = nullptr; }
@@ -380,6 +388,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   // layers >= 3 share an event: a wait on it then covers every later record too (correct, less overlap)
   auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
   bool side_work[TF_MAX_LAYERS] = {};
+  if (side != nullptr && e->overlap->pending != 0u) TF_TRY(tf_overlap_join(e->overlap, s), "fwd join");   // events are about to be reused
   if (e->repack) TF_TRY(pack_layer(c, 0, c.st), "pack layer 0");
   if (side != nullptr) {
     TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
@@ -471,7 +480,10 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (l_hi >= D.L || l_lo < 0 || l_lo > l_hi) return fail(-1, "tf_encoder_bwd(layer range)");
   const bool head = l_hi == D.L - 1, tail = l_lo == 0;
   Side sd;
-  if (e->overlap != nullptr && e->overlap->stream != nullptr) { sd.st = (hipStream_t)e->overlap->stream; sd.ev = (hipEvent_t*)e->overlap->ev; }
+  if (e->overlap != nullptr && e->overlap->stream != nullptr) {
+    sd.st = (hipStream_t)e->overlap->stream; sd.ev = (hipEvent_t*)e->overlap->ev;
+    sd.pending[0] = (e->overlap->pending & 1u) != 0; sd.pending[1] = (e->overlap->pending & 2u) != 0;   // left by a defer_join call
+  }
   // ---- gradient w.r.t. the last layer's output X[L] -> dxa ----
   if (head && D.Nv > 0) {
     if (e->final_norm && e->d_vis_out != nullptr) {
@@ -556,9 +568,14 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_bwd(&a, c.st), "assemble_bwd");
   }
+  if (sd.st != nullptr && e->defer_join) {
+    e->overlap->pending = (sd.pending[0] ? 1u : 0u) | (sd.pending[1] ? 2u : 0u);      // the next call / tf_overlap_join takes over
+    return 0;
+  }
   // join: the side stream is FIFO, so its last recorded event covers everything before it -- one wait, not one per group
   if (sd.pending[1]) { sd.pending[0] = false; TF_TRY(guard(c, sd, 1), "join"); }
   TF_TRY(guard(c, sd, 0), "join");
+  if (sd.st != nullptr) e->overlap->pending = 0u;
   return 0;
 }
 

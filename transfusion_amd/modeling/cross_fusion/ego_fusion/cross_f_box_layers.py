@@ -130,12 +130,17 @@ class _EncoderFn(torch.autograd.Function):
         else:
             # one runtime call per layer, top layer first; after each, the hook may start reducing that layer's gradients
             # (data-parallel all-reduce overlapped with the rest of the backward)
+            # The side stream is NOT joined after each call (defer_join): the hook orders its collective after the
+            # side stream's own events, and whoever consumes the gradients calls ops.join_overlap() first.
             st = ops._stream()
+            desc.defer_join = 1
             for layer in range(desc.L - 1, -1, -1):
                 desc.bwd_hi, desc.bwd_nlayers = layer, 1
                 L.call("tf_encoder_bwd", desc, st)
                 hook(mod, layer)
-            desc.bwd_nlayers = 0
+            desc.bwd_nlayers, desc.defer_join = 0, 0
+            if not getattr(getattr(hook, "__self__", None), "joins_overlap", False):
+                ops.join_overlap(dev)
         mod._release(keep)
         if direct:
             return (None, d_vis, d_lang, None) + (None,) * ctx.nparams

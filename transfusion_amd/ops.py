@@ -105,6 +105,15 @@ def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 
 _overlap_cache = {}
 
 
+def overlap_handle(device):
+    """The device's ``TfOverlap`` ctypes object (None when disabled); see ``wgrad_overlap``."""
+    addr = wgrad_overlap(device)
+    if addr is None:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _overlap_cache[idx]
+
+
 def wgrad_overlap(device):
     """Address of this device's ``TfOverlap`` (side stream + events on which ``tf_encoder_bwd`` issues its weight-gradient
     GEMMs), created on first use; ``TF_WGRAD_OVERLAP=0`` keeps everything on the caller's stream (A/B switch)."""
@@ -118,6 +127,29 @@ def wgrad_overlap(device):
             L.check(L.load().tf_overlap_create(C.byref(o)), "tf_overlap_create")
         _overlap_cache[idx] = o
     return C.addressof(o)
+
+
+def join_overlap(device):
+    """Make the current stream wait for every weight-gradient GEMM the side stream still owes (tf_overlap_join)."""
+    o = overlap_handle(device)
+    if o is not None:
+        L.check(L.load().tf_overlap_join(C.byref(o), C.c_void_p(_stream())), "tf_overlap_join")
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """The side stream of ``overlap_handle(device)`` as a torch stream object (for event ordering from Python), or None."""
+    o = overlap_handle(device)
+    if o is None:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(idx)
+    if s is None:
+        s = torch.cuda.ExternalStream(o.stream, device=torch.device("cuda", idx))
+        _side_streams[idx] = s
+    return s
 
 
 _zeros_cache = {}
