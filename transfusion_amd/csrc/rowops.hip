@@ -258,14 +258,23 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
   const TfPackArgs& a = pb.a[blockIdx.z];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   if (r0 >= a.rows_p || c0 >= a.cols_p) return;        // block-uniform
+  // a thread keeps its column for the whole tile (256 % 64 == 0): the padded -> source column map (an integer division)
+  // is computed once, and ungrouped dimensions (group size "BIG") skip the division altogether
+  const int cl = threadIdx.x & 63, cp = c0 + cl;
+  int cs = -1;
+  if (cp < a.cols_p) {
+    const int cgq = a.cgp >= (1 << 28) ? 0 : cp / a.cgp, cge = cp - cgq * a.cgp;
+    if (cge < a.cg && cgq * a.cg + cge < a.cols) cs = cgq * a.cg + cge;
+  }
+  const bool row_grouped = a.rgp < (1 << 28);
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int rl = i >> 6, cl = i & 63;
-    const int rp = r0 + rl, cp = c0 + cl;
+    const int rl = i >> 6;
+    const int rp = r0 + rl;
     float v = 0.f;
-    if (rp < a.rows_p && cp < a.cols_p) {
-      const int rgq = rp / a.rgp, rge = rp - rgq * a.rgp, cgq = cp / a.cgp, cge = cp - cgq * a.cgp;
-      const int rs = rgq * a.rg + rge, cs = cgq * a.cg + cge;
-      if (rge < a.rg && cge < a.cg && rs < a.rows && cs < a.cols) v = a.src[(size_t)rs * a.cols + cs];
+    if (rp < a.rows_p && cs >= 0) {
+      const int rgq = row_grouped ? rp / a.rgp : 0, rge = rp - rgq * a.rgp;
+      const int rs = rgq * a.rg + rge;
+      if (rge < a.rg && rs < a.rows) v = a.src[(size_t)rs * a.cols + cs];
     }
     if (a.dst_is_f32) {
       if (rp < a.rows_p && cp < a.cols_p) ((float*)a.dst)[(size_t)rp * a.ld_dst + cp] = v;
