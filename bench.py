@@ -314,7 +314,8 @@ def main():
     result = {
         "metric": "train samples/sec, Ego4D NAO B=32 (14x14 vis + 512 txt tok), 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8 projections + bf16" if os.environ.get("TF_FP8_PROJ") == "1" else "bf16",   # the headline run is bf16 (default)
         "data": "synthetic",
         "config": {"workload": f"fusion-encoder train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
                                f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding",

@@ -48,7 +48,15 @@ typedef struct TfGemmArgs {
   int M, N, K;
   int epilogue;
   unsigned drop_thr, drop_key; float drop_scale;   // drop_thr == 0 -> no dropout
+  // fp8 operands (BASELINE configs[4]: fp8 MFMA for the QKV / FFN projections, fp32 accumulate).  fp8 != 0: A and W hold OCP
+  // e4m3 bytes (lda / ldw / K in elements = bytes, K % 64 == 0) as produced by tf_quant_rows_fp8, and the result is
+  // acc * scale_a[m] * scale_w[n] (+ bias ...).  Epilogues NONE, BIAS, BIAS_DROP_RES, BIAS_GELU_DROP_G.
+  int fp8; const float* scale_a; const float* scale_w;
 } TfGemmArgs;
+
+/* row-wise fp8 (e4m3) quantisation: dst[r][c] = fp8(src[r][c] / scale[r]), scale[r] = max|src[r][:]| / 448 (1 for an all-zero row);
+ * src bf16 [rows, ld_src] (cols valid, cols % 8 == 0), dst bytes [rows, ld_dst] with columns [cols, ld_dst) zero-filled */
+int tf_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, tf_stream_t s);
 
 typedef struct TfWgradArgs {
   const void* dY; int ldy;    // [M,N] bf16
@@ -265,6 +273,9 @@ typedef struct TfEncoderDesc {
                                  * are recorded in the handle, guarded by the next tf_encoder_bwd call on the same handle and joined by
                                  * tf_overlap_join (per-layer calls of the data-parallel reducer: the collective of a layer waits for
                                  * the side stream's events on its own stream instead of stalling the backward chain) */
+  int fp8_proj;                 /* forward QKV / FFN-up / FFN-down projections with fp8 (e4m3) operands and fp32 accumulation
+                                 * (BASELINE configs[4]): activations quantised per token in front of each of the three GEMMs,
+                                 * weights per output channel when the shadows are packed; backward unchanged (bf16) */
   int repack;                   /* tf_encoder_fwd only: refresh the bf16 weight shadows first (what tf_encoder_pack does); with an
                                  * overlap handle only layer 0 is packed on the caller's stream, layers >= 1 and the attention
                                  * dropout masks are produced on the side stream while the chain already runs layer 0 */

@@ -308,3 +308,32 @@ def test_golden_local_mask(dev, golden_dir):
     # the mask matters: without it the visual outputs differ
     v0, _, _, _ = enc(x.detach(), lang.detach(), mask)
     assert rel(v0, g["train_vis"]) > 5 * FWD_TOL
+
+
+@pytest.mark.gpu
+def test_fp8_projections_against_bf16(dev):
+    """BASELINE.json configs[4]: fp8 (e4m3) MFMA with fp32 accumulation for the QKV / FFN projections, "parity check vs bf16
+    within tol".  Same module, same inputs, dropout off; forward projections in fp8, everything else (attention, out_proj,
+    LayerNorm, the whole backward) as in the bf16 path.  Tolerance: two e4m3 operands (3 mantissa bits, per-token and
+    per-output-channel scales) put ~3-4 % relative L2 error on each projection; LayerNorm keeps it from compounding, so the
+    encoder outputs stay within 6e-2 of the bf16 path and the gradients within 1e-1."""
+    cfg = dict(B=4, Nv=196, Nl=128, d=768, h=4, L=2, mask_lens=[128, 40, 77, 100], seed=21)
+    enc, params = build(cfg, dev)
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    outs = {}
+    for mode in (False, True):
+        enc.fp8_projections = mode
+        enc.zero_grad(set_to_none=True)
+        xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+        ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+        vis, lo, _, _ = enc(xd, ld, torch.from_numpy(mask).to(dev))
+        ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+        outs[mode] = (vis.detach().cpu(), lo.detach().cpu(), xd.grad.cpu(), {k: p.grad.detach().cpu().clone() for k, p in enc.named_parameters() if p.grad is not None})
+    enc.fp8_projections = False
+    valid = ~mask
+    e_v, e_l = rel(outs[True][0], outs[False][0]), rel(outs[True][1][valid], outs[False][1][valid])
+    assert 1e-4 < e_v < 6e-2 and e_l < 6e-2, (e_v, e_l)          # really a different arithmetic, and within tolerance
+    assert rel(outs[True][2], outs[False][2]) < 1e-1
+    for k in ("t_encoder.layers.0.self_attn.in_proj_weight", "t_encoder.layers.1.linear2.weight", "t_encoder.layers.0.norm1.weight"):
+        assert rel(outs[True][3][k], outs[False][3][k]) < 1e-1, k

@@ -362,3 +362,26 @@ def test_attention_block_mask(dev, B, S, H, hd, p):
     g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)
     for which, nm in enumerate("qkv"):
         assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm}"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2500, 768, 768), (4096, 1536, 768), (700, 768, 1536)])
+def test_gemm_fp8_operands(dev, M, N, K):
+    """BASELINE configs[4]: fp8 (OCP e4m3) MFMA with fp32 accumulation for the projections.  Exactness: against the fp64
+    product of the DEQUANTISED operands (only the bf16 rounding of the result remains); accuracy: against the product of the
+    original bf16 operands (two 3-bit-mantissa operands: relative L2 error of a K-term dot product ~ 3-4 %)."""
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(M + N)
+    x = bf(torch.randn(M, K, generator=g)).to(dev)
+    w = bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    xq, sx = ops.quant_rows_fp8(x)
+    wq, sw = ops.quant_rows_fp8(w)
+    xd = xq.view(torch.float8_e4m3fn).double().cpu()[:, :K] * sx.double().cpu()[:, None]
+    wd = wq.view(torch.float8_e4m3fn).double().cpu()[:, :K] * sw.double().cpu()[:, None]
+    assert (xd - x.double().cpu()).abs().max() <= 0.0625 * x.double().abs().max().cpu() + 1e-6    # half an e4m3 ulp at the top binade
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(xq, wq, out, N, xq.shape[1], L.TF_EPI_BIAS, bias=bias, scale_a=sx, scale_w=sw)
+    ref_q = xd @ wd.t() + bias.double().cpu()
+    ref = x.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    assert rel(out, ref_q) < 6e-3
+    assert rel(out, ref) < 6e-2

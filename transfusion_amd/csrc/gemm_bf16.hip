@@ -218,8 +218,12 @@ __device__ __forceinline__ void wait_vm_barrier8() { asm volatile("s_waitcnt vmc
 __device__ __forceinline__ void wait_vm_barrier4() { asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int EPI, int MF>
+// FP8: operands are OCP e4m3 bytes.  The byte geometry is unchanged (64-B tile rows = 64 values, one K-step = 64 values): a
+// 16-B fragment feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes; both operands use the same k <-> byte map,
+// so every k is multiplied exactly once), and the per-row / per-output-channel scales are applied with the bias.
+template <int EPI, int MF, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g) {
+  constexpr int ES = FP8 ? 1 : 2;                                  // bytes per operand element
   constexpr int BM = 32 * MF;
   constexpr int A_BYTES = BM * BIG_ROWB, W_BYTES = BIG_BN * BIG_ROWB, SLOT = A_BYTES + W_BYTES;
   constexpr int NA = BM / 16, NW = BIG_BN / 16, NINST = NA + NW;   // DMA instructions per K-step (34 / 36 / 36)
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     const int r = (isW ? j - NA : j) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ swz<32>(r);
     const int grow = isW ? min(n0 + r, g.N - 1) : min(m0 + r, g.M - 1);
-    src_off[i] = ((size_t)grow * (isW ? g.ldw : g.lda) + c * 8) * 2;
+    src_off[i] = (size_t)grow * (isW ? g.ldw : g.lda) * ES + c * 16;
   }
   auto stage = [&](int slot, int kstep) {
     unsigned char* sl = smem + slot * SLOT;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / BIG_BK;
+  const int nk = g.K * ES / (BIG_BK * 2);                          // K-steps of 64 operand bytes
   const int frow = lane & 15, fch = lane >> 4;
   // fragment j sits 16 rows = 1024 B after fragment 0 with the SAME swizzle: one base register each plus immediates
   const int rn0 = wc * 64 + frow, rm0 = wr * (BM / 2) + frow;
@@ -289,17 +293,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+      for (int ni = 0; ni < 4; ++ni) {
+        if constexpr (FP8) {
+          typedef long long2_t __attribute__((ext_vector_type(2)));
+          const long2_t w2 = __builtin_bit_cast(long2_t, wf[ni]), x2 = __builtin_bit_cast(long2_t, xf[mi]);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], acc[ni][mi], 0, 0, 0);
+        } else {
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+      }
     // schedule: fragment reads first, then the step's DMA instructions spread one per 7 MFMAs, so that a wave's DMA
     // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
+    constexpr int MM = FP8 ? 2 : 1;
     __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 7 * MM, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MF - 7 * PER_WAVE, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MF - 7 * PER_WAVE) * MM, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers must land before LDS is reused
 
@@ -310,12 +323,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     const int nl = wc * 64 + ni * 16 + (lane >> 4) * 4;
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
     if (g.bias != nullptr && n0 + nl < g.N) b = *(const f32x4*)(g.bias + n0 + nl);
+    f32x4 sw = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (FP8) { if (g.scale_w != nullptr && n0 + nl < g.N) sw = *(const f32x4*)(g.scale_w + n0 + nl); }
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
       const int ml = wr * (BM / 2) + mi * 16 + (lane & 15);
+      f32x4 c4 = acc[ni][mi];
+      if constexpr (FP8) {
+        const float sa = g.scale_a != nullptr ? g.scale_a[min(m0 + ml, g.M - 1)] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4[e] *= sa * sw[e];
+      }
       u32x2 v;
-      v[0] = pack2bf(acc[ni][mi][0] + b[0], acc[ni][mi][1] + b[1]);
-      v[1] = pack2bf(acc[ni][mi][2] + b[2], acc[ni][mi][3] + b[3]);
+      v[0] = pack2bf(c4[0] + b[0], c4[1] + b[1]);
+      v[1] = pack2bf(c4[2] + b[2], c4[3] + b[3]);
       *(u32x2*)(ct + ml * BIG_CT_STRIDE + nl * 2) = v;
     }
   }
@@ -699,6 +720,23 @@ template <int MF> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
     if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
     hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF>), grid, block, lds, stream, *a);                                \
   } break;
+#define TF_GEMM_CASE8(E)                                                                                          \
+  case E: {                                                                                                       \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a);                          \
+  } break;
+  if (a->fp8) {
+    switch (a->epilogue) {
+      TF_GEMM_CASE8(TF_EPI_NONE)
+      TF_GEMM_CASE8(TF_EPI_BIAS)
+      TF_GEMM_CASE8(TF_EPI_BIAS_DROP_RES)
+      TF_GEMM_CASE8(TF_EPI_BIAS_GELU_DROP_G)
+      default: return -4;
+    }
+    return (int)hipGetLastError();
+  }
+#undef TF_GEMM_CASE8
   switch (a->epilogue) {
     TF_GEMM_CASE(TF_EPI_NONE)
     TF_GEMM_CASE(TF_EPI_BIAS)
@@ -742,6 +780,14 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
   static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
   const double fl = 2.0 * a->M * a->N * a->K;
+  if (a->fp8) {                                   // fp8 operands: large-tile kernel only (any shape; rows are clamped)
+    if ((a->lda % 16) || (a->ldw % 16)) return -3;
+    const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    char nm[56];
+    snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d, fp8>", a->epilogue, mf);
+    TfTraceScope tr(nm, stream, fl);
+    return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+  }
   if (big && a->M >= 2048 && a->N >= 256) {
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
     char nm[56];

@@ -439,6 +439,48 @@ __global__ void col2im_kernel(const TfPatchArgs a, int out_is_f32) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-wise fp8 (OCP e4m3) quantisation: one wave per row, 16-B lanes; scale[r] = max|row| / 448.
+// Feeds the fp8 operand variant of the large-tile GEMM (activations per token, weights per output channel).
+// ------------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const u16* __restrict__ src, int ld_src, unsigned char* __restrict__ dst,
+                                                             int ld_dst, float* __restrict__ scale, int rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    float v[MAXC][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      if (c < cols) {
+        unpack8(*(const u32x4*)(src + (size_t)row * ld_src + c), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+      }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < ld_dst) {                                   // pad columns [cols, ld_dst) become zero bytes (fp8 +0)
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, w1, true);
+        u32x2 o; o[0] = (unsigned)w0; o[1] = (unsigned)w1;
+        *(u32x2*)(dst + (size_t)row * ld_dst + c) = o;
+      }
+    }
+  }
+}
+
 inline int grid_for(long long n, int per_block, int cap = 2048) {
   long long g = (n + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -558,6 +600,17 @@ extern "C" int tf_launch_cast_bf16_f32(const void* s, float* d, long long n, hip
   if (n <= 0) return 0;
   TfTraceScope tr("cast_bf16_f32_kernel", st);
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const u16*)s, d, n);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int width = max(cols, ld_dst);
+  if ((cols % 8) || (ld_src % 8) || (ld_dst % 8) || cols > ld_src || cols > ld_dst || width > 64 * MAXC_MAX * 8) return -2;
+  const dim3 grid(grid_for(rows, 4, 4096));
+  TfTraceScope tr("quant_rows_fp8_kernel", st, 0.0, 3.0 * rows * cols);
+  if (width <= 512) hipLaunchKernelGGL(quant_rows_fp8_kernel<1>, grid, dim3(256), 0, st, (const u16*)src, ld_src, (unsigned char*)dst, ld_dst, scale, rows, cols);
+  else if (width <= 1024) hipLaunchKernelGGL(quant_rows_fp8_kernel<2>, grid, dim3(256), 0, st, (const u16*)src, ld_src, (unsigned char*)dst, ld_dst, scale, rows, cols);
+  else hipLaunchKernelGGL(quant_rows_fp8_kernel<4>, grid, dim3(256), 0, st, (const u16*)src, ld_src, (unsigned char*)dst, ld_dst, scale, rows, cols);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {

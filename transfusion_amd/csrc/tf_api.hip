@@ -58,7 +58,9 @@ bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o) {
   return true;
 }
 struct WOff {   // byte offsets inside wpack, per layer
-  size_t win, winT, wo, woT, w1, w1T, w2, w2T, bin, bo, b1, b2, stride;
+  size_t win, winT, wo, woT, w1, w1T, w2, w2T, bin, bo, b1, b2;
+  size_t win8, w18, w28, s_in, s_w1, s_w2;        // fp8 (e4m3) shadows of the three forward projections + per-output-channel scales
+  size_t stride;
 };
 WOff make_woff(const Dims& D) {
   WOff w; size_t o = 0;
@@ -68,6 +70,8 @@ WOff make_woff(const Dims& D) {
   w.w1 = take((size_t)D.ffp * D.dp * 2);     w.w1T = take((size_t)D.dp * D.ffp * 2);
   w.w2 = take((size_t)D.dp * D.ffp * 2);     w.w2T = take((size_t)D.ffp * D.dp * 2);
   w.bin = take((size_t)D.ldq * 4); w.bo = take((size_t)D.dp * 4); w.b1 = take((size_t)D.ffp * 4); w.b2 = take((size_t)D.dp * 4);
+  w.win8 = take((size_t)D.nqkv * D.dp); w.w18 = take((size_t)D.ffp * D.dp); w.w28 = take((size_t)D.dp * D.ffp);
+  w.s_in = take((size_t)D.ldq * 4); w.s_w1 = take((size_t)D.ffp * 4); w.s_w2 = take((size_t)D.dp * 4);
   w.stride = o;
   return w;
 }
@@ -77,6 +81,7 @@ struct AOff {   // byte offsets inside work
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
   size_t dxa, dxb, dz, dy, dzb, dyb, du, d_o, dqkv, delta;
+  size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
   size_t total;
 };
 AOff make_aoff(const Dims& D) {
@@ -100,6 +105,7 @@ AOff make_aoff(const Dims& D) {
   a.meanf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4); a.rstdf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4);
   a.dxa = take(md); a.dxb = take(md); a.dz = take(md); a.dy = take(md); a.dzb = take(md); a.dyb = take(md); a.du = take(mf); a.d_o = take(md); a.dqkv = take(mq);
   a.delta = take(st);
+  a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
   return a;
 }
@@ -135,6 +141,18 @@ int gemm(const Ctx& c, const void* A, int lda, const void* W, int ldw, void* C, 
   TfGemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
+  return tf_launch_gemm_nt(&g, c.st);
+}
+// forward projection with fp8 operands: quantise the bf16 activation per token, then the fp8 large-tile GEMM
+int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const float* sw, void* C, int ldc, const float* bias, const void* R,
+             int ldr, void* C2, int ldc2, int N, int epi, Drop dr) {
+  unsigned char* a8 = c.wk + c.A.a8; float* sa = (float*)(c.wk + c.A.sa8);
+  int rc = tf_launch_quant_rows_fp8(A, lda, a8, K, sa, c.D.M, K, c.st);
+  if (rc != 0) return rc;
+  TfGemmArgs g{};
+  g.A = a8; g.lda = K; g.W = W8; g.ldw = K; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
+  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
+  g.fp8 = 1; g.scale_a = sa; g.scale_w = sw;
   return tf_launch_gemm_nt(&g, c.st);
 }
 // Side stream of one tf_encoder_bwd call.  An event record or wait on the chain is a barrier packet and costs ~5 us of
@@ -271,6 +289,11 @@ int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr
 }
 
 #define TF_WRAP(name, call) do { if (a == nullptr) return fail(-1, name); TF_TRY(call, name); return 0; } while (0)
+int tf_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, tf_stream_t s) {
+  if (src == nullptr || dst == nullptr || scale == nullptr) return fail(-1, "tf_quant_rows_fp8");
+  TF_TRY(tf_launch_quant_rows_fp8(src, ld_src, dst, ld_dst, scale, rows, cols, (hipStream_t)s), "tf_quant_rows_fp8");
+  return 0;
+}
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_fwd", tf_launch_gemm_nt(a, (hipStream_t)s)); }
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_wgrad", tf_launch_wgrad_tn(a, (hipStream_t)s)); }
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s) { TF_WRAP("tf_attn_fwd", tf_launch_attn_fwd(a, (hipStream_t)s)); }
@@ -354,7 +377,13 @@ int pack_layer(const Ctx& c, int l, hipStream_t st) {
   pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
   pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
   pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-  return tf_launch_pack_batch(batch, nb, st);
+  int rc = tf_launch_pack_batch(batch, nb, st);
+  if (rc == 0 && c.e->fp8_proj) {                 // fp8 shadows of the forward projections, one scale per output channel
+    rc = tf_launch_quant_rows_fp8(w + c.W.win, D.dp, w + c.W.win8, D.dp, (float*)(w + c.W.s_in), D.nqkv, D.dp, st);
+    if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w1, D.dp, w + c.W.w18, D.dp, (float*)(w + c.W.s_w1), D.ffp, D.dp, st);
+    if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w2, D.ffp, w + c.W.w28, D.ffp, (float*)(w + c.W.s_w2), D.dp, D.ffp, st);
+  }
+  return rc;
 }
 }  // namespace
 extern "C" {
@@ -409,6 +438,10 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l];
     const Drop none{0u, 0u, 1.f};
+    if (e->fp8_proj)
+      TF_TRY(gemm_fp8(c, c.X(l), D.dp, D.dp, w + c.W.win8, (const float*)(w + c.W.s_in), b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin),
+                      nullptr, 0, nullptr, 0, D.nqkv, TF_EPI_BIAS, none), "gemm qkv (fp8)");
+    else
     TF_TRY(gemm(c, c.X(l), D.dp, w + c.W.win, D.dp, b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin), nullptr, 0, nullptr, 0, D.nqkv, D.dp,
                 TF_EPI_BIAS, none), "gemm qkv");
     {
@@ -430,10 +463,17 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln1_fwd");
     }
+    if (e->fp8_proj) {
+      TF_TRY(gemm_fp8(c, b + c.A.x1, D.dp, D.dp, w + c.W.w18, (const float*)(w + c.W.s_w1), b + c.A.u, D.ffp, (const float*)(w + c.W.b1),
+                      nullptr, 0, b + c.A.h, D.ffp, D.ffp, TF_EPI_BIAS_GELU_DROP_G, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up (fp8)");
+      TF_TRY(gemm_fp8(c, b + c.A.h, D.ffp, D.ffp, w + c.W.w28, (const float*)(w + c.W.s_w2), b + c.A.z2, D.dp, (const float*)(w + c.W.b2),
+                      b + c.A.x1, D.dp, nullptr, 0, D.dp, TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down (fp8)");
+    } else {
     TF_TRY(gemm(c, b + c.A.x1, D.dp, w + c.W.w1, D.dp, b + c.A.u, D.ffp, (const float*)(w + c.W.b1), nullptr, 0, b + c.A.h, D.ffp, D.ffp, D.dp,
                 TF_EPI_BIAS_GELU_DROP_G, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");   // slot "u" holds G = d h / d u
     TF_TRY(gemm(c, b + c.A.h, D.ffp, w + c.W.w2, D.ffp, b + c.A.z2, D.dp, (const float*)(w + c.W.b2), b + c.A.x1, D.dp, nullptr, 0, D.dp, D.ffp,
                 TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down");
+    }
     {
       TfLnArgs n{};
       n.x = b + c.A.z2; n.ldx = D.dp; n.y = c.X(l + 1); n.ldy = D.dp; n.y_is_f32 = 0; n.gamma = p.n2_w; n.beta = p.n2_b;

@@ -24,6 +24,7 @@ int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsig
 int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t stream);
 int tf_launch_cast_f32_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 int tf_launch_cast_bf16_f32(const void* src, float* dst, long long n, hipStream_t stream);
+int tf_launch_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, hipStream_t stream);
 int tf_launch_radam(const TfRadamArgs* a, hipStream_t stream);
 int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);
 int tf_launch_im2col(const TfPatchArgs* a, hipStream_t stream);       // feat -> cols

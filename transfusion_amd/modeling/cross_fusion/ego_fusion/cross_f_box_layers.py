@@ -11,6 +11,7 @@ autograd node.  Compute dtype is bf16 (fp32 statistics / accumulation); paramete
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -204,6 +205,7 @@ class CrossTransformerModuleBox(nn.Module):
 
         # runtime state (not part of state_dict)
         self.accumulate_into_grad = False     # True: backward adds straight into p.grad (flat-buffer training loop)
+        self.fp8_projections = os.environ.get("TF_FP8_PROJ") == "1"   # forward QKV / FFN GEMMs with fp8 (e4m3) operands (BASELINE configs[4])
         self.layer_grad_hook = None           # callable(module, layer): called as soon as that layer's gradients are enqueued
         self._wpack = None
         self._wpack_versions = None
@@ -223,7 +225,7 @@ class CrossTransformerModuleBox(nn.Module):
         return ps
 
     def _wpack_dirty(self) -> bool:
-        vers = tuple((p.data_ptr(), p._version) for p in self._param_list())
+        vers = tuple((p.data_ptr(), p._version) for p in self._param_list()) + (bool(self.fp8_projections),)
         if vers != self._wpack_versions:
             self._wpack_versions = vers
             return True
@@ -269,6 +271,7 @@ class CrossTransformerModuleBox(nn.Module):
         e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward
         e.training = 1 if self.training else 0
         e.final_norm = 1 if self.final_norm == "ln" else 0
+        e.fp8_proj = 1 if self.fp8_projections else 0
         e.p_token, e.p_patch = float(self.token_dropout), float(self.patch_dropout)
         self._last_seed = ops.next_seed() if self.training else 0
         e.seed = self._last_seed

@@ -93,13 +93,28 @@ def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, w
     return dst, dst_t
 
 
-def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0)):
+def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0), scale_a=None, scale_w=None):
+    """C = epilogue(A @ W^T).  A / W are bf16, or -- when ``scale_a`` / ``scale_w`` are given -- uint8 tensors of OCP e4m3
+    values from ``quant_rows_fp8`` (fp8 MFMA, fp32 accumulate, result scaled per row and per output channel)."""
+    fp8 = scale_a is not None or scale_w is not None
     g = L.TfGemmArgs(A=L.ptr(A), lda=A.stride(0), W=L.ptr(W), ldw=W.stride(0), C=L.ptr(C_out), ldc=C_out.stride(0),
                      bias=L.ptr(bias), R=L.ptr(R), ldr=0 if R is None else R.stride(0), C2=L.ptr(C2),
                      ldc2=0 if C2 is None else C2.stride(0), M=A.shape[0], N=N, K=K,
                      epilogue=L.TF_EPI_NONE if epilogue is None else epilogue,
-                     drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2])
+                     drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
+                     fp8=1 if fp8 else 0, scale_a=L.ptr(scale_a), scale_w=L.ptr(scale_w))
     L.call("tf_gemm_fwd", g, _stream())
+
+
+def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
+    """bf16 [rows, cols] -> (uint8 [rows, ld_out] of OCP e4m3 values, fp32 [rows] scales): x ~= q * scale[:, None]."""
+    _require_cuda(x)
+    rows, cols = x.shape
+    ld_out = (cols + 63) // 64 * 64 if ld_out is None else ld_out
+    q = torch.empty(rows, ld_out, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.load().tf_quant_rows_fp8(x.data_ptr(), x.stride(0), q.data_ptr(), ld_out, sc.data_ptr(), rows, cols, _stream()), "tf_quant_rows_fp8")
+    return q, sc
 
 
 _overlap_cache = {}
