@@ -530,8 +530,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
   const unsigned char* __restrict__ X = (const unsigned char*)g.X;
   const unsigned char* __restrict__ Z = (const unsigned char*)g.zeros;
 
-  // one step = 16 KiB of dY (16 wave-instructions of 2 rows) + 8 KiB of X (8 of 4 rows): 6 per wave
-  auto stage = [&](int slot, int st) {
+  // one step = 16 KiB of dY (16 wave-instructions of 2 rows) + 8 KiB of X (8 of 4 rows): 6 per wave.
+  // Per-lane source pointers of the six pieces at step 0 are computed ONCE (columns clamped, swizzle folded in); a step only
+  // adds a wave-uniform byte stride.  (Recomputing row index, clamps, the 64-bit multiply-add and the zero-source select for
+  // every piece of every step was ~57 VALU instructions per 16 MFMAs.)  Only a ragged final step (rows past m_end must read
+  // zeros) takes the general path.
+  const unsigned char* py[4];
+  const unsigned char* px[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = i * 4 + wave;
+    const int r = 2 * j + (lane >> 5);
+    const int c = (lane & 31) ^ ((r & 3) << 2);
+    const int cn = min(n0 + c * 8, g.N - 8);                                     // clamp: never stored
+    py[i] = dY + ((size_t)min(m_begin + r, g.M - 1) * g.ldy + cn) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = i * 4 + wave;
+    const int r = 4 * j + (lane >> 4);
+    const int c = (lane & 15) ^ ((r & 3) << 2);
+    const int ck = min(k0 + c * 8, g.K - 8);
+    px[i] = X + ((size_t)min(m_begin + r, g.M - 1) * g.ldx + ck) * 2;
+  }
+  const size_t step_y = (size_t)STEP * g.ldy * 2, step_x = (size_t)STEP * g.ldx * 2;
+  const bool ragged = ((m_end - m_begin) % STEP) != 0;        // block-uniform; false whenever M is a multiple of 32
+  auto stage_general = [&](int slot, int st) {
     unsigned char* ybase = smem + slot * SLOT;
     unsigned char* xbase = ybase + YB;
 #pragma unroll
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       const int r = 2 * j + (lane >> 5);
       const int c = (lane & 31) ^ ((r & 3) << 2);
       const int gm = m_begin + st * STEP + r;
-      const int cn = min(n0 + c * 8, g.N - 8);                                   // clamp: never stored
+      const int cn = min(n0 + c * 8, g.N - 8);
       const unsigned char* sy = gm < m_end ? dY + ((size_t)gm * g.ldy + cn) * 2 : Z + (c & 15) * 16;
       glds16(sy, ybase + j * 1024);
     }
@@ -554,6 +578,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       const unsigned char* sx = gm < m_end ? X + ((size_t)gm * g.ldx + ck) * 2 : Z + c * 16;
       glds16(sx, xbase + j * 1024);
     }
+  };
+  auto stage = [&](int slot, int st) {
+    if (ragged && st == nsteps - 1) { stage_general(slot, st); return; }
+    unsigned char* ybase = smem + slot * SLOT;
+    unsigned char* xbase = ybase + YB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(py[i] + (size_t)st * step_y, ybase + (i * 4 + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(px[i] + (size_t)st * step_x, xbase + (i * 4 + wave) * 1024);
   };
 
   f32x16 acc[4][2], accb;
