@@ -56,18 +56,20 @@ def make_batch(B, device, rank, d=D, nv=NV, nl=NL):
     lang = torch.nn.functional.normalize(torch.randn(B, nl, d, generator=g), dim=-1)     # SBERT normalize: True
     lens = torch.randint(nl // 4, nl + 1, (B,), generator=g)
     pad = torch.arange(nl).view(1, -1) >= lens.view(-1, 1)                                # True = ignore
-    return x.to(device), lang.to(device), pad.to(device)
+    valid = (~pad).unsqueeze(-1).float()                                                  # batch constants of the synthetic loss
+    km = torch.tensor(1.0 / (float(valid.sum()) * d))
+    return x.to(device), lang.to(device), pad.to(device), valid.to(device), km.to(device)
 
 
 class _MaskedSquareLoss(torch.autograd.Function):
     """mean(vis^2) + mean(lang[valid]^2) with a hand-written backward: 3 elementwise passes and 2 dot products per step
-    instead of autograd's ~10 (the harness's own loss was ~1 GB/step of fp32 traffic next to the block it is timing)."""
+    instead of autograd's ~10 (the harness's own loss was ~1 GB/step of fp32 traffic next to the block it is timing); the mask
+    in float form and 1 / (valid count * d) come with the batch."""
 
     @staticmethod
-    def forward(ctx, vis, lo, valid):
+    def forward(ctx, vis, lo, valid, km):
         m = lo * valid
         kv = 1.0 / vis.numel()
-        km = 1.0 / (valid.sum() * lo.shape[-1])                   # 0-dim tensor: no host sync
         ctx.save_for_backward(vis, m, km)
         ctx.kv = kv
         v1, m1 = vis.reshape(-1), m.reshape(-1)
@@ -76,15 +78,14 @@ class _MaskedSquareLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         vis, m, km = ctx.saved_tensors
-        return vis * (g * (2.0 * ctx.kv)), m * (g * (2.0 * km)), None      # valid is 0/1: d/dlo = 2 km lo valid^2 = 2 km m
+        return vis * (g * (2.0 * ctx.kv)), m * (g * (2.0 * km)), None, None      # valid is 0/1: d/dlo = 2 km lo valid^2 = 2 km m
 
 
 def loss_fn(module, batch):
     """mean(vis^2) + mean(lang[valid]^2)."""
-    x, lang, pad = batch
+    x, lang, pad, valid, km = batch
     vis, lo, _, _ = module(x, lang, pad)
-    valid = (~pad).unsqueeze(-1).to(lo.dtype)
-    return _MaskedSquareLoss.apply(vis, lo, valid)
+    return _MaskedSquareLoss.apply(vis, lo, valid, km)
 
 
 def flops_per_sample_layer(S, d):
@@ -204,7 +205,7 @@ def cpu_baseline(seconds_budget=25.0):
     enc = make_encoder("cpu")
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "pos_embedding" not in k and "heatmap" not in k)
           for k, v in enc.state_dict().items()}
-    x, lang, pad = make_batch(B, "cpu", 0)
+    x, lang, pad, _, _ = make_batch(B, "cpu", 0)
     S = NV + NL
 
     def step():

@@ -300,7 +300,13 @@ class CrossTransformerModuleBox(nn.Module):
         if pad_mask is not None:
             if pad_mask.shape != (B, Nl):
                 raise RuntimeError(f"language_tokens_att_maks must be [B, Nl] = {(B, Nl)}, got {tuple(pad_mask.shape)}")
-            m8 = pad_mask.to(torch.uint8).contiguous()
+            ck = (pad_mask.data_ptr(), pad_mask._version, tuple(pad_mask.shape))
+            cache = getattr(self, "_pad_u8_cache", None)              # the same mask tensor step after step (one conversion kernel less)
+            if cache is not None and cache[0] == ck:
+                m8 = cache[1]
+            else:
+                m8 = pad_mask.to(torch.uint8).contiguous()
+                self._pad_u8_cache = (ck, m8)
             keep["mask"] = m8
             e.lang_pad_mask = m8.data_ptr()
         return e, keep
