@@ -1,6 +1,7 @@
 // C-ABI layer of libtfusion_hip.so (see include/tfusion.h) and the native encoder runtime: the launch
-// sequence of one CrossTransformerModuleBox forward / backward, enqueued on the caller's stream with no
-// allocation, no synchronisation and no host-side state (graph-capturable, callable from any thread).
+// sequence of one CrossTransformerModuleBox forward / backward, enqueued on the caller's stream (plus, with a
+// TfOverlap handle, the caller-owned side stream) with no allocation and no host synchronisation; callable from any
+// thread.  State: none of its own except the opt-in launch tracer; a TfOverlap handle carries its pending-join bits.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
