@@ -130,9 +130,9 @@ def kernel_census(B, device, reps=20):
         # name, kernel symbol, launches per layer-step, callable, algorithmic flops per launch, algorithmic HBM bytes per launch
         ("gemm_qkv", "gemm_nt<BIAS>", 1, lambda: ops.gemm(X, W_qkv, QKV, 3 * d, d, E.TF_EPI_BIAS, bias=bias3), GF(M, 3 * d, d), 2 * (M * d + M * 3 * d)),
         ("gemm_outproj+drop+res", "gemm_nt<BIAS_DROP_RES>", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, d), 2 * 3 * M * d),
-        ("gemm_ffn_up+gelu+drop", "gemm_nt<BIAS_GELU_DROP>", 1, lambda: ops.gemm(X, W_1, U, ff, d, E.TF_EPI_BIAS_GELU_DROP, bias=biasf, C2=Hh, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("gemm_ffn_up+gelu+G+drop", "gemm_nt<BIAS_GELU_DROP_G>", 1, lambda: ops.gemm(X, W_1, U, ff, d, E.TF_EPI_BIAS_GELU_DROP_G, bias=biasf, C2=Hh, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
         ("gemm_ffn_down+drop+res", "gemm_nt<BIAS_DROP_RES>", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_BIAS_DROP_RES, bias=bias1, R=Y, drop=drop), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
-        ("dgrad_ffn_down+dgelu", "gemm_nt<DGELU_DROP>", 1, lambda: ops.gemm(X, W_1, Hh, ff, d, E.TF_EPI_DGELU_DROP, R=U, drop=drop), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
+        ("dgrad_ffn_down*G", "gemm_nt<MUL>", 1, lambda: ops.gemm(X, W_1, Hh, ff, d, E.TF_EPI_MUL, R=U), GF(M, ff, d), 2 * (M * d + 2 * M * ff)),
         ("dgrad_ffn_up+add", "gemm_nt<ADD>", 1, lambda: ops.gemm(Xf, W_2, O, d, ff, E.TF_EPI_ADD, R=Y), GF(M, d, ff), 2 * (M * ff + 2 * M * d)),
         ("dgrad_outproj", "gemm_nt<NONE>", 1, lambda: ops.gemm(X, W_o, O, d, d, E.TF_EPI_NONE), GF(M, d, d), 2 * 2 * M * d),
         ("dgrad_qkv+add", "gemm_nt<ADD>", 1, lambda: ops.gemm(QKV, W_qkvT, O, d, 3 * d, E.TF_EPI_ADD, R=Y), GF(M, d, 3 * d), 2 * (M * 3 * d + 2 * M * d)),
