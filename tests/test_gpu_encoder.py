@@ -337,3 +337,62 @@ def test_fp8_projections_against_bf16(dev):
     assert rel(outs[True][2], outs[False][2]) < 1e-1
     for k in ("t_encoder.layers.0.self_attn.in_proj_weight", "t_encoder.layers.1.linear2.weight", "t_encoder.layers.0.norm1.weight"):
         assert rel(outs[True][3][k], outs[False][3][k]) < 1e-1, k
+
+
+@pytest.mark.gpu
+def test_fully_padded_language_sample_against_oracle(dev):
+    """One sample has NO valid language token (its keys are the visual tokens only; whole key tiles are skipped), another has all
+    of them: outputs on valid rows and all gradients against the oracle."""
+    from oracle import fusion_oracle as O
+    cfg = dict(B=3, Nv=70, Nl=90, d=64, h=2, L=2, mask_lens=[0, 90, 1], seed=31)
+    enc, params = build(cfg, dev)
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    gl = gl * (~mask)[..., None]                     # cotangents only where the reference's outputs are meaningful
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+    vis, lo, _, _ = enc(xd, ld, torch.from_numpy(mask).to(dev))
+    ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+    xr, lr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+    v_ref, l_ref = O.encoder_forward(sd, xr, lr, torch.from_numpy(mask), cfg["h"], cfg["L"])
+    ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+    valid = ~mask
+    assert rel(vis, v_ref.detach()) < FWD_TOL
+    assert rel(lo.detach().cpu()[valid], l_ref.detach()[valid]) < FWD_TOL
+    assert rel(xd.grad, xr.grad) < GRAD_TOL and rel(ld.grad, lr.grad) < GRAD_TOL
+    for k, p in enc.named_parameters():
+        if k in sd and sd[k].grad is not None:
+            assert rel(p.grad, sd[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_equals_concatenated_batch(dev):
+    """accumulate_into_grad: two micro-batches accumulated into p.grad give the gradients of the concatenated batch (dropout off;
+    the per-sample arithmetic does not depend on the batch a sample travels in), and eval-mode forwards are bitwise repeatable."""
+    cfg = dict(B=4, Nv=49, Nl=40, d=128, h=4, L=2, mask_lens=[40, 13, 25, 40], seed=41)
+    enc, _ = build(cfg, dev)
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    t = lambda a: torch.from_numpy(a).to(dev)
+
+    def run(slices):
+        enc.train()
+        enc.accumulate_into_grad = True
+        for p in enc.parameters():
+            p.grad = None
+        for sl in slices:
+            v, l_, _, _ = enc(t(x[sl]), t(lang[sl]), t(mask[sl]))
+            ((v * t(gv[sl])).sum() + (l_ * t(gl[sl])).sum()).backward()
+        enc.accumulate_into_grad = False
+        return {k: p.grad.detach().cpu().clone() for k, p in enc.named_parameters() if p.grad is not None}
+
+    whole = run([slice(0, 4)])
+    parts = run([slice(0, 2), slice(2, 4)])
+    for k in whole:
+        assert rel(parts[k], whole[k]) < 2e-3, k           # same products, different fp32 summation order (atomics)
+    enc.eval()
+    with torch.no_grad():
+        a = enc(t(x), t(lang), t(mask))[0]
+        b = enc(t(x), t(lang), t(mask))[0]
+    assert torch.equal(a, b)

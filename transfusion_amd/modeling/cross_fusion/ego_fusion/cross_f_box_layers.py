@@ -300,13 +300,14 @@ class CrossTransformerModuleBox(nn.Module):
         if pad_mask is not None:
             if pad_mask.shape != (B, Nl):
                 raise RuntimeError(f"language_tokens_att_maks must be [B, Nl] = {(B, Nl)}, got {tuple(pad_mask.shape)}")
-            ck = (pad_mask.data_ptr(), pad_mask._version, tuple(pad_mask.shape))
-            cache = getattr(self, "_pad_u8_cache", None)              # the same mask tensor step after step (one conversion kernel less)
-            if cache is not None and cache[0] == ck:
-                m8 = cache[1]
+            # the same mask TENSOR OBJECT step after step saves one conversion kernel; identity + version, and the cache holds
+            # the tensor (a data_ptr key would match a freed temporary's successor)
+            cache = getattr(self, "_pad_u8_cache", None)
+            if cache is not None and cache[0] is pad_mask and cache[1] == pad_mask._version:
+                m8 = cache[2]
             else:
                 m8 = pad_mask.to(torch.uint8).contiguous()
-                self._pad_u8_cache = (ck, m8)
+                self._pad_u8_cache = (pad_mask, pad_mask._version, m8)
             keep["mask"] = m8
             e.lang_pad_mask = m8.data_ptr()
         return e, keep
@@ -363,17 +364,17 @@ class CrossTransformerModuleBox(nn.Module):
         (cross_f_box_layers.py:87-95), i.e. only visual-visual pairs can be blocked.  Cached per mask tensor."""
         if tuple(vis_tokens_mask.shape) != (Nv, Nv):
             raise RuntimeError(f"vis_tokens_mask must be [Nv, Nv] = {(Nv, Nv)}, got {tuple(vis_tokens_mask.shape)}")
-        key = (vis_tokens_mask.data_ptr(), vis_tokens_mask._version, Nv, Nl, str(device))
+        key = (vis_tokens_mask._version, Nv, Nl, str(device))
         cache = getattr(self, "_block_bits_cache", None)
-        if cache is not None and cache[0] == key:
-            return cache[1]
+        if cache is not None and cache[0] is vis_tokens_mask and cache[1] == key:     # identity, not data_ptr (see the padding-mask cache)
+            return cache[2]
         S = Nv + Nl
         SW = (S + 63) // 64
         full = torch.zeros(S, SW * 64, dtype=torch.bool)
         full[:Nv, :Nv] = vis_tokens_mask.detach().to("cpu") != 0
         words = (full.view(S, SW, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1)   # wraps mod 2^64: bit 63 is the sign
         bits = words.contiguous().to(device)
-        self._block_bits_cache = (key, bits)
+        self._block_bits_cache = (vis_tokens_mask, key, bits)
         return bits
 
     def peek(self, desc_keep, name):
