@@ -396,3 +396,49 @@ def test_gradient_accumulation_equals_concatenated_batch(dev):
         a = enc(t(x), t(lang), t(mask))[0]
         b = enc(t(x), t(lang), t(mask))[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_training_steps_with_changing_batches_track_the_oracle(dev):
+    """Three optimiser steps of FusionTrainStep, every step a DIFFERENT batch (new tensors, new padding lengths): after each
+    update the gradients of the next batch are compared with the oracle evaluated at the parameters read back from the device.
+    Covers what single-call tests cannot: weight re-pack after the fused RAdam wrote through raw pointers, mask / work-buffer
+    reuse across calls, accumulation into the flat gradient buffer."""
+    from oracle import fusion_oracle as O
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    cfg = dict(B=3, Nv=36, Nl=50, d=64, h=4, L=2, mask_lens=None, seed=51)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    tr = FusionTrainStep(enc, lr=3e-2, weight_decay=1e-3, grad_clip=1.0)       # a large step: the parameters really move
+    names = [n for n, _, _, _ in tr.flat.slices]
+    losses = []
+    for step, lens in enumerate(([50, 7, 31], [12, 50, 50], [1, 44, 20])):
+        x, lang, mask, gv, gl = make_encoder_inputs(100 + step, cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], lens)
+        gl = gl * (~mask)[..., None]
+        t = lambda a: torch.from_numpy(a).to(dev)
+        # --- gradients of this batch at the CURRENT parameters, on the device (what trainer.step does before the update) ---
+        tr.zero_grad()
+        vis, lo, _, _ = enc(t(x), t(lang), t(mask))
+        loss = (vis * t(gv)).sum() + (lo * t(gl)).sum()
+        loss.backward()
+        losses.append(float(loss.detach()))
+        # --- the same on the CPU oracle with the parameters read back ---
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items() if v.is_floating_point() and "pos_embedding" not in k}
+        sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+        v_ref, l_ref = O.encoder_forward(sd, torch.from_numpy(x), torch.from_numpy(lang), torch.from_numpy(mask), cfg["h"], cfg["L"])
+        ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+        assert rel(vis, v_ref.detach()) < FWD_TOL, step
+        for n, p in enc.named_parameters():
+            if n in names and sd[n].grad is not None:
+                assert rel(p.grad, sd[n].grad) < GRAD_TOL, (step, n)
+        # --- update: the fused RAdam call of trainer.step (no movement yet in its first, un-rectified steps, as in the reference's
+        # optimiser) followed by a plain SGD step THROUGH THE FLAT BUFFER so that the parameters really move between batches ---
+        before = tr.flat.flat.clone()
+        tr._norm.zero_()
+        tr.opt.grad_sumsq(tr._norm)
+        tr.opt.step(grad_scale=1.0, sumsq=tr._norm, clip=tr.grad_clip)
+        tr.flat.flat.add_(tr.flat.grad, alpha=-2e-3)
+        enc.mark_weights_updated()
+        assert torch.isfinite(tr.flat.flat).all()
+        assert (tr.flat.flat - before).abs().max().item() > 1e-3
+    assert all(np.isfinite(losses))
