@@ -176,6 +176,19 @@ def traced_kernels(trainer, batch, nsteps):
     n = lib.tf_trace_stop(ctypes.addressof(recs), cap)
     if n < 0:
         Lb.check(int(n), "tf_trace_stop")
+    # GPU occupancy of the traced window by THIS library's kernels: union of the launch intervals (both streams)
+    iv = sorted((recs[i].start_us, recs[i].start_us + recs[i].us) for i in range(min(n, cap)))
+    busy, cs, ce = 0.0, iv[0][0], iv[0][1]
+    for s0, e0 in iv[1:]:
+        if s0 > ce:
+            busy += ce - cs
+            cs, ce = s0, e0
+        else:
+            ce = max(ce, e0)
+    busy += ce - cs
+    span = max(e0 for _, e0 in iv) - iv[0][0]
+    log(f"  traced window {span / nsteps:.0f} us/step (tracing on), library kernels busy {busy / nsteps:.0f} us/step, "
+        f"other (harness torch kernels + idle) {(span - busy) / nsteps:.0f} us/step")
     by = {}
     for i in range(min(n, cap)):
         r = recs[i]

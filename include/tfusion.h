@@ -296,6 +296,7 @@ long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, 
 typedef struct TfTraceRecord {
   char name[56];                /* kernel symbol as rocprofv3 prints it (short form) */
   float us;                     /* duration of this launch */
+  float start_us;               /* start of this launch relative to the start of the first traced launch */
   int side;                     /* 1: launched on a TfOverlap side stream */
   double flops, bytes;          /* algorithmic work of this launch (SURVEY.md 8(d) accounting; 0 where not applicable) */
 } TfTraceRecord;

@@ -228,14 +228,15 @@ long long tf_trace_stop(TfTraceRecord* out, long long cap) {
       TfTraceRecord& o = out[n];
       memset(&o, 0, sizeof(o));
       strncpy(o.name, r.name, sizeof(o.name) - 1);
-      float ms = 0.f;
+      float ms = 0.f, ms0 = 0.f;
       (void)hipEventElapsedTime(&ms, r.e0, r.e1);
-      o.us = ms * 1e3f; o.flops = r.flops; o.bytes = r.bytes;
+      (void)hipEventElapsedTime(&ms0, g_trace.front().e0, r.e0);
+      o.us = ms * 1e3f; o.start_us = ms0 * 1e3f; o.flops = r.flops; o.bytes = r.bytes;
       for (hipStream_t sd : g_trace_sides) if (sd == r.st) o.side = 1;
     }
-    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     ++n;
   }
+  for (auto& r : g_trace) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }   // (the first record's e0 is every record's time base)
   g_trace.clear();
   return n;
 }
