@@ -85,3 +85,27 @@ def test_cpu_tensors_fail_loudly():
     enc = _build()
     with pytest.raises(_lib.TfError):
         enc(torch.randn(1, 4, 64), torch.randn(1, 3, 64), None)
+
+
+def test_block_bits_layout_matches_the_reference_mask():
+    """vis_tokens_mask [Nv,Nv] -> [S, ceil(S/64)] little-endian u64 words over the JOINT sequence: only visual-visual pairs can be
+    blocked (the reference pads the mask with zeros for language rows / columns, cross_f_box_layers.py:87-95), and the cache is
+    keyed on tensor identity + version (an in-place edit or a new tensor must not hit it)."""
+    import numpy as np
+    from oracle import fusion_oracle as O
+    enc = _build(d=32, L=1, h=2)
+    m = O.local_visual_mask(6, 13, 1)                       # Nv = 78 > 64: the visual block spans two words per row
+    Nv, Nl = m.shape[0], 70
+    bits = enc._pack_block_bits(m, Nv, Nl, torch.device("cpu"))
+    S, SW = Nv + Nl, (Nv + Nl + 63) // 64
+    assert bits.shape == (S, SW) and bits.dtype == torch.int64
+    words = bits.numpy().view(np.uint64)
+    unpacked = ((words[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).reshape(S, SW * 64)[:, :S].astype(bool)
+    expect = np.zeros((S, S), bool)
+    expect[:Nv, :Nv] = m.numpy() != 0
+    assert np.array_equal(unpacked, expect)
+    assert enc._pack_block_bits(m, Nv, Nl, torch.device("cpu")) is bits            # same tensor object, same version: cached
+    m[0, 5] = 1 - m[0, 5]                                                          # in-place edit bumps the version
+    edited = enc._pack_block_bits(m, Nv, Nl, torch.device("cpu"))
+    assert edited is not bits and not torch.equal(edited, bits)
+    assert enc._pack_block_bits(m.clone(), Nv, Nl, torch.device("cpu")) is not edited     # a different tensor object never hits the cache
