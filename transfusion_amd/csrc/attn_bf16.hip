@@ -126,7 +126,7 @@ __device__ __forceinline__ int pair_of_group(int g, int npairs) {
 // forward
 // ================================================================================================
 template <int HDP, bool BLK>       // BLK: a block-bit matrix (TfAttnArgs.block_bits) is present
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const TfAttnArgs a) {
+__global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kt = smem;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < G::KSTEPS; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dp, 0, 0, 0);
       {
-        constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : 8;
+        constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : (HDP <= 192 ? 8 : 4);   // hd > 192: fewer fragments in flight (512-register budget)
         __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
         for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -384,11 +384,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       // K^T fragments of the dQ product do not depend on the softmax: issue their reads before the VALU block
+      constexpr bool KT_EARLY = HDP <= 192;       // hd > 192: the 2 * DBLK fragments held across the softmax would spill
       bf16x8 ktf[2][G::DBLK];
+      if constexpr (KT_EARLY) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int d = 0; d < G::DBLK; ++d) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
+          for (int d = 0; d < G::DBLK; ++d) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
+      }
       // dSt = P * (keep/(1-p) * dPt - delta); the key-validity select only exists on tiles that contain padded or
       // out-of-range keys (wave-uniform branch: with right padding that is the last tile of a sample)
       if (all_valid) {
@@ -412,7 +415,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       for (int s = 0; s < 2; ++s) {
         const bf16x8 dsf = acc_frag(st, s);
 #pragma unroll
-        for (int d = 0; d < G::DBLK; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s][d], dsf, dq[d], 0, 0, 0);
+        for (int d = 0; d < G::DBLK; ++d) {
+          if constexpr (!KT_EARLY) ktf[s][d] = tr_frag<HDP>(kt, kb * 32 + 16 * s, d * 32, lane);
+          dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s][d], dsf, dq[d], 0, 0, 0);
+        }
       }
     }
   }
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[ks], vf[ks], dp, 0, 0, 0);
       }
-      constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : 8;
+      constexpr int NR = 2 * G::KSTEPS, AHEAD = NR < 8 ? NR : (HDP <= 192 ? 8 : 4);   // hd > 192: fewer fragments in flight (512-register budget)
       __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
       for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
     }
     {
       // dV^T += dO^T . Pd and dK^T += Q^T . dS: 4 DBLK transposed fragments (2 reads each), 4 fragments ahead of the MFMAs
-      constexpr int NF = 4 * G::DBLK, AH = 4;
+      constexpr int NF = 4 * G::DBLK, AH = HDP <= 192 ? 4 : 2;
       const bf16x8 pf[2] = {acc_frag(st, 0), acc_frag(st, 1)}, dsf[2] = {acc_frag(dp, 0), acc_frag(dp, 1)};
       __builtin_amdgcn_sched_barrier(0);        // own scheduling region: the groups below then only see these reads / MFMAs
       bf16x8 tf[NF];
