@@ -38,3 +38,21 @@ ms = (time.perf_counter() - t0) / n * 1e3
 S = NV + NL
 fl = 3 * L * (16 * S * D * D + 4 * S * S * D) * B
 print(f"stress shape: {ms:.2f} ms/step, {B / ms * 1e3:.1f} samples/s, {fl / ms / 1e9:.0f} TFLOP/s on the block ({fl / ms / 1e9 / 2500 * 100:.1f} % of peak), loss {float(loss):.4f}")
+
+# in-situ kernel table of this shape (library launch tracer, 3 steps)
+import ctypes
+from transfusion_amd import _lib as Lb
+lib = Lb.load()
+Lb.check(lib.tf_trace_start(), "tf_trace_start")
+for _ in range(3):
+    tr.step([None], loss_fn)
+cap = 1 << 13
+recs = (Lb.TfTraceRecord * cap)()
+nrec = lib.tf_trace_stop(ctypes.addressof(recs), cap)
+agg = {}
+for i in range(min(nrec, cap)):
+    r = recs[i]
+    a = agg.setdefault(r.name.decode(), [0.0, 0, 0.0])
+    a[0] += r.us; a[1] += 1; a[2] += r.flops
+for name, (us, cnt, fl2) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f"  {name:36s} {us / cnt:9.1f} us x{cnt / 3:5.1f} = {us / 3:8.1f} us/step  {'' if not fl2 else f'{fl2 / us / 1e6:7.1f} TF/s'}")
