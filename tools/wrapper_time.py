@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Forward + backward time of the full CrossFusionBoxWrapper path (4 feature levels: patch-embedding GEMM, patchify, 4-layer
+encoder, regroup + fold each) with a stub detector, at the shipped config's geometry: level maps 14p x 14p for p = (4, 4, 2, 1),
+C = (256, 512, 1024, 2048), 512 language tokens, d = 768.  A sanity data point (nothing here is a bench line)."""
+import ctypes, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from test_gpu_wrapper import StubDetector
+from transfusion_amd.modeling.model_factory import get_fusion_model
+from transfusion_amd.runner.config import load_fusion_config
+from transfusion_amd import _lib as Lb
+
+B, NL, D = int(os.environ.get("B", 8)), 512, 768
+dev = torch.device("cuda", 0)
+torch.manual_seed(42)
+ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]
+shapes = [(14 * p, 14 * p) for p in ps]
+fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})       # run.narr_fusion.* keys of the experiment YAML
+fusion["args"].update({"input_f_size": D})
+run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0},
+           "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": D,
+                                                     "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+model = get_fusion_model(StubDetector(shapes, chans), {}, run_cfg, None).to(dev).train()
+g = torch.Generator().manual_seed(1)
+feats = [torch.randn(B, c, h, w, generator=g).to(dev).requires_grad_(True) for c, (h, w) in zip(chans, shapes)]
+lens = torch.randint(NL // 4, NL + 1, (B,), generator=g).tolist()
+lang = [torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1).to(dev) for n in lens]
+
+def step():
+    out = model({"image": feats, "language_f": lang})
+    loss = sum(f.float().square().mean() for f in out["features"].values())
+    loss.backward()
+    return loss
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+n = 5
+t0 = time.perf_counter()
+for _ in range(n):
+    loss = step()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+print(f"wrapper fwd+bwd, B={B}, 4 levels x 4 layers: {ms:.2f} ms/step ({B / ms * 1e3:.1f} samples/s), loss {float(loss):.4f}")
+lib = Lb.load()
+Lb.check(lib.tf_trace_start(), "trace")
+for _ in range(2):
+    step()
+cap = 1 << 14
+recs = (Lb.TfTraceRecord * cap)()
+nrec = lib.tf_trace_stop(ctypes.addressof(recs), cap)
+agg = {}
+for i in range(min(nrec, cap)):
+    r = recs[i]
+    a = agg.setdefault(r.name.decode(), [0.0, 0])
+    a[0] += r.us; a[1] += 1
+tot = sum(v[0] for v in agg.values()) / 2
+for name, (us, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {name:36s} {us / cnt:9.1f} us x{cnt / 2:6.1f} = {us / 2:8.1f} us/step")
+print(f"  library kernels (sum of durations) {tot:.0f} us/step")

@@ -821,7 +821,22 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     TfTraceScope tr(nm, stream, fl);
     return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
   }
-  if (big && a->M >= 2048 && a->N >= 256) {
+  // Which kernel: the large tile (288/256 x 256, one workgroup per CU) is ~1.8x as efficient per CU as the 128-wide one (two
+  // per CU) once the chip is full, but at small M its grid is a fraction of a round -- M = 5664, N = 768 is 69 tiles for 256
+  // CUs, 76 us for 20 GFLOP.  Estimated time = rounds x (fixed + per-K cost of one tile), constants from the K-sweeps on
+  // MI355X (large: 13.3 us + 26.4 us per 1000 K; 128-wide at two per CU: ~8 us + 21 us per 1000 K).
+  bool use_big = big && a->M >= 1024 && a->N >= 256;
+  if (use_big) {
+    const int mfp = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
+    const int mi = pick_mi(a->M, a->N);
+    const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
+    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
+    const double t_small = (double)((ts + 2 * num_cus() - 1) / (2 * num_cus())) * (8.0 + 0.021 * a->K) * (mi / 4.0);
+    static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
+    if (model && t_small < t_big) use_big = false;
+  }
+  if (use_big) {
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
     char nm[56];
     snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
