@@ -204,6 +204,42 @@ def traced_kernels(trainer, batch, nsteps):
     return rows
 
 
+def wgrad_alone(B, device, reps=20):
+    """The overlapped weight-gradient kernel with the chip to itself: the four wgrad shapes of a layer, sized exactly as the encoder
+    runtime sizes them on its side stream (caller-sized M-splits, M/44 blocks capped at 256), back to back on one stream."""
+    from transfusion_amd import ops
+    M, d, ff = B * (NV + NL), D, D * FF_MULT
+    g = torch.Generator().manual_seed(2)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(device=device, dtype=torch.bfloat16)
+    X, Xf, dYq, dYd, dYf = rnd(M, d), rnd(M, ff), rnd(M, 3 * d), rnd(M, d), rnd(M, ff)
+    dW, db = torch.zeros(3 * d, max(d, ff), device=device), torch.zeros(3 * d, device=device)
+    target = min(256, max(32, M // 44))
+
+    def chunk(N, K):
+        tiles = ((N + 255) // 256) * ((K + 127) // 128)
+        steps = (M + 31) // 32
+        splits = max(1, min(steps, (target + tiles // 2) // tiles))
+        return ((steps + splits - 1) // splits) * 32
+
+    cases = [(dYq, 3 * d, X, d), (dYd, d, X, d), (dYf, ff, X, d), (dYd, d, Xf, ff)]        # in_proj, out_proj, linear1, linear2
+    tot_us, tot_fl = 0.0, 0.0
+    for dY, N, Xin, K in cases:
+        fn = lambda: ops.wgrad(dY, N, Xin, K, dW[:N, :K], db[:N], m_chunk=chunk(N, K))
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot_us += e0.elapsed_time(e1) * 1e3 / reps
+        tot_fl += 2.0 * M * N * K
+    return dict(avg_launch_us=round(tot_us / len(cases), 1), achieved=round(tot_fl / tot_us / 1e6, 1),
+                frac=round(tot_fl / tot_us / 1e6 / PEAK_BF16_TFLOPS, 4),
+                note="same kernel and sizing, launched alone back to back (mean over the four wgrad shapes of a layer)")
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle (a port of the reference arithmetic) timed on this host: forward + backward of the same
     4-layer encoder with dropout masks drawn on the host (as the reference does), B=2 samples per step."""
@@ -365,6 +401,9 @@ def main():
                                   "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                                   "us_per_step": dom["us_per_step"],
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
+        if dom["kernel"].startswith("wgrad_tn2") and "roofline" in result:
+            # the dominant kernel runs on the side stream and SHARES the chip with the backward chain in situ; its own rate too:
+            result["roofline"]["alone"] = wgrad_alone(args.batch, device)
         result["kernels"] = [{k: r[k] for k in ("kernel", "avg_us", "launches_per_step", "us_per_step", "tflops", "gbs", "side_stream")} for r in rows]
         if args.isolated_census:
             census = kernel_census(args.batch, device)
