@@ -157,6 +157,26 @@ typedef struct TfRadamArgs {
   const float* sumsq; float clip;                 // optional device scalar sum(g^2): global-norm clip without a host sync
 } TfRadamArgs;
 
+// language auxiliary head, pooling stage (modeling/cross_fusion/ego_fusion/lm_layers.py:59-72, PoolPredictor.forward):
+//   pooled[b, c] = mean_l / max_l ( x[b, l, c] * mask[b, l] )      (the mean divides by L, padded rows count as zeros)
+//   feat         = GELU( LayerNorm(pooled) )                        (LN iff ln_w != null, GELU iff gelu != 0)
+// The two Linear heads that follow (mlp_noun / mlp_verb, :74-77) are tf_gemm_fwd calls.
+typedef struct TfLmPoolArgs {
+  const void* x; int x_is_f32;       // [B, L, d] dense
+  const uint8_t* mask;               // [B, L], 1 = real token (HF convention, wrapper :226), or null
+  int B, L, d;                       // d % 8 == 0, d <= 2048
+  int type;                          // 0 = mean, 1 = max
+  const float* ln_w; const float* ln_b; float eps;
+  int gelu;
+  float* pooled;                     // [B, d] fp32, saved for backward
+  int* arg;                          // [B, d] arg-max row (type 1 only), saved for backward
+  float* feat;                       // forward out [B, d] fp32
+  const float* dfeat;                // backward in  [B, d] fp32
+  void* dx; int dx_is_f32;           // backward out [B, L, d]
+  float* dln_w; float* dln_b;        // backward out [d] (overwritten), when ln_w != null
+  float* scratch;                    // backward work [2, B, d] fp32, when ln_w != null
+} TfLmPoolArgs;
+
 // patch <-> token permutations for K1 / K9
 typedef struct TfPatchArgs {
   const void* feat; int feat_is_f32;     // [B,C,H,W]
@@ -189,6 +209,7 @@ const char* tf_last_error(void);
  * tf_patchify_*      cross_fusion/utils.py:35-39 (patchify_image) fused with the im2col of the k=s=p Conv2d
  * tf_regroup_*       cross_fusion/utils.py:42-46 (regroup_patches: transpose + F.fold, kernel == stride)
  * tf_radam_step      runner/metrics_losses/radam_optim.py:30-104
+ * tf_lm_pool_*       ego_fusion/lm_layers.py:59-72 (PoolPredictor: masked mean/max pooling, LayerNorm, GELU)
  */
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
@@ -206,6 +227,8 @@ int tf_pack_weight(const TfPackArgs* a, tf_stream_t s);
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s);
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s);
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
+int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s);
+int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s);
 /* y = dropout(x) over a dense bf16 array of n (multiple of 8) elements; the same call is its backward (utils.py:115) */
 int tf_dropout_apply(const void* x, void* y, long long n, uint32_t key, uint32_t thr, float scale, tf_stream_t s);
 int tf_dropout_mask(uint8_t* out, long long n, uint32_t key, uint32_t thr, tf_stream_t s);   /* test hook */

@@ -214,3 +214,39 @@ def fusion_level_forward(feat: torch.Tensor, conv_w: torch.Tensor, enc_sd, lang,
     vis, lang_out = encoder_forward(enc_sd, tok, lang, lang_pad_mask, num_heads, num_layers, vis_tokens_mask)
     # F.fold needs Nv == (H//ph)*(W//pw); the zero border comes from init_h/init_w = live H, W (:180-181)
     return regroup(vis, reg_w, reg_b, H, W, ph, pw), lang_out
+
+
+# ----------------------------------------------------------------------------
+# language auxiliary head
+# ----------------------------------------------------------------------------
+def lm_pool_predictor(sd: Dict[str, torch.Tensor], tokens: torch.Tensor, att_mask: Optional[torch.Tensor], pool_type: str,
+                      prefix: str = "") -> Dict[str, Optional[torch.Tensor]]:
+    """modeling/cross_fusion/ego_fusion/lm_layers.py:59-81 (PoolPredictor.forward).  ``att_mask`` is the HF-convention
+    mask (True = real token).  Which stages exist is read off the state dict, as the constructor (:47-57) creates them:
+    ``ln.*`` (optional), ``repr_mlp.1.*`` (optional, preceded by a GELU), ``mlp_noun.*``, ``mlp_verb.*`` (optional)."""
+    x = tokens if att_mask is None else tokens * att_mask.unsqueeze(2).to(tokens.dtype)         # :60-61
+    if pool_type == "max":
+        f = x.max(dim=1)[0]                                                                     # :63-64
+    elif pool_type == "mean":
+        f = x.sum(dim=1) / x.shape[1]                                                           # :65-66 (padded rows count)
+    else:
+        raise NotImplementedError(pool_type)
+    if prefix + "ln.weight" in sd:
+        f = layer_norm(f, sd[prefix + "ln.weight"], sd[prefix + "ln.bias"])                     # :68-69
+    if prefix + "repr_mlp.1.weight" in sd:
+        f = gelu(f) @ sd[prefix + "repr_mlp.1.weight"].t() + sd[prefix + "repr_mlp.1.bias"]     # :71-72
+    noun = f @ sd[prefix + "mlp_noun.weight"].t() + sd[prefix + "mlp_noun.bias"]                # :74
+    verb = None
+    if prefix + "mlp_verb.weight" in sd:
+        verb = f @ sd[prefix + "mlp_verb.weight"].t() + sd[prefix + "mlp_verb.bias"]            # :76-77
+    return {"noun_logits": noun, "verb_logits": verb}
+
+
+def lm_multi_pool_predictor(sd, tokens_per_scale, att_mask, pool_type: str, separate: bool = False):
+    """lm_layers.py:84-100 (MultiPoolPredictor: one shared head) and :103-125 (MultiPoolPredictorSep: ``predictors.{i}.``):
+    per-scale logits averaged over the scales."""
+    outs = [lm_pool_predictor(sd, t, att_mask, pool_type, prefix=f"predictors.{i}." if separate else "")
+            for i, t in enumerate(tokens_per_scale)]
+    noun = torch.stack([o["noun_logits"] for o in outs]).mean(dim=0)
+    verb = None if outs[0]["verb_logits"] is None else torch.stack([o["verb_logits"] for o in outs]).mean(dim=0)
+    return {"noun_logits": noun, "verb_logits": verb}

@@ -91,3 +91,63 @@ def make_level_extras(seed: int, B, C, H, W, p, d):
     reg_b = (0.1 * rs.randn(p * p * C)).astype(np.float32)
     gout = rs.randn(B, C, H, W).astype(np.float32)
     return feat, conv_w, reg_w, reg_b, gout
+
+
+# language auxiliary head (lm_layers.py).  "multi": False | True (shared head over the scales) | "sep"
+LM_CASES = {
+    "lm_mean_ln_repr": dict(B=3, Nl=7, d=32, pool="mean", ln=True, repr_size=24, nouns=11, verbs=5, multi=False,
+                            mask_lens=[7, 4, 1], seed=301),
+    "lm_max_plain": dict(B=2, Nl=5, d=16, pool="max", ln=False, repr_size=None, nouns=87, verbs=74, multi=False,
+                         mask_lens=[3, 5], seed=302),
+    "lm_max_ln_noverb": dict(B=2, Nl=6, d=24, pool="max", ln=True, repr_size=None, nouns=9, verbs=0, multi=False,
+                             mask_lens=[6, 2], seed=303),
+    "lm_multi_mean": dict(B=2, Nl=6, d=32, pool="mean", ln=True, repr_size=16, nouns=10, verbs=6, multi=True,
+                          mask_lens=[5, 6], seed=304, scales=3),
+    "lm_sep_max": dict(B=2, Nl=4, d=16, pool="max", ln=False, repr_size=8, nouns=7, verbs=3, multi="sep",
+                       mask_lens=[4, 2], seed=305, scales=3),
+}
+
+
+def lm_param_shapes(cfg, prefix=""):
+    d = cfg["d"]
+    r = cfg["repr_size"] or d
+    shapes = {}
+    if cfg["ln"]:
+        shapes[prefix + "ln.weight"] = (d,)
+        shapes[prefix + "ln.bias"] = (d,)
+    if cfg["repr_size"]:
+        shapes[prefix + "repr_mlp.1.weight"] = (r, d)
+        shapes[prefix + "repr_mlp.1.bias"] = (r,)
+    shapes[prefix + "mlp_noun.weight"] = (cfg["nouns"], r)
+    shapes[prefix + "mlp_noun.bias"] = (cfg["nouns"],)
+    if cfg["verbs"]:
+        shapes[prefix + "mlp_verb.weight"] = (cfg["verbs"], r)
+        shapes[prefix + "mlp_verb.bias"] = (cfg["verbs"],)
+    return shapes
+
+
+def make_lm_case(cfg):
+    """-> (params, tokens [scales][B, Nl, d], att_mask [B, Nl] bool (True = token), cot_noun, cot_verb | None)"""
+    rs = np.random.RandomState(cfg["seed"])
+    shapes = {}
+    if cfg["multi"] == "sep":
+        for i in range(3):
+            shapes.update(lm_param_shapes(cfg, f"predictors.{i}."))
+    else:
+        shapes = lm_param_shapes(cfg)
+    params = {}
+    for name, shp in shapes.items():
+        if name.endswith("ln.weight"):
+            params[name] = (1.0 + 0.1 * rs.randn(*shp)).astype(np.float32)
+        elif len(shp) == 2:
+            params[name] = (rs.randn(*shp) / np.sqrt(shp[1])).astype(np.float32)
+        else:
+            params[name] = (0.1 * rs.randn(*shp)).astype(np.float32)
+    n_scales = cfg.get("scales", 1)
+    tokens = [rs.randn(cfg["B"], cfg["Nl"], cfg["d"]).astype(np.float32) for _ in range(n_scales)]
+    att = np.zeros((cfg["B"], cfg["Nl"]), dtype=bool)
+    for b, n in enumerate(cfg["mask_lens"]):
+        att[b, :n] = True
+    cot_noun = rs.randn(cfg["B"], cfg["nouns"]).astype(np.float32)
+    cot_verb = rs.randn(cfg["B"], cfg["verbs"]).astype(np.float32) if cfg["verbs"] else None
+    return params, tokens, att, cot_noun, cot_verb

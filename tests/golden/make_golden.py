@@ -24,8 +24,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ENCODER_CASES, LEVEL_CASES, make_encoder_inputs, make_encoder_params,  # noqa: E402
-                   make_level_extras)
+from cases import (ENCODER_CASES, LEVEL_CASES, LM_CASES, make_encoder_inputs, make_encoder_params,  # noqa: E402
+                   make_level_extras, make_lm_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -152,6 +152,38 @@ def run_level_case(name, cfg, Enc, ref_utils):
     print(name, "ok", fused.shape)
 
 
+def run_lm_case(name, cfg):
+    """The reference's language head (lm_layers.py imports only torch) on seeded tokens; outputs + autograd gradients."""
+    from modeling.cross_fusion.ego_fusion import lm_layers as ref_lm
+    params, tokens, att, cot_noun, cot_verb = make_lm_case(cfg)
+    pooling = {"type": cfg["pool"], "ln": cfg["ln"], "repr_size": cfg["repr_size"]}
+    clzz = {False: ref_lm.PoolPredictor, True: ref_lm.MultiPoolPredictor, "sep": ref_lm.MultiPoolPredictorSep}[cfg["multi"]]
+    head = clzz(pooling, cfg["d"], cfg["nouns"], cfg["verbs"])
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    assert not missing and not unexpected
+    head.train()
+    toks = [torch.from_numpy(t).requires_grad_(True) for t in tokens]
+    outs = head(toks if cfg["multi"] else toks[0], torch.from_numpy(att))
+    loss = (outs["noun_logits"] * torch.from_numpy(cot_noun)).sum()
+    if cfg["verbs"]:
+        loss = loss + (outs["verb_logits"] * torch.from_numpy(cot_verb)).sum()
+    loss.backward()
+    out = {"att_mask": att, "cot_noun": cot_noun, "noun_logits": outs["noun_logits"].detach().numpy(),
+           "state_dict_keys": np.array(sorted(head.state_dict().keys()))}
+    if cfg["verbs"]:
+        out["cot_verb"] = cot_verb
+        out["verb_logits"] = outs["verb_logits"].detach().numpy()
+    for i, t in enumerate(toks):
+        out[f"tokens/{i}"] = tokens[i]
+        out[f"grad_tokens/{i}"] = t.grad.numpy()
+    for k, v_ in params.items():
+        out["param/" + k] = v_
+    for k, p_ in head.named_parameters():
+        out["gradp/" + k] = p_.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", out["noun_logits"].shape)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -160,6 +192,8 @@ def main():
         run_encoder_case(name, cfg, Enc, ref_utils)
     for name, cfg in LEVEL_CASES.items():
         run_level_case(name, cfg, Enc, ref_utils)
+    for name, cfg in LM_CASES.items():
+        run_lm_case(name, cfg)
     # sin1d table spot values (utils.py:267-273) at the real width
     pe = ref_utils.get_sin1d_embed(8192, 768)
     np.savez_compressed(os.path.join(HERE, "sin1d_768.npz"), rows=pe[0, [0, 1, 2, 195, 4000, 8191]].numpy(),

@@ -131,3 +131,78 @@ def test_slowfast_pooling_contract():
     w, b = layer.out_mlp.weight.detach().cpu(), layer.out_mlp.bias.detach().cpu()
     ref = torch.nn.functional.normalize(toks[0].cpu().to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t() + b, p=2, dim=0)
     assert rel(y[0], ref) < 1e-2
+
+
+@pytest.mark.parametrize("mode", ["use_lm_f", "fused", "multi"])
+def test_wrapper_language_head(golden_dir, mode):
+    """criterion.lm > 0 (cross_f_box_wrapper.py:77-81, :199-200, :223-228): which tokens feed the head in each mode, the
+    reference's state-dict names, logits against the oracle, and gradients reaching the encoder through the head."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import fusion_oracle as O
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    dev = torch.device("cuda:0")
+    name = "level_p2"
+    cfg = LEVEL_CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    B, C, H, W, p, d = cfg["B"], cfg["C"], cfg["H"], cfg["W"], cfg["p"], cfg["d"]
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": [0], "replace_fpn_features": True, "patch_h": [p], "patch_w": [p], "backproj_dropout": 0.0,
+                   "forward_language_f": False})
+    fusion["args"].update({"num_layers": [cfg["L"]], "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    assert fusion["lm_args"]["pooling"] == {"type": "mean", "ln": True, "repr_size": 0} and fusion["lm_args"]["use_lm_f"] is True
+    fusion["lm_args"]["use_lm_f"] = mode == "use_lm_f"
+    fusion["lm_args"]["multi"] = mode == "multi"
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 1},
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    model = get_fusion_model(StubDetector([(H, W)], [C]), {}, run_cfg, None).to(dev).train()
+    assert {"lm_layer.ln.weight", "lm_layer.ln.bias", "lm_layer.mlp_noun.weight", "lm_layer.mlp_noun.bias",
+            "lm_layer.mlp_verb.weight", "lm_layer.mlp_verb.bias"} <= set(model.state_dict())
+    assert model.lm_layer.mlp_noun.weight.shape == (87, d) and model.lm_layer.mlp_verb.weight.shape == (74, d)
+    assert type(model.lm_layer).__name__ == ("MultiPoolPredictor" if mode == "multi" else "PoolPredictor")
+    enc_sd = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    model.cross_fusion_encoders[0].load_state_dict(enc_sd, strict=False)
+    model.patches_to_token[0].weight.data.copy_(torch.from_numpy(g["conv_w"]))
+    lens = [int((~g["in_mask"][b]).sum()) for b in range(B)]
+
+    class PassThroughPooling(torch.nn.Module):
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, n in enumerate(lens):
+                m[b, n:] = 0
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    feat = torch.from_numpy(g["in_feat"]).to(dev)
+    lang_dev = torch.from_numpy(g["in_lang"]).to(dev).requires_grad_(True)
+    out = model({"image": [feat], "language_f": [lang_dev[b] for b in range(B)]})
+    lm = out["lm"]
+    assert lm["noun_logits"].shape == (B, 87) and lm["verb_logits"].shape == (B, 74)
+
+    sd = {k: v.clone() for k, v in enc_sd.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+    lang_ref = torch.from_numpy(g["in_lang"]).requires_grad_(True)
+    if mode == "use_lm_f":
+        toks = lang_ref                                             # the narration tokens themselves (wrapper :225)
+    else:
+        _, toks = O.fusion_level_forward(torch.from_numpy(g["in_feat"]), torch.from_numpy(g["conv_w"]), sd, lang_ref,
+                                         torch.from_numpy(g["in_mask"]), cfg["h"], cfg["L"], torch.from_numpy(g["reg_w"]),
+                                         torch.from_numpy(g["reg_b"]), p, p)
+    lm_sd = {k: v.detach().cpu().clone() for k, v in model.lm_layer.state_dict().items()}
+    att = torch.from_numpy(~g["in_mask"])
+    ref = O.lm_multi_pool_predictor(lm_sd, [toks], att, "mean") if mode == "multi" else O.lm_pool_predictor(lm_sd, toks, att, "mean")
+    assert rel(lm["noun_logits"], ref["noun_logits"]) < 1e-2
+    assert rel(lm["verb_logits"], ref["verb_logits"]) < 1e-2
+    gen = torch.Generator().manual_seed(3)
+    cn, cv = torch.randn(B, 87, generator=gen), torch.randn(B, 74, generator=gen)
+    ((lm["noun_logits"].float() * cn.to(dev)).sum() + (lm["verb_logits"].float() * cv.to(dev)).sum()).backward()
+    ((ref["noun_logits"] * cn).sum() + (ref["verb_logits"] * cv).sum()).backward()
+    assert rel(lang_dev.grad, lang_ref.grad) < 3e-2                 # through the encoder in the fused / multi modes
+    if mode != "use_lm_f":
+        assert model.cross_fusion_encoders[0].t_encoder.layers[0].linear1.weight.grad.abs().sum().item() > 0

@@ -120,3 +120,36 @@ def test_sin1d_and_local_mask(golden_dir):
     assert abs(pe.double().sum().item() - float(g["total"])) < 1e-2
     m = _load(golden_dir, "local_mask_3x4_k1")["mask"]
     assert np.array_equal(O.local_visual_mask(3, 4, 1).numpy(), m)
+
+
+# ---- language auxiliary head (lm_layers.py) -------------------------------------------------------------------------
+from cases import LM_CASES, make_lm_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(LM_CASES))
+def test_lm_head_cases(golden_dir, name):
+    cfg = LM_CASES[name]
+    g = _load(golden_dir, name)
+    params, tokens, att, cot_noun, cot_verb = make_lm_case(cfg)
+    assert all(np.array_equal(params[k], g["param/" + k]) for k in params)            # fixtures == seeded generator
+    assert all(np.array_equal(t, g[f"tokens/{i}"]) for i, t in enumerate(tokens)) and np.array_equal(att, g["att_mask"])
+    assert sorted(params) == list(g["state_dict_keys"])                               # the reference's parameter names
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    toks = [torch.from_numpy(t).requires_grad_(True) for t in tokens]
+    if cfg["multi"]:
+        out = O.lm_multi_pool_predictor(sd, toks, torch.from_numpy(att), cfg["pool"], separate=cfg["multi"] == "sep")
+    else:
+        out = O.lm_pool_predictor(sd, toks[0], torch.from_numpy(att), cfg["pool"])
+    _close(out["noun_logits"], g["noun_logits"], what="noun_logits")
+    loss = (out["noun_logits"] * torch.from_numpy(cot_noun)).sum()
+    if cfg["verbs"]:
+        _close(out["verb_logits"], g["verb_logits"], what="verb_logits")
+        loss = loss + (out["verb_logits"] * torch.from_numpy(cot_verb)).sum()
+    else:
+        assert out["verb_logits"] is None
+    loss.backward()
+    for i, t in enumerate(toks):
+        _close(t.grad, g[f"grad_tokens/{i}"], what=f"grad_tokens/{i}")
+        assert np.all(t.grad.numpy()[~att] == 0)                                      # padded rows receive no gradient
+    for k, v in sd.items():
+        _close(v.grad, g["gradp/" + k], what="gradp/" + k)

@@ -486,6 +486,176 @@ inline int grid_for(long long n, int per_block, int cap = 2048) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Language head pooling (lm_layers.py:59-72): pooled = mean_l / max_l (x * mask), then LayerNorm and
+// GELU.  One wave per sample: the row statistics are wave-shuffle reductions, the L token rows stream
+// through 16-B (bf16) / 32-B (fp32) loads.  The first maximal row wins ties (rows tie only among the
+// zeroed padded ones, whose gradient is multiplied by mask = 0 anyway).
+// ------------------------------------------------------------------------------------------------
+template <int MAXC>
+__device__ __forceinline__ void lm_pool_stats(const float (&p)[MAXC][8], int lane, int nch, int d, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) if (lane + 64 * c < nch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += p[c][i];
+  }
+  mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) if (lane + 64 * c < nch) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float t = p[c][i] - mean; q += t * t; }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(64) void lm_pool_fwd_kernel(const TfLmPoolArgs a) {
+  const int lane = threadIdx.x, b = blockIdx.x, nch = a.d / 8;
+  float acc[MAXC][8];
+  int arg[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[c][i] = a.type ? -INFINITY : 0.f; arg[c][i] = 0; }
+  for (int l = 0; l < a.L; ++l) {
+    const float m = a.mask ? (a.mask[(size_t)b * a.L + l] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch >= nch) continue;
+      float f[8];
+      load8_any(a.x, ((size_t)b * a.L + l) * a.d + (size_t)ch * 8, a.x_is_f32, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = f[i] * m;
+        if (a.type) { if (v > acc[c][i]) { acc[c][i] = v; arg[c][i] = l; } }
+        else acc[c][i] += v;
+      }
+    }
+  }
+  if (!a.type) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[c][i] /= (float)a.L;
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch >= nch) continue;
+    const size_t off = (size_t)b * a.d + (size_t)ch * 8;
+    store8_f32(a.pooled + off, acc[c]);
+    if (a.type) { *(i32x4*)(a.arg + off) = i32x4{arg[c][0], arg[c][1], arg[c][2], arg[c][3]}; *(i32x4*)(a.arg + off + 4) = i32x4{arg[c][4], arg[c][5], arg[c][6], arg[c][7]}; }
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (a.ln_w) lm_pool_stats<MAXC>(acc, lane, nch, a.d, a.eps, mean, rstd);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch >= nch) continue;
+    float y[8];
+    if (a.ln_w) {
+      float g[8], be[8];
+      load8_f32(a.ln_w + ch * 8, g); load8_f32(a.ln_b + ch * 8, be);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = (acc[c][i] - mean) * rstd * g[i] + be[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = acc[c][i];
+    }
+    if (a.gelu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = gelu_f(y[i]);
+    }
+    store8_f32(a.feat + (size_t)b * a.d + (size_t)ch * 8, y);
+  }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(64) void lm_pool_bwd_kernel(const TfLmPoolArgs a) {
+  const int lane = threadIdx.x, b = blockIdx.x, nch = a.d / 8;
+  float p[MAXC][8], dp[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch >= nch) continue;
+    load8_f32(a.pooled + (size_t)b * a.d + (size_t)ch * 8, p[c]);
+    load8_f32(a.dfeat + (size_t)b * a.d + (size_t)ch * 8, dp[c]);
+  }
+  if (a.ln_w) {
+    float mean, rstd;
+    lm_pool_stats<MAXC>(p, lane, nch, a.d, a.eps, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch >= nch) continue;
+      float g[8], be[8], dg[8];
+      load8_f32(a.ln_w + ch * 8, g); load8_f32(a.ln_b + ch * 8, be);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (p[c][i] - mean) * rstd;
+        float du = dp[c][i];
+        if (a.gelu) du *= gelu_grad_f(xh * g[i] + be[i]);
+        dg[i] = du * xh;
+        be[i] = du;                       // d(beta) contribution of this sample
+        const float dxh = du * g[i];
+        s1 += dxh; s2 += dxh * xh;
+        p[c][i] = xh; dp[c][i] = dxh;
+      }
+      store8_f32(a.scratch + (size_t)b * a.d + (size_t)ch * 8, dg);
+      store8_f32(a.scratch + ((size_t)a.B + b) * a.d + (size_t)ch * 8, be);
+    }
+    s1 = wave_sum(s1) / (float)a.d; s2 = wave_sum(s2) / (float)a.d;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dp[c][i] = rstd * (dp[c][i] - s1 - p[c][i] * s2);
+  } else if (a.gelu) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dp[c][i] *= gelu_grad_f(p[c][i]);
+  }
+  int arg[MAXC][8];
+  if (a.type) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch >= nch) continue;
+      const size_t off = (size_t)b * a.d + (size_t)ch * 8;
+      const i32x4 lo = *(const i32x4*)(a.arg + off), hi = *(const i32x4*)(a.arg + off + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { arg[c][i] = lo[i]; arg[c][4 + i] = hi[i]; }
+    }
+  }
+  const float invL = 1.f / (float)a.L;
+  for (int l = 0; l < a.L; ++l) {
+    const float m = a.mask ? (a.mask[(size_t)b * a.L + l] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch >= nch) continue;
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = a.type ? (arg[c][i] == l ? dp[c][i] * m : 0.f) : dp[c][i] * invL * m;
+      store8_any(a.dx, ((size_t)b * a.L + l) * a.d + (size_t)ch * 8, a.dx_is_f32, g);
+    }
+  }
+}
+
+// d(gamma)[c] = sum_b scratch[0][b][c], d(beta)[c] = sum_b scratch[1][b][c] in a fixed order (deterministic).
+__global__ void lm_pool_affine_kernel(const float* __restrict__ scratch, float* __restrict__ dw, float* __restrict__ db, int B, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float sw = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) { sw += scratch[(size_t)b * d + c]; sb += scratch[((size_t)B + b) * d + c]; }
+  dw[c] = sw; db[c] = sb;
+}
+
 }  // namespace
 
 extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
@@ -638,5 +808,39 @@ extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_
   if (total <= 0) return 0;
   TfTraceScope tr("col2im_kernel", st);
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a, out_is_f32);
+  return (int)hipGetLastError();
+}
+
+static int lm_pool_check(const TfLmPoolArgs* a) {
+  if (a->B <= 0) return 0;
+  if (a->L <= 0 || a->d <= 0 || (a->d % 8) || a->d > 64 * MAXC_MAX * 8 || (a->type != 0 && a->type != 1)) return -2;
+  if (a->pooled == nullptr || (a->type == 1 && a->arg == nullptr) || ((a->ln_w == nullptr) != (a->ln_b == nullptr))) return -2;
+  return 1;
+}
+extern "C" int tf_launch_lm_pool_fwd(const TfLmPoolArgs* a, hipStream_t st) {
+  const int ok = lm_pool_check(a);
+  if (ok <= 0) return ok;
+  if (a->x == nullptr || a->feat == nullptr) return -2;
+  TfTraceScope tr("lm_pool_fwd_kernel", st);
+  if (a->d <= 512) hipLaunchKernelGGL(lm_pool_fwd_kernel<1>, dim3(a->B), dim3(64), 0, st, *a);
+  else if (a->d <= 1024) hipLaunchKernelGGL(lm_pool_fwd_kernel<2>, dim3(a->B), dim3(64), 0, st, *a);
+  else hipLaunchKernelGGL(lm_pool_fwd_kernel<4>, dim3(a->B), dim3(64), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_lm_pool_bwd(const TfLmPoolArgs* a, hipStream_t st) {
+  const int ok = lm_pool_check(a);
+  if (ok <= 0) return ok;
+  if (a->dfeat == nullptr || a->dx == nullptr) return -2;
+  if (a->ln_w && (a->scratch == nullptr || a->dln_w == nullptr || a->dln_b == nullptr)) return -2;
+  {
+    TfTraceScope tr("lm_pool_bwd_kernel", st);
+    if (a->d <= 512) hipLaunchKernelGGL(lm_pool_bwd_kernel<1>, dim3(a->B), dim3(64), 0, st, *a);
+    else if (a->d <= 1024) hipLaunchKernelGGL(lm_pool_bwd_kernel<2>, dim3(a->B), dim3(64), 0, st, *a);
+    else hipLaunchKernelGGL(lm_pool_bwd_kernel<4>, dim3(a->B), dim3(64), 0, st, *a);
+  }
+  if (a->ln_w) {
+    TfTraceScope tr("lm_pool_affine_kernel", st);
+    hipLaunchKernelGGL(lm_pool_affine_kernel, dim3((a->d + 255) / 256), dim3(256), 0, st, a->scratch, a->dln_w, a->dln_b, a->B, a->d);
+  }
   return (int)hipGetLastError();
 }

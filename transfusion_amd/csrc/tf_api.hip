@@ -319,6 +319,8 @@ int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bw
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s) { TF_WRAP("tf_radam_step", tf_launch_radam(a, (hipStream_t)s)); }
+int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_fwd(a, (hipStream_t)s), "tf_lm_pool_fwd"); return 0; }
+int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_bwd(a, (hipStream_t)s), "tf_lm_pool_bwd"); return 0; }
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq(x, n, out, (hipStream_t)s), "tf_sumsq"); return 0; }
 int tf_dropout_mask(uint8_t* out, long long n, uint32_t key, uint32_t thr, tf_stream_t s) {
   TF_TRY(tf_launch_dropout_mask(out, n, key, thr, (hipStream_t)s), "tf_dropout_mask"); return 0;

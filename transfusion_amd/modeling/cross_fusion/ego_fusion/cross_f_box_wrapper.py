@@ -15,6 +15,7 @@ from torch import nn
 
 from transfusion_amd import ops
 from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+from transfusion_amd.modeling.cross_fusion.ego_fusion.lm_layers import get_lm_layer
 from transfusion_amd.modeling.cross_fusion.utils import (PositionalEmbeddingLayer, RegroupPatchesLayerBox,
                                                           get_visual_token_mask)
 from transfusion_amd.modeling.narration_embeds.narr_pooling_layers import get_narr_pooling_layer
@@ -87,7 +88,7 @@ class CrossFusionBoxWrapper(nn.Module):
 
         self.criterion = criterion
         if criterion.get("lm", None):
-            raise NotImplementedError("criterion.lm > 0 (auxiliary language head, lm_layers.py) is a 'next' row (SURVEY.md 8f-3)")
+            self.lm_layer = get_lm_layer(self)         # reference :77-78
         self.lm_on = criterion.get("lm", False)
         self.use_lm_f = self.cross_encoder_args["lm_args"].get("use_lm_f", False)
         self.multi_lm = self.cross_encoder_args["lm_args"].get("multi", False) and self.lm_on and not self.use_lm_f
@@ -146,6 +147,7 @@ class CrossFusionBoxWrapper(nn.Module):
             raise RuntimeError("the pooling layer returned no attention mask (IdentityLayer trap, narr_pooling_layers.py:409-414)")
         pad_mask = ~(att_mask.type(torch.bool))     # HF mask (1 = token) -> torch convention (True = ignore), reference :196
         fused_l_features = None
+        mscale_l_features = []
         for i, key in enumerate(self.fpn_features_idx):
             key = str(key)
             feat = features_dict["features"][key]
@@ -157,6 +159,8 @@ class CrossFusionBoxWrapper(nn.Module):
             fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
                 vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
             )
+            if self.multi_lm:
+                mscale_l_features.append(fused_l_features)
             if self.forward_language_f:
                 if self.forward_language_f == "direct":
                     language_f = fused_l_features
@@ -171,7 +175,13 @@ class CrossFusionBoxWrapper(nn.Module):
             features_dict["hand_boxes"] = x["hand_boxes"]
         if "hand_poses" in x:
             features_dict["hand_poses"] = x["hand_poses"]
-        return self.rcnn_model.apply_rpn_roi_on_features(features_dict)
+        rcnn_outs = self.rcnn_model.apply_rpn_roi_on_features(features_dict)
+        if self.lm_on:                                  # reference :223-228
+            rcnn_outs["lm"] = self.lm_layer(
+                mscale_l_features if self.multi_lm else fused_l_features if not self.use_lm_f else language_f,
+                att_mask.type(torch.bool),
+            )
+        return rcnn_outs
 
     def call_model_epoch_triggers(self, epoch):
         if epoch >= self.narr_embed_args["train_ep"] and self.narr_embed_args["train_ep"] != -1:

@@ -269,8 +269,9 @@ class _LinearFn(torch.autograd.Function):
         _require_cuda(x2d, weight)
         M, K = x2d.shape
         N = weight.shape[0]
-        if N % 8 or K % 8:
-            raise L.TfError(f"linear: N={N}, K={K} must be multiples of 8")
+        if K % 8:
+            raise L.TfError(f"linear: K={K} must be a multiple of 8")
+        N8 = _up(N, 8)      # class-count heads (87 nouns, 74 verbs): zero weight rows up to the 16-B store width
         Kp, Np = _up(K, 64), _up(N, 64)
         xb = to_bf16_padded(x2d, Kp)
         drop = drop_params(p_drop_in, seed, 7)
@@ -278,26 +279,31 @@ class _LinearFn(torch.autograd.Function):
             xd = torch.empty_like(xb)
             L.check(L.load().tf_dropout_apply(L.ptr(xb), L.ptr(xd), xb.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
             xb = xd
-        wsh, wsh_t = pack_weight(weight, N, Kp, Kp, Np)
+        wsh, wsh_t = pack_weight(weight, N8, Kp, Kp, Np)
         y = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device) if Np != N else torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
         bf = None if bias is None else bias.detach().float().contiguous()
-        gemm(xb, wsh, y, N, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf)
+        if bf is not None and N8 != N:
+            bf = torch.nn.functional.pad(bf, (0, N8 - N))
+        gemm(xb, wsh, y, N8, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf)
         ctx.save_for_backward(xb, wsh_t)
-        ctx.meta = (M, K, N, Kp, Np, x2d.dtype, drop, bias is not None, weight.shape)
+        ctx.meta = (M, K, N, N8, Kp, Np, x2d.dtype, drop, bias is not None, weight.shape)
         return y[:, :N] if Np != N else y
 
     @staticmethod
     def backward(ctx, gy):
         xb, wsh_t = ctx.saved_tensors
-        M, K, N, Kp, Np, xdtype, drop, has_bias, wshape = ctx.meta
-        gyb = to_bf16_padded(gy.reshape(M, N), Np)
+        M, K, N, N8, Kp, Np, xdtype, drop, has_bias, wshape = ctx.meta
+        gy = gy.reshape(M, N)
+        if N8 != N:
+            gy = torch.nn.functional.pad(gy, (0, N8 - N))
+        gyb = to_bf16_padded(gy, Np)
         dx = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
         gemm(gyb, wsh_t, dx, Kp, Np, L.TF_EPI_NONE)
         if drop[0]:
             L.check(L.load().tf_dropout_apply(L.ptr(dx), L.ptr(dx), dx.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
-        wgrad(gyb, N, xb, Kp, dW.view(N, -1), db)
+        wgrad(gyb, N8, xb, Kp, dW.view(N, -1), db)      # rows >= N are masked by n_src = N
         return from_padded(dx, K, xdtype), dW, db, None, None
 
 
@@ -307,6 +313,57 @@ def linear(x, weight, bias=None, p_drop_in: float = 0.0):
     w2 = weight.reshape(weight.shape[0], -1)
     y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0)
     return y.reshape(*lead, weight.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------------
+# language auxiliary head: masked pooling + LayerNorm + GELU (lm_layers.py:59-72)
+# ------------------------------------------------------------------------------------------------------
+class _LmPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask_u8, pool_type, ln_w, ln_b, eps, gelu):
+        _require_cuda(x)
+        B, Lt, d = x.shape
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise L.TfError(f"lm_pool: dtype {x.dtype}")
+        x = x.contiguous()
+        pooled = torch.empty(B, d, dtype=torch.float32, device=x.device)
+        feat = torch.empty(B, d, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, d, dtype=torch.int32, device=x.device) if pool_type == 1 else None
+        lw = None if ln_w is None else ln_w.detach().float().contiguous()
+        lb = None if ln_b is None else ln_b.detach().float().contiguous()
+        a = L.TfLmPoolArgs(x=L.ptr(x), x_is_f32=_is_f32(x), mask=L.ptr(mask_u8), B=B, L=Lt, d=d, type=pool_type,
+                           ln_w=L.ptr(lw), ln_b=L.ptr(lb), eps=eps, gelu=1 if gelu else 0,
+                           pooled=L.ptr(pooled), arg=L.ptr(arg), feat=L.ptr(feat))
+        L.call("tf_lm_pool_fwd", a, _stream())
+        ctx.save_for_backward(pooled, arg, mask_u8, lw, lb)
+        ctx.meta = (B, Lt, d, pool_type, eps, gelu, x.dtype)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        pooled, arg, mask_u8, lw, lb = ctx.saved_tensors
+        B, Lt, d, pool_type, eps, gelu, xdtype = ctx.meta
+        dfeat = dfeat.float().contiguous()
+        dx = torch.empty(B, Lt, d, dtype=xdtype, device=dfeat.device)
+        dlw = dlb = scratch = None
+        if lw is not None:
+            dlw = torch.empty(d, dtype=torch.float32, device=dfeat.device)
+            dlb = torch.empty(d, dtype=torch.float32, device=dfeat.device)
+            scratch = torch.empty(2, B, d, dtype=torch.float32, device=dfeat.device)
+        a = L.TfLmPoolArgs(mask=L.ptr(mask_u8), B=B, L=Lt, d=d, type=pool_type, ln_w=L.ptr(lw), ln_b=L.ptr(lb), eps=eps,
+                           gelu=1 if gelu else 0, pooled=L.ptr(pooled), arg=L.ptr(arg), dfeat=L.ptr(dfeat),
+                           dx=L.ptr(dx), dx_is_f32=_is_f32(dx), dln_w=L.ptr(dlw), dln_b=L.ptr(dlb), scratch=L.ptr(scratch))
+        L.call("tf_lm_pool_bwd", a, _stream())
+        return dx, None, None, dlw, dlb, None, None
+
+
+def lm_pool(x, att_mask, pool_type: str, ln_w=None, ln_b=None, eps: float = 1e-5, gelu: bool = False):
+    """[B, L, d] language tokens -> [B, d] fp32 features: GELU(LN(mean|max over L of x * att_mask)); att_mask is the
+    HF-convention mask (True / 1 = real token) or None."""
+    if pool_type not in ("mean", "max"):
+        raise NotImplementedError(pool_type)
+    m = None if att_mask is None else att_mask.to(torch.uint8).contiguous()
+    return _LmPoolFn.apply(x, m, 1 if pool_type == "max" else 0, ln_w, ln_b, float(eps), bool(gelu))
 
 
 def attn_dropmask(B: int, H: int, S: int, p: float, seed: int, site: int, device) -> torch.Tensor:
