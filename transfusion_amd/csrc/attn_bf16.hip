@@ -18,6 +18,7 @@
 // row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16) bank-conflict free.
 #include "tf_common.h"
 #include <cstdio>
+#include <cstdlib>
 #include "tf_kernels.h"
 
 namespace {
@@ -437,6 +438,234 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
 }
 
 // ================================================================================================
+// backward, dQ, two waves per SIMD: the same algorithm on v_mfma_f32_16x16x32_bf16 with 16 queries per wave
+// (8 waves = 128 queries per workgroup).  Halving the rows a wave owns halves everything it keeps resident
+// (dQ^T 48 + Q 24 + dO 24 registers at hd = 192), so the kernel fits 256 registers and a second wave per SIMD
+// issues its MFMAs under this wave's softmax VALU and LDS round trips -- the overlap one wave per SIMD could only
+// get from instruction order.  Accumulator layout: lane (g = lane>>4, n = lane&15) holds query n, rows 4g..4g+3
+// of each 16-key block, which are exactly elements 0..3 / 4..7 of its B fragment for the 32-key k-step, so dSt feeds
+// the dQ product from registers as before (k index 8g+e <-> key 16(e>>2) + 4g + (e&3); the K^T A-fragment is
+// fetched in that order by two ds_read_b64_tr_b16 of 4 rows x 16 hd columns per 16-lane group).
+// LDS tile: same 64 (mod 256)-byte row stride, 16-B chunk ^= {0,2,3,1}[(row>>2)&3]: conflict-free for the ds_read_b128
+// lane groups of the 16-row operand AND for the transposed reads (the 32x32 swizzle is 2-way on the former).
+// ================================================================================================
+__device__ __forceinline__ int swz16(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+__device__ __forceinline__ int tile_off16(int row, int chunk, int tstr) { return row * tstr + ((chunk ^ swz16(row)) << 4); }
+
+template <int ROWS, int HDP, int NT> struct TileRegs16 {
+  static constexpr int TOTAL = ROWS * (HDP / 8);
+  static constexpr int PER = (TOTAL + NT - 1) / NT;
+  u32x4 v[PER];
+  __device__ __forceinline__ void load(const u16* __restrict__ base, size_t ld, int row0, int row_max, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = i * NT + tid;
+      if (TOTAL % NT == 0 || id < TOTAL) {
+        const int r = id / (HDP / 8), c = id % (HDP / 8);
+        v[i] = *(const u32x4*)(base + (size_t)min(row0 + r, row_max) * ld + c * 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = i * NT + tid;
+      if (TOTAL % NT == 0 || id < TOTAL) {
+        const int r = id / (HDP / 8), c = id % (HDP / 8);
+        *(u32x4*)(lds + tile_off16(r, c, Geo<HDP>::TSTR)) = v[i];
+      }
+    }
+  }
+};
+
+template <int HDP, int NW>          // NW waves per workgroup, 16 queries each
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  constexpr int NT = 64 * NW, QB = 16 * NW;
+  constexpr int KS = HDP / 32;     // 32-deep k-steps over the head dim (St, dPt)
+  constexpr int DB = HDP / 16;     // 16-row blocks of dQ^T
+  constexpr int TSTR = G::TSTR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, n = lane & 15;
+  const int S = a.S;
+  const int nqb = (S + QB - 1) / QB;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int q0 = (logical % nqb) * QB + wave * 16;
+  const size_t ld = a.ld_qkv;
+  const u16* qkv = (const u16*)a.qkv;
+  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+
+  // the first K/V tile is requested before anything else: with one workgroup per CU nothing but this workgroup's own
+  // instruction order overlaps the prologue's global round trips (tile, Q / dO / O rows, key-mask scan)
+  TileRegs16<64, HDP, NT> kr, vr;
+  kr.load(kbase, ld, 0, S - 1, tid);
+  vr.load(vbase, ld, 0, S - 1, tid);
+  const int qrow = q0 + n;
+  const int qr = min(qrow, S - 1);
+  bf16x8 qf[KS], dof[KS];          // B operands: query n, hd elements 32ks + 8g .. +7
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ld + ks * 32 + 8 * g));
+    dof[ks] = as_bf16x8(*(const u32x4*)(dobase + (size_t)qr * a.ld_dout + ks * 32 + 8 * g));
+  }
+  const float lse = a.lse[(size_t)bh * S + qr];
+  float delta = 0.f;               // rowsum(dO . O): each lane group owns a quarter of the row
+  {
+    const u16* orow = (const u16*)a.out + ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float of[8], df[8];
+      unpack8(*(const u32x4*)(orow + ks * 32 + 8 * g), of);
+      unpack8(__builtin_bit_cast(u32x4, dof[ks]), df);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+  }
+  f32x4 dq[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sc = a.scale * LOG2E;
+  const int SW = (S + 63) / 64;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
+
+  // per-lane LDS addresses: everything else is a compile-time offset
+  const int rbase = n * TSTR + ((g ^ swz16(n)) << 4);                 // row read: + (32kb + 16j) * TSTR + 64 * ks
+  const int q4 = n >> 2, p = n & 3, fz = swz16(4 * g);
+  const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + (32kb + 16t) * TSTR + 64 * (db>>1) + xe|xo
+  const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
+
+  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  const uint8_t* kmrow = a.key_mask ? a.key_mask + (size_t)b * S : nullptr;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
+  unsigned long long dm_n = ~0ull, blk_n = 0ull;
+  uint8_t km_n = 0;
+  // LDS holds TWO K/V tile pairs (4 x 64 rows): tile t+1 is written into the other pair in the middle of tile t's work
+  // (its global loads were issued a tile earlier), so a tile costs one barrier and no store phase of its own.
+  constexpr int PAIR = 128 * TSTR;
+  if (ntiles > 0) {
+    if (a.drop_thr) dm_n = drow[0];
+    if (brow) blk_n = brow[0];
+    if (kmrow) km_n = kmrow[min(lane, S - 1)];
+    kr.store(smem, tid);
+    vr.store(smem + 64 * TSTR, tid);
+    if (ntiles > 1) {
+      kr.load(kbase, ld, 64, S - 1, tid);
+      vr.load(vbase, ld, 64, S - 1, tid);
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    const unsigned char* kt = smem + (t & 1) * PAIR;
+    const unsigned char* vt = kt + 64 * TSTR;
+    const unsigned long long dm = dm_n >> (4 * g);
+    const unsigned long long vlane = __ballot(kv0 + lane < S && km_n == 0) & ~blk_n;
+    const bool all_valid = __all(vlane == ~0ull);
+    const unsigned long long vbits = vlane >> (4 * g);
+    if (t + 1 < ntiles) {
+      if (a.drop_thr) dm_n = drow[t + 1];
+      if (brow) blk_n = brow[t + 1];
+      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, S - 1)];
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 st[2], dp[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { st[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      // phase A: the 4*KS row fragments run AHEAD of the MFMAs that consume them (an LDS round trip is ~8 MFMA slots)
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 kfr[2 * KS], vfr[2 * KS];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kfr[j * KS + ks] = *(const bf16x8*)(kt + rbase + (32 * kb + 16 * j) * TSTR + 64 * ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vfr[j * KS + ks] = *(const bf16x8*)(vt + rbase + (32 * kb + 16 * j) * TSTR + 64 * ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[j * KS + ks], qf[ks], st[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[j * KS + ks], dof[ks], dp[j], 0, 0, 0);
+      {
+        constexpr int NR = 4 * KS, AHEAD = NR < 8 ? NR : (HDP >= 192 ? 6 : 8);
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+        for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // phase C operands (K^T) do not depend on the softmax: their reads are issued before the VALU block
+      s16x4 tlo[DB], thi[DB];
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* tp = kt + tbase + (32 * kb) * TSTR + 64 * (d >> 1) + ((d & 1) ? xo : xe);
+        tlo[d] = lds_read_tr16(tp);
+        thi[d] = lds_read_tr16(tp + 16 * TSTR);
+      }
+      // phase B: dSt = P * (keep/(1-p) * dPt - delta)
+      bf16x8 dsf;
+      if (all_valid) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int bit = kb * 32 + 16 * j + i;
+            const float pr = fast_exp2(fmaf(st[j][i], sc, -lse));
+            const float ks = ((dm >> bit) & 1ull) ? dscale : 0.f;
+            dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], ks, -delta));
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int bit = kb * 32 + 16 * j + i;
+            const float pr = ((vbits >> bit) & 1ull) ? fast_exp2(fmaf(st[j][i], sc, -lse)) : 0.f;
+            const float ks = ((dm >> bit) & 1ull) ? dscale : 0.f;
+            dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], ks, -delta));
+          }
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(tlo[d], thi[d]), dsf, dq[d], 0, 0, 0);
+      if (kb == 0 && t + 1 < ntiles) {
+        // the other pair was last read in tile t-1, which every wave left through the barrier below
+        unsigned char* nk = smem + ((t + 1) & 1) * PAIR;
+        kr.store(nk, tid);
+        vr.store(nk + 64 * TSTR, tid);
+        if (t + 2 < ntiles) {
+          kr.load(kbase, ld, kv0 + 128, S - 1, tid);
+          vr.load(vbase, ld, kv0 + 128, S - 1, tid);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (qrow < S) {
+    u16* orow = (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      u32x2 v;
+      v[0] = pack2bf(dq[d][0] * a.scale, dq[d][1] * a.scale);
+      v[1] = pack2bf(dq[d][2] * a.scale, dq[d][3] * a.scale);
+      *(u32x2*)(orow + d * 16 + 4 * g) = v;
+    }
+  }
+}
+
+// ================================================================================================
 // backward, dK / dV: key on the lane, loop over query tiles of 32
 //   S[q][key] = Q.K^T -> P ;  dP[q][key] = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
 //   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key] ; dK *= scale
@@ -629,7 +858,15 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
   const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;
   char nm[56];
-  {
+  const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
+  static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
+  (void)once_q16;
+  static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
+  if (dq16 && HDP <= 192) {
+    snprintf(nm, sizeof(nm), "attn_bwd_dq16_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl);
+    hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 8>), grid, dim3(512), lds_q16, st, *a);
+  } else {
     snprintf(nm, sizeof(nm), "attn_bwd_dq_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
