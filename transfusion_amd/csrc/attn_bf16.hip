@@ -456,13 +456,14 @@ template <int ROWS, int HDP, int NT> struct TileRegs16 {
   static constexpr int TOTAL = ROWS * (HDP / 8);
   static constexpr int PER = (TOTAL + NT - 1) / NT;
   u32x4 v[PER];
-  __device__ __forceinline__ void load(const u16* __restrict__ base, size_t ld, int row0, int row_max, int tid) {
+  __device__ __forceinline__ void load(const u16* __restrict__ base, size_t ld, int row0, int row_max, int tid, bool zero_fill = false) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int id = i * NT + tid;
       if (TOTAL % NT == 0 || id < TOTAL) {
         const int r = id / (HDP / 8), c = id % (HDP / 8);
-        v[i] = *(const u32x4*)(base + (size_t)min(row0 + r, row_max) * ld + c * 8);
+        if (zero_fill && row0 + r > row_max) v[i] = u32x4{0, 0, 0, 0};
+        else v[i] = *(const u32x4*)(base + (size_t)min(row0 + r, row_max) * ld + c * 8);
       }
     }
   }
@@ -835,6 +836,204 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   }
 }
 
+// ================================================================================================
+// backward, dK / dV, two waves per SIMD: 16 keys per wave on v_mfma_f32_16x16x32_bf16 (8 waves = 128 keys per
+// workgroup), the same restructuring as attn_bwd_dq16_kernel.  Resident per wave: dK^T + dV^T (96 registers at
+// hd = 192) + the K / V B-operand fragments (48).  Q / dO tiles of 32 query rows are double-buffered in LDS together
+// with their row scalars (LSE, delta, the keep-bit / block-bit words of each wave's keys): one barrier per tile.
+//   S[q][key] = Q.K^T -> P ;  dP = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
+//   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+// ================================================================================================
+template <int HDP, bool BLK>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  constexpr int NT = 512;
+  constexpr int KS = HDP / 32, DB = HDP / 16, TSTR = G::TSTR;
+  constexpr int PAIR = 64 * TSTR;                         // Q tile (32 rows) + dO tile (32 rows)
+  constexpr int ROWS_BYTES = 256 + 1024 + 1024;           // lse[32], delta[32], keep words [8][32], block words [8][32]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, n = lane & 15;
+  const int S = a.S;
+  const int nkb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int key0 = (logical % nkb) * 128 + wave * 16;
+  const size_t ld = a.ld_qkv;
+  const u16* qkv = (const u16*)a.qkv;
+  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+
+  TileRegs16<32, HDP, NT> qr, dr;
+  qr.load(qbase, ld, 0, S - 1, tid);
+  dr.load(dobase, a.ld_dout, 0, S - 1, tid, true);       // rows >= S contribute nothing
+  const int key = key0 + n;
+  const int kr_ = min(key, S - 1);
+  bool key_ok = key < S;
+  if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
+  bf16x8 kf[KS], vf[KS];           // B operands: key n, hd elements 32ks + 8g .. +7
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = as_bf16x8(*(const u32x4*)(kbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
+    vf[ks] = as_bf16x8(*(const u32x4*)(vbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
+  }
+  f32x4 dk[DB], dv[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float sc = a.scale * LOG2E;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
+  const int kbit = (key0 & 16) + n;                       // this lane's key inside the 32-bit keep / block words
+
+  const int rbase = n * TSTR + ((g ^ swz16(n)) << 4);                 // row read: + 16j * TSTR + 64 * ks
+  const int q4 = n >> 2, p = n & 3, fz = swz16(4 * g);
+  const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + 16t * TSTR + 64 * (db>>1) + xe|xo
+  const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
+
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
+  const int dw_ld = 2 * ((S + 63) / 64);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  float lse_n = 1.0e30f, del_n = 0.f;
+  unsigned dw_n = 0xffffffffu, bw_n = 0u;
+  // (RAW loaded values are carried; the row-validity selects happen when they are stored)
+  auto prefetch_rows = [&](int q0n) {
+    if (tid < 32) {
+      const int q = min(q0n + tid, S - 1);
+      lse_n = a.lse[(size_t)bh * S + q];
+      del_n = a.delta[(size_t)bh * S + q];
+    }
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
+  };
+  auto store_tile = [&](int q0s, int buf) {
+    unsigned char* qt_w = smem + buf * PAIR;
+    qr.store(qt_w, tid);
+    dr.store(qt_w + 32 * TSTR, tid);
+    float* lse_w = (float*)(smem + 2 * PAIR + buf * ROWS_BYTES);
+    unsigned* dw_w = (unsigned*)(lse_w + 64);
+    if (tid < 32) {
+      const bool in = q0s + tid < S;
+      lse_w[tid] = in ? lse_n : 1.0e30f;                   // P = 0 for rows past the end
+      lse_w[32 + tid] = in ? del_n : 0.f;
+    }
+    if (lane < 32) dw_w[wave * 32 + lane] = (!a.drop_thr || q0s + lane < S) ? dw_n : 0u;
+    if (BLK && lane < 32) dw_w[256 + wave * 32 + lane] = bw_n;
+  };
+  if (ntiles > 0) {
+    prefetch_rows(0);
+    store_tile(0, 0);
+    if (ntiles > 1) {
+      qr.load(qbase, ld, 32, S - 1, tid);
+      dr.load(dobase, a.ld_dout, 32, S - 1, tid, true);
+      prefetch_rows(32);
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = t * 32;
+    const unsigned char* qt = smem + (t & 1) * PAIR;
+    const unsigned char* dot = qt + 32 * TSTR;
+    const float* lse_s = (const float*)(smem + 2 * PAIR + (t & 1) * ROWS_BYTES);
+    const unsigned* dw_s = (const unsigned*)(lse_s + 64) + wave * 32;
+    f32x4 st[2], dp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { st[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // phase A: S and dP, the row fragments of Q / dO run ahead of the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      bf16x8 qfr[2 * KS], dfr[2 * KS];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qfr[j * KS + ks] = *(const bf16x8*)(qt + rbase + 16 * j * TSTR + 64 * ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dfr[j * KS + ks] = *(const bf16x8*)(dot + rbase + 16 * j * TSTR + 64 * ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[j * KS + ks], kf[ks], st[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[j * KS + ks], vf[ks], dp[j], 0, 0, 0);
+      constexpr int NR = 4 * KS, AHEAD = NR < 6 ? NR : 6;
+      __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+      for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile goes into the other buffer (last read in tile t-1, which every wave left through the barrier below)
+    if (t + 1 < ntiles) {
+      store_tile(q0 + 32, (t + 1) & 1);
+      if (t + 2 < ntiles) {
+        qr.load(qbase, ld, q0 + 64, S - 1, tid);
+        dr.load(dobase, a.ld_dout, q0 + 64, S - 1, tid, true);
+        prefetch_rows(q0 + 64);
+      }
+    }
+    // phase B: registers i of block j are query rows q0 + 16j + 4g + i
+    bf16x8 pf, dsf;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 l4 = *(const f32x4*)(lse_s + 16 * j + 4 * g);
+      const f32x4 d4 = *(const f32x4*)(lse_s + 32 + 16 * j + 4 * g);
+      const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
+      u32x4 b4 = {0u, 0u, 0u, 0u};
+      if (BLK) b4 = *(const u32x4*)(dw_s + 256 + 16 * j + 4 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool att = BLK ? (key_ok && !((b4[i] >> kbit) & 1u)) : key_ok;
+        const float pr = att ? fast_exp2(fmaf(st[j][i], sc, -l4[i])) : 0.f;
+        const float keep_scale = ((w4[i] >> kbit) & 1u) ? dscale : 0.f;
+        pf[4 * j + i] = (__bf16)(pr * keep_scale);                             // Pd
+        dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], keep_scale, -d4[i]));   // dS
+      }
+    }
+    // phase C: dV^T += dO^T . Pd and dK^T += Q^T . dS; 2 * DB transposed fragments (2 reads each), AH fragments ahead
+    {
+      constexpr int NF = 2 * DB, AH = 4;
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 tf[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int d = i >> 1;
+        const unsigned char* tp = ((i & 1) ? qt : dot) + tbase + 64 * (d >> 1) + ((d & 1) ? xo : xe);
+        tf[i] = join_tr(lds_read_tr16(tp), lds_read_tr16(tp + 16 * TSTR));
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int d = i >> 1;
+        if (i & 1) dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], dsf, dk[d], 0, 0, 0);
+        else dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], pf, dv[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);
+#pragma unroll
+      for (int i = 0; i < NF - AH; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  if (key < S) {
+    u16* krow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
+    u16* vrow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      u32x2 v;
+      v[0] = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
+      v[1] = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
+      *(u32x2*)(krow + d * 16 + 4 * g) = v;
+      v[0] = pack2bf(dv[d][0], dv[d][1]);
+      v[1] = pack2bf(dv[d][2], dv[d][3]);
+      *(u32x2*)(vrow + d * 16 + 4 * g) = v;
+    }
+  }
+}
+
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 128 * Geo<HDP>::TSTR;
   static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -871,7 +1070,17 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
   }
-  {
+  const size_t lds_kv16 = 128 * Geo<HDP>::TSTR + 2 * (256 + 1024 + 1024);
+  static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+  static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+  (void)once_kv16; (void)once_kv16b;
+  static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
+  if (dkv16 && HDP <= 192) {
+    snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl);
+    if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true>), grid, dim3(512), lds_kv16, st, *a);
+    else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false>), grid, dim3(512), lds_kv16, st, *a);
+  } else {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, true>), grid, dim3(256), lds_kv, st, *a);
