@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
 // LDS tile: same 64 (mod 256)-byte row stride, 16-B chunk ^= {0,2,3,1}[(row>>2)&3]: conflict-free for the ds_read_b128
 // lane groups of the 16-row operand AND for the transposed reads (the 32x32 swizzle is 2-way on the former).
 // ================================================================================================
+#ifndef TF_DKV16_QT
+#define TF_DKV16_QT 64
+#endif
 __device__ __forceinline__ int swz16(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 __device__ __forceinline__ int tile_off16(int row, int chunk, int tstr) { return row * tstr + ((chunk ^ swz16(row)) << 4); }
 
@@ -844,13 +847,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 //   S[q][key] = Q.K^T -> P ;  dP = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
 //   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
 // ================================================================================================
-template <int HDP, bool BLK>
+template <int HDP, bool BLK, int QT>     // QT query rows per LDS tile (32 or 64)
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   constexpr int NT = 512;
   constexpr int KS = HDP / 32, DB = HDP / 16, TSTR = G::TSTR;
-  constexpr int PAIR = 64 * TSTR;                         // Q tile (32 rows) + dO tile (32 rows)
-  constexpr int ROWS_BYTES = 256 + 1024 + 1024;           // lse[32], delta[32], keep words [8][32], block words [8][32]
+  constexpr int PAIR = 2 * QT * TSTR;                     // Q tile (QT rows) + dO tile (QT rows)
+  constexpr int ROWS_BYTES = 8 * QT + 32 * QT + 32 * QT;  // lse[QT], delta[QT], keep words [8][QT], block words [8][QT]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, n = lane & 15;
   const int S = a.S;
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
   const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
 
-  TileRegs16<32, HDP, NT> qr, dr;
+  TileRegs16<QT, HDP, NT> qr, dr;
   qr.load(qbase, ld, 0, S - 1, tid);
   dr.load(dobase, a.ld_dout, 0, S - 1, tid, true);       // rows >= S contribute nothing
   const int key = key0 + n;
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + 16t * TSTR + 64 * (db>>1) + xe|xo
   const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
 
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + QT - 1) / QT;
   const int dw_ld = 2 * ((S + 63) / 64);
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
   const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
@@ -898,44 +901,46 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   unsigned dw_n = 0xffffffffu, bw_n = 0u;
   // (RAW loaded values are carried; the row-validity selects happen when they are stored)
   auto prefetch_rows = [&](int q0n) {
-    if (tid < 32) {
+    if (tid < QT) {
       const int q = min(q0n + tid, S - 1);
       lse_n = a.lse[(size_t)bh * S + q];
       del_n = a.delta[(size_t)bh * S + q];
     }
-    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
-    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & (QT - 1)), S - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & (QT - 1)), S - 1) * dw_ld];
   };
   auto store_tile = [&](int q0s, int buf) {
     unsigned char* qt_w = smem + buf * PAIR;
     qr.store(qt_w, tid);
-    dr.store(qt_w + 32 * TSTR, tid);
+    dr.store(qt_w + QT * TSTR, tid);
     float* lse_w = (float*)(smem + 2 * PAIR + buf * ROWS_BYTES);
-    unsigned* dw_w = (unsigned*)(lse_w + 64);
-    if (tid < 32) {
+    unsigned* dw_w = (unsigned*)(lse_w + 2 * QT);
+    if (tid < QT) {
       const bool in = q0s + tid < S;
       lse_w[tid] = in ? lse_n : 1.0e30f;                   // P = 0 for rows past the end
-      lse_w[32 + tid] = in ? del_n : 0.f;
+      lse_w[QT + tid] = in ? del_n : 0.f;
     }
-    if (lane < 32) dw_w[wave * 32 + lane] = (!a.drop_thr || q0s + lane < S) ? dw_n : 0u;
-    if (BLK && lane < 32) dw_w[256 + wave * 32 + lane] = bw_n;
+    if (lane < QT) dw_w[wave * QT + lane] = (!a.drop_thr || q0s + lane < S) ? dw_n : 0u;
+    if (BLK && lane < QT) dw_w[8 * QT + wave * QT + lane] = bw_n;
   };
   if (ntiles > 0) {
     prefetch_rows(0);
     store_tile(0, 0);
     if (ntiles > 1) {
-      qr.load(qbase, ld, 32, S - 1, tid);
-      dr.load(dobase, a.ld_dout, 32, S - 1, tid, true);
-      prefetch_rows(32);
+      qr.load(qbase, ld, QT, S - 1, tid);
+      dr.load(dobase, a.ld_dout, QT, S - 1, tid, true);
+      prefetch_rows(QT);
     }
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    const int q0 = t * 32;
-    const unsigned char* qt = smem + (t & 1) * PAIR;
-    const unsigned char* dot = qt + 32 * TSTR;
-    const float* lse_s = (const float*)(smem + 2 * PAIR + (t & 1) * ROWS_BYTES);
-    const unsigned* dw_s = (const unsigned*)(lse_s + 64) + wave * 32;
+    const int q0 = t * QT;
+#pragma unroll
+    for (int u = 0; u < QT / 32; ++u) {
+    const unsigned char* qt = smem + (t & 1) * PAIR + 32 * u * TSTR;
+    const unsigned char* dot = qt + QT * TSTR;
+    const float* lse_s = (const float*)(smem + 2 * PAIR + (t & 1) * ROWS_BYTES) + 32 * u;
+    const unsigned* dw_s = (const unsigned*)(lse_s - 32 * u + 2 * QT) + wave * QT + 32 * u;
     f32x4 st[2], dp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { st[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -967,12 +972,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     }
     __builtin_amdgcn_sched_barrier(0);
     // the next tile goes into the other buffer (last read in tile t-1, which every wave left through the barrier below)
-    if (t + 1 < ntiles) {
-      store_tile(q0 + 32, (t + 1) & 1);
+    if (u == 0 && t + 1 < ntiles) {
+      store_tile(q0 + QT, (t + 1) & 1);
       if (t + 2 < ntiles) {
-        qr.load(qbase, ld, q0 + 64, S - 1, tid);
-        dr.load(dobase, a.ld_dout, q0 + 64, S - 1, tid, true);
-        prefetch_rows(q0 + 64);
+        qr.load(qbase, ld, q0 + 2 * QT, S - 1, tid);
+        dr.load(dobase, a.ld_dout, q0 + 2 * QT, S - 1, tid, true);
+        prefetch_rows(q0 + 2 * QT);
       }
     }
     // phase B: registers i of block j are query rows q0 + 16j + 4g + i
@@ -980,10 +985,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const f32x4 l4 = *(const f32x4*)(lse_s + 16 * j + 4 * g);
-      const f32x4 d4 = *(const f32x4*)(lse_s + 32 + 16 * j + 4 * g);
+      const f32x4 d4 = *(const f32x4*)(lse_s + QT + 16 * j + 4 * g);
       const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
       u32x4 b4 = {0u, 0u, 0u, 0u};
-      if (BLK) b4 = *(const u32x4*)(dw_s + 256 + 16 * j + 4 * g);
+      if (BLK) b4 = *(const u32x4*)(dw_s + 8 * QT + 16 * j + 4 * g);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool att = BLK ? (key_ok && !((b4[i] >> kbit) & 1u)) : key_ok;
@@ -1015,6 +1020,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
       for (int i = 0; i < NF - AH; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
       __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     __syncthreads();
   }
@@ -1070,16 +1076,17 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
   }
-  const size_t lds_kv16 = 128 * Geo<HDP>::TSTR + 2 * (256 + 1024 + 1024);
-  static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
-  static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
-  (void)once_kv16; (void)once_kv16b;
   static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
+  constexpr int QT = TF_DKV16_QT;
+  const size_t lds_kv16 = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT);
+  static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+  static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+  (void)once_kv16; (void)once_kv16b;
   if (dkv16 && HDP <= 192) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
-    if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true>), grid, dim3(512), lds_kv16, st, *a);
-    else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false>), grid, dim3(512), lds_kv16, st, *a);
+    if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT>), grid, dim3(512), lds_kv16, st, *a);
+    else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT>), grid, dim3(512), lds_kv16, st, *a);
   } else {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
