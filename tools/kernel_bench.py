@@ -82,6 +82,9 @@ if which in ("epi",):
     timeit("ffn_up GELU p=.15", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_GELU_DROP, bias=bff, C2=Hh, drop=d15), fl)
     timeit("ffn_up DROP_RES p=0", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_DROP_RES, bias=bff, R=Y, drop=d0), fl)
     timeit("ffn_up DROP_RES p=.15", lambda: ops.gemm(X, W1, U, ff, D, Lb.TF_EPI_BIAS_DROP_RES, bias=bff, R=Y, drop=d15), fl)
+    G2 = torch.empty(M, ff, device=dev, dtype=bf)
+    timeit("ffn_up GELU_G p=0", lambda: ops.gemm(X, W1, G2, ff, D, Lb.TF_EPI_BIAS_GELU_DROP_G, bias=bff, C2=Hh, drop=d0), fl)
+    timeit("ffn_up GELU_G p=.15", lambda: ops.gemm(X, W1, G2, ff, D, Lb.TF_EPI_BIAS_GELU_DROP_G, bias=bff, C2=Hh, drop=d15), fl)
     timeit("ffn_up DGELU p=0", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d0), fl)
     timeit("ffn_up DGELU p=.15", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d15), fl)
 if which in ("ln",):
