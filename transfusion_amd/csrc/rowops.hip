@@ -252,29 +252,79 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
 
 // fp32 parameter [rows, cols] -> bf16 shadow (padded / head-grouped) and its transpose, via a 64x64 LDS tile.
 // Up to 8 tensors per launch (blockIdx.z): one launch re-packs a whole encoder layer.
+// Fast path (column groups and the source width multiples of 4, i.e. every real weight matrix): a thread converts 16
+// consecutive columns of one row from four 16-B loads and writes them with two 16-B stores; the transpose goes through
+// the LDS tile and leaves as 16 consecutive source rows of one column, again two 16-B stores (2-B stores made this
+// kernel 0.8 TB/s).  The element-wise path serves odd head widths (hd = 18) and the fp32 bias copies.
 struct PackBatch { TfPackArgs a[8]; };
+__device__ __forceinline__ int pack_src_index(int p, int g, int gp, int n_src) {      // padded index -> source index or -1
+  const int q = gp >= (1 << 28) ? 0 : p / gp, e = p - q * gp;
+  const int s = q * g + e;
+  return (e < g && s < n_src) ? s : -1;
+}
 __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
-  __shared__ u16 tile[64][66];
+  __shared__ __attribute__((aligned(16))) u16 tile[64][72];        // 144-B rows: 16-B aligned, 36 words (= 4 mod 32 banks)
   const TfPackArgs& a = pb.a[blockIdx.z];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   if (r0 >= a.rows_p || c0 >= a.cols_p) return;        // block-uniform
-  // a thread keeps its column for the whole tile (256 % 64 == 0): the padded -> source column map (an integer division)
-  // is computed once, and ungrouped dimensions (group size "BIG") skip the division altogether
-  const int cl = threadIdx.x & 63, cp = c0 + cl;
-  int cs = -1;
-  if (cp < a.cols_p) {
-    const int cgq = a.cgp >= (1 << 28) ? 0 : cp / a.cgp, cge = cp - cgq * a.cgp;
-    if (cge < a.cg && cgq * a.cg + cge < a.cols) cs = cgq * a.cg + cge;
+  const bool fast = !a.dst_is_f32 && (a.cols & 3) == 0 && (((size_t)a.src) & 15) == 0 &&
+                    (a.cgp >= (1 << 28) || (((a.cg | a.cgp) & 3) == 0)) && (a.cols_p & 15) == 0 && (a.ld_dst & 7) == 0;
+  if (fast) {
+    const int rl = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;
+    const int rp = r0 + rl, cp = c0 + cq;
+    const int rs = rp < a.rows_p ? pack_src_index(rp, a.rg, a.rgp, a.rows) : -1;
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cs = (rs >= 0 && cp + 4 * k < a.cols_p) ? pack_src_index(cp + 4 * k, a.cg, a.cgp, a.cols) : -1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cs >= 0) v = *(const f32x4*)(a.src + (size_t)rs * a.cols + cs);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[4 * k + e] = v[e];
+    }
+    u32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = pack2bf(f[2 * e], f[2 * e + 1]); hi[e] = pack2bf(f[8 + 2 * e], f[8 + 2 * e + 1]); }
+    *(u32x4*)&tile[rl][cq] = lo;
+    *(u32x4*)&tile[rl][cq + 8] = hi;
+    if (a.dst != nullptr && rp < a.rows_p && cp < a.cols_p) {
+      u16* d = (u16*)a.dst + (size_t)rp * a.ld_dst + cp;
+      *(u32x4*)d = lo;
+      *(u32x4*)(d + 8) = hi;
+    }
+    if (a.dst_t == nullptr) return;                     // block-uniform
+    __syncthreads();
+    // transposed: thread -> source column cl (row of dst_t), 16 consecutive tile rows
+    const int cl = threadIdx.x >> 2, rq = (threadIdx.x & 3) * 16;
+    if (c0 + cl < a.cols_p && r0 + rq < a.rows_p) {
+      u32x4 tlo, thi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tlo[e] = (unsigned)tile[rq + 2 * e][cl] | ((unsigned)tile[rq + 2 * e + 1][cl] << 16);
+        thi[e] = (unsigned)tile[rq + 8 + 2 * e][cl] | ((unsigned)tile[rq + 8 + 2 * e + 1][cl] << 16);
+      }
+      u16* d = (u16*)a.dst_t + (size_t)(c0 + cl) * a.ld_dst_t + r0 + rq;
+      if ((a.ld_dst_t & 7) == 0 && r0 + rq + 16 <= a.rows_p) {
+        *(u32x4*)d = tlo;
+        *(u32x4*)(d + 8) = thi;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (r0 + rq + e < a.rows_p) d[e] = tile[rq + e][cl];
+      }
+    }
+    return;
   }
-  const bool row_grouped = a.rgp < (1 << 28);
+  // ---- element-wise path ----
+  const int cl = threadIdx.x & 63, cp = c0 + cl;
+  const int cs = cp < a.cols_p ? pack_src_index(cp, a.cg, a.cgp, a.cols) : -1;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int rl = i >> 6;
     const int rp = r0 + rl;
     float v = 0.f;
     if (rp < a.rows_p && cs >= 0) {
-      const int rgq = row_grouped ? rp / a.rgp : 0, rge = rp - rgq * a.rgp;
-      const int rs = rgq * a.rg + rge;
-      if (rge < a.rg && rs < a.rows) v = a.src[(size_t)rs * a.cols + cs];
+      const int rs = pack_src_index(rp, a.rg, a.rgp, a.rows);
+      if (rs >= 0) v = a.src[(size_t)rs * a.cols + cs];
     }
     if (a.dst_is_f32) {
       if (rp < a.rows_p && cp < a.cols_p) ((float*)a.dst)[(size_t)rp * a.ld_dst + cp] = v;
@@ -285,12 +335,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
   if (a.dst_is_f32) return;
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int rl = i >> 6, cl = i & 63;
-    if (a.dst != nullptr && r0 + rl < a.rows_p && c0 + cl < a.cols_p)
-      ((u16*)a.dst)[(size_t)(r0 + rl) * a.ld_dst + c0 + cl] = tile[rl][cl];
+    const int rl = i >> 6, cl2 = i & 63;
+    if (a.dst != nullptr && r0 + rl < a.rows_p && c0 + cl2 < a.cols_p)
+      ((u16*)a.dst)[(size_t)(r0 + rl) * a.ld_dst + c0 + cl2] = tile[rl][cl2];
     // transposed: row index = column of the source
-    if (a.dst_t != nullptr && c0 + rl < a.cols_p && r0 + cl < a.rows_p)
-      ((u16*)a.dst_t)[(size_t)(c0 + rl) * a.ld_dst_t + r0 + cl] = tile[cl][rl];
+    if (a.dst_t != nullptr && c0 + rl < a.cols_p && r0 + cl2 < a.rows_p)
+      ((u16*)a.dst_t)[(size_t)(c0 + rl) * a.ld_dst_t + r0 + cl2] = tile[cl2][rl];
   }
 }
 
