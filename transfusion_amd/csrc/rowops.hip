@@ -386,18 +386,23 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict
                                                             unsigned thr16) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= nrows * SW32) return;
-  const long long row = t / SW32;
-  const int w = (int)(t - row * SW32);
-  const unsigned base = (unsigned)(row * S) + (unsigned)w * 32u;
-  unsigned m = 0, last_pair = 0xffffffffu, h = 0;
-#pragma unroll 4
-  for (int k = 0; k < 32; ++k) {
-    if (w * 32 + k >= S) break;
-    const unsigned idx = base + k, pair = idx >> 1;
-    if (pair != last_pair) { h = tf_hash32(pair, key); last_pair = pair; }
-    const unsigned b = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
-    m |= (b >= thr16 ? 1u : 0u) << k;
+  // (the grid is checked against 2^32 elements by the launcher, so the row / word split fits 32-bit arithmetic)
+  const unsigned row = (unsigned)t / (unsigned)SW32, w = (unsigned)t - row * (unsigned)SW32;
+  const unsigned base = row * (unsigned)S + w * 32u;
+  // Branch-free: the word's 32 elements span 16 or (odd base) 17 index PAIRS; hash all 17, lay their keep bits out as a
+  // 34-bit stream and shift by the base's parity.  x >= thr16  <=>  carry out of x + (65536 - thr16).
+  const unsigned p0 = base >> 1, add = 65536u - thr16;
+  unsigned lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 17; ++i) {
+    const unsigned h = tf_hash32(p0 + i, key);
+    const unsigned two = (((h & 0xffffu) + add) >> 16) | ((((h >> 16) + add) >> 16) << 1);
+    if (i < 16) lo |= two << (2 * i);
+    else hi = two;
   }
+  unsigned m = (base & 1u) ? ((lo >> 1) | (hi << 31)) : lo;
+  const int valid = S - (int)w * 32;                      // elements of this word inside the row (may be <= 0 for pad words)
+  m = valid >= 32 ? m : (valid <= 0 ? 0u : (m & ((1u << valid) - 1u)));
   bits[t] = m;
 }
 
