@@ -375,6 +375,11 @@ def main():
         "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if world > 1 else 0.0,
         "final_loss": round(final_loss, 5),
     }
+    if rank != 0 and world > 1 and not args.no_census:
+        # the traced steps below contain the gradient collectives: EVERY rank has to take them (rank 0 alone would pair its
+        # all-reduces with the other ranks' final barrier)
+        for _ in range(args.trace_steps):
+            trainer.step([batch], loss_fn)
     if rank == 0 and not args.no_census:
         # in-situ kernel table: traced steps run AFTER the timed region (two event records per launch would perturb it)
         rows = traced_kernels(trainer, batch, args.trace_steps)
