@@ -50,15 +50,15 @@ def make_encoder(device, d=D, h=H, layers=L, p_tok=P_TOKEN, p_patch=P_PATCH):
     return enc.to(device)
 
 
-def make_batch(B, device, rank, d=D, nv=NV, nl=NL):
-    g = torch.Generator().manual_seed(42 + 1000 * rank)
+def make_batch(B, device, rank, d=D, nv=NV, nl=NL, variant=0):
+    g = torch.Generator().manual_seed(42 + 1000 * rank + 77 * variant)
     x = torch.randn(B, nv, d, generator=g)
     lang = torch.nn.functional.normalize(torch.randn(B, nl, d, generator=g), dim=-1)     # SBERT normalize: True
     lens = torch.randint(nl // 4, nl + 1, (B,), generator=g)
     pad = torch.arange(nl).view(1, -1) >= lens.view(-1, 1)                                # True = ignore
     valid = (~pad).unsqueeze(-1).float()                                                  # batch constants of the synthetic loss
     km = torch.tensor(1.0 / (float(valid.sum()) * d))
-    return x.to(device), lang.to(device), pad.to(device), valid.to(device), km.to(device)
+    return x.to(device), lang.to(device), pad.to(device), valid.to(device), km.to(device), lens.tolist()
 
 
 class _MaskedSquareLoss(torch.autograd.Function):
@@ -83,7 +83,7 @@ class _MaskedSquareLoss(torch.autograd.Function):
 
 def loss_fn(module, batch):
     """mean(vis^2) + mean(lang[valid]^2)."""
-    x, lang, pad, valid, km = batch
+    x, lang, pad, valid, km = batch[:5]
     vis, lo, _, _ = module(x, lang, pad)
     return _MaskedSquareLoss.apply(vis, lo, valid, km)
 
@@ -161,7 +161,7 @@ def kernel_census(B, device, reps=20):
 
 
 
-def traced_kernels(trainer, batch, nsteps):
+def traced_kernels(step, nsteps):
     """Per-kernel durations IN SITU: `nsteps` further training steps with the library's launch tracer on (a HIP event pair
     around every kernel, on the stream it is launched on -- the side stream for the overlapped weight-gradient GEMMs).
     Aggregated by kernel symbol, i.e. the rows of `rocprofv3 --kernel-trace --stats` for the same command."""
@@ -169,8 +169,8 @@ def traced_kernels(trainer, batch, nsteps):
     from transfusion_amd import _lib as Lb
     lib = Lb.load()
     Lb.check(lib.tf_trace_start(), "tf_trace_start")
-    for _ in range(nsteps):
-        trainer.step([batch], loss_fn)
+    for j in range(nsteps):
+        step(j)
     cap = 1 << 14
     recs = (Lb.TfTraceRecord * cap)()
     n = lib.tf_trace_stop(ctypes.addressof(recs), cap)
@@ -254,7 +254,7 @@ def cpu_baseline(seconds_budget=25.0):
     enc = make_encoder("cpu")
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "pos_embedding" not in k and "heatmap" not in k)
           for k, v in enc.state_dict().items()}
-    x, lang, pad, _, _ = make_batch(B, "cpu", 0)
+    x, lang, pad = make_batch(B, "cpu", 0)[:3]
     S = NV + NL
 
     def step():
@@ -286,12 +286,77 @@ def cpu_baseline(seconds_budget=25.0):
                        f"best of {len(times)} steps after 1 warm-up ({best * 1e3:.0f} ms/step)")
 
 
+class _Comm:
+    """The collectives bench.py's control flow issues itself (the gradient all-reduces are issued by the trainer inside step())."""
+
+    def __init__(self, world, device):
+        self.world, self.device = world, device
+
+    def sync(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_schedule(step, comm, rank, warmup, steps, trace_steps, traced):
+    """The benchmark's control flow, the same on EVERY rank: W untimed steps, barrier + sync, K timed steps, barrier + sync,
+    max over ranks; then `trace_steps` further steps which rank 0 runs under the launch tracer (`traced(n)`) and every other rank
+    runs plainly -- each step contains the gradient collectives, so a rank that skipped them would leave rank 0's all-reduces
+    paired with the others' final barrier (the hang of round 1's 2-rank rehearsal).  `step(i)` runs training step number i.
+    tests/test_bench_schedule_cpu.py drives this with recording fakes and asserts identical collective sequences per rank."""
+    i = 0
+    for _ in range(warmup):
+        step(i); i += 1
+    comm.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(i); i += 1
+    comm.sync()
+    elapsed = comm.max(time.perf_counter() - t0)
+    rows = None
+    if trace_steps > 0:
+        if rank == 0:
+            rows = traced(lambda j: step(i + j), trace_steps)
+        else:
+            for j in range(trace_steps):
+                step(i + j)
+    return elapsed, rows
+
+
+def allreduce_busbw(trainer, comm, reps=10):
+    """Stand-alone all-reduce of the flat gradient buffer, per layer range as the trainer issues it: algorithm and bus bandwidth
+    (busbw = algbw * 2 (N - 1) / N, the per-link figure to hold against xGMI's ~153 GB/s per direction per link)."""
+    world = comm.world
+    g = trainer.flat.grad
+    ranges = sorted(trainer.layerwise.ranges.values()) if trainer.layerwise is not None else trainer.reducer.buckets
+    comm.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for lo, hi in ranges:
+            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+    comm.sync()
+    dt = comm.max(time.perf_counter() - t0) / reps
+    nbytes = g.numel() * 4
+    g.zero_()
+    return dict(bytes=nbytes, collectives_per_step=len(ranges), ms=round(dt * 1e3, 3), algbw_gbs=round(nbytes / dt / 1e9, 1),
+                busbw_gbs=round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 1),
+                note="all-reduce alone, back to back (not overlapped with the backward)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true", help="skip the traced steps / kernel table / roofline object")
     ap.add_argument("--trace-steps", type=int, default=5)
@@ -325,26 +390,17 @@ def main():
     enc = make_encoder(device)
     enc.train()
     trainer = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap)
-    batch = make_batch(args.batch, device, rank)
+    # distinct batches (tensors, padding lengths) rotated through the steps: a real loader hands the encoder a new mask tensor
+    # every step, so the padding-mask conversion cache never hits
+    batches = [make_batch(args.batch, device, rank, variant=v) for v in range(max(1, args.batches))]
+    comm = _Comm(world, device)
+    last = {}
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(i):
+        last["loss"] = trainer.step([batches[i % len(batches)]], loss_fn)
 
-    for _ in range(args.warmup):
-        loss = trainer.step([batch], loss_fn)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step([batch], loss_fn)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = float(loss.item())
+    elapsed, rows = run_schedule(step, comm, rank, args.warmup, args.steps, 0 if args.no_census else args.trace_steps, traced_kernels)
+    final_loss = float(last["loss"].item())
     if world > 1 and os.environ.get("TF_CHECK_SYNC"):
         # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
         mine = trainer.flat.flat.double().sum().reshape(1)
@@ -360,7 +416,13 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * args.batch / (elapsed / args.steps)
     S = NV + NL
-    train_flops_step = 3 * L * flops_per_sample_layer(S, D) * args.batch          # per GPU
+    train_flops_step = 3 * L * flops_per_sample_layer(S, D) * args.batch          # per GPU, dense S (padded tokens credited)
+    # valid-token accounting (BASELINE.md section 3 / SURVEY.md 8d): only the Nv + len_b real tokens of each sample, averaged over
+    # the rotated batches.  The kernels do compute the padded query rows (their outputs are defined by the reference) and skip
+    # key tiles that hold only padding, so the executed work lies between the two figures.
+    valid_S = [[NV + n for n in b[5]] for b in batches]
+    train_flops_valid = sum(3 * L * sum(flops_per_sample_layer(sb, D) for sb in vs) for vs in valid_S) / len(valid_S)
+    attn_valid_ratio = sum(sum(sb * sb for sb in vs) for vs in valid_S) / (len(valid_S) * args.batch * S * S)
     result = {
         "metric": "train samples/sec, Ego4D NAO B=32 (14x14 vis + 512 txt tok), 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -372,21 +434,23 @@ def main():
                    "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}"},
         "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "block_tflops_per_gpu": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
+        "block_mfma_util_valid_tokens": round(train_flops_valid / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "block_tflops_valid_tokens": round(train_flops_valid / (ms * 1e-3) / 1e12, 1),
+        "mean_valid_tokens": round(sum(sum(vs) for vs in valid_S) / (len(valid_S) * args.batch), 1),
         "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if world > 1 else 0.0,
         "final_loss": round(final_loss, 5),
     }
-    if rank != 0 and world > 1 and not args.no_census:
-        # the traced steps below contain the gradient collectives: EVERY rank has to take them (rank 0 alone would pair its
-        # all-reduces with the other ranks' final barrier)
-        for _ in range(args.trace_steps):
-            trainer.step([batch], loss_fn)
-    if rank == 0 and not args.no_census:
-        # in-situ kernel table: traced steps run AFTER the timed region (two event records per launch would perturb it)
-        rows = traced_kernels(trainer, batch, args.trace_steps)
+    if world > 1:
+        result["allreduce"] = allreduce_busbw(trainer, comm)          # every rank takes part; rank 0 prints
+    if rank == 0 and rows is not None:
+        # in-situ kernel table: the traced steps ran AFTER the timed region (two event records per launch would perturb it)
         total = sum(r["us_per_step"] for r in rows)
         for r in rows:
+            # attention kernels: rate on valid (query, key) pairs next to the dense-S rate the tracer credits
+            r["tflops_valid"] = round(r["tflops"] * attn_valid_ratio, 1) if r["kernel"].startswith("attn_") and r["tflops"] else None
+        for r in rows:
             log(f"  {r['kernel']:34s} {r['avg_us']:9.1f} us x{r['launches_per_step']:6.1f} = {r['us_per_step']:8.1f} us/step  "
-                f"{'' if r['tflops'] is None else str(r['tflops']) + ' TF/s':>12s} {'' if r['gbs'] is None else str(r['gbs']) + ' GB/s':>12s}"
+                f"{'' if r['tflops'] is None else str(r['tflops']) + ' TF/s':>12s}{'' if r.get('tflops_valid') is None else ' (' + str(r['tflops_valid']) + ' valid)':>16s} {'' if r['gbs'] is None else str(r['gbs']) + ' GB/s':>12s}"
                 f"{'  [side stream]' if r['side_stream'] else ''}")
         log(f"  sum of kernel durations {total:.0f} us/step (streams overlap) vs measured step {ms * 1e3:.0f} us")
         dom = rows[0]                                            # the kernel symbol with the largest time per step
@@ -409,7 +473,7 @@ def main():
         if dom["kernel"].startswith("wgrad_tn2") and "roofline" in result:
             # the dominant kernel runs on the side stream and SHARES the chip with the backward chain in situ; its own rate too:
             result["roofline"]["alone"] = wgrad_alone(args.batch, device)
-        result["kernels"] = [{k: r[k] for k in ("kernel", "avg_us", "launches_per_step", "us_per_step", "tflops", "gbs", "side_stream")} for r in rows]
+        result["kernels"] = [{k: r[k] for k in ("kernel", "avg_us", "launches_per_step", "us_per_step", "tflops", "tflops_valid", "gbs", "side_stream")} for r in rows]
         if args.isolated_census:
             census = kernel_census(args.batch, device)
             result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]

@@ -250,3 +250,32 @@ def lm_multi_pool_predictor(sd, tokens_per_scale, att_mask, pool_type: str, sepa
     noun = torch.stack([o["noun_logits"] for o in outs]).mean(dim=0)
     verb = None if outs[0]["verb_logits"] is None else torch.stack([o["verb_logits"] for o in outs]).mean(dim=0)
     return {"noun_logits": noun, "verb_logits": verb}
+
+
+# ----------------------------------------------------------------------------
+# optimiser
+# ----------------------------------------------------------------------------
+def radam_step(p: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int, lr: float,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, degenerated_to_sgd: bool = False):
+    """One RAdam step on one tensor, runner/metrics_losses/radam_optim.py:47-100; ``step`` is the 1-based count AFTER the
+    increment of :63.  Moments are always updated (:60-61); the parameter moves only when the variance is rectifiable
+    (N_sma >= 5, :87-92) or in the SGD-degenerated mode (:93-97); weight decay is ``p += -wd * lr * p`` before the update.
+    Returns the new (p, exp_avg, exp_avg_sq)."""
+    beta1, beta2 = betas
+    exp_avg_sq = exp_avg_sq * beta2 + (1 - beta2) * grad * grad            # :60
+    exp_avg = exp_avg * beta1 + (1 - beta1) * grad                         # :61
+    beta2_t = beta2 ** step                                                # :69
+    n_sma_max = 2 / (1 - beta2) - 1                                        # :70
+    n_sma = n_sma_max - 2 * step * beta2_t / (1 - beta2_t)                 # :71
+    if n_sma >= 5:                                                         # :75-83
+        step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max / (n_sma_max - 2)) / (
+            1 - beta1 ** step)
+        if weight_decay != 0:
+            p = p + (-weight_decay * lr) * p                               # :89
+        p = p + (-step_size * lr) * exp_avg / (exp_avg_sq.sqrt() + eps)    # :90-91
+    elif degenerated_to_sgd:                                               # :84-85, :93-97
+        step_size = 1.0 / (1 - beta1 ** step)
+        if weight_decay != 0:
+            p = p + (-weight_decay * lr) * p
+        p = p + (-step_size * lr) * exp_avg
+    return p, exp_avg, exp_avg_sq

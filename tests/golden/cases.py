@@ -15,6 +15,10 @@ ENCODER_CASES = {
     "enc_local1": dict(B=2, Nv=20, Nl=6, d=64, h=4, L=1, mask_lens=[4, 6], seed=104, grid=(4, 5), local_k=1),
     # real width, weights regenerated from the seed (not stored), outputs stored sub-sampled
     "enc_d768": dict(B=1, Nv=196, Nl=64, d=768, h=4, L=1, mask_lens=[40], seed=105, big=True),
+    # the reference's TRUE widths: out_mlp = 712 (Ego4Dv1, head dim 178 -> padded to 192 inside the runtime) and
+    # 896 (Ego4Dv2, head dim 224); sub-sampled like enc_d768
+    "enc_d712": dict(B=2, Nv=196, Nl=128, d=712, h=4, L=1, mask_lens=[128, 57], seed=106, big=True),
+    "enc_d896": dict(B=2, Nv=196, Nl=128, d=896, h=4, L=1, mask_lens=[90, 128], seed=107, big=True),
 }
 
 LEVEL_CASES = {
@@ -151,3 +155,24 @@ def make_lm_case(cfg):
     cot_noun = rs.randn(cfg["B"], cfg["nouns"]).astype(np.float32)
     cot_verb = rs.randn(cfg["B"], cfg["verbs"]).astype(np.float32) if cfg["verbs"] else None
     return params, tokens, att, cot_noun, cot_verb
+
+
+# fused RAdam (runner/metrics_losses/radam_optim.py): tensors per group, per-group lr, weight decay, SGD-degenerated mode.
+# With beta2 = 0.999 the update is un-rectified (N_sma < 5) for steps 1-5: >= 12 steps cover both regimes.
+RADAM_CASES = {
+    "radam_wd": dict(steps=14, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=2e-4, degenerated_to_sgd=False,
+                     groups=[dict(shapes=[(257,), (33, 7)])], seed=401),
+    "radam_groups": dict(steps=12, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, degenerated_to_sgd=False,
+                         groups=[dict(shapes=[(130,)], lr=2e-4), dict(shapes=[(64, 3), (5,)])], seed=402),
+    "radam_sgd": dict(steps=12, lr=1e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.0, degenerated_to_sgd=True,
+                      groups=[dict(shapes=[(300,)])], seed=403),
+}
+
+
+def make_radam_case(cfg):
+    """-> (params [group][tensor] fp32, grads [step][group][tensor] fp32)"""
+    rs = np.random.RandomState(cfg["seed"])
+    params = [[rs.randn(*shp).astype(np.float32) for shp in g["shapes"]] for g in cfg["groups"]]
+    grads = [[[(rs.randn(*shp) * (0.5 + rs.rand())).astype(np.float32) for shp in g["shapes"]] for g in cfg["groups"]]
+             for _ in range(cfg["steps"])]
+    return params, grads

@@ -24,8 +24,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ENCODER_CASES, LEVEL_CASES, LM_CASES, make_encoder_inputs, make_encoder_params,  # noqa: E402
-                   make_level_extras, make_lm_case)
+from cases import (ENCODER_CASES, LEVEL_CASES, LM_CASES, RADAM_CASES, make_encoder_inputs, make_encoder_params,  # noqa: E402
+                   make_level_extras, make_lm_case, make_radam_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -184,24 +184,69 @@ def run_lm_case(name, cfg):
     print(name, "ok", out["noun_logits"].shape)
 
 
+def run_radam_case(name, cfg):
+    """The reference's own optimiser class (radam_optim.py imports only math and torch) stepped on seeded parameters and
+    gradients; parameters after every step and the final moments are the fixture."""
+    from runner.metrics_losses.radam_optim import RAdam
+    import warnings
+    params, grads = make_radam_case(cfg)
+    tp = [[torch.nn.Parameter(torch.from_numpy(p.copy())) for p in grp] for grp in params]
+    groups = []
+    for g, ps in zip(cfg["groups"], tp):
+        d = {"params": ps}
+        if "lr" in g:
+            d["lr"] = g["lr"]
+        groups.append(d)
+    opt = RAdam(groups, lr=cfg["lr"], betas=cfg["betas"], eps=cfg["eps"], weight_decay=cfg["weight_decay"],
+                degenerated_to_sgd=cfg["degenerated_to_sgd"])
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # the deprecated add_(Number, Tensor) overloads still execute on torch 2.10
+        for step in range(cfg["steps"]):
+            for gi, ps in enumerate(tp):
+                for ti, p in enumerate(ps):
+                    p.grad = torch.from_numpy(grads[step][gi][ti].copy())
+            opt.step()
+            for gi, ps in enumerate(tp):
+                for ti, p in enumerate(ps):
+                    out[f"p/{step}/{gi}/{ti}"] = p.detach().numpy().copy()
+    for gi, ps in enumerate(tp):
+        for ti, p in enumerate(ps):
+            out[f"exp_avg/{gi}/{ti}"] = opt.state[p]["exp_avg"].numpy().copy()
+            out[f"exp_avg_sq/{gi}/{ti}"] = opt.state[p]["exp_avg_sq"].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", len(out))
+
+
 def main():
+    """python tests/golden/make_golden.py [case-name ...]   (no names: every fixture)"""
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
     torch.manual_seed(0)
     torch.set_num_threads(4)
     Enc, ref_utils = import_reference()
     for name, cfg in ENCODER_CASES.items():
-        run_encoder_case(name, cfg, Enc, ref_utils)
+        if want(name):
+            run_encoder_case(name, cfg, Enc, ref_utils)
     for name, cfg in LEVEL_CASES.items():
-        run_level_case(name, cfg, Enc, ref_utils)
+        if want(name):
+            run_level_case(name, cfg, Enc, ref_utils)
     for name, cfg in LM_CASES.items():
-        run_lm_case(name, cfg)
-    # sin1d table spot values (utils.py:267-273) at the real width
-    pe = ref_utils.get_sin1d_embed(8192, 768)
-    np.savez_compressed(os.path.join(HERE, "sin1d_768.npz"), rows=pe[0, [0, 1, 2, 195, 4000, 8191]].numpy(),
-                        idx=np.array([0, 1, 2, 195, 4000, 8191]), total=np.float64(pe.double().sum().item()))
-    # local visual mask (utils.py:14-30)
-    ref_utils.cache_masks.clear()
-    np.savez_compressed(os.path.join(HERE, "local_mask_3x4_k1.npz"),
-                        mask=ref_utils.get_visual_token_mask((3, 4), "local_1").numpy())
+        if want(name):
+            run_lm_case(name, cfg)
+    for name, cfg in RADAM_CASES.items():
+        if want(name):
+            run_radam_case(name, cfg)
+    if want("sin1d_768"):
+        # sin1d table spot values (utils.py:267-273) at the real width
+        pe = ref_utils.get_sin1d_embed(8192, 768)
+        np.savez_compressed(os.path.join(HERE, "sin1d_768.npz"), rows=pe[0, [0, 1, 2, 195, 4000, 8191]].numpy(),
+                            idx=np.array([0, 1, 2, 195, 4000, 8191]), total=np.float64(pe.double().sum().item()))
+    if want("local_mask_3x4_k1"):
+        # local visual mask (utils.py:14-30)
+        ref_utils.cache_masks.clear()
+        np.savez_compressed(os.path.join(HERE, "local_mask_3x4_k1.npz"),
+                            mask=ref_utils.get_visual_token_mask((3, 4), "local_1").numpy())
 
 
 if __name__ == "__main__":

@@ -59,3 +59,28 @@ def test_no_cpu_fallback():
     from transfusion_amd import _lib, ops
     with pytest.raises(_lib.TfError):
         ops.linear(torch.randn(4, 8), torch.randn(8, 8))
+
+
+def test_integration_md_stub_matches_header(lib, tmp_path):
+    """The ctypes stub INTEGRATION.md tells a maintainer to paste must be the struct the library reads: extract the class from the
+    document, and compare its fields with the header-generated mirror and its size with what gcc gives the C struct."""
+    import re
+    from transfusion_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    src = next(b for b in blocks if "class TfGemmArgs(ctypes.Structure)" in b)
+    cls_src = src[src.index("class TfGemmArgs"):src.index("def linear_bf16")]
+    ns = {"ctypes": C}
+    exec(cls_src, ns)
+    stub = ns["TfGemmArgs"]
+    mirror = _lib.STRUCTS["TfGemmArgs"]
+    assert [n for n, _ in stub._fields_] == [n for n, _ in mirror._fields_]
+    assert [C.sizeof(t) for _, t in stub._fields_] == [C.sizeof(t) for _, t in mirror._fields_]
+    assert C.sizeof(stub) == C.sizeof(mirror)
+    for n, _ in stub._fields_:
+        assert getattr(stub, n).offset == getattr(mirror, n).offset, n
+    csrc = tmp_path / "g.c"
+    csrc.write_text('#include "tfusion.h"\n#include <stdio.h>\nint main(void){printf("%zu\\n", sizeof(TfGemmArgs));return 0;}\n')
+    exe = tmp_path / "g"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(csrc), "-o", str(exe)])
+    assert int(subprocess.check_output([str(exe)], text=True)) == C.sizeof(stub)

@@ -90,9 +90,9 @@ def test_layerwise_ranges_cover_flat_buffer_once():
     red = LayerwiseReducer(flat)
     assert red.num_layers == 3 and red.world == 1
     spans = sorted(red.ranges.values())
-    assert spans[0][0] == 0 and spans[-1][1] == max(off + n for _, _, off, n in flat.slices)
+    assert spans[0][0] == 0 and spans[-1][1] == flat.grad.numel()
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
-        assert a1 <= b0
+        assert a1 == b0                      # exact tiling: no gap, no overlap
     # every parameter slice lies in exactly one range, final norm with the top layer, kind embeddings with layer 0
     where = {}
     for name, _, off, num in flat.slices:
@@ -101,3 +101,137 @@ def test_layerwise_ranges_cover_flat_buffer_once():
         where[name] = hits[0]
     assert where["final_norm_layer.weight"] == 2 and where["image_kind_embedding"] == 0
     assert where["t_encoder.layers.1.linear1.weight"] == 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the DEFAULT N > 1 path: LayerwiseReducer.hook driven layer by layer (top first) from inside the backward
+# ----------------------------------------------------------------------------------------------------------------------
+class _StubEncoderFn(torch.autograd.Function):
+    """Backward of a stack of tanh(Linear) layers written the way the encoder runtime's is: one layer at a time, top first,
+    gradients ACCUMULATED straight into p.grad, the module's layer_grad_hook called after each layer."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):       # params: only so that autograd builds a node (gradients go straight to p.grad)
+        ctx.nparams = len(params)
+        acts = [x]
+        for lin in mod.t_encoder.layers:
+            acts.append(torch.tanh(acts[-1] @ lin.weight.t() + lin.bias))
+        ctx.mod, ctx.acts = mod, acts
+        return acts[-1] * mod.final_norm_layer.weight + mod.image_kind_embedding.view(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, acts = ctx.mod, ctx.acts
+        mod.final_norm_layer.weight.grad += (g * acts[-1]).sum(0)
+        g_kind = g.sum(0)
+        g = g * mod.final_norm_layer.weight
+        for layer in range(len(mod.t_encoder.layers) - 1, -1, -1):
+            lin = mod.t_encoder.layers[layer]
+            gz = g * (1 - acts[layer + 1] ** 2)
+            lin.weight.grad += gz.t() @ acts[layer]
+            lin.bias.grad += gz.sum(0)
+            g = gz @ lin.weight
+            if layer == 0:
+                mod.image_kind_embedding.grad += g_kind.view(1, 1, -1)
+            if mod.layer_grad_hook is not None:
+                mod.layer_grad_hook(mod, layer)
+        return (None, g) + (None,) * ctx.nparams
+
+
+class StubEncoder(torch.nn.Module):
+    """Parameter names of CrossTransformerModuleBox (kind embedding, t_encoder.layers.{j}.*, final_norm_layer.*) so that
+    LayerwiseReducer derives its ranges exactly as for the real encoder."""
+
+    def __init__(self, d=6, L=3):
+        super().__init__()
+        torch.manual_seed(1)
+        self.image_kind_embedding = torch.nn.Parameter(torch.randn(1, 1, d))
+        self.heatmap_token = torch.nn.Parameter(torch.randn(1, 1, d))
+        self.t_encoder = torch.nn.Module()
+        self.t_encoder.layers = torch.nn.ModuleList([torch.nn.Linear(d, d) for _ in range(L)])
+        self.final_norm_layer = torch.nn.Module()
+        self.final_norm_layer.weight = torch.nn.Parameter(torch.rand(d) + 0.5)
+        self.layer_grad_hook = None
+        self.accumulate_into_grad = False
+
+    def forward(self, x):
+        return _StubEncoderFn.apply(self, x, *[p for n, p in self.named_parameters() if n != "heatmap_token"])
+
+
+class _PlainSGD:
+    """CPU stand-in for the fused optimiser (the HIP RAdam needs a GPU): same call protocol as FusedRAdam.step."""
+
+    def __init__(self, params, lr, weight_decay):
+        self.params, self.lr = list(params), lr
+
+    def grad_sumsq(self, out):
+        for p in self.params:
+            out += p.grad.double().pow(2).sum().float()
+
+    def step(self, grad_scale=1.0, sumsq=None, clip=0.0):
+        for p in self.params:
+            p.data.add_(p.grad, alpha=-self.lr * grad_scale)
+
+
+def _layerwise_worker(rank, world, port, out, accumulate):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transfusion_amd.runner import trainer as T
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real(t, *a, **k)
+
+    T.dist.all_reduce = counting
+    torch.manual_seed(7)
+    data = torch.randn(2 * world * accumulate, 6)
+    model = StubEncoder()
+    tr = T.FusionTrainStep(model, lr=0.1, weight_decay=0.0, grad_clip=None, accumulate=accumulate, optimizer_cls=_PlainSGD)
+    assert tr.layerwise is not None and model.layer_grad_hook is not None        # the default N > 1 path
+    mine = data[rank::world]                                                     # this rank's samples
+    mbs = list(mine.chunk(accumulate))
+    loss_fn = lambda m, b: m(b).pow(2).sum()
+    tr.step(mbs, loss_fn)
+    # second step: the reducer state (handles, active flag) must have been left clean
+    before2 = tr.flat.flat.clone()
+    tr.step(mbs, loss_fn)
+    counts = [None] * world
+    dist.all_gather_object(counts, calls)
+    if rank == 0:
+        torch.save({"grad": tr.flat.grad.clone(), "param": tr.flat.flat.clone(), "before2": before2, "counts": counts,
+                    "slices": [(n, o, k) for n, _, o, k in tr.flat.slices], "ranges": dict(tr.layerwise.ranges)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_gloo_world2_layerwise_hook_path(tmp_path, accumulate):
+    """FusionTrainStep with world 2 takes the LayerwiseReducer path: per-layer all-reduces issued from inside the backward.
+    The reduced gradient equals the single-process gradient over all samples (x 1/accumulate for the micro-batch scaling,
+    x 1 for the SUM over ranks), both ranks issue the SAME collectives (count and sizes: a mismatch is the hang of round 1's
+    rehearsal), and with accumulate_grad_batches = 2 the reduction happens once per optimiser step, on the last micro-batch."""
+    out = str(tmp_path / "lw.pt")
+    world = 2
+    mp.spawn(_layerwise_worker, args=(world, _free_port(), out, accumulate), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["counts"][0] == got["counts"][1]
+    L = 3
+    assert len(got["counts"][0]) == 2 * L                                       # L collectives per optimiser step, 2 steps
+    assert sum(got["counts"][0][:L]) == got["grad"].numel()                      # the ranges tile the flat buffer exactly
+    # reference: one process, all samples, parameters as they were before the second step
+    torch.manual_seed(7)
+    data = torch.randn(2 * world * accumulate, 6)
+    ref = StubEncoder()
+    named = dict(ref.named_parameters())
+    for n, off, k in got["slices"]:
+        named[n].data.copy_(got["before2"][off:off + k].view_as(named[n]))
+        named[n].grad = torch.zeros_like(named[n])
+    ref(data).pow(2).sum().backward()
+    for n, off, k in got["slices"]:
+        torch.testing.assert_close(got["grad"][off:off + k], named[n].grad.reshape(-1) / accumulate, rtol=1e-4, atol=1e-5)
+        # and the update used grad / world (FusionTrainStep's mean over ranks)
+        want = named[n].data.reshape(-1) - 0.1 * named[n].grad.reshape(-1) / accumulate / world
+        torch.testing.assert_close(got["param"][off:off + k], want, rtol=1e-4, atol=1e-5)

@@ -277,30 +277,56 @@ def test_linear_fn_fwd_bwd(dev):
     assert rel(x.grad, xr.grad) < 1e-2 and rel(w.grad, wr.grad) < 1e-2 and rel(b.grad, br.grad) < 1e-2
 
 
-def test_radam_matches_reference_arithmetic(dev):
+@pytest.mark.parametrize("name", ["radam_wd", "radam_groups", "radam_sgd"])
+def test_radam_matches_reference_optimizer(dev, golden_dir, name):
+    """FusedRAdam (tf_radam_step) against the parameters the reference's own RAdam class produced step by step
+    (tests/golden/radam_*.npz: weight decay, two groups with different lr, degenerated_to_sgd), plus the optimiser protocol the
+    reference relies on: per-group lr, state_dict round trip mid-run, parameter versions bumped by the raw-pointer update."""
+    import os
+    import numpy as np
+    from cases import RADAM_CASES, make_radam_case
     from transfusion_amd.optim import FusedRAdam
-    g = torch.Generator().manual_seed(2)
-    p0 = torch.randn(5000, generator=g)
-    p = p0.clone().to(dev)
-    opt = FusedRAdam([p], lr=1e-3, weight_decay=2e-4)
-    # straight restatement of runner/metrics_losses/radam_optim.py:55-100 in fp64
-    pr, m, v = p0.double(), torch.zeros(5000).double(), torch.zeros(5000).double()
-    b1, b2, eps, lr, wd = 0.9, 0.999, 1e-8, 1e-3, 2e-4
-    for step in range(1, 9):
-        grad = torch.randn(5000, generator=g)
-        p.grad = grad.clone().to(dev)
+    cfg = RADAM_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params, grads = make_radam_case(cfg)
+
+    def make():
+        tp = [[torch.nn.Parameter(torch.from_numpy(p.copy()).to(dev)) for p in grp] for grp in params]
+        groups = [dict({"params": ps}, **({"lr": gr["lr"]} if "lr" in gr else {})) for gr, ps in zip(cfg["groups"], tp)]
+        return tp, FusedRAdam(groups, lr=cfg["lr"], betas=cfg["betas"], eps=cfg["eps"], weight_decay=cfg["weight_decay"],
+                              degenerated_to_sgd=cfg["degenerated_to_sgd"])
+
+    tp, opt = make()
+    assert isinstance(opt, torch.optim.Optimizer)
+    half = cfg["steps"] // 2
+    for step in range(cfg["steps"]):
+        if step == half:                       # checkpoint / resume: moments AND step counts travel in the state dict
+            sd = opt.state_dict()
+            old = tp
+            tp, opt = make()
+            for grp_new, grp_old in zip(tp, old):
+                for pn, po in zip(grp_new, grp_old):
+                    pn.data.copy_(po.data)
+            opt.load_state_dict(sd)
+        for gi, ps in enumerate(tp):
+            for ti, p in enumerate(ps):
+                p.grad = torch.from_numpy(grads[step][gi][ti].copy()).to(dev)
+        v0 = tp[0][0]._version
         opt.step()
-        gd = grad.double()
-        v = v * b2 + (1 - b2) * gd * gd
-        m = m * b1 + (1 - b1) * gd
-        b2t = b2 ** step
-        nmax = 2 / (1 - b2) - 1
-        nsma = nmax - 2 * step * b2t / (1 - b2t)
-        if nsma >= 5:
-            ss = math.sqrt((1 - b2t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) / (1 - b1 ** step)
-            pr = pr - wd * lr * pr
-            pr = pr - ss * lr * m / (v.sqrt() + eps)
-    assert (p.cpu().double() - pr).abs().max().item() < 1e-5
+        assert tp[0][0]._version > v0
+        for gi, ps in enumerate(tp):
+            for ti, p in enumerate(ps):
+                ref = torch.from_numpy(g[f"p/{step}/{gi}/{ti}"])
+                assert (p.detach().cpu() - ref).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item()), (step, gi, ti)
+    for gi, ps in enumerate(tp):
+        for ti, p in enumerate(ps):
+            assert torch.allclose(opt.state[p]["exp_avg"].cpu(), torch.from_numpy(g[f"exp_avg/{gi}/{ti}"]), rtol=1e-5, atol=1e-7)
+            assert torch.allclose(opt.state[p]["exp_avg_sq"].cpu(), torch.from_numpy(g[f"exp_avg_sq/{gi}/{ti}"]), rtol=1e-5, atol=1e-8)
+    # a parameter without a gradient is skipped entirely (no moments, no weight decay), as in the reference
+    tp, opt = make()
+    before = tp[0][0].detach().clone()
+    opt.step()
+    assert torch.equal(tp[0][0].detach(), before) and len(opt.state) == 0
 
 
 def _pack_bits(m):

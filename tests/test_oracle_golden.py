@@ -66,9 +66,11 @@ def test_encoder_small_cases(golden_dir, name):
     assert "gradp/heatmap_token" not in g
 
 
-def test_encoder_d768_subsampled(golden_dir):
-    cfg = ENCODER_CASES["enc_d768"]
-    g = _load(golden_dir, "enc_d768")
+@pytest.mark.parametrize("name", ["enc_d768", "enc_d712", "enc_d896"])
+def test_encoder_real_width_subsampled(golden_dir, name):
+    """d = 768 (BASELINE's synthetic width) and the reference's true widths 712 / 896 (head dims 178 / 224)."""
+    cfg = ENCODER_CASES[name]
+    g = _load(golden_dir, name)
     params = make_encoder_params(cfg["seed"], cfg["d"], cfg["L"])
     x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
     sd = _sd(params, cfg["d"])
@@ -153,3 +155,29 @@ def test_lm_head_cases(golden_dir, name):
         assert np.all(t.grad.numpy()[~att] == 0)                                      # padded rows receive no gradient
     for k, v in sd.items():
         _close(v.grad, g["gradp/" + k], what="gradp/" + k)
+
+
+@pytest.mark.parametrize("name", ["radam_wd", "radam_groups", "radam_sgd"])
+def test_radam_oracle_matches_reference_optimizer(golden_dir, name):
+    """oracle.radam_step against parameters the reference's own RAdam class produced (per-group lr, weight decay, the
+    un-rectified first five steps, the SGD-degenerated mode)."""
+    from cases import RADAM_CASES, make_radam_case
+    cfg = RADAM_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params, grads = make_radam_case(cfg)
+    moved_early = False
+    for gi, grp in enumerate(cfg["groups"]):
+        lr = grp.get("lr", cfg["lr"])
+        for ti in range(len(grp["shapes"])):
+            p = torch.from_numpy(params[gi][ti])
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            for step in range(cfg["steps"]):
+                p, m, v = O.radam_step(p, torch.from_numpy(grads[step][gi][ti]), m, v, step + 1, lr, cfg["betas"], cfg["eps"],
+                                       cfg["weight_decay"], cfg["degenerated_to_sgd"])
+                ref = torch.from_numpy(g[f"p/{step}/{gi}/{ti}"])
+                assert (p - ref).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item()), (step, gi, ti)
+                if step == 2 and not torch.equal(ref, torch.from_numpy(params[gi][ti])):
+                    moved_early = True
+            assert torch.allclose(m, torch.from_numpy(g[f"exp_avg/{gi}/{ti}"]), rtol=1e-5, atol=1e-7)
+            assert torch.allclose(v, torch.from_numpy(g[f"exp_avg_sq/{gi}/{ti}"]), rtol=1e-5, atol=1e-8)
+    assert moved_early == cfg["degenerated_to_sgd"]      # only the SGD-degenerated mode moves parameters before step 6

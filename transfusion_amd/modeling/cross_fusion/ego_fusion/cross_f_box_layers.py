@@ -86,11 +86,11 @@ _LAYER_FIELDS = (
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, x, lang, pad_mask, *params):
+    def forward(ctx, mod, need_grad, x, lang, pad_mask, *params):
+        # need_grad comes from the caller: inside Function.forward grad mode is always off
         desc, keep = mod._make_desc(x, lang, pad_mask)
         B, Nv, d = x.shape
         Nl = lang.shape[1]
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or lang.requires_grad or any(p.requires_grad for p in params))
         out_dtype = x.dtype
         vis_out = torch.empty(B, Nv, d, dtype=out_dtype, device=x.device)
         lang_out = torch.empty(B, Nl, d, dtype=out_dtype, device=x.device)
@@ -100,16 +100,21 @@ class _EncoderFn(torch.autograd.Function):
         desc.repack = 1 if mod._wpack_dirty() else 0     # bf16 weight shadows are refreshed inside the forward call
         L.call("tf_encoder_fwd", desc, st)
         desc.repack = 0
-        ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
+        ctx.mod, ctx.desc, ctx.keep, ctx.gen = mod, desc, keep, keep["gen"]
+        # per-call tensors the descriptor points at live on ctx (the workspace item may be recycled by a later forward)
+        ctx.held = (keep["inputs"], keep.get("mask"), keep.get("block_bits"))
         ctx.io = (x.dtype, lang.dtype, x.requires_grad, lang.requires_grad)
         ctx.nparams = len(params)
         if not need_grad:
-            mod._release(keep)
+            mod._release(keep)           # no graph: the saved activations are not needed
         return vis_out, lang_out
 
     @staticmethod
     def backward(ctx, g_vis, g_lang):
         mod, desc, keep = ctx.mod, ctx.desc, ctx.keep
+        if keep["gen"] != ctx.gen:
+            raise L.TfError("the activations of this forward were recycled: its workspace was released (a backward already ran, "
+                            "e.g. retain_graph=True) and reused by a later forward of the same shape")
         x_dtype, lang_dtype, x_rg, lang_rg = ctx.io
         B, Nv, Nl, d = desc.B, desc.Nv, desc.Nl, desc.d
         dev = keep["work"].device
@@ -117,7 +122,7 @@ class _EncoderFn(torch.autograd.Function):
         g_lang = None if g_lang is None else g_lang.contiguous()
         if g_vis is None and g_lang is None:
             mod._release(keep)
-            return (None,) * (4 + ctx.nparams)
+            return (None,) * (5 + ctx.nparams)
         desc.d_vis_out, desc.d_vis_out_is_f32 = L.ptr(g_vis), 0 if g_vis is None else ops._is_f32(g_vis)
         desc.d_lang_out, desc.d_lang_out_is_f32 = L.ptr(g_lang), 0 if g_lang is None else ops._is_f32(g_lang)
         d_vis = torch.empty(B, Nv, d, dtype=x_dtype, device=dev) if x_rg else None
@@ -144,8 +149,8 @@ class _EncoderFn(torch.autograd.Function):
                 ops.join_overlap(dev)
         mod._release(keep)
         if direct:
-            return (None, d_vis, d_lang, None) + (None,) * ctx.nparams
-        return (None, d_vis, d_lang, None) + tuple(grads)
+            return (None, None, d_vis, d_lang, None) + (None,) * ctx.nparams
+        return (None, None, d_vis, d_lang, None) + tuple(grads)
 
 
 class CrossTransformerModuleBox(nn.Module):
@@ -238,10 +243,11 @@ class CrossTransformerModuleBox(nn.Module):
         pool = self._work_pool.setdefault(key, [])
         for item in pool:
             if not item["busy"]:
+                item["gen"] += 1
                 return item
-        if len(pool) >= 4:      # forwards without backward: drop the oldest instead of growing without bound
+        if len(pool) >= 4:      # many forwards awaiting their backward: the pool stops tracking the oldest (its graph keeps it alive)
             pool.pop(0)
-        item = {"work": torch.zeros(plan.work_bytes, dtype=torch.uint8, device=device), "busy": False}
+        item = {"work": torch.zeros(plan.work_bytes, dtype=torch.uint8, device=device), "busy": False, "gen": 0}
         pool.append(item)
         return item
 
@@ -355,7 +361,9 @@ class CrossTransformerModuleBox(nn.Module):
         self._block_bits = None
         if vis_tokens_mask is not None:
             self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)
-        vis_tokens, lang_tokens = _EncoderFn.apply(self, x, language_tokens, language_tokens_att_maks, *self._param_list())
+        params = self._param_list()
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or language_tokens.requires_grad or any(p.requires_grad for p in params))
+        vis_tokens, lang_tokens = _EncoderFn.apply(self, need_grad, x, language_tokens, language_tokens_att_maks, *params)
         return vis_tokens, lang_tokens, None, None
 
     def _pack_block_bits(self, vis_tokens_mask, Nv, Nl, device):

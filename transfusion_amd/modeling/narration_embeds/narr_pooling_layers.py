@@ -41,13 +41,16 @@ class SlowFastPooling(nn.Module):
         if min(lens) != T:
             tensor = [F.pad(t, (0, 0, 0, T - t.shape[0])) for t in tensor]
         tensor = torch.stack(tensor, dim=0)
-        att_mask = torch.ones(tensor.shape[:2], device=tensor.device)      # HF style: 1 = keep, 0 = cancelled
-        for b, n in enumerate(lens):
-            att_mask[b, n:] = 0
+        # HF style: 1 = keep, 0 = cancelled; built on the host in one piece (no per-sample device writes)
+        att_mask = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).to(device=tensor.device, dtype=torch.float32)
         if self.out_mlp:
             tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias).float()
         if self.use_out_tanh:
             tensor = torch.tanh(tensor)
+        if min(lens) != T:
+            # ragged extension: padded rows became tanh(bias) above; zero them so that the L2 norm over the token axis (and
+            # hence every real token's value) does not depend on how much padding the batch happens to carry
+            tensor = tensor * att_mask.unsqueeze(-1)
         if tensor.shape[1] > 1:
             tensor = F.normalize(tensor, p=2, dim=1)
         tensor = self.out_dropout(tensor)

@@ -1,7 +1,14 @@
 """Fused RAdam on the device (tf_radam_step) with the reference's exact rectification schedule
 (runner/metrics_losses/radam_optim.py:30-104) and global-norm clipping (run_experiment.py:444-446,
 ``gradient_clip_val`` with the norm algorithm).  The reference runs a Python loop of ~10 torch ops per
-parameter tensor between backward and the next all-reduce; here one launch covers a whole flat buffer.
+parameter tensor between backward and the next all-reduce; here one launch covers a whole tensor (ideally one flat
+buffer holding every parameter).
+
+``FusedRAdam`` is a ``torch.optim.Optimizer``: same constructor as the reference class (radam_optim.py:7-25), per-group
+``lr`` / ``betas`` / ``eps`` / ``weight_decay`` (ego_nao_trainer.py:440-497 builds groups with ``lr / div_rate``), per-parameter
+``state["step"]`` driving the rectification schedule, ``state_dict()`` / ``load_state_dict()`` (moments and step counts are
+checkpointed), usable under the reference's LR schedulers (abc_nao_trainer.py:203-235).  Parameters whose ``grad`` is None
+are skipped entirely, as in the reference (no moment update, no weight decay).
 """
 from __future__ import annotations
 
@@ -27,11 +34,11 @@ def radam_schedule(step: int, beta1: float, beta2: float, degenerated_to_sgd: bo
     return n_sma, -1.0, 0
 
 
-class FusedRAdam:
-    """Groups of fp32 tensors (ideally a few large flat buffers).  ``step(grad_scale)`` multiplies the
-    gradient first (1/world_size, loss scale, clip coefficient)."""
+class FusedRAdam(torch.optim.Optimizer):
+    """``step(grad_scale=..., sumsq=..., clip=...)``: the gradient is multiplied by ``grad_scale`` first (1 / world size, loss
+    scale) and, with ``sumsq`` + ``clip``, by torch's clip_grad_norm_ coefficient computed on the device."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, degenerated_to_sgd=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, degenerated_to_sgd=False):
         if not 0.0 <= lr:
             raise ValueError("Invalid learning rate: {}".format(lr))
         if not 0.0 <= eps:
@@ -40,19 +47,8 @@ class FusedRAdam:
             raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
         if not 0.0 <= betas[1] < 1.0:
             raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
-        if isinstance(params, (list, tuple)) and len(params) and isinstance(params[0], dict):
-            self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **g) for g in params]
-        else:
-            self.param_groups = [dict(params=list(params), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.degenerated_to_sgd = degenerated_to_sgd
-        self.state = {}
-        self.step_count = 0
-
-    def zero_grad(self):
-        for g in self.param_groups:
-            for p in g["params"]:
-                if p.grad is not None:
-                    p.grad.zero_()
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     def grad_sumsq(self, out: torch.Tensor):
         """Accumulates sum(g^2) of every gradient into the 1-element fp32 tensor ``out`` (device side)."""
@@ -62,27 +58,38 @@ class FusedRAdam:
                 if p.grad is not None:
                     L.check(lib.tf_sumsq(L.ptr(p.grad), p.grad.numel(), L.ptr(out), ops._stream()), "tf_sumsq")
 
-    def step(self, grad_scale: float = 1.0, sumsq: torch.Tensor = None, clip: float = 0.0):
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0, sumsq: torch.Tensor = None, clip: float = 0.0):
         """``sumsq`` (1-element device tensor holding sum(g^2) over ALL gradients) + ``clip`` > 0 apply torch's
         clip_grad_norm_ coefficient on the device, with no host synchronisation."""
-        self.step_count += 1
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         st = ops._stream()
         for g in self.param_groups:
             beta1, beta2 = g["betas"]
-            n_sma, step_size, mode = radam_schedule(self.step_count, beta1, beta2, self.degenerated_to_sgd)
             for p in g["params"]:
                 if p.grad is None:
                     continue
                 ops._require_cuda(p)
                 if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise L.TfError("FusedRAdam needs contiguous fp32 parameters and gradients")
-                s = self.state.get(id(p))
-                if s is None:
-                    s = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
-                    self.state[id(p)] = s
+                s = self.state[p]
+                if len(s) == 0:
+                    s["step"] = 0
+                    s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                s["step"] += 1
+                step = int(s["step"])
+                n_sma, step_size, mode = radam_schedule(step, beta1, beta2, self.degenerated_to_sgd)
                 a = L.TfRadamArgs(p=L.ptr(p), g=L.ptr(p.grad), m=L.ptr(s["exp_avg"]), v=L.ptr(s["exp_avg_sq"]), n=p.numel(),
                                   lr=g["lr"], beta1=beta1, beta2=beta2, eps=g["eps"], weight_decay=g["weight_decay"],
-                                  beta2_t=beta2 ** self.step_count, bias1=1 - beta1 ** self.step_count, n_sma=n_sma,
+                                  beta2_t=beta2 ** step, bias1=1 - beta1 ** step, n_sma=n_sma,
                                   step_size=step_size, rectified=mode, grad_scale=grad_scale, sumsq=L.ptr(sumsq),
                                   clip=float(clip))
                 L.call("tf_radam_step", a, st)
+                # the kernel wrote through a raw pointer: tell autograd / the encoders' bf16 weight-shadow cache
+                # (CrossTransformerModuleBox._wpack_dirty keys on (data_ptr, _version)) that the tensor changed
+                torch._C._increment_version(p)
+        return loss

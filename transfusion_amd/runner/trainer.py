@@ -23,7 +23,9 @@ from torch import nn
 class FlatParams:
     """Re-homes a module's trainable parameters (and their gradients) as views into two flat fp32 buffers."""
 
-    def __init__(self, module: nn.Module, exclude: Iterable[str] = ("heatmap_token",)):
+    def __init__(self, module: nn.Module, exclude: Iterable[str] = ("heatmap_token", "class_token")):
+        # heatmap_token / class_token are created by the reference constructor but never used by its forward
+        # (cross_f_box_layers.py:38-43): their grad stays None there and RAdam skips them (no weight decay either)
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and not any(n.endswith(e) for e in exclude)]
         if not named:
             raise ValueError("no trainable parameters")
@@ -42,6 +44,14 @@ class FlatParams:
             p.grad = self.grad[off:off + num].view_as(p)
         self.names = [n for n, _, _, _ in self.slices]
         self.numel = sum(num for _, _, _, num in self.slices)
+
+    def check_bound(self):
+        """The parameters' ``.grad`` must still be the views into ``self.grad`` (``module.zero_grad(set_to_none=True)`` or an
+        optimiser that replaces ``p.grad`` silently detaches them: the all-reduce and the fused optimiser would then see zeros)."""
+        base = self.grad.data_ptr()
+        for n, p, off, num in self.slices:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                raise RuntimeError(f"gradient of {n} is no longer a view of the flat gradient buffer (set_to_none / replaced .grad?)")
 
 
 class DataParallelReducer:
@@ -97,8 +107,19 @@ class LayerwiseReducer:
             if layer == 0 and "head" in ends:
                 lo, hi = min(lo, ends["head"][0]), max(hi, ends["head"][1])
             self.ranges[layer] = (lo, hi)
-        covered = sorted(self.ranges.values())
-        assert covered[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), covered
+        # the ranges must tile the flat buffer exactly (alignment padding between parameters belongs to the range before it; it holds
+        # zeros): nothing reduced twice, nothing forgotten, no gap
+        order = sorted(self.ranges, key=lambda l: self.ranges[l][0])
+        total = flat.grad.numel()
+        for a, b in zip(order, order[1:] + [None]):
+            nxt = total if b is None else self.ranges[b][0]
+            if self.ranges[a][1] > nxt:
+                raise ValueError(f"layer gradient ranges overlap: {self.ranges}")
+            self.ranges[a] = (self.ranges[a][0], nxt)
+        if self.ranges[order[0]][0] != 0:
+            raise ValueError(f"layer gradient ranges do not start at 0: {self.ranges}")
+        self.active = True            # False: the hook does nothing (micro-batches of an accumulation window before the last one)
+        self.collectives = 0          # all-reduces issued so far (every rank must issue the same number: tests assert it)
 
     joins_overlap = True      # finish() joins the encoder runtime's side stream: the per-layer backward calls need not
 
@@ -107,10 +128,11 @@ class LayerwiseReducer:
         chain's stream and partly on the runtime's side stream, which the per-layer calls do not join (a join stalls the chain
         until that layer's last wgrad has finished: -2.5 % on one GPU).  The collective therefore runs behind a communication
         stream that waits for an event on each of the two."""
-        if self.world == 1:
+        if self.world == 1 or not self.active:
             return
         from transfusion_amd import ops
         lo, hi = self.ranges[layer]
+        self.collectives += 1
         g = self.flat.grad
         main = torch.cuda.current_stream(g.device) if g.is_cuda else None
         side = ops.side_stream(g.device) if g.is_cuda else None
@@ -151,7 +173,7 @@ class FusionTrainStep:
         self.layerwise = None
         encoders = [m for m in module.modules() if hasattr(m, "layer_grad_hook")]
         force = os.environ.get("TF_FORCE_LAYERWISE") == "1"      # measurement hook: the per-layer call path on one GPU (no-op reduce)
-        if overlap and (self.world > 1 or force) and accumulate == 1 and len(encoders) == 1 and encoders[0] is module:
+        if overlap and (self.world > 1 or force) and len(encoders) == 1 and encoders[0] is module:
             self.layerwise = LayerwiseReducer(self.flat)
             module.layer_grad_hook = self.layerwise.hook
         self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
@@ -170,8 +192,13 @@ class FusionTrainStep:
     def step(self, micro_batches: List, loss_fn):
         """``loss_fn(module, batch) -> scalar``; returns the last loss (detached)."""
         self.zero_grad()
+        self.flat.check_bound()
         loss = None
-        for mb in micro_batches:
+        for i, mb in enumerate(micro_batches):
+            if self.layerwise is not None:
+                # accumulate_grad_batches: gradients are reduced once per optimiser step, during the LAST micro-batch's backward
+                # (Lightning's no_sync on the others, run_experiment.py:444-446)
+                self.layerwise.active = i == len(micro_batches) - 1
             loss = loss_fn(self.module, mb)
             (loss / len(micro_batches)).backward()
         if self.layerwise is not None:
