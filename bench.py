@@ -315,11 +315,15 @@ def run_schedule(step, comm, rank, warmup, steps, trace_steps, traced):
     for _ in range(warmup):
         step(i); i += 1
     comm.sync()
+    if rank == 0:
+        log(f"  warm-up done ({warmup} steps)")
     t0 = time.perf_counter()
     for _ in range(steps):
         step(i); i += 1
     comm.sync()
     elapsed = comm.max(time.perf_counter() - t0)
+    if rank == 0:
+        log(f"  timed region done ({steps} steps, {elapsed / max(steps, 1) * 1e3:.3f} ms/step)")
     rows = None
     if trace_steps > 0:
         if rank == 0:
@@ -365,6 +369,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     args = ap.parse_args()
 
+    # a hang must end with a Python stack on stderr, not with the driver's silence timeout
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("TF_BENCH_WATCHDOG_S", "900")), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -479,6 +486,7 @@ def main():
             result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+    faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

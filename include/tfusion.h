@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 1
+#define TF_ABI_VERSION 2
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -52,6 +52,14 @@ typedef struct TfGemmArgs {
   // e4m3 bytes (lda / ldw / K in elements = bytes, K % 64 == 0) as produced by tf_quant_rows_fp8, and the result is
   // acc * scale_a[m] * scale_w[n] (+ bias ...).  Epilogues NONE, BIAS, BIAS_DROP_RES, BIAS_GELU_DROP_G.
   int fp8; const float* scale_a; const float* scale_w;
+  // activation of the two *_GELU_* epilogues and of DGELU: 0 = exact (erf) GELU, 1 = ReLU -- the reference constructor's
+  // activ_f ("gelu" in the shipped YAMLs, "relu" its default: cross_f_box_layers.py:26,56)
+  int act;
+  // fp32-accuracy mode (BASELINE configs[2], run.precision: 32): every tensor is a PAIR of bf16 planes, value = hi + lo
+  // (16 significant bits), and the product is three bf16 MFMA passes into one fp32 accumulator:
+  // A_hi.W_hi + A_lo.W_hi + A_hi.W_lo.  A_lo != null selects it; then W_lo and C_lo are required, and R_lo / C2_lo
+  // wherever R / C2 are.  Planes share the leading dimension of their hi plane.  Not combinable with fp8.
+  const void* A_lo; const void* W_lo; void* C_lo; const void* R_lo; void* C2_lo;
 } TfGemmArgs;
 
 /* row-wise fp8 (e4m3) quantisation: dst[r][c] = fp8(src[r][c] / scale[r]), scale[r] = max|src[r][:]| / 448 (1 for an all-zero row);
@@ -68,6 +76,7 @@ typedef struct TfWgradArgs {
   int rg, rgp, n_src;         // padded row n -> source row (n/rgp)*rg + n%rgp, valid iff n%rgp < rg
   int cg, cgp, k_src;         // same for columns
   int m_chunk;                // rows of M per block (0 = auto)
+  const void* dY_lo; const void* X_lo;   // fp32-accuracy mode (see TfGemmArgs): lo planes, dW += dY_hi^T X_hi + dY_lo^T X_hi + dY_hi^T X_lo
 } TfWgradArgs;
 
 
@@ -86,6 +95,9 @@ typedef struct TfAttnArgs {
   const void* dout; int ld_dout; // [B*S, H*HDP] bf16
   void* dqkv; int ld_dqkv;       // [B*S, 3*H*HDP] bf16
   float* delta;                  // [B,H,S] fp32 workspace: rowsum(dO . O)
+  // fp32-accuracy mode (see TfGemmArgs): lo planes of qkv / out / dout / dqkv, same leading dimensions.  qkv_lo != null selects
+  // the split kernels (attn_x3.hip): every S x S x hd product is three bf16 MFMA passes, probabilities are split in registers.
+  const void* qkv_lo; void* out_lo; const void* dout_lo; void* dqkv_lo;
 } TfAttnArgs;
 
 
@@ -107,12 +119,15 @@ typedef struct TfLnArgs {
   unsigned drop_thr, drop_key; float drop_scale; int drop_ld;
   float* dgamma; float* dbeta;   // fp32, atomically accumulated
   const void* dres; int lddres;  // optional bf16 tensor added to dy before the backward (residual-path gradient)
+  // fp32-accuracy mode: lo planes of the bf16 tensors above (value = hi + lo); each is used iff its hi plane is bf16 and it is non-null
+  const void* x_lo; void* y_lo; const void* dy_lo; void* dx_lo; void* dx_drop_lo; const void* dres_lo;
 } TfLnArgs;
 
 typedef struct TfAssembleArgs {
   const void* vis; int vis_is_f32; int ld_vis;   // [B,Nv,d]
   const void* lang; int lang_is_f32; int ld_lang;// [B,Nl,d]
-  const float* pe;                               // [>=Nv, d] fp32
+  const float* pe;                               // [>=Nv, d] fp32, or null (nothing added)
+  const float* pe_lang;                          // [>=Nl, d] fp32 or null: lang_pos_embedding (cross_f_box_layers.py:77-78)
   const float* kind_v; const float* kind_l;      // [d]
   void* out; int ld_out;                         // [B,S,ld_out] bf16
   int B, Nv, Nl, d;
@@ -122,6 +137,7 @@ typedef struct TfAssembleArgs {
   void* dvis; int dvis_is_f32; int ld_dvis;
   void* dlang; int dlang_is_f32; int ld_dlang;
   float* dkind_v; float* dkind_l;
+  void* out_lo; const void* dout_lo;             // fp32-accuracy mode: lo planes of out / dout
 } TfAssembleArgs;
 
 // rowsum(dO . O) per (b, head, s)
@@ -134,6 +150,7 @@ typedef struct TfPackArgs {
   int rows_p, cols_p;
   int rg, rgp, cg, cgp;                  // group maps as in TfWgradArgs
   int dst_is_f32;                        // biases keep fp32
+  int residual;                          // 1: store bf16(w - bf16(w)) instead of bf16(w) -- the lo plane of the fp32-accuracy mode
 } TfPackArgs;
 
 // dst[map(r), 0:cols] = src[map(r), 0:cols] with dtype conversion; columns [cols, ld_dst) of a bf16 dst are zeroed.
@@ -142,6 +159,7 @@ typedef struct TfCopyRowsArgs {
   const void* src; int src_is_f32; int ld_src; int src_rpg, src_gstride;
   void* dst; int dst_is_f32; int ld_dst; int dst_rpg, dst_gstride;
   int rows, cols;
+  const void* src_lo; void* dst_lo;      // fp32-accuracy mode: lo plane of a bf16 src (added) / of a bf16 dst (residual written)
 } TfCopyRowsArgs;
 // key_mask[b, s] = s < Nv ? 0 : lang_pad_mask[b, s - Nv]
 
@@ -302,9 +320,16 @@ typedef struct TfEncoderDesc {
   int repack;                   /* tf_encoder_fwd only: refresh the bf16 weight shadows first (what tf_encoder_pack does); with an
                                  * overlap handle only layer 0 is packed on the caller's stream, layers >= 1 and the attention
                                  * dropout masks are produced on the side stream while the chain already runs layer 0 */
+  int precision;                /* 0: bf16 compute (run.precision 16 / bf16).  1: fp32-accuracy mode for run.precision: 32
+                                 * (ego_nao_res50_ego4dv2.yml:124, BASELINE configs[2]): activations and weight shadows are hi + lo
+                                 * bf16 plane pairs and every contraction runs as three bf16 MFMA passes with fp32 accumulation
+                                 * (results within 1e-3 of the fp32 reference; ~1e-5 measured).  wpack / work sizes: tf_encoder_plan_ex */
+  int act;                      /* FFN activation: 0 = GELU (activ_f: "gelu"), 1 = ReLU (the reference constructor's default) */
+  const float* pe_lang;         /* lang_pos_embedding table [>=Nl, d] fp32 or null (cross_f_box_layers.py:77-78) */
 } TfEncoderDesc;
 
-int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);
+int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);   /* precision 0 */
+int tf_encoder_plan_ex(const TfEncoderDesc* e, TfEncoderPlan* out);   /* reads B, Nv, Nl, d, H, L, ff and precision of *e */
 int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s);   /* fp32 parameters -> bf16 shadows in wpack */
 int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s);
 int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);

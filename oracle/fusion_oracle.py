@@ -154,7 +154,7 @@ def mha(x: torch.Tensor, in_w, in_b, out_w, out_b, num_heads: int,
 
 
 def encoder_layer(x, sd: Dict[str, torch.Tensor], pre: str, num_heads: int, key_padding_mask, attn_mask=None,
-                  masks=None, p: float = 0.0):
+                  masks=None, p: float = 0.0, activation: str = "gelu"):
     """Post-norm TransformerEncoderLayer, torch18_adapters.py:108-113.
 
     src = norm1(src + dropout1(attn)); src = norm2(src + dropout2(W2 . dropout(gelu(W1 . src)))).
@@ -163,7 +163,8 @@ def encoder_layer(x, sd: Dict[str, torch.Tensor], pre: str, num_heads: int, key_
             sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"], num_heads,
             key_padding_mask, attn_mask, masks, pre, p)
     x = layer_norm(x + _drop(a, masks, pre + "dropout1", p), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
-    hdn = gelu(x @ sd[pre + "linear1.weight"].t() + sd[pre + "linear1.bias"])
+    pre_act = x @ sd[pre + "linear1.weight"].t() + sd[pre + "linear1.bias"]
+    hdn = gelu(pre_act) if activation == "gelu" else torch.clamp(pre_act, min=0.0)     # activ_f: "gelu" | "relu" (cross_f_box_layers.py:26,56)
     hdn = _drop(hdn, masks, pre + "dropout", p)
     y = hdn @ sd[pre + "linear2.weight"].t() + sd[pre + "linear2.bias"]
     return layer_norm(x + _drop(y, masks, pre + "dropout2", p), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
@@ -173,7 +174,7 @@ def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch.Te
                     lang_pad_mask: Optional[torch.Tensor], num_heads: int, num_layers: int,
                     vis_tokens_mask: Optional[torch.Tensor] = None, final_norm: bool = True,
                     masks: Optional[Dict[str, torch.Tensor]] = None, token_dropout: float = 0.0,
-                    patch_dropout: float = 0.0):
+                    patch_dropout: float = 0.0, activation: str = "gelu"):
     """CrossTransformerModuleBox.forward, cross_f_box_layers.py:69-108.
 
     sd uses the reference's state_dict names.  x [B,Nv,d],
@@ -189,6 +190,8 @@ def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch.Te
     x = x + sd["image_kind_embedding"]                   # :73
     x = _drop(x, masks, "patch", patch_dropout)          # :74
     lang = lang + sd["lang_kind_embedding"]              # :76
+    if "lang_pos_embedding.pos_embedding" in sd:         # :77-78 (PositionalEmbeddingLayer.forward, utils.py:209-214)
+        lang = lang + sd["lang_pos_embedding.pos_embedding"][:, :Nl]
     kpm = None
     if lang_pad_mask is not None:                        # :80-82
         kpm = torch.cat([torch.zeros(B, Nv, dtype=torch.bool), lang_pad_mask], dim=1)
@@ -199,7 +202,7 @@ def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch.Te
         attn_mask[:Nv, :Nv] = vis_tokens_mask.to(torch.bool)
     h = torch.cat([x, lang], dim=1)                      # :86
     for j in range(num_layers):                          # :97
-        h = encoder_layer(h, sd, f"t_encoder.layers.{j}.", num_heads, kpm, attn_mask, masks, token_dropout)
+        h = encoder_layer(h, sd, f"t_encoder.layers.{j}.", num_heads, kpm, attn_mask, masks, token_dropout, activation)
     vis = h[:, :Nv]
     if final_norm:                                       # :104-107
         vis = layer_norm(vis, sd["final_norm_layer.weight"], sd["final_norm_layer.bias"])

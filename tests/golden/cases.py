@@ -13,6 +13,9 @@ ENCODER_CASES = {
     "enc_hd18": dict(B=2, Nv=20, Nl=7, d=72, h=4, L=1, mask_lens=[7, 3], seed=102),
     "enc_nomask": dict(B=1, Nv=9, Nl=5, d=32, h=2, L=1, mask_lens=None, seed=103),
     "enc_local1": dict(B=2, Nv=20, Nl=6, d=64, h=4, L=1, mask_lens=[4, 6], seed=104, grid=(4, 5), local_k=1),
+    # the reference constructor's default activation (cross_f_box_layers.py:26) and a language positional table (:77-78, wrapper :100-105)
+    "enc_relu": dict(B=2, Nv=10, Nl=8, d=64, h=4, L=2, mask_lens=[8, 5], seed=108, activ="relu"),
+    "enc_langpos": dict(B=2, Nv=9, Nl=7, d=32, h=2, L=1, mask_lens=[7, 4], seed=109, lang_pos="sin1d"),
     # real width, weights regenerated from the seed (not stored), outputs stored sub-sampled
     "enc_d768": dict(B=1, Nv=196, Nl=64, d=768, h=4, L=1, mask_lens=[40], seed=105, big=True),
     # the reference's TRUE widths: out_mlp = 712 (Ego4Dv1, head dim 178 -> padded to 192 inside the runtime) and

@@ -45,12 +45,13 @@ def import_reference():
 
 def build_encoder(Enc, ref_utils, cfg, p_tok=0.0, p_patch=0.0):
     pe = ref_utils.PositionalEmbeddingLayer("sin1d", 8192, cfg["d"])
-    enc = Enc(no_patches=8192, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=cfg["L"],
+    lpe = ref_utils.PositionalEmbeddingLayer(cfg["lang_pos"], 256, cfg["d"]) if cfg.get("lang_pos") else None    # wrapper :100-105
+    enc = Enc(no_patches=8192, pos_embedding_layer=pe, lang_pos_embedding=lpe, num_layers=cfg["L"],
               patch_dropout=p_patch, num_heads=cfg["h"], fforward_multiplier=2, token_dropout=p_tok,
-              back_to_img_fn="regroup", activ_f="gelu", final_norm="ln", input_f_size=cfg["d"])
+              back_to_img_fn="regroup", activ_f=cfg.get("activ", "gelu"), final_norm="ln", input_f_size=cfg["d"])
     params = make_encoder_params(cfg["seed"], cfg["d"], cfg["L"])
     missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
-    assert set(missing) == {"padding_mask", "pos_embedding_layer.pos_embedding"}, missing
+    assert set(missing) == {"padding_mask", "pos_embedding_layer.pos_embedding"} | ({"lang_pos_embedding.pos_embedding"} if lpe else set()), missing
     assert not unexpected, unexpected
     return enc, params
 

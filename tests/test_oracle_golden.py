@@ -40,11 +40,13 @@ def test_encoder_small_cases(golden_dir, name):
     assert all(np.array_equal(regen[k], params[k]) for k in params)
 
     sd = _sd(params, cfg["d"])
+    if cfg.get("lang_pos") == "sin1d":
+        sd["lang_pos_embedding.pos_embedding"] = O.sin1d_table(256, cfg["d"])          # wrapper :100-105
     tx = torch.from_numpy(x).requires_grad_(True)
     tl = torch.from_numpy(lang).requires_grad_(True)
     tm = None if mask is None else torch.from_numpy(mask)
     vm = torch.from_numpy(g["in_vis_tokens_mask"]) if "in_vis_tokens_mask" in g else None
-    vis, lo = O.encoder_forward(sd, tx, tl, tm, cfg["h"], cfg["L"], vis_tokens_mask=vm)
+    vis, lo = O.encoder_forward(sd, tx, tl, tm, cfg["h"], cfg["L"], vis_tokens_mask=vm, activation=cfg.get("activ", "gelu"))
     _close(vis, g["train_vis"], what="train_vis")
     _close(lo, g["train_lang"], what="train_lang")
     # eval fast path: visual rows equal, language rows equal where not padded (padded rows are zeros there)

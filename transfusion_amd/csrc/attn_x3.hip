@@ -1,0 +1,486 @@
+// Attention for the fp32-accuracy mode (TfEncoderDesc.precision = 1, BASELINE configs[2] "fp32"): same algorithm and the same
+// reference lines as attn_bf16.hip (torch18_adapters.py:756-799, mask merge :578-597), on tensors that are hi + lo bf16 plane
+// pairs.  Every S x S x hd contraction is three bf16 MFMA passes into one fp32 accumulator,
+//        X . Y  ~=  X_lo . Y_hi  +  X_hi . Y_lo  +  X_hi . Y_hi          (error ~2^-17 per product),
+// probabilities / dS leave the softmax as fp32 registers and are split there into their own hi + lo operand fragments; all
+// softmax statistics (max, sum, LSE, delta) are fp32.  gfx950 has f32-input MFMA at 1/16 of the bf16 rate; three bf16 passes
+// cost 3/16 of that.
+//
+// Register budget decides the structure: with lo planes the resident operand fragments double, so
+//   * every kernel runs one wave per SIMD (512 registers), 4 waves x 32 rows per workgroup, tiles staged load -> LDS directly;
+//   * dK and dV are two launches of one kernel (WHICH): a wave that kept K, V (hi + lo) resident AND both accumulators would need
+//     ~450 registers at head dim 192.  The dV launch needs only K resident, the dK launch K and V.
+// The bf16 kernels' tuning (two waves per SIMD, register prefetch, read-ahead pipelines) is deliberately absent here.
+#include "tf_common.h"
+#include <cstdio>
+#include "tf_kernels.h"
+#include "attn_common.h"
+
+namespace {
+
+typedef const u16* __restrict__ cu16p;
+
+__device__ __forceinline__ f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);       // small terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+// registers 8s..8s+7 of a 32x32 fp32 accumulator -> hi + lo bf16 B-operand fragments of k-step s
+__device__ __forceinline__ void acc_frag_split(const f32x16& x, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[8 * s + j];
+    const __bf16 hb = (__bf16)v;
+    hi[j] = hb;
+    lo[j] = (__bf16)(v - (float)hb);
+  }
+}
+// 4 consecutive fp32 values -> 8-B hi and lo stores
+__device__ __forceinline__ void store4_split(u16* hi, u16* lo, float a, float b, float c, float d) {
+  u32x2 h, l;
+  h[0] = pack2bf(a, b); h[1] = pack2bf(c, d);
+  l[0] = pack2bf(a - bf2f((u16)(h[0] & 0xffffu)), b - bf2f((u16)(h[0] >> 16)));
+  l[1] = pack2bf(c - bf2f((u16)(h[1] & 0xffffu)), d - bf2f((u16)(h[1] >> 16)));
+  *(u32x2*)hi = h;
+  *(u32x2*)lo = l;
+}
+// one 64- or 32-row tile of both planes: global -> registers -> LDS (256 threads)
+template <int ROWS, int HDP>
+__device__ __forceinline__ void stage_pair(cu16p hi, cu16p lo, size_t ld, int row0, int row_max, bool zero_fill, unsigned char* lds_hi,
+                                           unsigned char* lds_lo, int tid) {
+  TileRegs<ROWS, HDP> r;
+  r.load(hi, ld, row0, row_max, zero_fill, tid);
+  r.store(lds_hi, tid);
+  r.load(lo, ld, row0, row_max, zero_fill, tid);
+  r.store(lds_lo, tid);
+}
+
+// ================================================================================================
+// forward: St[key][q] = K . Q^T (3 passes), online softmax in fp32, O^T += V^T . Pt (3 passes)
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kt_h = smem;
+  unsigned char* kt_l = smem + 64 * G::TSTR;
+  unsigned char* vt_h = smem + 128 * G::TSTR;
+  unsigned char* vt_l = smem + 192 * G::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int S = a.S;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int q0 = (logical % nqb) * 128 + wave * 32;
+  const size_t ld = a.ld_qkv;
+  const size_t boff = (size_t)b * S * ld;
+  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
+  cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
+
+  bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS];
+  {
+    const int qr = min(q0 + (lane & 31), S - 1);
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ld + ks * 16 + 8 * h));
+      qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ld + ks * 16 + 8 * h));
+    }
+  }
+  f32x16 o[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+  const int qrow = q0 + (lane & 31);
+  const int SW = (S + 63) / 64;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, S - 1) * SW : nullptr;
+
+  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();                       // previous tile fully consumed
+    stage_pair<64, HDP>(k_h, k_l, ld, kv0, S - 1, false, kt_h, kt_l, tid);
+    stage_pair<64, HDP>(v_h, v_l, ld, kv0, S - 1, false, vt_h, vt_l, tid);
+    __syncthreads();
+    const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
+    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long blk = brow ? brow[t] : 0ull;
+    const unsigned long long vbits = (vall & ~blk) >> (4 * h);
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        st[kb] = mfma3(row_frag<HDP>(kt_h, kb * 32, ks, lane), row_frag<HDP>(kt_l, kb * 32, ks, lane), qf_h[ks], qf_l[ks], st[kb]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (!((vbits >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull)) st[kb][r] = -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+    const bool need = mx - m_run > RESCALE_THR;   // per row (see attn_fwd_kernel): rows that keep their max multiply by exactly 1
+    if (__any(need)) {
+      const float m_new = need ? fmaxf(m_run, mx) : m_run;
+      const float alpha = need ? fast_exp2(m_run - m_new) : 1.0f;
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(fmaf(st[kb][r], sc, -m_run));
+        psum += p;
+        st[kb][r] = ((dm >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull) ? p : 0.f;
+      }
+    l_run += psum;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf_h, pf_l;
+        acc_frag_split(st[kb], s, pf_h, pf_l);
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d)
+          o[d] = mfma3(tr_frag<HDP>(vt_h, kb * 32 + 16 * s, d * 32, lane), tr_frag<HDP>(vt_l, kb * 32 + 16 * s, d * 32, lane), pf_h, pf_l, o[d]);
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
+  if (qrow < S) {
+    const size_t off = ((size_t)b * S + qrow) * a.ld_out + (size_t)head * HDP;
+    u16* orow_h = (u16*)a.out + off;
+    u16* orow_l = (u16*)a.out_lo + off;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = d * 32 + 8 * g4 + 4 * h;
+        store4_split(orow_h + c, orow_l + c, o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv, o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+      }
+    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * S + qrow] = m_run + log2f(l_tot);
+  }
+}
+
+// ================================================================================================
+// backward, dQ: query on the lane, loop over key tiles (see attn_bwd_dq_kernel)
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kt_h = smem;
+  unsigned char* kt_l = smem + 64 * G::TSTR;
+  unsigned char* vt_h = smem + 128 * G::TSTR;
+  unsigned char* vt_l = smem + 192 * G::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int S = a.S;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int q0 = (logical % nqb) * 128 + wave * 32;
+  const size_t ld = a.ld_qkv;
+  const size_t boff = (size_t)b * S * ld;
+  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
+  cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
+  const size_t dooff = (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
+
+  const int qrow = q0 + (lane & 31);
+  const int qr = min(qrow, S - 1);
+  bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS], dof_h[G::KSTEPS], dof_l[G::KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < G::KSTEPS; ++ks) {
+    qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ld + ks * 16 + 8 * h));
+    qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ld + ks * 16 + 8 * h));
+    dof_h[ks] = as_bf16x8(*(const u32x4*)(do_h + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
+    dof_l[ks] = as_bf16x8(*(const u32x4*)(do_l + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
+  }
+  const float lse = a.lse[(size_t)bh * S + qr];
+  float delta = 0.f;                       // rowsum(dO . O) in fp32 from both planes of both tensors
+  {
+    const size_t ooff = ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      float of[8], df[8];
+      load8_split(a.out, a.out_lo, ooff + ks * 16 + 8 * h, of);
+      join8(__builtin_bit_cast(u32x4, dof_h[ks]), __builtin_bit_cast(u32x4, dof_l[ks]), df);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (h == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+  }
+  f32x16 dq[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+  const float sc = a.scale * LOG2E;
+  const int SW = (S + 63) / 64;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
+
+  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * 64;
+    __syncthreads();
+    stage_pair<64, HDP>(k_h, k_l, ld, kv0, S - 1, false, kt_h, kt_l, tid);
+    stage_pair<64, HDP>(v_h, v_l, ld, kv0, S - 1, false, vt_h, vt_l, tid);
+    __syncthreads();
+    const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
+    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long blk = brow ? brow[t] : 0ull;
+    const unsigned long long vbits = (vall & ~blk) >> (4 * h);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        st = mfma3(row_frag<HDP>(kt_h, kb * 32, ks, lane), row_frag<HDP>(kt_l, kb * 32, ks, lane), qf_h[ks], qf_l[ks], st);
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        dp = mfma3(row_frag<HDP>(vt_h, kb * 32, ks, lane), row_frag<HDP>(vt_l, kb * 32, ks, lane), dof_h[ks], dof_l[ks], dp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bit = kb * 32 + (r & 3) + 8 * (r >> 2);
+        const float p = ((vbits >> bit) & 1ull) ? fast_exp2(fmaf(st[r], sc, -lse)) : 0.f;
+        const float ks = ((dm >> bit) & 1ull) ? dscale : 0.f;
+        st[r] = p * fmaf(dp[r], ks, -delta);          // dSt
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 ds_h, ds_l;
+        acc_frag_split(st, s, ds_h, ds_l);
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d)
+          dq[d] = mfma3(tr_frag<HDP>(kt_h, kb * 32 + 16 * s, d * 32, lane), tr_frag<HDP>(kt_l, kb * 32 + 16 * s, d * 32, lane), ds_h, ds_l, dq[d]);
+      }
+    }
+  }
+  if (qrow < S) {
+    const size_t off = ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+    u16* r_h = (u16*)a.dqkv + off;
+    u16* r_l = (u16*)a.dqkv_lo + off;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = d * 32 + 8 * g4 + 4 * h;
+        store4_split(r_h + c, r_l + c, dq[d][4 * g4] * a.scale, dq[d][4 * g4 + 1] * a.scale, dq[d][4 * g4 + 2] * a.scale, dq[d][4 * g4 + 3] * a.scale);
+      }
+  }
+}
+
+// ================================================================================================
+// backward, dV (WHICH = 0) or dK (WHICH = 1): key on the lane, loop over query tiles of 32 (see attn_bwd_dkv_kernel)
+//   S[q][key] = Q.K^T -> P ;  dP = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
+//   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key] ; dK *= scale
+// ================================================================================================
+template <int HDP, int WHICH>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* qt_h = smem;
+  unsigned char* qt_l = smem + 32 * G::TSTR;
+  unsigned char* dot_h = smem + 64 * G::TSTR;
+  unsigned char* dot_l = smem + 96 * G::TSTR;
+  float* lse_s = (float*)(smem + 128 * G::TSTR);
+  float* del_s = lse_s + 32;
+  unsigned* dw_s = (unsigned*)(del_s + 32);                       // [4 waves][32 query rows] keep-bit words of the wave's 32 keys
+  unsigned* bw_s = dw_s + 128;                                    // [4 waves][32 query rows] block-bit words
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int S = a.S;
+  const int nkb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int key0 = (logical % nkb) * 128 + wave * 32;
+  const size_t ld = a.ld_qkv;
+  const size_t boff = (size_t)b * S * ld;
+  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
+  cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
+  const size_t dooff = (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
+
+  const int key = key0 + (lane & 31);
+  const int kr_ = min(key, S - 1);
+  bool key_ok = key < S;
+  if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
+  constexpr int NV = WHICH == 1 ? G::KSTEPS : 1;                  // V fragments are resident only in the dK launch
+  bf16x8 kf_h[G::KSTEPS], kf_l[G::KSTEPS], vf_h[NV], vf_l[NV];
+#pragma unroll
+  for (int ks = 0; ks < G::KSTEPS; ++ks) {
+    kf_h[ks] = as_bf16x8(*(const u32x4*)(k_h + (size_t)kr_ * ld + ks * 16 + 8 * h));
+    kf_l[ks] = as_bf16x8(*(const u32x4*)(k_l + (size_t)kr_ * ld + ks * 16 + 8 * h));
+    if constexpr (WHICH == 1) {
+      vf_h[ks] = as_bf16x8(*(const u32x4*)(v_h + (size_t)kr_ * ld + ks * 16 + 8 * h));
+      vf_l[ks] = as_bf16x8(*(const u32x4*)(v_l + (size_t)kr_ * ld + ks * 16 + 8 * h));
+    }
+  }
+  f32x16 acc[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const float sc = a.scale * LOG2E;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
+  const bool blk = a.block_bits != nullptr;
+
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
+  const int dw_ld = 2 * ((S + 63) / 64);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  const unsigned* bbits = blk ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = t * 32;
+    __syncthreads();
+    stage_pair<32, HDP>(q_h, q_l, ld, q0, S - 1, false, qt_h, qt_l, tid);
+    stage_pair<32, HDP>(do_h, do_l, a.ld_dout, q0, S - 1, true, dot_h, dot_l, tid);       // rows >= S contribute nothing
+    if (tid < 32) {
+      const bool in = q0 + tid < S;
+      const int q = min(q0 + tid, S - 1);
+      lse_s[tid] = in ? a.lse[(size_t)bh * S + q] : 1.0e30f;      // P = 0 for rows past the end
+      del_s[tid] = in ? a.delta[(size_t)bh * S + q] : 0.f;
+    }
+    if (lane < 32) {
+      const int q = min(q0 + lane, S - 1);
+      dw_s[wave * 32 + lane] = a.drop_thr ? (q0 + lane < S ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
+      bw_s[wave * 32 + lane] = blk ? bbits[(size_t)q * dw_ld] : 0u;
+    }
+    __syncthreads();
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks)
+      st = mfma3(row_frag<HDP>(qt_h, 0, ks, lane), row_frag<HDP>(qt_l, 0, ks, lane), kf_h[ks], kf_l[ks], st);
+    if constexpr (WHICH == 1) {
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        dp = mfma3(row_frag<HDP>(dot_h, 0, ks, lane), row_frag<HDP>(dot_l, 0, ks, lane), vf_h[ks], vf_l[ks], dp);
+    }
+    // registers 4g..4g+3 are query rows 8g + 4h + (0..3)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 l4 = *(const f32x4*)(lse_s + 8 * g4 + 4 * h);
+      const f32x4 d4 = *(const f32x4*)(del_s + 8 * g4 + 4 * h);
+      const u32x4 w4 = *(const u32x4*)(dw_s + wave * 32 + 8 * g4 + 4 * h);
+      const u32x4 b4 = *(const u32x4*)(bw_s + wave * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        const bool att = key_ok && !((b4[i] >> (lane & 31)) & 1u);
+        const float p = att ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;
+        const float keep_scale = ((w4[i] >> (lane & 31)) & 1u) ? dscale : 0.f;
+        if constexpr (WHICH == 0) st[r] = p * keep_scale;                              // Pd
+        else st[r] = p * fmaf(dp[r], keep_scale, -d4[i]);                              // dS
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 f_h, f_l;
+      acc_frag_split(st, s2, f_h, f_l);
+      const unsigned char* th = WHICH == 0 ? dot_h : qt_h;
+      const unsigned char* tl = WHICH == 0 ? dot_l : qt_l;
+#pragma unroll
+      for (int d = 0; d < G::DBLK; ++d)
+        acc[d] = mfma3(tr_frag<HDP>(th, 16 * s2, d * 32, lane), tr_frag<HDP>(tl, 16 * s2, d * 32, lane), f_h, f_l, acc[d]);
+    }
+  }
+  if (key < S) {
+    const size_t off = ((size_t)b * S + key) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
+    u16* r_h = (u16*)a.dqkv + off;
+    u16* r_l = (u16*)a.dqkv_lo + off;
+    const float osc = WHICH == 0 ? 1.0f : a.scale;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = d * 32 + 8 * g4 + 4 * h;
+        store4_split(r_h + c, r_l + c, acc[d][4 * g4] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc);
+      }
+  }
+}
+
+template <int HDP> int launch_fwd_x3(const TfAttnArgs* a, hipStream_t st) {
+  const size_t lds = 256 * Geo<HDP>::TSTR;
+  static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)once;
+  char nm[56];
+  snprintf(nm, sizeof(nm), "attn_fwd_x3_kernel<%d>", HDP);
+  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)a->S * a->S * HDP);
+  hipLaunchKernelGGL(attn_fwd_x3_kernel<HDP>, dim3(((a->S + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
+  return (int)hipGetLastError();
+}
+template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
+  const size_t lds_q = 256 * Geo<HDP>::TSTR, lds_kv = 128 * Geo<HDP>::TSTR + 256 + 1024;
+  static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dq_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+  static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_x3_kernel<HDP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  static const hipError_t o3 = hipFuncSetAttribute((const void*)attn_bwd_dkv_x3_kernel<HDP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  (void)o1; (void)o2; (void)o3;
+  const dim3 grid(((a->S + 127) / 128) * a->B * a->H);
+  const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;       // credited as in attn_bf16.hip: backward = 2x forward over dq + dkv
+  char nm[56];
+  {
+    snprintf(nm, sizeof(nm), "attn_bwd_dq_x3_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl);
+    hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
+  }
+  {
+    snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dV>", HDP);
+    TfTraceScope tr(nm, st, fl / 2);
+    hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<HDP, 0>), grid, dim3(256), lds_kv, st, *a);
+  }
+  {
+    snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dK>", HDP);
+    TfTraceScope tr(nm, st, fl / 2);
+    hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<HDP, 1>), grid, dim3(256), lds_kv, st, *a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// head dims up to 224 (d = 896, 4 heads): 256 would need > 160 KiB of LDS for the four 64-row tiles of the dQ kernel
+#define TF_ATTN_X3_DISPATCH(FN)                  \
+  switch (a->HDP) {                              \
+    case 32: return FN<32>(a, st);               \
+    case 64: return FN<64>(a, st);               \
+    case 96: return FN<96>(a, st);               \
+    case 128: return FN<128>(a, st);             \
+    case 160: return FN<160>(a, st);             \
+    case 192: return FN<192>(a, st);             \
+    case 224: return FN<224>(a, st);             \
+    default: return -3;                          \
+  }
+
+extern "C" int tf_launch_attn_fwd_x3(const TfAttnArgs* a, hipStream_t st) {
+  if (a->qkv_lo == nullptr || a->out_lo == nullptr) return -6;
+  TF_ATTN_X3_DISPATCH(launch_fwd_x3)
+}
+extern "C" int tf_launch_attn_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
+  if (a->qkv_lo == nullptr || a->out_lo == nullptr || a->dout_lo == nullptr || a->dqkv_lo == nullptr) return -6;
+  TF_ATTN_X3_DISPATCH(launch_bwd_x3)
+}

@@ -28,6 +28,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds(TF_GLB_PTR(gsrc), TF_LDS_PTR(lds_dst), 16, 0, 0);
 }
 
+// FFN activation (TfGemmArgs.act): h = act(u), dh = act'(u); 0 = exact GELU, 1 = ReLU
+__device__ __forceinline__ void act_parts(int act, float u, float& h, float& dh) {
+  if (act == 1) { h = fmaxf(u, 0.f); dh = u > 0.f ? 1.f : 0.f; return; }
+  float cdf, ex;
+  gelu_parts(u, cdf, ex);
+  h = u * cdf;
+  dh = cdf + u * 0.39894228040143268f * ex;
+}
+
 // elementwise epilogue of one 16-B chunk (8 consecutive columns of one output row) -- shared by both GEMM kernels
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __restrict__ C, u32x4 v, int gm, int gn) {
@@ -40,18 +49,22 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? gelu_f(f[e]) * g.drop_scale : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        float hh, dh;
+        act_parts(g.act, f[e], hh, dh);
+        f[e] = ((km >> e) & 1u) ? hh * g.drop_scale : 0.f;
+      }
       *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP_G) {
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
       float gd[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float cdf, ex;
-        gelu_parts(f[e], cdf, ex);
+        float hh, dh;
+        act_parts(g.act, f[e], hh, dh);
         const float keep = ((km >> e) & 1u) ? g.drop_scale : 0.f;
-        gd[e] = keep * (cdf + f[e] * 0.39894228040143268f * ex);     // d dropout(gelu(u)) / du
-        f[e] = keep * (f[e] * cdf);
+        gd[e] = keep * dh;                                           // d dropout(act(u)) / du
+        f[e] = keep * hh;
       }
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(gd);
       *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
@@ -80,9 +93,96 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
       unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), u);
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * gelu_grad_f(u[e]) : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        float hh, dh;
+        act_parts(g.act, u[e], hh, dh);
+        f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
+      }
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     }
+  }
+}
+
+// ---- fp32-accuracy mode (TfGemmArgs.A_lo != null): the same epilogues on fp32 values, every bf16 tensor a hi + lo plane pair ----
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, float (&f)[8], int gm, int gn) {
+  const size_t oc = (size_t)gm * g.ldc + gn;
+  if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
+    store8_split(g.C, g.C_lo, oc, f);
+  } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP || EPI == TF_EPI_BIAS_GELU_DROP_G) {
+    const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+    float gd[8], hv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float hh, dh;
+      act_parts(g.act, f[e], hh, dh);
+      const float keep = ((km >> e) & 1u) ? g.drop_scale : 0.f;
+      gd[e] = keep * dh;
+      hv[e] = keep * hh;
+    }
+    if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) store8_split(g.C, g.C_lo, oc, f);      // pre-activation U
+    else store8_split(g.C, g.C_lo, oc, gd);                                             // G = d h / d u
+    store8_split(g.C2, g.C2_lo, (size_t)gm * g.ldc2 + gn, hv);
+  } else {
+    float r[8];
+    load8_split(g.R, g.R_lo, (size_t)gm * g.ldr + gn, r);
+    if constexpr (EPI == TF_EPI_MUL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= r[e];
+    } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
+    } else if constexpr (EPI == TF_EPI_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
+      const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float hh, dh;
+        act_parts(g.act, r[e], hh, dh);
+        f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
+      }
+    }
+    store8_split(g.C, g.C_lo, oc, f);
+  }
+}
+
+// The accumulators of a workgroup (waves NWR x NWC, each 64 columns x 16*MBLK rows as f32x4 blocks acc[ni][mi]: row
+// 16 mi + (lane & 15), columns 16 ni + 4 (lane >> 4) .. +3) pass through LDS as FP32, PM 16-row blocks of every wave at a time,
+// and leave as row-contiguous 8-column chunks for gemm_epilogue_chunk_f32.
+template <int EPI, int MBLK, int PM, int TBN, int NT>
+__device__ __forceinline__ void split_epilogue(const TfGemmArgs& g, f32x4 (&acc)[4][MBLK], unsigned char* ct, int m0, int n0, int wave_rows,
+                                               int wr, int wc, int lane, int tid) {
+  constexpr int RS = TBN * 4 + 16, CH = TBN / 8;
+#pragma unroll
+  for (int p0 = 0; p0 < MBLK; p0 += PM) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = wc * 64 + ni * 16 + (lane >> 4) * 4;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias != nullptr && n0 + nl < g.N) b = *(const f32x4*)(g.bias + n0 + nl);
+#pragma unroll
+      for (int pm = 0; pm < PM; ++pm) {
+        if (p0 + pm < MBLK) {
+          const int row_l = (wr * PM + pm) * 16 + (lane & 15);
+          *(f32x4*)(ct + row_l * RS + nl * 4) = acc[ni][p0 + pm] + b;
+        }
+      }
+    }
+    __syncthreads();
+    for (int id = tid; id < 2 * PM * 16 * CH; id += NT) {
+      const int row_l = id / CH, c = id - row_l * CH;
+      const int w = row_l / (PM * 16), rem = row_l - w * (PM * 16);
+      if (p0 + rem / 16 >= MBLK) continue;
+      const int gm = m0 + w * wave_rows + p0 * 16 + rem, gn = n0 + c * 8;
+      if (gm >= g.M || gn >= g.N) continue;
+      const f32x4 lo4 = *(const f32x4*)(ct + row_l * RS + c * 32), hi4 = *(const f32x4*)(ct + row_l * RS + c * 32 + 16);
+      float f[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      gemm_epilogue_chunk_f32<EPI>(g, f, gm, gn);
+    }
+    __syncthreads();
   }
 }
 
@@ -90,7 +190,9 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
 // span one 256-B bank row): ^ g[(r>>2)&3], g = {0,2,3,1}.  Both make the 16 rows of a ds_read_b128 lane group hit 16 distinct slots.
 template <int BK> __device__ __forceinline__ int swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((0x78 >> ((r >> 1) & 6)) & 3); }
 
-template <int EPI, int MI, int BK>
+// SPLIT (fp32-accuracy mode): the K loop runs three times over the operands' planes -- (A_hi, W_hi), (A_lo, W_hi), (A_hi, W_lo) -- into
+// the same fp32 accumulators; the epilogue works on fp32 values and writes hi + lo planes.
+template <int EPI, int MI, int BK, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
   constexpr int BM = 32 * MI;
   constexpr int ROWB = BK * 2;                                   // bytes per tile row (128 or 64)
@@ -104,10 +206,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
   const int tiles_n = (g.N + BN - 1) / BN;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
-  const u16* __restrict__ A = (const u16*)g.A;
-  const u16* __restrict__ W = (const u16*)g.W;
+  const int nk0 = g.K / BK;
 
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](int buf, int kstep) {
+    const u16* __restrict__ A = (const u16*)g.A;
+    const u16* __restrict__ W = (const u16*)g.W;
+    int kt = kstep;
+    if constexpr (SPLIT) {                                    // wave-uniform plane selection
+      const int seg = kstep >= 2 * nk0 ? 2 : (kstep >= nk0 ? 1 : 0);
+      kt = kstep - seg * nk0;
+      if (seg == 1) A = (const u16*)g.A_lo;
+      if (seg == 2) W = (const u16*)g.W_lo;
+    }
     unsigned char* abase = smem + buf * BUF_BYTES;
     unsigned char* bbase = abase + A_BYTES;
 #pragma unroll
@@ -140,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / BK;
+  const int nk = SPLIT ? 3 * nk0 : nk0;
   stage(0, 0);
   __syncthreads();
   const int frow = lane & 15, fch = lane >> 4;
@@ -171,6 +281,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
     __syncthreads();
   }
 
+  if constexpr (SPLIT) {
+    split_epilogue<EPI, MI, 2, BN, 256>(g, acc, smem, m0, n0, BM / 2, wr, wc, lane, tid);
+    return;
+  }
   // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [BM][CT_STRIDE] ----
   unsigned char* ct = smem;
 #pragma unroll
@@ -221,8 +335,9 @@ __device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmc
 // FP8: operands are OCP e4m3 bytes.  The byte geometry is unchanged (64-B tile rows = 64 values, one K-step = 64 values): a
 // 16-B fragment feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes; both operands use the same k <-> byte map,
 // so every k is multiplied exactly once), and the per-row / per-output-channel scales are applied with the bias.
-template <int EPI, int MF, bool FP8 = false>
+template <int EPI, int MF, bool FP8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g) {
+  static_assert(!(FP8 && SPLIT), "fp8 operands have no lo plane");
   constexpr int ES = FP8 ? 1 : 2;                                  // bytes per operand element
   constexpr int BM = 32 * MF;
   constexpr int A_BYTES = BM * BIG_ROWB, W_BYTES = BIG_BN * BIG_ROWB, SLOT = A_BYTES + W_BYTES;
@@ -249,13 +364,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     const int grow = isW ? min(n0 + r, g.N - 1) : min(m0 + r, g.M - 1);
     src_off[i] = (size_t)grow * (isW ? g.ldw : g.lda) * ES + c * 16;
   }
-  auto stage = [&](int slot, int kstep) {
+  const int nk0 = g.K * ES / (BIG_BK * 2);                         // K-steps of 64 operand bytes in one pass over K
+  auto stage = [&](int slot, int step) {
     unsigned char* sl = smem + slot * SLOT;
+    int kstep = step;
+    const unsigned char* Ap = A;
+    const unsigned char* Wp = W;
+    if constexpr (SPLIT) {                                        // pass 0: A_hi.W_hi, pass 1: A_lo.W_hi, pass 2: A_hi.W_lo (wave-uniform)
+      const int seg = step >= 2 * nk0 ? 2 : (step >= nk0 ? 1 : 0);
+      kstep = step - seg * nk0;
+      Ap = seg == 1 ? (const unsigned char*)g.A_lo : A;
+      Wp = seg == 2 ? (const unsigned char*)g.W_lo : W;
+    }
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int j = min(i * 8 + wave, NINST - 1);               // wave-uniform, branch-free (keeps the K loop one basic block)
       const bool isW = j >= NA;
-      const unsigned char* base = (isW ? W : A) + (size_t)kstep * (BIG_BK * 2);
+      const unsigned char* base = (isW ? Wp : Ap) + (size_t)kstep * (BIG_BK * 2);
       unsigned char* dst = sl + (isW ? A_BYTES + (j - NA) * 1024 : j * 1024);
       glds16(base + src_off[i], dst);
     }
@@ -267,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K * ES / (BIG_BK * 2);                          // K-steps of 64 operand bytes
+  const int nk = SPLIT ? 3 * nk0 : nk0;
   const int frow = lane & 15, fch = lane >> 4;
   // fragment j sits 16 rows = 1024 B after fragment 0 with the SAME swizzle: one base register each plus immediates
   const int rn0 = wc * 64 + frow, rm0 = wr * (BM / 2) + frow;
@@ -316,6 +441,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers must land before LDS is reused
 
+  if constexpr (SPLIT) {
+    split_epilogue<EPI, MF, 3, BIG_BN, 512>(g, acc, smem, m0, n0, BM / 2, wr, wc, lane, tid);
+    return;
+  }
   // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [BM][BIG_CT_STRIDE] ----
   unsigned char* ct = smem;
 #pragma unroll
@@ -363,6 +492,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
 // full-rate shape for global_atomic_add_f32.  Bias grad (column sums of dY) = one extra MFMA against a
 // ones operand in the k-tile-0 blocks.
 // ------------------------------------------------------------------------------------------------
+// SPLIT (fp32-accuracy mode): three passes over the block's rows -- (dY_hi, X_hi), (dY_lo, X_hi), (dY_hi, X_lo) -- into the same
+// accumulators; the bias grad (column sums of dY) takes passes 0 and 1.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   // K (= rows of M) advances in 32-row steps through a 4-slot LDS ring (16 KiB per slot: dY [32][128] | X [32][128]);
   // the DMA of step i+3 is issued in phase i, so a transfer has three phases to land (with one-step prefetch the loop
@@ -382,14 +514,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
   const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
   const int m_begin = split * g.m_chunk;
   const int m_end = min(g.M, m_begin + g.m_chunk);
-  const int nsteps = (m_end - m_begin + STEP - 1) / STEP;
-  const unsigned char* __restrict__ dY = (const unsigned char*)g.dY;
-  const unsigned char* __restrict__ X = (const unsigned char*)g.X;
+  const int nsteps0 = (m_end - m_begin + STEP - 1) / STEP;
+  const int nsteps = SPLIT ? 3 * nsteps0 : nsteps0;
   const unsigned char* __restrict__ Z = (const unsigned char*)g.zeros;
 
   // one step = 32 rows x 256 B per operand = 8 wave-instructions per operand, 2 per wave: rows R0..R0+3, R0 = (i*4+wave)*4
   const int lr = lane >> 4, lc = lane & 15;
-  auto stage = [&](int slot, int st) {
+  auto stage = [&](int slot, int step) {
+    const unsigned char* __restrict__ dY = (const unsigned char*)g.dY;
+    const unsigned char* __restrict__ X = (const unsigned char*)g.X;
+    int st = step;
+    if constexpr (SPLIT) {
+      const int seg = step >= 2 * nsteps0 ? 2 : (step >= nsteps0 ? 1 : 0);
+      st = step - seg * nsteps0;
+      if (seg == 1) dY = (const unsigned char*)g.dY_lo;
+      if (seg == 2) X = (const unsigned char*)g.X_lo;
+    }
     unsigned char* ybase = smem + slot * SLOT;
     unsigned char* xbase = ybase + STEP * 256;
 #pragma unroll
@@ -470,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
         for (int kb = 0; kb < 2; ++kb)
           acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][nb], bfr[ms][kb], acc[nb][kb], 0, 0, 0);
       }
-      const bool my_turn = has_bias && bias_cnt == 0;             // wave-uniform
+      const bool my_turn = has_bias && bias_cnt == 0 && (!SPLIT || st < 2 * nsteps0);             // wave-uniform
       bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
       if (my_turn) {
         accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][0], ones, accb[0], 0, 0, 0);
@@ -512,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 // Bias grad: ONE extra accumulator for all four n-blocks -- D += SEL_nb . dYfrag_nb with SEL_nb[i][m] = (i >> 3 == nb),
 // so rows 8nb..8nb+7 of the 32x32 result (= accumulator registers 4nb..4nb+3) hold the column sums of n-block nb.
 // ------------------------------------------------------------------------------------------------
+template <bool SPLIT>        // see wgrad_tn_kernel
 __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) {
   constexpr int STEP = 32, YB = STEP * 512, XB = STEP * 256, SLOT = YB + XB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -525,10 +666,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
   const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 128;
   const int m_begin = split * g.m_chunk;
   const int m_end = min(g.M, m_begin + g.m_chunk);
-  const int nsteps = (m_end - m_begin + STEP - 1) / STEP;
+  const int nsteps0 = (m_end - m_begin + STEP - 1) / STEP;
+  const int nsteps = SPLIT ? 3 * nsteps0 : nsteps0;
   const unsigned char* __restrict__ dY = (const unsigned char*)g.dY;
   const unsigned char* __restrict__ X = (const unsigned char*)g.X;
   const unsigned char* __restrict__ Z = (const unsigned char*)g.zeros;
+  // byte distance from a hi plane to its lo plane (wave-uniform; planes share the leading dimension)
+  const ptrdiff_t lo_y = SPLIT ? (const unsigned char*)g.dY_lo - dY : 0, lo_x = SPLIT ? (const unsigned char*)g.X_lo - X : 0;
 
   // one step = 16 KiB of dY (16 wave-instructions of 2 rows) + 8 KiB of X (8 of 4 rows): 6 per wave.
   // Per-lane source pointers of the six pieces at step 0 are computed ONCE (columns clamped, swizzle folded in); a step only
@@ -555,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
   }
   const size_t step_y = (size_t)STEP * g.ldy * 2, step_x = (size_t)STEP * g.ldx * 2;
   const bool ragged = ((m_end - m_begin) % STEP) != 0;        // block-uniform; false whenever M is a multiple of 32
-  auto stage_general = [&](int slot, int st) {
+  auto stage_general = [&](int slot, int st, ptrdiff_t py_off, ptrdiff_t px_off) {
     unsigned char* ybase = smem + slot * SLOT;
     unsigned char* xbase = ybase + YB;
 #pragma unroll
@@ -565,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       const int c = (lane & 31) ^ ((r & 3) << 2);
       const int gm = m_begin + st * STEP + r;
       const int cn = min(n0 + c * 8, g.N - 8);
-      const unsigned char* sy = gm < m_end ? dY + ((size_t)gm * g.ldy + cn) * 2 : Z + (c & 15) * 16;
+      const unsigned char* sy = gm < m_end ? dY + py_off + ((size_t)gm * g.ldy + cn) * 2 : Z + (c & 15) * 16;
       glds16(sy, ybase + j * 1024);
     }
 #pragma unroll
@@ -575,18 +719,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       const int c = (lane & 15) ^ ((r & 3) << 2);
       const int gm = m_begin + st * STEP + r;
       const int ck = min(k0 + c * 8, g.K - 8);
-      const unsigned char* sx = gm < m_end ? X + ((size_t)gm * g.ldx + ck) * 2 : Z + c * 16;
+      const unsigned char* sx = gm < m_end ? X + px_off + ((size_t)gm * g.ldx + ck) * 2 : Z + c * 16;
       glds16(sx, xbase + j * 1024);
     }
   };
-  auto stage = [&](int slot, int st) {
-    if (ragged && st == nsteps - 1) { stage_general(slot, st); return; }
+  auto stage = [&](int slot, int step) {
+    int st = step;
+    ptrdiff_t py_off = 0, px_off = 0;
+    if constexpr (SPLIT) {
+      const int seg = step >= 2 * nsteps0 ? 2 : (step >= nsteps0 ? 1 : 0);
+      st = step - seg * nsteps0;
+      py_off = seg == 1 ? lo_y : 0;
+      px_off = seg == 2 ? lo_x : 0;
+    }
+    if (ragged && st == nsteps0 - 1) { stage_general(slot, st, py_off, px_off); return; }
     unsigned char* ybase = smem + slot * SLOT;
     unsigned char* xbase = ybase + YB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(py[i] + (size_t)st * step_y, ybase + (i * 4 + wave) * 1024);
+    for (int i = 0; i < 4; ++i) glds16(py[i] + py_off + (size_t)st * step_y, ybase + (i * 4 + wave) * 1024);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(px[i] + (size_t)st * step_x, xbase + (i * 4 + wave) * 1024);
+    for (int i = 0; i < 2; ++i) glds16(px[i] + px_off + (size_t)st * step_x, xbase + (i * 4 + wave) * 1024);
   };
 
   f32x16 acc[4][2], accb;
@@ -646,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
-      const bool my_turn = has_bias && bias_cnt == 0;          // wave-uniform
+      const bool my_turn = has_bias && bias_cnt == 0 && (!SPLIT || st < 2 * nsteps0);          // wave-uniform
       bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
       if (my_turn) {
 #pragma unroll
@@ -699,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
 // launchers (host)
 // ------------------------------------------------------------------------------------------------
 namespace {
-template <int MI, int BK> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
+template <int MI, int BK, bool SPLIT = false> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
   constexpr int BM = 32 * MI;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   size_t lds = 2 * (size_t)(BM + 128) * BK * 2;                    // BK 64: 64 / 72 / 80 KiB
@@ -708,8 +860,8 @@ template <int MI, int BK> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t st
 #define TF_GEMM_CASE(E)                                                                                           \
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
-    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_kernel<E, MI, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
-    hipLaunchKernelGGL((gemm_nt_kernel<E, MI, BK>), grid, block, lds, stream, *a);                                \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, MI, BK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_kernel<E, MI, BK, SPLIT>), grid, block, lds, stream, *a);                         \
   } break;
   switch (a->epilogue) {
     TF_GEMM_CASE(TF_EPI_NONE)
@@ -741,7 +893,7 @@ int pick_mi(int M, int N) {
 }  // namespace
 
 namespace {
-template <int MF> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
+template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
   constexpr int BM = 32 * MF;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BIG_BN - 1) / BIG_BN);
   size_t lds = 4 * (size_t)(BM + BIG_BN) * BIG_ROWB;               // 4-slot ring
@@ -750,16 +902,16 @@ template <int MF> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
 #define TF_GEMM_CASE(E)                                                                                           \
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
-    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
-    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF>), grid, block, lds, stream, *a);                                \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, false, SPLIT>), grid, block, lds, stream, *a);                  \
   } break;
 #define TF_GEMM_CASE8(E)                                                                                          \
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
-    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
     hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a);                          \
   } break;
-  if (a->fp8) {
+  if constexpr (!SPLIT) if (a->fp8) {
     switch (a->epilogue) {
       TF_GEMM_CASE8(TF_EPI_NONE)
       TF_GEMM_CASE8(TF_EPI_BIAS)
@@ -812,7 +964,15 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
   static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
-  const double fl = 2.0 * a->M * a->N * a->K;
+  const double fl = 2.0 * a->M * a->N * a->K;          // algorithmic (the fp32-accuracy mode executes three bf16 passes of it)
+  const bool split = a->A_lo != nullptr;
+  if (split) {
+    if (a->fp8 || a->W_lo == nullptr || a->C_lo == nullptr) return -6;
+    const int e = a->epilogue;
+    const bool needs_r = e == TF_EPI_MUL || e == TF_EPI_BIAS_DROP_RES || e == TF_EPI_ADD || e == TF_EPI_DGELU_DROP;
+    if (needs_r && (a->R == nullptr || a->R_lo == nullptr)) return -6;
+    if ((e == TF_EPI_BIAS_GELU_DROP || e == TF_EPI_BIAS_GELU_DROP_G) && (a->C2 == nullptr || a->C2_lo == nullptr)) return -6;
+  }
   if (a->fp8) {                                   // fp8 operands: large-tile kernel only (any shape; rows are clamped)
     if ((a->lda % 16) || (a->ldw % 16)) return -3;
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
@@ -839,9 +999,16 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (use_big) {
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
     char nm[56];
-    snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
+    snprintf(nm, sizeof(nm), split ? "gemm_nt_big_kernel<%d, %d, x3>" : "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
+    if (split) return mf == 9 ? launch_gemm_big<9, true>(a, stream) : launch_gemm_big<8, true>(a, stream);
     return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+  }
+  if (split) {                                     // one tile height in this mode (fewer instantiations)
+    char nm[56];
+    snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, 4, 64, x3>", a->epilogue);
+    TfTraceScope tr(nm, stream, fl);
+    return launch_gemm_mi<4, 64, true>(a, stream);
   }
   char nm[56];
   snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64>", a->epilogue, pick_mi(a->M, a->N));
@@ -892,14 +1059,20 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 32;
   splits = (a.M + a.m_chunk - 1) / a.m_chunk;
   dim3 grid(tiles * splits), block(256);
-  TfTraceScope tr(v2 ? "wgrad_tn2_kernel" : "wgrad_tn_kernel", stream, 2.0 * a.M * a.N * a.K);
+  const bool split = a.dY_lo != nullptr;
+  if (split && a.X_lo == nullptr) return -6;
+  TfTraceScope tr(v2 ? (split ? "wgrad_tn2_kernel<x3>" : "wgrad_tn2_kernel") : (split ? "wgrad_tn_kernel<x3>" : "wgrad_tn_kernel"), stream,
+                  2.0 * a.M * a.N * a.K);
   if (v2) {
     constexpr int LDS2 = 3 * (32 * 512 + 32 * 256);
-    static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-    (void)once;
-    hipLaunchKernelGGL(wgrad_tn2_kernel, grid, block, LDS2, stream, a);
+    static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+    static const hipError_t once3 = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+    (void)once; (void)once3;
+    if (split) hipLaunchKernelGGL(wgrad_tn2_kernel<true>, grid, block, LDS2, stream, a);
+    else hipLaunchKernelGGL(wgrad_tn2_kernel<false>, grid, block, LDS2, stream, a);
   } else {
-    hipLaunchKernelGGL(wgrad_tn_kernel, grid, block, 4 * TILE_BYTES, stream, a);
+    if (split) hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, block, 4 * TILE_BYTES, stream, a);
+    else hipLaunchKernelGGL(wgrad_tn_kernel<false>, grid, block, 4 * TILE_BYTES, stream, a);
   }
   return (int)hipGetLastError();
 }

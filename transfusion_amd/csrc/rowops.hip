@@ -39,14 +39,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   if (row >= a.rows) return;
   const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
   const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
-  const u16* x = (const u16*)a.x + (size_t)xr * a.ldx;
   float v[MAXC][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = (lane + 64 * i) * 8;
     if (c < a.d) {
-      unpack8(*(const u32x4*)(x + c), v[i]);
+      load8_split(a.x, a.x_lo, (size_t)xr * a.ldx + c, v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
@@ -72,9 +71,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
       load8_f32(a.beta + c, b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-      store8_any(a.y, (size_t)yr * a.ldy + c, a.y_is_f32, o);
+      if (a.y_is_f32) store8_f32((float*)a.y + (size_t)yr * a.ldy + c, o);
+      else store8_split(a.y, a.y_lo, (size_t)yr * a.ldy + c, o);
     } else if (c < a.ldy && !a.y_is_f32) {
       *(u32x4*)((u16*)a.y + (size_t)yr * a.ldy + c) = u32x4{0, 0, 0, 0};
+      if (a.y_lo != nullptr) *(u32x4*)((u16*)a.y_lo + (size_t)yr * a.ldy + c) = u32x4{0, 0, 0, 0};
     }
   }
 }
@@ -109,11 +110,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
       const int c = (lane + 64 * i) * 8;
       if (c < a.d) {
         float xv[8], dy[8], gm[8];
-        unpack8(*(const u32x4*)((const u16*)a.x + (size_t)xr * a.ldx + c), xv);
-        load8_any(a.dy, (size_t)yr * a.lddy + c, a.dy_is_f32, dy);
+        load8_split(a.x, a.x_lo, (size_t)xr * a.ldx + c, xv);
+        if (a.dy_is_f32) load8_f32((const float*)a.dy + (size_t)yr * a.lddy + c, dy);
+        else load8_split(a.dy, a.dy_lo, (size_t)yr * a.lddy + c, dy);
         if (a.dres != nullptr) {
           float r[8];
-          unpack8(*(const u32x4*)((const u16*)a.dres + (size_t)xr * a.lddres + c), r);
+          load8_split(a.dres, a.dres_lo, (size_t)xr * a.lddres + c, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) dy[e] += r[e];
         }
@@ -137,18 +139,25 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
-        *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = pack8(o);
+        store8_split(a.dx, a.dx_lo, (size_t)xr * a.lddx + c, o);
         if (a.dx_drop != nullptr) {
           if (a.drop_thr) {
             const unsigned km = tf_keep8((unsigned)xr * (unsigned)a.drop_ld + (unsigned)c, a.drop_key, a.drop_thr);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = ((km >> e) & 1u) ? o[e] * a.drop_scale : 0.f;
           }
-          *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = pack8(o);
+          store8_split(a.dx_drop, a.dx_drop_lo, (size_t)xr * a.lddxd + c, o);
         }
       } else {
-        if (c < a.lddx) *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = u32x4{0, 0, 0, 0};
-        if (a.dx_drop != nullptr && c < a.lddxd) *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = u32x4{0, 0, 0, 0};
+        const u32x4 z = {0, 0, 0, 0};
+        if (c < a.lddx) {
+          *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = z;
+          if (a.dx_lo != nullptr) *(u32x4*)((u16*)a.dx_lo + (size_t)xr * a.lddx + c) = z;
+        }
+        if (a.dx_drop != nullptr && c < a.lddxd) {
+          *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = z;
+          if (a.dx_drop_lo != nullptr) *(u32x4*)((u16*)a.dx_drop_lo + (size_t)xr * a.lddxd + c) = z;
+        }
       }
     }
   }
@@ -182,12 +191,16 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   const int b = row / S, s = row - b * S;
   u16* out = (u16*)a.out + (size_t)row * a.ld_out;
   for (int c = lane * 8; c < a.ld_out; c += 512) {
-    if (c >= a.d) { *(u32x4*)(out + c) = u32x4{0, 0, 0, 0}; continue; }
+    if (c >= a.d) {
+      *(u32x4*)(out + c) = u32x4{0, 0, 0, 0};
+      if (a.out_lo != nullptr) *(u32x4*)((u16*)a.out_lo + (size_t)row * a.ld_out + c) = u32x4{0, 0, 0, 0};
+      continue;
+    }
     float v[8], k[8];
     if (s < a.Nv) {
-      float pe[8];
+      float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       load8_any(a.vis, (size_t)(b * a.Nv + s) * a.ld_vis + c, a.vis_is_f32, v);
-      load8_f32(a.pe + (size_t)s * a.d + c, pe);
+      if (a.pe != nullptr) load8_f32(a.pe + (size_t)s * a.d + c, pe);
       load8_f32(a.kind_v + c, k);
       const unsigned km = a.drop_thr ? tf_keep8((unsigned)row * (unsigned)a.ld_out + (unsigned)c, a.drop_key, a.drop_thr) : 0xffu;
 #pragma unroll
@@ -197,8 +210,14 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
       load8_f32(a.kind_l + c, k);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += k[e];
+      if (a.pe_lang != nullptr) {                                  // lang_pos_embedding: added after the kind embedding (:76-78)
+        float pl[8];
+        load8_f32(a.pe_lang + (size_t)(s - a.Nv) * a.d + c, pl);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += pl[e];
+      }
     }
-    *(u32x4*)(out + c) = pack8(v);
+    store8_split(a.out, a.out_lo, (size_t)row * a.ld_out + c, v);
   }
 }
 
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
       const int c = (lane + 64 * i) * 8;
       if (c >= a.d) continue;
       float g[8];
-      unpack8(*(const u32x4*)((const u16*)a.dout + (size_t)row * a.ld_dout + c), g);
+      load8_split(a.dout, a.dout_lo, (size_t)row * a.ld_dout + c, g);
       if (s < a.Nv) {
         if (a.drop_thr) {
           const unsigned km = tf_keep8((unsigned)row * (unsigned)a.ld_dout + (unsigned)c, a.drop_key, a.drop_thr);
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (cs >= 0) v = *(const f32x4*)(a.src + (size_t)rs * a.cols + cs);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) f[4 * k + e] = v[e];
+      for (int e = 0; e < 4; ++e) f[4 * k + e] = a.residual ? v[e] - bf2f(f2bf(v[e])) : v[e];
     }
     u32x4 lo, hi;
 #pragma unroll
@@ -326,6 +345,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
       const int rs = pack_src_index(rp, a.rg, a.rgp, a.rows);
       if (rs >= 0) v = a.src[(size_t)rs * a.cols + cs];
     }
+    if (a.residual && !a.dst_is_f32) v = v - bf2f(f2bf(v));
     if (a.dst_is_f32) {
       if (rp < a.rows_p && cp < a.cols_p) ((float*)a.dst)[(size_t)rp * a.ld_dst + cp] = v;
     } else {
@@ -355,8 +375,12 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const TfCopyRowsArgs a) 
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (c < a.cols && a.src != nullptr) load8_any(a.src, sr + c, a.src_is_f32, v);
-    store8_any(a.dst, dr + c, a.dst_is_f32, v);
+    if (c < a.cols && a.src != nullptr) {
+      if (a.src_is_f32) load8_f32((const float*)a.src + sr + c, v);
+      else load8_split(a.src, a.src_lo, sr + c, v);
+    }
+    if (a.dst_is_f32) store8_f32((float*)a.dst + dr + c, v);
+    else store8_split(a.dst, a.dst_lo, dr + c, v);
   }
 }
 __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restrict__ km, int B, int Nv, int Nl) {

@@ -42,8 +42,10 @@ uint64_t splitmix64(uint64_t x) {
 struct Dims {
   int B, Nv, Nl, d, H, L, ff;
   int S, M, hd, hdp, dp, ffp, nqkv, ldq;
+  int split;        // fp32-accuracy mode: every bf16 tensor of the workspace and of the weight shadows is a hi + lo plane pair
 };
-bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o) {
+bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0) {
+  o->split = split ? 1 : 0;
   if (B <= 0 || Nv < 0 || Nl < 0 || Nv + Nl <= 0 || d <= 0 || H <= 0 || L <= 0 || L > TF_MAX_LAYERS || ff <= 0) return false;
   if (d % H != 0 || d % 8 != 0) return false;
   o->B = B; o->Nv = Nv; o->Nl = Nl; o->d = d; o->H = H; o->L = L; o->ff = ff;
@@ -56,6 +58,7 @@ bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o) {
   o->nqkv = 3 * H * o->hdp;
   o->ldq = (int)up(o->nqkv, 64);
   if (o->d > 2048) return false;
+  if (o->split && o->hdp > 224) return false;      // attn_x3.hip: head dims up to 224
   return true;
 }
 struct WOff {   // byte offsets inside wpack, per layer
@@ -63,13 +66,16 @@ struct WOff {   // byte offsets inside wpack, per layer
   size_t win8, w18, w28, s_in, s_w1, s_w2;        // fp8 (e4m3) shadows of the three forward projections + per-output-channel scales
   size_t stride;
 };
+// bytes of ONE plane of a bf16 tensor inside wpack / work: its lo plane (split mode) starts this many bytes after its hi plane
+inline size_t plane(size_t bytes) { return up(bytes, 256); }
 WOff make_woff(const Dims& D) {
   WOff w; size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += up(bytes, 256); return r; };
-  w.win = take((size_t)D.nqkv * D.dp * 2);   w.winT = take((size_t)D.dp * D.ldq * 2);
-  w.wo = take((size_t)D.dp * D.dp * 2);      w.woT = take((size_t)D.dp * D.dp * 2);
-  w.w1 = take((size_t)D.ffp * D.dp * 2);     w.w1T = take((size_t)D.dp * D.ffp * 2);
-  w.w2 = take((size_t)D.dp * D.ffp * 2);     w.w2T = take((size_t)D.ffp * D.dp * 2);
+  auto take2 = [&](size_t bytes) { size_t r = o; o += plane(bytes) * (size_t)(1 + D.split); return r; };   // bf16 tensor (+ lo plane)
+  w.win = take2((size_t)D.nqkv * D.dp * 2);   w.winT = take2((size_t)D.dp * D.ldq * 2);
+  w.wo = take2((size_t)D.dp * D.dp * 2);      w.woT = take2((size_t)D.dp * D.dp * 2);
+  w.w1 = take2((size_t)D.ffp * D.dp * 2);     w.w1T = take2((size_t)D.dp * D.ffp * 2);
+  w.w2 = take2((size_t)D.dp * D.ffp * 2);     w.w2T = take2((size_t)D.ffp * D.dp * 2);
   w.bin = take((size_t)D.ldq * 4); w.bo = take((size_t)D.dp * 4); w.b1 = take((size_t)D.ffp * 4); w.b2 = take((size_t)D.dp * 4);
   w.win8 = take((size_t)D.nqkv * D.dp); w.w18 = take((size_t)D.ffp * D.dp); w.w28 = take((size_t)D.dp * D.ffp);
   w.s_in = take((size_t)D.ldq * 4); w.s_w1 = take((size_t)D.ffp * 4); w.s_w2 = take((size_t)D.dp * 4);
@@ -88,43 +94,59 @@ struct AOff {   // byte offsets inside work
 AOff make_aoff(const Dims& D) {
   AOff a; size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += up(bytes, 256); return r; };
+  auto take2 = [&](size_t bytes) { size_t r = o; o += plane(bytes) * (size_t)(1 + D.split); return r; };      // bf16 tensor (+ lo plane)
   const size_t md = (size_t)D.M * D.dp * 2, mf = (size_t)D.M * D.ffp * 2, mq = (size_t)D.M * D.ldq * 2;
   const size_t st = (size_t)D.B * D.H * D.S * 4, mr = (size_t)D.M * 4;
   a.zeros = take(256);
   a.keymask = take((size_t)D.M);
-  a.x0 = o; a.x_stride = up(md, 256); o += a.x_stride * (D.L + 1);
+  a.x0 = o; a.x_stride = plane(md) * (size_t)(1 + D.split); o += a.x_stride * (D.L + 1);
   a.layer0 = o;
   {
     size_t lo = 0;
     auto ltake = [&](size_t bytes) { size_t r = lo; lo += up(bytes, 256); return r; };
-    a.qkv = ltake(mq); a.o = ltake(md); a.lse = ltake(st); a.z1 = ltake(md); a.mean1 = ltake(mr); a.rstd1 = ltake(mr);
-    a.x1 = ltake(md); a.u = ltake(mf); a.h = ltake(mf); a.z2 = ltake(md); a.mean2 = ltake(mr); a.rstd2 = ltake(mr);
+    auto ltake2 = [&](size_t bytes) { size_t r = lo; lo += plane(bytes) * (size_t)(1 + D.split); return r; };
+    a.qkv = ltake2(mq); a.o = ltake2(md); a.lse = ltake(st); a.z1 = ltake2(md); a.mean1 = ltake(mr); a.rstd1 = ltake(mr);
+    a.x1 = ltake2(md); a.u = ltake2(mf); a.h = ltake2(mf); a.z2 = ltake2(md); a.mean2 = ltake(mr); a.rstd2 = ltake(mr);
     a.dbits = ltake(tf_attn_dropmask_bytes(D.B, D.H, D.S));
     a.layer_stride = lo;
   }
   o += a.layer_stride * D.L;
   a.meanf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4); a.rstdf = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4);
-  a.dxa = take(md); a.dxb = take(md); a.dz = take(md); a.dy = take(md); a.dzb = take(md); a.dyb = take(md); a.du = take(mf); a.d_o = take(md); a.dqkv = take(mq);
+  a.dxa = take2(md); a.dxb = take2(md); a.dz = take2(md); a.dy = take2(md); a.dzb = take2(md); a.dyb = take2(md); a.du = take2(mf); a.d_o = take2(md);
+  a.dqkv = take2(mq);
   a.delta = take(st);
   a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
   return a;
 }
 
+// a bf16 tensor of the runtime: hi plane, lo plane (null in bf16 mode), leading dimension
+struct Buf { const void* p; const void* lo; int ld; };
 struct Ctx {
   Dims D; WOff W; AOff A;
   const TfEncoderDesc* e;
   unsigned char* wp; unsigned char* wk;
   hipStream_t st;
+  size_t pd, pf, pq;                                  // plane sizes of [M, dp], [M, ffp], [M, ldq] activations
+  const void* lo(const void* p, size_t plane_bytes) const { return D.split ? (const unsigned char*)p + plane_bytes : nullptr; }
+  Buf act_d(const void* p) const { return Buf{p, lo(p, pd), D.dp}; }
+  Buf act_f(const void* p) const { return Buf{p, lo(p, pf), D.ffp}; }
+  Buf act_q(const void* p) const { return Buf{p, lo(p, pq), D.ldq}; }
+  // weight shadow [rows, ld] bf16 inside a layer's wpack block
+  Buf wgt(const unsigned char* p, int rows, int ld) const { return Buf{p, lo(p, plane((size_t)rows * ld * 2)), ld}; }
   void* X(int l) const { return wk + A.x0 + (size_t)l * A.x_stride; }
   unsigned char* LB(int l) const { return wk + A.layer0 + (size_t)l * A.layer_stride; }
   unsigned char* WB(int l) const { return wp + (size_t)l * W.stride; }
 };
 bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
   if (e == nullptr || e->wpack == nullptr || e->work == nullptr) return false;
-  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D)) return false;
+  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision)) return false;
+  if (e->precision != 0 && e->precision != 1) return false;
+  if (e->precision && e->fp8_proj) return false;      // fp8 operands have no lo plane
+  if (e->act != 0 && e->act != 1) return false;
   c->W = make_woff(c->D); c->A = make_aoff(c->D);
   c->e = e; c->wp = (unsigned char*)e->wpack; c->wk = (unsigned char*)e->work; c->st = st;
+  c->pd = plane((size_t)c->D.M * c->D.dp * 2); c->pf = plane((size_t)c->D.M * c->D.ffp * 2); c->pq = plane((size_t)c->D.M * c->D.ldq * 2);
   return true;
 }
 
@@ -137,11 +159,13 @@ Drop drop_for(const TfEncoderDesc* e, float p, unsigned site) {
 enum Site { SITE_PATCH = 0, SITE_ATTN = 1, SITE_DROP1 = 2, SITE_FFN = 3, SITE_DROP2 = 4 };
 inline unsigned site_of(int layer, int which) { return 16u + (unsigned)layer * 8u + (unsigned)which; }
 
-int gemm(const Ctx& c, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias, const void* R, int ldr,
-         void* C2, int ldc2, int N, int K, int epi, Drop dr) {
+const Buf NOBUF{nullptr, nullptr, 0};
+int gemm(const Ctx& c, Buf A, Buf W, Buf C, const float* bias, Buf R, Buf C2, int N, int K, int epi, Drop dr) {
   TfGemmArgs g{};
-  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
-  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
+  g.A = A.p; g.lda = A.ld; g.W = W.p; g.ldw = W.ld; g.C = (void*)C.p; g.ldc = C.ld; g.bias = bias; g.R = R.p; g.ldr = R.ld;
+  g.C2 = (void*)C2.p; g.ldc2 = C2.ld;
+  g.A_lo = A.lo; g.W_lo = W.lo; g.C_lo = (void*)C.lo; g.R_lo = R.lo; g.C2_lo = (void*)C2.lo;
+  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
   return tf_launch_gemm_nt(&g, c.st);
 }
 // forward projection with fp8 operands: quantise the bf16 activation per token, then the fp8 large-tile GEMM
@@ -152,7 +176,7 @@ int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const 
   if (rc != 0) return rc;
   TfGemmArgs g{};
   g.A = a8; g.lda = K; g.W = W8; g.ldw = K; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
-  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale;
+  g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
   g.fp8 = 1; g.scale_a = sa; g.scale_w = sw;
   return tf_launch_gemm_nt(&g, c.st);
 }
@@ -183,10 +207,11 @@ int guard(const Ctx& c, Side& sd, int grp) {                    // the chain is 
   if (sd.st != nullptr && sd.pending[grp]) { sd.pending[grp] = false; return (int)hipStreamWaitEvent(c.st, sd.ev[EV_DONE_A + grp], 0); }
   return 0;
 }
-int wgrad(const Ctx& c, Side& sd, const void* dY, int ldy, int N, const void* X, int ldx, int K, float* dW, int lddw, float* db,
+int wgrad(const Ctx& c, Side& sd, Buf dY, int N, Buf X, int K, float* dW, int lddw, float* db,
           int rg, int rgp, int n_src, int cg, int cgp, int k_src, bool alone = false) {
   TfWgradArgs w{};
-  w.dY = dY; w.ldy = ldy; w.X = X; w.ldx = ldx; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
+  w.dY = dY.p; w.ldy = dY.ld; w.X = X.p; w.ldx = X.ld; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
+  w.dY_lo = dY.lo; w.X_lo = X.lo;
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
   static const int tail_alone = getenv("TF_WGRAD_TAIL_ALONE") ? atoi(getenv("TF_WGRAD_TAIL_ALONE")) : 1;   // experiment switch
@@ -368,33 +393,55 @@ int pack_layer(const Ctx& c, int l, hipStream_t st) {
   const Dims& D = c.D;
   unsigned char* w = c.WB(l);
   const TfLayerParams& p = c.e->p[l];
-  TfPackArgs batch[8];
-  int nb = 0;
-  auto pack = [&](const float* src, int rows, int cols, void* dst, int ld, void* dstT, int ldT, int rows_p, int cols_p, int rg, int rgp,
-                  int cg, int cgp, int f32) {
-    TfPackArgs a{};
-    a.src = src; a.rows = rows; a.cols = cols; a.dst = dst; a.ld_dst = ld; a.dst_t = dstT; a.ld_dst_t = ldT; a.rows_p = rows_p;
-    a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32;
-    batch[nb++] = a;
-  };
-  pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0);
-  pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0);
-  pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0);
-  pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0);
-  pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1);
-  pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-  pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
-  pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-  int rc = tf_launch_pack_batch(batch, nb, st);
-  if (rc == 0 && c.e->fp8_proj) {                 // fp8 shadows of the forward projections, one scale per output channel
+  for (int residual = 0; residual <= D.split; ++residual) {      // split mode: a second launch writes the lo planes, bf16(w - bf16(w))
+    TfPackArgs batch[8];
+    int nb = 0;
+    auto pack = [&](const float* src, int rows, int cols, unsigned char* dst, int ld, unsigned char* dstT, int ldT, int rows_p, int cols_p, int rg,
+                    int rgp, int cg, int cgp, int f32) {
+      if (f32 && residual) return;                               // biases are fp32: no lo plane
+      TfPackArgs a{};
+      a.src = src; a.rows = rows; a.cols = cols; a.ld_dst = ld; a.ld_dst_t = ldT; a.rows_p = rows_p;
+      a.cols_p = cols_p; a.rg = rg; a.rgp = rgp; a.cg = cg; a.cgp = cgp; a.dst_is_f32 = f32; a.residual = residual;
+      a.dst = residual ? dst + plane((size_t)rows_p * ld * 2) : dst;
+      a.dst_t = dstT == nullptr ? nullptr : (residual ? dstT + plane((size_t)cols_p * ldT * 2) : dstT);
+      batch[nb++] = a;
+    };
+    pack(p.in_w, 3 * D.d, D.d, w + c.W.win, D.dp, w + c.W.winT, D.ldq, D.nqkv, D.dp, D.hd, D.hdp, BIG, BIG, 0);
+    pack(p.out_w, D.d, D.d, w + c.W.wo, D.dp, w + c.W.woT, D.dp, D.dp, D.dp, BIG, BIG, D.hd, D.hdp, 0);
+    pack(p.w1, D.ff, D.d, w + c.W.w1, D.dp, w + c.W.w1T, D.ffp, D.ffp, D.dp, BIG, BIG, BIG, BIG, 0);
+    pack(p.w2, D.d, D.ff, w + c.W.w2, D.ffp, w + c.W.w2T, D.dp, D.dp, D.ffp, BIG, BIG, BIG, BIG, 0);
+    pack(p.in_b, 1, 3 * D.d, w + c.W.bin, D.ldq, nullptr, 0, 1, D.nqkv, BIG, BIG, D.hd, D.hdp, 1);
+    pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+    pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
+    pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
+    const int rc = tf_launch_pack_batch(batch, nb, st);
+    if (rc != 0) return rc;
+  }
+  int rc = 0;
+  if (c.e->fp8_proj) {                 // fp8 shadows of the forward projections, one scale per output channel
     rc = tf_launch_quant_rows_fp8(w + c.W.win, D.dp, w + c.W.win8, D.dp, (float*)(w + c.W.s_in), D.nqkv, D.dp, st);
     if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w1, D.dp, w + c.W.w18, D.dp, (float*)(w + c.W.s_w1), D.ffp, D.dp, st);
     if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w2, D.ffp, w + c.W.w28, D.ffp, (float*)(w + c.W.s_w2), D.dp, D.ffp, st);
   }
   return rc;
 }
+// LayerNorm over all M rows of a [M, dp] activation
+void ln_rows(const Ctx& c, TfLnArgs& n, Buf x, const float* gamma, float* mean, float* rstd) {
+  n.x = x.p; n.x_lo = x.lo; n.ldx = x.ld; n.gamma = gamma; n.mean = mean; n.rstd = rstd;
+  n.rows = c.D.M; n.d = c.D.d; n.rows_per_group = c.D.M; n.x_group_stride = c.D.M; n.y_group_stride = c.D.M; n.eps = 1e-5f;
+}
 }  // namespace
 extern "C" {
+
+int tf_encoder_plan_ex(const TfEncoderDesc* e, TfEncoderPlan* out) {
+  Dims D;
+  if (e == nullptr || out == nullptr || (e->precision != 0 && e->precision != 1) ||
+      !make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &D, e->precision)) return fail(-1, "tf_encoder_plan_ex");
+  const WOff W = make_woff(D); const AOff A = make_aoff(D);
+  out->hd = D.hd; out->hdp = D.hdp; out->dp = D.dp; out->ffp = D.ffp; out->ldq = D.ldq; out->S = D.S; out->M = D.M;
+  out->wpack_bytes = W.stride * (size_t)D.L; out->work_bytes = A.total;
+  return 0;
+}
 
 int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s) {
   Ctx c;
@@ -407,13 +454,15 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   Ctx c;
   if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_fwd");
   const Dims& D = c.D;
-  if (e->vis == nullptr || e->lang == nullptr || e->vis_out == nullptr || e->pe == nullptr) return fail(-1, "tf_encoder_fwd(null io)");
+  if (e->vis == nullptr || e->lang == nullptr || e->vis_out == nullptr) return fail(-1, "tf_encoder_fwd(null io)");
   uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
   TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
   {
     TfAssembleArgs a{};
+    const Buf x0 = c.act_d(c.X(0));
     a.vis = e->vis; a.vis_is_f32 = e->vis_is_f32; a.ld_vis = D.d; a.lang = e->lang; a.lang_is_f32 = e->lang_is_f32; a.ld_lang = D.d;
-    a.pe = e->pe; a.kind_v = e->kind_v; a.kind_l = e->kind_l; a.out = c.X(0); a.ld_out = D.dp; a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
+    a.pe = e->pe; a.pe_lang = e->pe_lang; a.kind_v = e->kind_v; a.kind_l = e->kind_l; a.out = (void*)x0.p; a.out_lo = (void*)x0.lo; a.ld_out = D.dp;
+    a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
@@ -446,68 +495,70 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l];
     const Drop none{0u, 0u, 1.f};
+    const Buf x = c.act_d(c.X(l)), qkv = c.act_q(b + c.A.qkv), o = c.act_d(b + c.A.o), z1 = c.act_d(b + c.A.z1), x1 = c.act_d(b + c.A.x1);
+    const Buf u = c.act_f(b + c.A.u), hh = c.act_f(b + c.A.h), z2 = c.act_d(b + c.A.z2), xn = c.act_d(c.X(l + 1));
     if (e->fp8_proj)
-      TF_TRY(gemm_fp8(c, c.X(l), D.dp, D.dp, w + c.W.win8, (const float*)(w + c.W.s_in), b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin),
+      TF_TRY(gemm_fp8(c, x.p, D.dp, D.dp, w + c.W.win8, (const float*)(w + c.W.s_in), b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin),
                       nullptr, 0, nullptr, 0, D.nqkv, TF_EPI_BIAS, none), "gemm qkv (fp8)");
     else
-    TF_TRY(gemm(c, c.X(l), D.dp, w + c.W.win, D.dp, b + c.A.qkv, D.ldq, (const float*)(w + c.W.bin), nullptr, 0, nullptr, 0, D.nqkv, D.dp,
-                TF_EPI_BIAS, none), "gemm qkv");
+      TF_TRY(gemm(c, x, c.wgt(w + c.W.win, D.nqkv, D.dp), qkv, (const float*)(w + c.W.bin), NOBUF, NOBUF, D.nqkv, D.dp, TF_EPI_BIAS, none), "gemm qkv");
     {
       TfAttnArgs a{};
-      a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
-      a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);
+      a.key_mask = km; a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
       if (dr.thr && side != nullptr && l == 0) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(0)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
     }
-    TF_TRY(gemm(c, b + c.A.o, D.dp, w + c.W.wo, D.dp, b + c.A.z1, D.dp, (const float*)(w + c.W.bo), c.X(l), D.dp, nullptr, 0, D.dp, D.dp,
-                TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP1))), "gemm out_proj");
+    TF_TRY(gemm(c, o, c.wgt(w + c.W.wo, D.dp, D.dp), z1, (const float*)(w + c.W.bo), x, NOBUF, D.dp, D.dp, TF_EPI_BIAS_DROP_RES,
+                drop_for(e, e->p_token, site_of(l, SITE_DROP1))), "gemm out_proj");
     {
       TfLnArgs n{};
-      n.x = b + c.A.z1; n.ldx = D.dp; n.y = b + c.A.x1; n.ldy = D.dp; n.y_is_f32 = 0; n.gamma = p.n1_w; n.beta = p.n1_b;
-      n.mean = (float*)(b + c.A.mean1); n.rstd = (float*)(b + c.A.rstd1); n.rows = D.M; n.d = D.d; n.rows_per_group = D.M;
-      n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      ln_rows(c, n, z1, p.n1_w, (float*)(b + c.A.mean1), (float*)(b + c.A.rstd1));
+      n.y = (void*)x1.p; n.y_lo = (void*)x1.lo; n.ldy = D.dp; n.y_is_f32 = 0; n.beta = p.n1_b;
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln1_fwd");
     }
     if (e->fp8_proj) {
-      TF_TRY(gemm_fp8(c, b + c.A.x1, D.dp, D.dp, w + c.W.w18, (const float*)(w + c.W.s_w1), b + c.A.u, D.ffp, (const float*)(w + c.W.b1),
+      TF_TRY(gemm_fp8(c, x1.p, D.dp, D.dp, w + c.W.w18, (const float*)(w + c.W.s_w1), b + c.A.u, D.ffp, (const float*)(w + c.W.b1),
                       nullptr, 0, b + c.A.h, D.ffp, D.ffp, TF_EPI_BIAS_GELU_DROP_G, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up (fp8)");
-      TF_TRY(gemm_fp8(c, b + c.A.h, D.ffp, D.ffp, w + c.W.w28, (const float*)(w + c.W.s_w2), b + c.A.z2, D.dp, (const float*)(w + c.W.b2),
-                      b + c.A.x1, D.dp, nullptr, 0, D.dp, TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down (fp8)");
+      TF_TRY(gemm_fp8(c, hh.p, D.ffp, D.ffp, w + c.W.w28, (const float*)(w + c.W.s_w2), b + c.A.z2, D.dp, (const float*)(w + c.W.b2),
+                      x1.p, D.dp, nullptr, 0, D.dp, TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down (fp8)");
     } else {
-    TF_TRY(gemm(c, b + c.A.x1, D.dp, w + c.W.w1, D.dp, b + c.A.u, D.ffp, (const float*)(w + c.W.b1), nullptr, 0, b + c.A.h, D.ffp, D.ffp, D.dp,
-                TF_EPI_BIAS_GELU_DROP_G, drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");   // slot "u" holds G = d h / d u
-    TF_TRY(gemm(c, b + c.A.h, D.ffp, w + c.W.w2, D.ffp, b + c.A.z2, D.dp, (const float*)(w + c.W.b2), b + c.A.x1, D.dp, nullptr, 0, D.dp, D.ffp,
-                TF_EPI_BIAS_DROP_RES, drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down");
+      TF_TRY(gemm(c, x1, c.wgt(w + c.W.w1, D.ffp, D.dp), u, (const float*)(w + c.W.b1), NOBUF, hh, D.ffp, D.dp, TF_EPI_BIAS_GELU_DROP_G,
+                  drop_for(e, e->p_token, site_of(l, SITE_FFN))), "gemm ffn_up");   // slot "u" holds G = d h / d u
+      TF_TRY(gemm(c, hh, c.wgt(w + c.W.w2, D.dp, D.ffp), z2, (const float*)(w + c.W.b2), x1, NOBUF, D.dp, D.ffp, TF_EPI_BIAS_DROP_RES,
+                  drop_for(e, e->p_token, site_of(l, SITE_DROP2))), "gemm ffn_down");
     }
     {
       TfLnArgs n{};
-      n.x = b + c.A.z2; n.ldx = D.dp; n.y = c.X(l + 1); n.ldy = D.dp; n.y_is_f32 = 0; n.gamma = p.n2_w; n.beta = p.n2_b;
-      n.mean = (float*)(b + c.A.mean2); n.rstd = (float*)(b + c.A.rstd2); n.rows = D.M; n.d = D.d; n.rows_per_group = D.M;
-      n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
+      ln_rows(c, n, z2, p.n2_w, (float*)(b + c.A.mean2), (float*)(b + c.A.rstd2));
+      n.y = (void*)xn.p; n.y_lo = (void*)xn.lo; n.ldy = D.dp; n.y_is_f32 = 0; n.beta = p.n2_b;
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "ln2_fwd");
     }
   }
   // visual rows: final LayerNorm (cross_f_box_layers.py:104-107) or plain copy
+  const Buf xl = c.act_d(c.X(D.L));
   if (D.Nv > 0) {
     if (e->final_norm) {
       TfLnArgs n{};
-      n.x = c.X(D.L); n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
+      n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
       n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
       n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
     } else {
       TfCopyRowsArgs r{};
-      r.src = c.X(D.L); r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S;
+      r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S;
       r.dst = e->vis_out; r.dst_is_f32 = e->vis_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nv; r.dst_gstride = D.Nv; r.rows = D.B * D.Nv; r.cols = D.d;
       TF_TRY(tf_launch_copy_rows(&r, c.st), "vis_copy");
     }
   }
   if (e->lang_out != nullptr && D.Nl > 0) {
     TfCopyRowsArgs r{};
-    r.src = (const unsigned char*)c.X(D.L) + (size_t)D.Nv * D.dp * 2; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nl; r.src_gstride = D.S;
+    const size_t lang_off = (size_t)D.Nv * D.dp * 2;
+    r.src = (const unsigned char*)xl.p + lang_off; r.src_lo = xl.lo ? (const unsigned char*)xl.lo + lang_off : nullptr;
+    r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nl; r.src_gstride = D.S;
     r.dst = e->lang_out; r.dst_is_f32 = e->lang_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nl; r.dst_gstride = D.Nl; r.rows = D.B * D.Nl; r.cols = D.d;
     TF_TRY(tf_launch_copy_rows(&r, c.st), "lang_copy");
   }
@@ -519,8 +570,9 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_bwd");
   const Dims& D = c.D;
   if (e->d_vis_out == nullptr && e->d_lang_out == nullptr) return fail(-1, "tf_encoder_bwd(no cotangent)");
-  unsigned char* dxa = c.wk + c.A.dxa; unsigned char* dxb = c.wk + c.A.dxb; unsigned char* dz = c.wk + c.A.dz; unsigned char* dy = c.wk + c.A.dy;
-  unsigned char* du = c.wk + c.A.du; unsigned char* d_o = c.wk + c.A.d_o; unsigned char* dqkv = c.wk + c.A.dqkv;
+  const Buf dxa = c.act_d(c.wk + c.A.dxa), dxb = c.act_d(c.wk + c.A.dxb), dz = c.act_d(c.wk + c.A.dz), dy = c.act_d(c.wk + c.A.dy);
+  const Buf dzb = c.act_d(c.wk + c.A.dzb), dyb = c.act_d(c.wk + c.A.dyb), du = c.act_f(c.wk + c.A.du), d_o = c.act_d(c.wk + c.A.d_o);
+  const Buf dqkv = c.act_q(c.wk + c.A.dqkv);
   float* delta = (float*)(c.wk + c.A.delta);
   const uint8_t* km = (const uint8_t*)(c.wk + c.A.keymask);
   const int l_hi = e->bwd_nlayers > 0 ? e->bwd_hi : D.L - 1;
@@ -536,80 +588,85 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (head && D.Nv > 0) {
     if (e->final_norm && e->d_vis_out != nullptr) {
       TfLnArgs n{};
-      n.x = c.X(D.L); n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
+      const Buf xl = c.act_d(c.X(D.L));
+      n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
       n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
-      n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = dxa; n.lddx = D.dp; n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
+      n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = (void*)dxa.p; n.dx_lo = (void*)dxa.lo; n.lddx = D.dp;
+      n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
     } else {
       TfCopyRowsArgs r{};
       r.src = e->d_vis_out; r.src_is_f32 = e->d_vis_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nv; r.src_gstride = D.Nv;
-      r.dst = dxa; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
+      r.dst = (void*)dxa.p; r.dst_lo = (void*)dxa.lo; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
       TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
     }
   }
   if (head && D.Nl > 0) {
     TfCopyRowsArgs r{};
+    const size_t lang_off = (size_t)D.Nv * D.dp * 2;
     r.src = e->d_lang_out; r.src_is_f32 = e->d_lang_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nl; r.src_gstride = D.Nl;
-    r.dst = dxa + (size_t)D.Nv * D.dp * 2; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nl; r.dst_gstride = D.S; r.rows = D.B * D.Nl; r.cols = D.d;
+    r.dst = (unsigned char*)dxa.p + lang_off; r.dst_lo = dxa.lo ? (unsigned char*)dxa.lo + lang_off : nullptr;
+    r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nl; r.dst_gstride = D.S; r.rows = D.B * D.Nl; r.cols = D.d;
     TF_TRY(tf_launch_copy_rows(&r, c.st), "dlang_copy");
   }
   const float scale = 1.0f / sqrtf((float)D.hd);
   const Drop none{0u, 0u, 1.f};
-  unsigned char* dzb = c.wk + c.A.dzb; unsigned char* dyb = c.wk + c.A.dyb;
   for (int l = l_hi; l >= l_lo; --l) {
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l]; const TfLayerParams& g = e->g[l];
+    const Buf x = c.act_d(c.X(l)), qkv = c.act_q(b + c.A.qkv), o = c.act_d(b + c.A.o), z1 = c.act_d(b + c.A.z1), x1 = c.act_d(b + c.A.x1);
+    const Buf u = c.act_f(b + c.A.u), hh = c.act_f(b + c.A.h), z2 = c.act_d(b + c.A.z2);
     // ---- LN2 backward: dxa -> dz (= d z2), dy (= dropout2-masked) ----
     const Drop d2 = drop_for(e, e->p_token, site_of(l, SITE_DROP2));
     TF_TRY(guard(c, sd, 0), "guard A");                      // previous layer's linear2 / linear1 wgrads read dy / dz / du
     {
       TfLnArgs n{};
-      n.x = b + c.A.z2; n.ldx = D.dp; n.gamma = p.n2_w; n.mean = (float*)(b + c.A.mean2); n.rstd = (float*)(b + c.A.rstd2);
-      n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
-      n.dy = dxa; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dz; n.lddx = D.dp; n.dgamma = g.n2_w; n.dbeta = g.n2_b;
-      if (d2.thr) { n.dx_drop = dy; n.lddxd = D.dp; n.drop_thr = d2.thr; n.drop_key = d2.key; n.drop_scale = d2.scale; n.drop_ld = D.dp; }
+      ln_rows(c, n, z2, p.n2_w, (float*)(b + c.A.mean2), (float*)(b + c.A.rstd2));
+      n.dy = dxa.p; n.dy_lo = dxa.lo; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = (void*)dz.p; n.dx_lo = (void*)dz.lo; n.lddx = D.dp;
+      n.dgamma = g.n2_w; n.dbeta = g.n2_b;
+      if (d2.thr) { n.dx_drop = (void*)dy.p; n.dx_drop_lo = (void*)dy.lo; n.lddxd = D.dp; n.drop_thr = d2.thr; n.drop_key = d2.key; n.drop_scale = d2.scale; n.drop_ld = D.dp; }
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln2_bwd");
     }
-    const unsigned char* dy2 = d2.thr ? dy : dz;
-    TF_TRY(gemm(c, dy2, D.dp, w + c.W.w2T, D.dp, du, D.ffp, nullptr, b + c.A.u, D.ffp, nullptr, 0, D.ffp, D.dp, TF_EPI_MUL, none),
+    const Buf dy2 = d2.thr ? dy : dz;
+    TF_TRY(gemm(c, dy2, c.wgt(w + c.W.w2T, D.ffp, D.dp), du, nullptr, u, NOBUF, D.ffp, D.dp, TF_EPI_MUL, none),
            "dgrad ffn_down");                                 // dU = dH . G (G stored by the forward FFN-up epilogue)
     TF_TRY(side_fork(c, sd, EV_FORK_A), "fork A");
-    TF_TRY(wgrad(c, sd, dy2, D.dp, D.dp, b + c.A.h, D.ffp, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
-    TF_TRY(wgrad(c, sd, du, D.ffp, D.ffp, b + c.A.x1, D.dp, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
+    TF_TRY(wgrad(c, sd, dy2, D.dp, hh, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
+    TF_TRY(wgrad(c, sd, du, D.ffp, x1, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
     TF_TRY(side_done(sd, 0), "done A");
-    TF_TRY(gemm(c, du, D.ffp, w + c.W.w1T, D.ffp, dxb, D.dp, nullptr, dz, D.dp, nullptr, 0, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
+    TF_TRY(gemm(c, du, c.wgt(w + c.W.w1T, D.dp, D.ffp), dxb, nullptr, dz, NOBUF, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
     // ---- LN1 backward: dxb -> dzb (= d z1), dyb (= dropout1-masked) ----
     const Drop d1 = drop_for(e, e->p_token, site_of(l, SITE_DROP1));
     TF_TRY(guard(c, sd, 1), "guard I");                      // previous layer's out_proj / in_proj wgrads read dyb / dzb / dqkv
     {
       TfLnArgs n{};
-      n.x = b + c.A.z1; n.ldx = D.dp; n.gamma = p.n1_w; n.mean = (float*)(b + c.A.mean1); n.rstd = (float*)(b + c.A.rstd1);
-      n.rows = D.M; n.d = D.d; n.rows_per_group = D.M; n.x_group_stride = D.M; n.y_group_stride = D.M; n.eps = 1e-5f;
-      n.dy = dxb; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = dzb; n.lddx = D.dp; n.dgamma = g.n1_w; n.dbeta = g.n1_b;
-      if (d1.thr) { n.dx_drop = dyb; n.lddxd = D.dp; n.drop_thr = d1.thr; n.drop_key = d1.key; n.drop_scale = d1.scale; n.drop_ld = D.dp; }
+      ln_rows(c, n, z1, p.n1_w, (float*)(b + c.A.mean1), (float*)(b + c.A.rstd1));
+      n.dy = dxb.p; n.dy_lo = dxb.lo; n.lddy = D.dp; n.dy_is_f32 = 0; n.dx = (void*)dzb.p; n.dx_lo = (void*)dzb.lo; n.lddx = D.dp;
+      n.dgamma = g.n1_w; n.dbeta = g.n1_b;
+      if (d1.thr) { n.dx_drop = (void*)dyb.p; n.dx_drop_lo = (void*)dyb.lo; n.lddxd = D.dp; n.drop_thr = d1.thr; n.drop_key = d1.key; n.drop_scale = d1.scale; n.drop_ld = D.dp; }
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln1_bwd");
     }
-    const unsigned char* dy1 = d1.thr ? dyb : dzb;
+    const Buf dy1 = d1.thr ? dyb : dzb;
     TF_TRY(side_fork(c, sd, EV_FORK_O), "fork O");
-    TF_TRY(wgrad(c, sd, dy1, D.dp, D.dp, b + c.A.o, D.dp, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
-    TF_TRY(gemm(c, dy1, D.dp, w + c.W.woT, D.dp, d_o, D.dp, nullptr, nullptr, 0, nullptr, 0, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
+    TF_TRY(wgrad(c, sd, dy1, D.dp, o, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
+    TF_TRY(gemm(c, dy1, c.wgt(w + c.W.woT, D.dp, D.dp), d_o, nullptr, NOBUF, NOBUF, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
     {
       TfAttnArgs a{};
-      a.qkv = b + c.A.qkv; a.ld_qkv = D.ldq; a.out = b + c.A.o; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse); a.key_mask = km;
-      a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);
+      a.key_mask = km; a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
-      a.dout = d_o; a.ld_dout = D.dp; a.dqkv = dqkv; a.ld_dqkv = D.ldq; a.delta = delta;
+      a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
     TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
-    TF_TRY(wgrad(c, sd, dqkv, D.ldq, D.nqkv, c.X(l), D.dp, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
+    TF_TRY(wgrad(c, sd, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
     TF_TRY(side_done(sd, 1), "done I");
-    TF_TRY(gemm(c, dqkv, D.ldq, w + c.W.winT, D.ldq, dxa, D.dp, nullptr, dzb, D.dp, nullptr, 0, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
+    TF_TRY(gemm(c, dqkv, c.wgt(w + c.W.winT, D.dp, D.ldq), dxa, nullptr, dzb, NOBUF, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
   if (tail) {
     TfAssembleArgs a{};
-    a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa; a.ld_dout = D.dp;
+    a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa.p; a.dout_lo = dxa.lo; a.ld_dout = D.dp;
     a.dvis = e->d_vis; a.dvis_is_f32 = e->d_vis_is_f32; a.ld_dvis = D.d; a.dlang = e->d_lang; a.dlang_is_f32 = e->d_lang_is_f32; a.ld_dlang = D.d;
     a.dkind_v = e->g_kind_v; a.dkind_l = e->g_kind_l;
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
@@ -631,25 +688,28 @@ long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, 
   Ctx c;
   if (name == nullptr || dst == nullptr || !make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_peek");
   const Dims& D = c.D;
-  const void* src = nullptr; long long cols = 0;
+  const void* src = nullptr; long long cols = 0; size_t pl = 0;
   int l = 0;
   auto lb = [&](size_t off) { return (const void*)(c.LB(l) + off); };
-  if (sscanf(name, "qkv%d", &l) == 1) { src = lb(c.A.qkv); cols = D.ldq; }
-  else if (sscanf(name, "z1_%d", &l) == 1) { src = lb(c.A.z1); cols = D.dp; }
-  else if (sscanf(name, "x1_%d", &l) == 1) { src = lb(c.A.x1); cols = D.dp; }
-  else if (sscanf(name, "z2_%d", &l) == 1) { src = lb(c.A.z2); cols = D.dp; }
-  else if (sscanf(name, "x%d", &l) == 1) { if (l < 0 || l > D.L) return fail(-1, "peek"); src = c.X(l); cols = D.dp; l = 0; }
-  else if (sscanf(name, "o%d", &l) == 1) { src = lb(c.A.o); cols = D.dp; }
-  else if (sscanf(name, "u%d", &l) == 1) { src = lb(c.A.u); cols = D.ffp; }
-  else if (sscanf(name, "h%d", &l) == 1) { src = lb(c.A.h); cols = D.ffp; }
-  else if (strcmp(name, "dqkv") == 0) { src = c.wk + c.A.dqkv; cols = D.ldq; }
-  else if (strcmp(name, "dxa") == 0) { src = c.wk + c.A.dxa; cols = D.dp; }
-  else if (strcmp(name, "do") == 0) { src = c.wk + c.A.d_o; cols = D.dp; }
+  if (sscanf(name, "qkv%d", &l) == 1) { src = lb(c.A.qkv); cols = D.ldq; pl = c.pq; }
+  else if (sscanf(name, "z1_%d", &l) == 1) { src = lb(c.A.z1); cols = D.dp; pl = c.pd; }
+  else if (sscanf(name, "x1_%d", &l) == 1) { src = lb(c.A.x1); cols = D.dp; pl = c.pd; }
+  else if (sscanf(name, "z2_%d", &l) == 1) { src = lb(c.A.z2); cols = D.dp; pl = c.pd; }
+  else if (sscanf(name, "x%d", &l) == 1) { if (l < 0 || l > D.L) return fail(-1, "peek"); src = c.X(l); cols = D.dp; pl = c.pd; l = 0; }
+  else if (sscanf(name, "o%d", &l) == 1) { src = lb(c.A.o); cols = D.dp; pl = c.pd; }
+  else if (sscanf(name, "u%d", &l) == 1) { src = lb(c.A.u); cols = D.ffp; pl = c.pf; }
+  else if (sscanf(name, "h%d", &l) == 1) { src = lb(c.A.h); cols = D.ffp; pl = c.pf; }
+  else if (strcmp(name, "dqkv") == 0) { src = c.wk + c.A.dqkv; cols = D.ldq; pl = c.pq; }
+  else if (strcmp(name, "dxa") == 0) { src = c.wk + c.A.dxa; cols = D.dp; pl = c.pd; }
+  else if (strcmp(name, "do") == 0) { src = c.wk + c.A.d_o; cols = D.dp; pl = c.pd; }
   else return fail(-1, "tf_encoder_peek(name)");
   if (l < 0 || l >= D.L) return fail(-1, "tf_encoder_peek(layer)");
   const long long n = (long long)D.M * cols;
   if (n > cap) return fail(-1, "tf_encoder_peek(cap)");
-  TF_TRY(tf_launch_cast_bf16_f32(src, dst, n, c.st), "peek cast");
+  TfCopyRowsArgs r{};                                   // bf16 (hi + lo in the fp32-accuracy mode) -> fp32
+  r.src = src; r.src_lo = c.lo(src, pl); r.src_is_f32 = 0; r.ld_src = (int)cols; r.src_rpg = D.M; r.src_gstride = D.M;
+  r.dst = dst; r.dst_is_f32 = 1; r.ld_dst = (int)cols; r.dst_rpg = D.M; r.dst_gstride = D.M; r.rows = D.M; r.cols = (int)cols;
+  TF_TRY(tf_launch_copy_rows(&r, c.st), "peek copy");
   return n;
 }
 

@@ -50,6 +50,38 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
   return v;
 }
 
+// ---- hi + lo bf16 plane pairs (fp32-accuracy mode): value = float(hi) + float(lo), 16 significant bits --------------
+__device__ __forceinline__ void split8(const float (&f)[8], u32x4& hi, u32x4& lo) {
+  float r[8];
+  hi = pack8(f);
+  unpack8(hi, r);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = f[e] - r[e];      // exact in fp32
+  lo = pack8(r);
+}
+__device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&f)[8]) {
+  float l[8];
+  unpack8(hi, f);
+  unpack8(lo, l);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] += l[e];
+}
+// 8 values of a bf16 tensor with an optional lo plane at the same element offset
+__device__ __forceinline__ void load8_split(const void* hi, const void* lo, size_t off, float (&f)[8]) {
+  if (lo != nullptr) join8(*(const u32x4*)((const u16*)hi + off), *(const u32x4*)((const u16*)lo + off), f);
+  else unpack8(*(const u32x4*)((const u16*)hi + off), f);
+}
+__device__ __forceinline__ void store8_split(void* hi, void* lo, size_t off, const float (&f)[8]) {
+  if (lo != nullptr) {
+    u32x4 h, l;
+    split8(f, h, l);
+    *(u32x4*)((u16*)hi + off) = h;
+    *(u32x4*)((u16*)lo + off) = l;
+  } else {
+    *(u32x4*)((u16*)hi + off) = pack8(f);
+  }
+}
+
 // ---- counter-based dropout RNG ----------------------------------------------------------------
 // keep(idx) is a pure function of (key, element index): forward and backward regenerate the same mask from
 // the element's logical index whatever the fragment layout, and tests can replay it (tf_dropout_mask).

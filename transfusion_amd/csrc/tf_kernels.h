@@ -11,6 +11,8 @@ int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
 int tf_wgrad_tiles(int N, int K, int caller_sized);                // output tiles of the wgrad kernel that will run
 int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t stream);
+int tf_launch_attn_fwd_x3(const TfAttnArgs* a, hipStream_t stream);    // fp32-accuracy mode (attn_x3.hip); reached through the two above
+int tf_launch_attn_bwd_x3(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t stream);
 int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t stream);
 int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t stream);

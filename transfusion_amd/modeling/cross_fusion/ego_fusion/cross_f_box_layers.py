@@ -192,8 +192,9 @@ class CrossTransformerModuleBox(nn.Module):
         self.dim_feedforward = int(self.token_dim * fforward_multiplier)
         self.register_buffer("padding_mask", torch.zeros(size=(1,), dtype=torch.bool))
 
-        if activ_f != "gelu":
-            raise NotImplementedError(f"activ_f={activ_f!r}: the HIP FFN epilogue implements exact GELU (the shipped configs' choice)")
+        if activ_f not in ("gelu", "relu"):          # nn.TransformerEncoderLayer's _get_activation_fn accepts exactly these two
+            raise RuntimeError("activation should be relu/gelu, not {}".format(activ_f))
+        self.activ_f = activ_f
         if self.token_dim % num_heads or self.token_dim % 8:
             raise ValueError(f"input_f_size={self.token_dim} must be divisible by num_heads={num_heads} and by 8")
         if num_layers > L.TF_MAX_LAYERS:
@@ -211,6 +212,9 @@ class CrossTransformerModuleBox(nn.Module):
         # runtime state (not part of state_dict)
         self.accumulate_into_grad = False     # True: backward adds straight into p.grad (flat-buffer training loop)
         self.fp8_projections = os.environ.get("TF_FP8_PROJ") == "1"   # forward QKV / FFN GEMMs with fp8 (e4m3) operands (BASELINE configs[4])
+        # "bf16": bf16 compute (run.precision 16 / bf16).  "fp32": the fp32-accuracy mode for run.precision: 32 (Ego4Dv2 YAML, BASELINE
+        # configs[2]): hi + lo bf16 planes, three MFMA passes per contraction (include/tfusion.h, TfEncoderDesc.precision)
+        self.precision = os.environ.get("TF_PRECISION", "bf16")
         self.layer_grad_hook = None           # callable(module, layer): called as soon as that layer's gradients are enqueued
         self._wpack = None
         self._wpack_versions = None
@@ -225,12 +229,10 @@ class CrossTransformerModuleBox(nn.Module):
             ps += [sd[name] for _, name in _LAYER_FIELDS]
         if self.final_norm == "ln":
             ps += [self.final_norm_layer.weight, self.final_norm_layer.bias]
-        if isinstance(self.pos_embedding_layer.pos_embedding, nn.Parameter):
-            raise NotImplementedError("learned positional embeddings: only the sin1d buffer is wired into the assemble kernel")
         return ps
 
     def _wpack_dirty(self) -> bool:
-        vers = tuple((p.data_ptr(), p._version) for p in self._param_list()) + (bool(self.fp8_projections),)
+        vers = tuple((p.data_ptr(), p._version) for p in self._param_list()) + (bool(self.fp8_projections), self.precision)
         if vers != self._wpack_versions:
             self._wpack_versions = vers
             return True
@@ -260,21 +262,25 @@ class CrossTransformerModuleBox(nn.Module):
         Nl = lang.shape[1]
         if d != self.token_dim or lang.shape[2] != d or lang.shape[0] != B:
             raise RuntimeError(f"token shapes {tuple(x.shape)} / {tuple(lang.shape)} do not match input_f_size={self.token_dim}")
-        if Nv > self.pos_embedding_layer.pos_embedding.shape[1]:
-            raise RuntimeError(f"{Nv} visual tokens exceed the positional table ({self.pos_embedding_layer.pos_embedding.shape[1]})")
         for p in self._param_list():
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise L.TfError("parameters must be contiguous fp32 (bf16 shadows are derived inside the runtime)")
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision={self.precision!r}: 'bf16' or 'fp32'")
+        if self.precision == "fp32" and self.fp8_projections:
+            raise ValueError("fp8_projections and precision='fp32' exclude each other")
         lib = L.load()
+        e = L.TfEncoderDesc()
+        e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward
+        e.precision = 1 if self.precision == "fp32" else 0
+        e.act = 1 if self.activ_f == "relu" else 0
         plan = L.TfEncoderPlan()
-        L.check(lib.tf_encoder_plan(B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward, C.byref(plan)), "tf_encoder_plan")
+        L.check(lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(plan)), "tf_encoder_plan_ex")
         if self._wpack is None or self._wpack.numel() != plan.wpack_bytes or self._wpack.device != x.device:
             self._wpack = torch.zeros(plan.wpack_bytes, dtype=torch.uint8, device=x.device)
             self._wpack_versions = None
-        keep = self._get_work((B, Nv, Nl), plan, x.device)
+        keep = self._get_work((B, Nv, Nl, self.precision), plan, x.device)
         keep["busy"] = True
-        e = L.TfEncoderDesc()
-        e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward
         e.training = 1 if self.training else 0
         e.final_norm = 1 if self.final_norm == "ln" else 0
         e.fp8_proj = 1 if self.fp8_projections else 0
@@ -288,10 +294,14 @@ class CrossTransformerModuleBox(nn.Module):
         e.kind_v, e.kind_l = self.image_kind_embedding.data_ptr(), self.lang_kind_embedding.data_ptr()
         if e.final_norm:
             e.fn_w, e.fn_b = self.final_norm_layer.weight.data_ptr(), self.final_norm_layer.bias.data_ptr()
+        # positional tables: the sin1d BUFFERS are read by the assemble kernel; learned / zero tables are Parameters (utils.py:181-184)
+        # whose gradient autograd needs, so forward() has already added those with a torch op and they are not passed here
         pe = self.pos_embedding_layer.pos_embedding
-        if pe.dtype != torch.float32 or not pe.is_contiguous():
-            raise L.TfError("pos_embedding must be contiguous fp32")
-        e.pe = pe.data_ptr()
+        if not isinstance(pe, nn.Parameter):
+            e.pe = self._table(pe, Nv, d, "pos_embedding")
+        lpe = None if not self.lang_pos_embedding else self.lang_pos_embedding.pos_embedding
+        if lpe is not None and not isinstance(lpe, nn.Parameter):
+            e.pe_lang = self._table(lpe, Nl, d, "lang_pos_embedding")
         e.wpack, e.work = self._wpack.data_ptr(), keep["work"].data_ptr()
         bb = getattr(self, "_block_bits", None)
         if bb is not None:
@@ -317,6 +327,14 @@ class CrossTransformerModuleBox(nn.Module):
             keep["mask"] = m8
             e.lang_pad_mask = m8.data_ptr()
         return e, keep
+
+    @staticmethod
+    def _table(pe, n, d, what):
+        if pe.dim() != 3 or pe.shape[1] < n or pe.shape[2] != d:
+            raise RuntimeError(f"{n} tokens exceed the {what} table {tuple(pe.shape)}")
+        if pe.dtype != torch.float32 or not pe.is_contiguous():
+            raise L.TfError(f"{what} must be contiguous fp32")
+        return pe.data_ptr()
 
     def _bind_grads(self, desc, device):
         """Point the runtime's gradient slots either at fresh zero buffers (returned through autograd) or,
@@ -356,8 +374,13 @@ class CrossTransformerModuleBox(nn.Module):
 
     # ---- reference forward contract (cross_f_box_layers.py:69-108) --------------------------------------
     def forward(self, x, language_tokens, language_tokens_att_maks, vis_tokens_mask=None):
-        if self.lang_pos_embedding:
-            raise NotImplementedError("lang_pos_embedding is not used by the shipped configs")
+        # learned / zero positional tables are Parameters: added here by torch so that autograd produces their gradient (the
+        # kernel then adds nothing for that table); the default sin1d buffers go into the assemble kernel
+        if isinstance(self.pos_embedding_layer.pos_embedding, nn.Parameter):
+            x = self.pos_embedding_layer(x)
+        if self.lang_pos_embedding and isinstance(self.lang_pos_embedding.pos_embedding, nn.Parameter):
+            # reference order (:76-78): (lang + kind) + pe; here (lang + pe) + kind -- the same sum up to fp32 rounding
+            language_tokens = self.lang_pos_embedding(language_tokens)
         self._block_bits = None
         if vis_tokens_mask is not None:
             self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)
@@ -390,7 +413,7 @@ class CrossTransformerModuleBox(nn.Module):
         desc, keep = desc_keep
         lib = L.load()
         plan = L.TfEncoderPlan()
-        L.check(lib.tf_encoder_plan(desc.B, desc.Nv, desc.Nl, desc.d, desc.H, desc.L, desc.ff, C.byref(plan)), "plan")
+        L.check(lib.tf_encoder_plan_ex(C.addressof(desc), C.addressof(plan)), "plan")
         cap = plan.M * max(plan.ldq, plan.ffp, plan.dp)
         buf = torch.empty(cap, dtype=torch.float32, device=keep["work"].device)
         n = lib.tf_encoder_peek(C.byref(desc), name.encode(), buf.data_ptr(), cap, ops._stream())

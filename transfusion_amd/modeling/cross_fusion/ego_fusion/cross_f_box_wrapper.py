@@ -93,6 +93,14 @@ class CrossFusionBoxWrapper(nn.Module):
         self.use_lm_f = self.cross_encoder_args["lm_args"].get("use_lm_f", False)
         self.multi_lm = self.cross_encoder_args["lm_args"].get("multi", False) and self.lm_on and not self.use_lm_f
 
+    def set_precision(self, precision):
+        """``run.precision`` of the reference's run YAML (run_experiment.py:450): 32 -> the fp32-accuracy mode of the fusion encoders
+        (Ego4Dv2 YAML), 16 / "bf16" -> bf16 compute (the Ego4Dv1 YAML's 16 is fp16 autocast in the reference)."""
+        mode = "fp32" if str(precision) in ("32", "32-true", "fp32") else "bf16"
+        for enc in self.cross_fusion_encoders:
+            enc.precision = mode
+        return mode
+
     def setup_cross_fusion_encoders(self, cross_encoder_args):
         cross_fusion_encoders = []
         cross_encoder_clzz = get_cross_box_encoder(
@@ -103,11 +111,12 @@ class CrossFusionBoxWrapper(nn.Module):
             all_num_layers = [all_num_layers] * len(self.dsampled_shapes)
         for i in range(len(self.dsampled_shapes)):
             pos_embedding_layer = PositionalEmbeddingLayer(cross_encoder_args["pos_embedding"], MAX_NUM_PATCHES, self.token_dim)
+            lang_pos_embedding_layer = None
             if cross_encoder_args.get("lang_pos_embedding", False):
-                raise NotImplementedError("lang_pos_embedding is not used by the shipped configs")
+                lang_pos_embedding_layer = PositionalEmbeddingLayer(cross_encoder_args["lang_pos_embedding"]["embedding_type"], 256, self.token_dim)
             cross_fusion_encoders.append(
-                cross_encoder_clzz(no_patches=MAX_NUM_PATCHES, pos_embedding_layer=pos_embedding_layer, lang_pos_embedding=None,
-                                   num_layers=all_num_layers[i], **cross_encoder_args["args"])
+                cross_encoder_clzz(no_patches=MAX_NUM_PATCHES, pos_embedding_layer=pos_embedding_layer,
+                                   lang_pos_embedding=lang_pos_embedding_layer, num_layers=all_num_layers[i], **cross_encoder_args["args"])
             )
         return cross_fusion_encoders
 

@@ -14,8 +14,11 @@ def get_fusion_model(base_model, model_cfg, run_cfg, class_sizes):
                 if run_cfg["narr_fusion"]["share_encoders"]:
                     raise NotImplementedError("share_encoders: True (CrossFusionBoxWrapperShared) is broken in the reference "
                                               "(cross_f_box_wrapper.py:307) and out of scope")
-                return CrossFusionBoxWrapper(base_model, run_cfg["narr_fusion"], narr_embed_args=run_cfg["narration_embeds"]["args"],
-                                             criterion=run_cfg["criterion"])
+                model = CrossFusionBoxWrapper(base_model, run_cfg["narr_fusion"], narr_embed_args=run_cfg["narration_embeds"]["args"],
+                                              criterion=run_cfg["criterion"])
+                # the reference hands run.precision to pl.Trainer (run_experiment.py:450); here it selects the encoders' arithmetic
+                model.set_precision(run_cfg.get("precision", 32))
+                return model
             raise NotImplementedError("only experiment: egonao reaches the fusion block (runner/utils/factories.py:11-20)")
         raise NotImplementedError(f'{run_cfg["narr_fusion"]["model"]=} is not implemented as fusion model.')
     return base_model

@@ -93,16 +93,28 @@ def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, w
     return dst, dst_t
 
 
-def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0), scale_a=None, scale_w=None):
+def split_planes(x: torch.Tensor):
+    """fp32 tensor -> (hi, lo) bf16 planes with hi + lo == x to 16 significant bits: the operand format of the fp32-accuracy
+    mode (include/tfusion.h, TfGemmArgs.A_lo).  Plain torch ops: a host-side helper for tests and stand-alone callers; the encoder
+    runtime produces its planes inside its own kernels."""
+    hi = x.to(torch.bfloat16)
+    lo = (x.float() - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0), scale_a=None, scale_w=None, act=0,
+         A_lo=None, W_lo=None, C_lo=None, R_lo=None, C2_lo=None):
     """C = epilogue(A @ W^T).  A / W are bf16, or -- when ``scale_a`` / ``scale_w`` are given -- uint8 tensors of OCP e4m3
-    values from ``quant_rows_fp8`` (fp8 MFMA, fp32 accumulate, result scaled per row and per output channel)."""
+    values from ``quant_rows_fp8`` (fp8 MFMA, fp32 accumulate, result scaled per row and per output channel), or -- with the
+    ``*_lo`` planes -- hi + lo bf16 pairs (fp32-accuracy mode: three MFMA passes, fp32 epilogue, hi + lo outputs)."""
     fp8 = scale_a is not None or scale_w is not None
     g = L.TfGemmArgs(A=L.ptr(A), lda=A.stride(0), W=L.ptr(W), ldw=W.stride(0), C=L.ptr(C_out), ldc=C_out.stride(0),
                      bias=L.ptr(bias), R=L.ptr(R), ldr=0 if R is None else R.stride(0), C2=L.ptr(C2),
                      ldc2=0 if C2 is None else C2.stride(0), M=A.shape[0], N=N, K=K,
                      epilogue=L.TF_EPI_NONE if epilogue is None else epilogue,
                      drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
-                     fp8=1 if fp8 else 0, scale_a=L.ptr(scale_a), scale_w=L.ptr(scale_w))
+                     fp8=1 if fp8 else 0, scale_a=L.ptr(scale_a), scale_w=L.ptr(scale_w), act=act,
+                     A_lo=L.ptr(A_lo), W_lo=L.ptr(W_lo), C_lo=L.ptr(C_lo), R_lo=L.ptr(R_lo), C2_lo=L.ptr(C2_lo))
     L.call("tf_gemm_fwd", g, _stream())
 
 
@@ -178,8 +190,9 @@ def _zeros256(device):
     return z
 
 
-def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0):
+def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0, dY_lo=None, X_lo=None):
     w = L.TfWgradArgs(dY=L.ptr(dY), ldy=dY.stride(0), X=L.ptr(X), ldx=X.stride(0), dW=L.ptr(dW), lddw=dW.stride(0), db=L.ptr(db),
+                      dY_lo=L.ptr(dY_lo), X_lo=L.ptr(X_lo),
                       zeros=L.ptr(_zeros256(dY.device)), M=dY.shape[0], N=N, K=K, rg=rg, rgp=rgp,
                       n_src=dW.shape[0] if n_src is None else n_src, cg=cg, cgp=cgp,
                       k_src=dW.shape[1] if k_src is None else k_src, m_chunk=m_chunk)
