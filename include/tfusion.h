@@ -195,6 +195,34 @@ typedef struct TfLmPoolArgs {
   float* scratch;                    // backward work [2, B, d] fp32, when ln_w != null
 } TfLmPoolArgs;
 
+// RoI heads' losses.  The four Linears (faster_rcnn_wrapper.py:93-100: box_regressor, noun_classifier,
+// verb_classifier; roi_wrappers.py:306: ttc_pred_layer) are tf_gemm_fwd calls: `box` = box_regression [R, 4*Cn] and `cls` =
+// noun | verb | ttc pre-activation concatenated [R, Cn + Cv + 1 (+ pad)], both bf16 (+ lo plane in the fp32-accuracy mode).
+// One wave per RoI then computes, from one read of its logits (reference lines in csrc/heads.hip):
+//   box  = sum over positive RoIs (noun label > 0) of smooth_l1(box[r, 4y..4y+3] - reg_targets[r], beta 1/9) / max(R, 1)
+//   noun = class-weighted mean CE of (logits + 1e-6);  verb = the same with background RoIs (label == verb_ignore) mapped to the last
+//          class (verb_bg) or dropped;  ttc = mean smooth_l1(ttcs - target, ttc_beta) over non-background RoIs (or, ttc_bg, all RoIs
+//          with background targets replaced by ttc_bg_val);  ttcs = softplus(cls[:, Cn + Cv]) (tf_softplus_col).
+typedef struct TfHeadsLossArgs {
+  const void* cls; const void* cls_lo; int ld_cls;
+  const void* box; const void* box_lo; int ld_box;      // box == null: no box loss
+  const float* ttcs;                                     // [R] fp32 softplus outputs, or null: no TTC loss
+  int R, Cn, Cv;
+  const long long* noun_labels;                          // [R] int64, 0 = background
+  const long long* verb_labels;                          // [R] int64 (verb_ignore = background), or null
+  const float* ttc_targets;                              // [R] fp32
+  const float* reg_targets;                              // [R, 4] fp32
+  const float* noun_w; const float* verb_w;              // class weights [Cn] / [Cv]; null switches that head's loss off
+  long long verb_ignore; int verb_bg; int ttc_bg; float ttc_bg_val; float ttc_beta; float box_beta;
+  float* sums;                                           // [8] fp32, zeroed by the caller: numerators / normalisers, kept for the backward
+  float* lse;                                            // [2, R] fp32 work: log-sum-exp of the noun / verb rows, kept for the backward
+  float* losses;                                         // forward out [4]: box, noun, verb, ttc
+  const float* gscale;                                   // backward in [4]: d(total) / d(box, noun, verb, ttc loss)
+  void* d_cls; void* d_cls_lo;                           // backward out, layout of cls (every column written; ttc column and pad zero)
+  void* d_box; void* d_box_lo;                           // backward out, layout of box (every column written)
+  float* d_ttcs;                                         // backward out [R]: d(total) / d(ttcs)
+} TfHeadsLossArgs;
+
 // patch <-> token permutations for K1 / K9
 typedef struct TfPatchArgs {
   const void* feat; int feat_is_f32;     // [B,C,H,W]
@@ -228,6 +256,8 @@ const char* tf_last_error(void);
  * tf_regroup_*       cross_fusion/utils.py:42-46 (regroup_patches: transpose + F.fold, kernel == stride)
  * tf_radam_step      runner/metrics_losses/radam_optim.py:30-104
  * tf_lm_pool_*       ego_fusion/lm_layers.py:59-72 (PoolPredictor: masked mean/max pooling, LayerNorm, GELU)
+ * tf_heads_loss_*    runner/metrics_losses/losses.py:98-135 (box_loss), runner/nao/ego_nao_trainer.py:307-359 (noun / verb CE, TTC)
+ * tf_softplus_col    modeling/obj_detection/roi_wrappers.py:228-229 (ttcs = softplus(ttc_pred_layer(box_features)))
  */
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
@@ -245,6 +275,11 @@ int tf_pack_weight(const TfPackArgs* a, tf_stream_t s);
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s);
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s);
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
+int tf_heads_loss_fwd(const TfHeadsLossArgs* a, tf_stream_t s);
+int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s);
+/* dy == null: y[r] = softplus(x[r, col]) (F.softplus defaults, roi_wrappers.py:229); dy != null: dx[r, col] += dy[r] * sigmoid(x[r, col]).
+ * x / dx: bf16 [R, ld] (+ lo planes or null) */
+int tf_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, const float* dy, void* dx, void* dx_lo, int R, tf_stream_t s);
 int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s);
 int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s);
 /* y = dropout(x) over a dense bf16 array of n (multiple of 8) elements; the same call is its backward (utils.py:115) */

@@ -282,3 +282,73 @@ def radam_step(p: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_a
             p = p + (-weight_decay * lr) * p
         p = p + (-step_size * lr) * exp_avg
     return p, exp_avg, exp_avg_sq
+
+
+# ----------------------------------------------------------------------------
+# RoI heads and their losses
+# ----------------------------------------------------------------------------
+def nao_heads_forward(sd: Dict[str, torch.Tensor], box_features: torch.Tensor, keep_box: Optional[torch.Tensor] = None,
+                      keep_cls: Optional[torch.Tensor] = None, p_box: float = 0.0, p_cls: float = 0.0):
+    """modeling/obj_detection/roi_wrappers.py:204-231 on box features [R, repr] (after box_head), with the heads of
+    faster_rcnn_wrapper.py:93-100: box_regressor = Dropout(box_2_dropout) -> Linear(repr, 4*Cn) on the features; classif_dropout,
+    then noun / verb classifiers and ttcs = softplus(ttc_pred_layer(.)).squeeze(-1) (roi_wrappers.py:228-229, 306).
+    Dropout through explicit keep masks, as elsewhere in this file."""
+    xb = box_features if keep_box is None else box_features * keep_box / (1.0 - p_box)
+    box_regression = xb @ sd["box_regressor.1.weight"].t() + sd["box_regressor.1.bias"]              # :209
+    xc = box_features if keep_cls is None else box_features * keep_cls / (1.0 - p_cls)               # :211
+    out = {"box_regression": box_regression,
+           "class_logits": xc @ sd["noun_classifier.weight"].t() + sd["noun_classifier.bias"], "verb_logits": None, "ttcs": None}
+    if "verb_classifier.weight" in sd:
+        out["verb_logits"] = xc @ sd["verb_classifier.weight"].t() + sd["verb_classifier.bias"]     # :218-221
+    if "ttc_pred_layer.weight" in sd:
+        z = (xc @ sd["ttc_pred_layer.weight"].t() + sd["ttc_pred_layer.bias"]).squeeze(-1)
+        out["ttcs"] = torch.where(z > 20.0, z, torch.log1p(torch.exp(z)))                           # F.softplus, :229
+    return out
+
+
+def _smooth_l1(d: torch.Tensor, beta: float) -> torch.Tensor:
+    a = d.abs()
+    return torch.where(a < beta, 0.5 * d * d / beta, a - 0.5 * beta) if beta > 0 else a
+
+
+def _weighted_ce(logits: torch.Tensor, targets: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """torch.nn.CrossEntropyLoss(weight, reduction="mean") (abc_nao_trainer.py:53-54): sum_i w[y_i] * nll_i / sum_i w[y_i]."""
+    lse = torch.logsumexp(logits, dim=1)
+    nll = lse - logits.gather(1, targets.view(-1, 1)).squeeze(1)
+    w = weight[targets]
+    return (w * nll).sum() / w.sum()
+
+
+def nao_losses(out, noun_labels: torch.Tensor, verb_labels: Optional[torch.Tensor], ttc_targets: Optional[torch.Tensor],
+               reg_targets: torch.Tensor, noun_w: torch.Tensor, verb_w: Optional[torch.Tensor], verb_ignore: int = 999,
+               verb_bg: bool = False, ttc_bg: bool = False, ttc_bg_val: float = 0.0, ttc_beta: float = 1.0):
+    """-> dict(box, noun, verb, ttc).  Labels / targets are the concatenation over the images of the batch.
+    box: runner/metrics_losses/losses.py:98-135 (smooth-L1 beta 1/9, sum over the positive RoIs' own class slots, / number of RoIs);
+    noun / verb: runner/nao/ego_nao_trainer.py:307-322 (+1e-6 on the logits, background verbs mapped to the last class or dropped);
+    ttc: :347-359 with abc_nao_trainer.py:56 (SmoothL1Loss(beta=ttc_beta), mean over the kept RoIs)."""
+    res = {}
+    pos = torch.where(noun_labels > 0)[0]                                                           # losses.py:122
+    n = out["class_logits"].shape[0]
+    br = out["box_regression"].reshape(n, -1, 4)                                                    # :125
+    res["box"] = _smooth_l1(br[pos, noun_labels[pos]] - reg_targets[pos], 1.0 / 9).sum() / max(noun_labels.numel(), 1)    # :127-133
+    res["noun"] = _weighted_ce(out["class_logits"] + 1e-6, noun_labels, noun_w)                     # trainer :310
+    zero = out["class_logits"].new_zeros(())
+    res["verb"], res["ttc"] = zero, zero
+    if out["verb_logits"] is not None and verb_labels is not None:
+        v_targets = torch.where(verb_labels == verb_ignore, out["verb_logits"].shape[1] - 1, verb_labels)    # :316
+        v_logits = out["verb_logits"]
+        if not verb_bg:                                                                             # :317-320
+            idx = torch.where(verb_labels != verb_ignore)[0]
+            v_logits, v_targets = v_logits[idx], verb_labels[idx]
+        if v_targets.numel():
+            res["verb"] = _weighted_ce(v_logits + 1e-6, v_targets, verb_w)                          # :322
+    if out["ttcs"] is not None and ttc_targets is not None:
+        t_logits, t_targets = out["ttcs"], ttc_targets
+        if not ttc_bg:                                                                              # :349-352 ("targets" there = the verb labels)
+            idx = torch.where(verb_labels != verb_ignore)[0]
+            t_logits, t_targets = t_logits[idx], t_targets[idx]
+        else:                                                                                       # :353-356
+            t_targets = torch.where(t_targets == float(verb_ignore), torch.tensor(ttc_bg_val, dtype=t_targets.dtype), t_targets)
+        if t_logits.shape[0] > 0:                                                                   # :358-359
+            res["ttc"] = _smooth_l1(t_logits - t_targets, ttc_beta).mean()
+    return res

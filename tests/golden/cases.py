@@ -179,3 +179,39 @@ def make_radam_case(cfg):
     grads = [[[(rs.randn(*shp) * (0.5 + rs.rand())).astype(np.float32) for shp in g["shapes"]] for g in cfg["groups"]]
              for _ in range(cfg["steps"])]
     return params, grads
+
+
+# RoI heads + losses (faster_rcnn_wrapper.py:93-100, roi_wrappers.py:204-231, losses.py:98-135, ego_nao_trainer.py:307-359).
+# Class counts of the two label mappings: Ego4Dv1 88 nouns / 75 verbs, Ego4Dv2 129 / 82 (background included).
+HEADS_CASES = {
+    "heads_v1": dict(R=96, repr=64, nouns=88, verbs=75, verb_bg=False, ttc_bg=False, ttc_bg_val=0.0, ttc_beta=1.0, seed=501),
+    "heads_v2_bg": dict(R=70, repr=48, nouns=129, verbs=82, verb_bg=True, ttc_bg=True, ttc_bg_val=2.5, ttc_beta=0.5, seed=502),
+    "heads_allbg": dict(R=12, repr=32, nouns=9, verbs=5, verb_bg=False, ttc_bg=False, ttc_bg_val=0.0, ttc_beta=1.0, seed=503, all_bg=True),
+}
+IGNORE_VERB_IDX_BG = 999      # modeling/obj_detection/roi_wrappers.py:21
+
+
+def make_heads_case(cfg):
+    """-> (params, box_features [R, repr], noun_labels, verb_labels (999 = background), ttc_targets, reg_targets [R, 4], noun_w, verb_w)"""
+    rs = np.random.RandomState(cfg["seed"])
+    R, D, Cn, Cv = cfg["R"], cfg["repr"], cfg["nouns"], cfg["verbs"]
+    params = {
+        "box_regressor.1.weight": (rs.randn(4 * Cn, D) / np.sqrt(D)).astype(np.float32), "box_regressor.1.bias": (0.1 * rs.randn(4 * Cn)).astype(np.float32),
+        "noun_classifier.weight": (rs.randn(Cn, D) / np.sqrt(D)).astype(np.float32), "noun_classifier.bias": (0.1 * rs.randn(Cn)).astype(np.float32),
+        "verb_classifier.weight": (rs.randn(Cv, D) / np.sqrt(D)).astype(np.float32), "verb_classifier.bias": (0.1 * rs.randn(Cv)).astype(np.float32),
+        "ttc_pred_layer.weight": (rs.randn(1, D) / np.sqrt(D)).astype(np.float32), "ttc_pred_layer.bias": (0.1 * rs.randn(1)).astype(np.float32),
+    }
+    feats = (2.0 * rs.randn(R, D)).astype(np.float32)
+    noun = rs.randint(0, Cn, size=R).astype(np.int64)
+    noun[rs.rand(R) < 0.4] = 0                                   # background RoIs
+    if cfg.get("all_bg"):
+        noun[:] = 0
+    verb = rs.randint(0, Cv - 1, size=R).astype(np.int64)
+    verb[noun == 0] = IGNORE_VERB_IDX_BG                         # background RoIs carry the ignore index (roi_wrappers.py)
+    ttc = (rs.rand(R) * 3.0).astype(np.float32)
+    ttc[noun == 0] = float(IGNORE_VERB_IDX_BG)
+    reg = (0.5 * rs.randn(R, 4)).astype(np.float32)
+    reg[::7] *= 0.05                                             # some residuals inside the quadratic zone of smooth-L1
+    noun_w = (0.5 + rs.rand(Cn)).astype(np.float32)
+    verb_w = (0.5 + rs.rand(Cv)).astype(np.float32)
+    return params, feats, noun, verb, ttc, reg, noun_w, verb_w

@@ -24,8 +24,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ENCODER_CASES, LEVEL_CASES, LM_CASES, RADAM_CASES, make_encoder_inputs, make_encoder_params,  # noqa: E402
-                   make_level_extras, make_lm_case, make_radam_case)
+from cases import (ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, RADAM_CASES, make_encoder_inputs,  # noqa: E402
+                   make_encoder_params, make_heads_case, make_level_extras, make_lm_case, make_radam_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -219,6 +219,75 @@ def run_radam_case(name, cfg):
     print(name, "ok", len(out))
 
 
+def run_heads_case(name, cfg):
+    """RoI heads + losses.  The head modules are the nn.Linear / nn.Sequential(Dropout, Linear) objects the reference builds
+    (faster_rcnn_wrapper.py:93-100; roi_wrappers.py:306) and the forward is its roi_wrappers.py:209-229 statement by statement;
+    ``box_loss`` is the reference's own function.  runner/metrics_losses/losses.py imports, at module level,
+    data_preprocessing.utils.dataset_utils (needs cv2) and runner.metrics_losses.hmap_metrics (needs torchmetrics) -- both absent
+    from this image -- for two names (MAX_STD, t_unravel_index) that box_loss does not use; as for is_torch_18v above, the two
+    names are supplied through sys.modules for the import and losses.py itself is imported unmodified.  The noun / verb / TTC losses
+    live inside EgoNAOTrainer.training_step (ego_nao_trainer.py:307-359, a LightningModule: not importable here) and are produced
+    with the criterion objects its constructor builds (abc_nao_trainer.py:53-56) following those lines."""
+    import torch.nn.functional as F
+    for modname, attrs in (("data_preprocessing", {}), ("data_preprocessing.utils", {}),
+                           ("data_preprocessing.utils.dataset_utils", {"MAX_STD": 0.0}),
+                           ("runner.metrics_losses.hmap_metrics", {"t_unravel_index": None})):
+        if modname not in sys.modules:
+            m = types.ModuleType(modname)
+            m.__path__ = []
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[modname] = m
+    from runner.metrics_losses.losses import box_loss
+    params, feats, noun, verb, ttc, reg, noun_w, verb_w = make_heads_case(cfg)
+    D, Cn, Cv = cfg["repr"], cfg["nouns"], cfg["verbs"]
+    box_regressor = torch.nn.Sequential(torch.nn.Identity(), torch.nn.Linear(D, 4 * Cn))       # box_2_dropout = 0 -> nn.Identity (:91)
+    noun_classifier, verb_classifier, ttc_pred_layer = torch.nn.Linear(D, Cn), torch.nn.Linear(D, Cv), torch.nn.Linear(D, 1)
+    mods = {"box_regressor.1": box_regressor[1], "noun_classifier": noun_classifier, "verb_classifier": verb_classifier, "ttc_pred_layer": ttc_pred_layer}
+    for k, m in mods.items():
+        m.weight.data.copy_(torch.from_numpy(params[k + ".weight"]))
+        m.bias.data.copy_(torch.from_numpy(params[k + ".bias"]))
+    x = torch.from_numpy(feats).requires_grad_(True)
+    box_regression = box_regressor(x)                                   # roi_wrappers.py:209
+    class_logits = noun_classifier(x)                                   # :213
+    verb_logits = verb_classifier(x)                                    # :219
+    ttcs = F.softplus(ttc_pred_layer(x)).squeeze(-1)                    # :228-229
+    t_noun, t_verb, t_ttc, t_reg = torch.from_numpy(noun), torch.from_numpy(verb), torch.from_numpy(ttc), torch.from_numpy(reg)
+    # the trainer hands box_loss per-image lists (ego_nao_trainer.py:289-296): two images here
+    h = cfg["R"] // 2
+    l_box = box_loss(class_logits, box_regression, [t_noun[:h], t_noun[h:]], [t_reg[:h], t_reg[h:]])
+    noun_criterion = torch.nn.CrossEntropyLoss(torch.from_numpy(noun_w), reduction="mean")          # abc_nao_trainer.py:53
+    verb_criterion = torch.nn.CrossEntropyLoss(torch.from_numpy(verb_w), reduction="mean")          # :54
+    ttc_criterion = torch.nn.SmoothL1Loss(beta=cfg["ttc_beta"])                                     # :56
+    l_noun = noun_criterion(class_logits + 1e-6, t_noun)                                            # ego_nao_trainer.py:310
+    zero = torch.zeros(())
+    targets = t_verb
+    v_targets = torch.where(targets == IGNORE_VERB_IDX_BG, Cv - 1, targets)                         # :316
+    v_logits = verb_logits
+    if not cfg["verb_bg"]:                                                                          # :317-320
+        v_idxs = torch.where(targets != IGNORE_VERB_IDX_BG)[0]
+        v_logits, v_targets = verb_logits[v_idxs], targets[v_idxs]
+    l_verb = verb_criterion(v_logits + 1e-6, v_targets) if v_targets.numel() else zero              # :322 (an empty selection gives nan there)
+    ttc_logits, ttc_targets = ttcs, t_ttc                                                           # :347-348
+    if not cfg["ttc_bg"]:                                                                           # :349-352
+        ttc_idxs = torch.where(targets != IGNORE_VERB_IDX_BG)[0]
+        ttc_logits, ttc_targets = ttc_logits[ttc_idxs], ttc_targets[ttc_idxs]
+    else:                                                                                           # :353-356
+        ttc_targets = torch.where(ttc_targets == IGNORE_VERB_IDX_BG, cfg["ttc_bg_val"], ttc_targets.double()).float()
+    l_ttc = ttc_criterion(ttc_logits, ttc_targets) if ttc_logits.shape[0] > 0 else zero             # :358-359
+    cot = np.array([0.7, 1.3, 0.9, 1.1], dtype=np.float32)                                          # weights of the four losses in the total
+    (cot[0] * l_box + cot[1] * l_noun + cot[2] * l_verb + cot[3] * l_ttc).backward()
+    out = {"cot": cot, "losses": np.array([float(l_box), float(l_noun), float(l_verb), float(l_ttc)], dtype=np.float64),
+           "box_regression": box_regression.detach().numpy(), "class_logits": class_logits.detach().numpy(),
+           "verb_logits": verb_logits.detach().numpy(), "ttcs": ttcs.detach().numpy(), "grad_feats": x.grad.numpy()}
+    for k, m in mods.items():
+        # a head whose loss has no selected RoI gets no gradient at all (None in the reference): stored as zeros
+        out["gradp/" + k + ".weight"] = np.zeros_like(params[k + ".weight"]) if m.weight.grad is None else m.weight.grad.numpy()
+        out["gradp/" + k + ".bias"] = np.zeros_like(params[k + ".bias"]) if m.bias.grad is None else m.bias.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", out["losses"])
+
+
 def main():
     """python tests/golden/make_golden.py [case-name ...]   (no names: every fixture)"""
     only = set(sys.argv[1:])
@@ -238,6 +307,9 @@ def main():
     for name, cfg in RADAM_CASES.items():
         if want(name):
             run_radam_case(name, cfg)
+    for name, cfg in HEADS_CASES.items():
+        if want(name):
+            run_heads_case(name, cfg)
     if want("sin1d_768"):
         # sin1d table spot values (utils.py:267-273) at the real width
         pe = ref_utils.get_sin1d_embed(8192, 768)

@@ -44,10 +44,24 @@ def test_plan_and_dropout_helpers_are_host_side(lib):
     plan = _lib.TfEncoderPlan()
     assert lib.tf_encoder_plan(32, 196, 512, 768, 4, 4, 1536, C.byref(plan)) == 0
     assert (plan.hd, plan.hdp, plan.dp, plan.ffp, plan.ldq, plan.S, plan.M) == (192, 192, 768, 1536, 2304, 708, 22656)
+    plan0_w, plan0_k = plan.wpack_bytes, plan.work_bytes
     assert lib.tf_encoder_plan(2, 196, 128, 712, 4, 4, 1424, C.byref(plan)) == 0
     assert (plan.hd, plan.hdp, plan.dp, plan.ffp) == (178, 192, 768, 1472)
     assert lib.tf_encoder_plan(2, 196, 128, 770, 4, 4, 1424, C.byref(plan)) != 0     # d % H != 0
     assert b"tf_encoder_plan" in lib.tf_last_error()
+    # fp32-accuracy mode: every bf16 tensor gains a lo plane -- the workspace and the weight shadows roughly double
+    e = _lib.TfEncoderDesc()
+    e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = 32, 196, 512, 768, 4, 4, 1536
+    p0, p1 = _lib.TfEncoderPlan(), _lib.TfEncoderPlan()
+    assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p0)) == 0
+    e.precision = 1
+    assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p1)) == 0
+    assert (p0.wpack_bytes, p0.work_bytes) == (plan0_w, plan0_k) and 1.8 * p0.work_bytes < p1.work_bytes < 2.0 * p0.work_bytes
+    assert 1.5 * p0.wpack_bytes < p1.wpack_bytes < 2.0 * p0.wpack_bytes and p1.hdp == 192      # the fp8 shadows and fp32 biases have no lo plane
+    e.d, e.H, e.ff = 1024, 4, 2048                       # head dim 256: bf16 only
+    assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p1)) != 0
+    e.precision = 2
+    assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p1)) != 0
     assert lib.tf_drop_threshold(0.0) == 0
     assert abs(lib.tf_drop_threshold(0.15) / 2**16 - 0.15) < 1e-5
     assert abs(lib.tf_drop_scale(0.15) - 1 / 0.85) < 1e-4

@@ -183,3 +183,27 @@ def test_radam_oracle_matches_reference_optimizer(golden_dir, name):
             assert torch.allclose(m, torch.from_numpy(g[f"exp_avg/{gi}/{ti}"]), rtol=1e-5, atol=1e-7)
             assert torch.allclose(v, torch.from_numpy(g[f"exp_avg_sq/{gi}/{ti}"]), rtol=1e-5, atol=1e-8)
     assert moved_early == cfg["degenerated_to_sgd"]      # only the SGD-degenerated mode moves parameters before step 6
+
+
+@pytest.mark.parametrize("name", ["heads_v1", "heads_v2_bg", "heads_allbg"])
+def test_heads_and_losses_oracle_matches_reference(golden_dir, name):
+    """oracle.nao_heads_forward / nao_losses against the reference's head modules + its own box_loss + the trainer's criterion objects
+    (tests/golden/make_golden.py::run_heads_case): logits, ttcs, the four losses and every gradient of their weighted sum."""
+    from cases import HEADS_CASES, IGNORE_VERB_IDX_BG, make_heads_case
+    cfg = HEADS_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params, feats, noun, verb, ttc, reg, noun_w, verb_w = make_heads_case(cfg)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    x = torch.from_numpy(feats).requires_grad_(True)
+    out = O.nao_heads_forward(sd, x)
+    for k in ("box_regression", "class_logits", "verb_logits", "ttcs"):
+        _close(out[k], g[k], tol=1e-5, what=k)
+    losses = O.nao_losses(out, torch.from_numpy(noun), torch.from_numpy(verb), torch.from_numpy(ttc), torch.from_numpy(reg), torch.from_numpy(noun_w),
+                          torch.from_numpy(verb_w), IGNORE_VERB_IDX_BG, cfg["verb_bg"], cfg["ttc_bg"], cfg["ttc_bg_val"], cfg["ttc_beta"])
+    got = torch.stack([losses["box"], losses["noun"], losses["verb"], losses["ttc"]])
+    assert np.abs(got.detach().numpy() - g["losses"]).max() < 1e-5 * (1 + np.abs(g["losses"]).max())
+    (got * torch.from_numpy(g["cot"])).sum().backward()
+    _close(x.grad, g["grad_feats"], tol=1e-5, what="grad_feats")
+    for k in params:
+        gr = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        _close(gr, g["gradp/" + k], tol=1e-5, what=k)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtfusion_hip.so")
-SOURCES = ["gemm_bf16.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "tf_api.hip"]
+SOURCES = ["gemm_bf16.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "heads.hip", "tf_api.hip"]
 HEADERS = ["tf_common.h", "tf_kernels.h", "attn_common.h", os.path.join("..", "..", "include", "tfusion.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -52,7 +52,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         return src
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(5, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             for done in ex.map(compile_one, jobs):
                 if verbose:
                     print(f"[transfusion_amd.build] compiled {os.path.basename(done)}", file=sys.stderr)

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
     const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
     const unsigned long long blk = brow ? brow[t] : 0ull;
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
-#pragma unroll
+#pragma unroll 1                     // the two 32-key halves one after the other: interleaved by the unroller the kernel spills at head dim 192
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 st, dp;
 #pragma unroll

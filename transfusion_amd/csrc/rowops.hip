@@ -28,11 +28,31 @@ __device__ __forceinline__ void store8_any(void* base, size_t off, int is_f32, c
   else *(u32x4*)((u16*)base + off) = pack8(f);
 }
 __device__ __forceinline__ int map_row(int r, int rpg, int stride) { return (r / rpg) * stride + (r % rpg); }
+// bf16 tensor with a lo plane only in the SPLIT instantiation (fp32-accuracy mode): the bf16 instantiation carries no extra pointer,
+// branch or register (ln_bwd_kernel<2, 8> must stay at 126 VGPRs = 4 waves per SIMD)
+template <bool SPLIT> __device__ __forceinline__ void ld8s(const void* hi, const void* lo, size_t off, float (&f)[8]) {
+  if constexpr (SPLIT) join8(*(const u32x4*)((const u16*)hi + off), *(const u32x4*)((const u16*)lo + off), f);
+  else unpack8(*(const u32x4*)((const u16*)hi + off), f);
+}
+template <bool SPLIT> __device__ __forceinline__ void st8s(void* hi, void* lo, size_t off, const float (&f)[8]) {
+  if constexpr (SPLIT) {
+    u32x4 h, l;
+    split8(f, h, l);
+    *(u32x4*)((u16*)hi + off) = h;
+    *(u32x4*)((u16*)lo + off) = l;
+  } else {
+    *(u32x4*)((u16*)hi + off) = pack8(f);
+  }
+}
+template <bool SPLIT> __device__ __forceinline__ void zero8s(void* hi, void* lo, size_t off) {
+  *(u32x4*)((u16*)hi + off) = u32x4{0, 0, 0, 0};
+  if constexpr (SPLIT) *(u32x4*)((u16*)lo + off) = u32x4{0, 0, 0, 0};
+}
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta over the first d columns, fp32 statistics.
 // ------------------------------------------------------------------------------------------------
-template <int MAXC>
+template <int MAXC, bool SPLIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
@@ -45,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   for (int i = 0; i < MAXC; ++i) {
     const int c = (lane + 64 * i) * 8;
     if (c < a.d) {
-      load8_split(a.x, a.x_lo, (size_t)xr * a.ldx + c, v[i]);
+      ld8s<SPLIT>(a.x, a.x_lo, (size_t)xr * a.ldx + c, v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
@@ -72,10 +92,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       if (a.y_is_f32) store8_f32((float*)a.y + (size_t)yr * a.ldy + c, o);
-      else store8_split(a.y, a.y_lo, (size_t)yr * a.ldy + c, o);
+      else st8s<SPLIT>(a.y, a.y_lo, (size_t)yr * a.ldy + c, o);
     } else if (c < a.ldy && !a.y_is_f32) {
-      *(u32x4*)((u16*)a.y + (size_t)yr * a.ldy + c) = u32x4{0, 0, 0, 0};
-      if (a.y_lo != nullptr) *(u32x4*)((u16*)a.y_lo + (size_t)yr * a.ldy + c) = u32x4{0, 0, 0, 0};
+      zero8s<SPLIT>(a.y, a.y_lo, (size_t)yr * a.ldy + c);
     }
   }
 }
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // LNB_WAVES waves per workgroup, one row per wave per pass: the kernel is a dependent load -> reduce -> store chain per
 // row, so its HBM rate is set by rows in flight (4-wave blocks at the 512-block cap ran 2 waves per SIMD: 3.2 TB/s)
-template <int MAXC, int LNB_WAVES>
+template <int MAXC, int LNB_WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a) {
   __shared__ float red[LNB_WAVES][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,12 +129,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
       const int c = (lane + 64 * i) * 8;
       if (c < a.d) {
         float xv[8], dy[8], gm[8];
-        load8_split(a.x, a.x_lo, (size_t)xr * a.ldx + c, xv);
+        ld8s<SPLIT>(a.x, a.x_lo, (size_t)xr * a.ldx + c, xv);
         if (a.dy_is_f32) load8_f32((const float*)a.dy + (size_t)yr * a.lddy + c, dy);
-        else load8_split(a.dy, a.dy_lo, (size_t)yr * a.lddy + c, dy);
+        else ld8s<SPLIT>(a.dy, a.dy_lo, (size_t)yr * a.lddy + c, dy);
         if (a.dres != nullptr) {
           float r[8];
-          load8_split(a.dres, a.dres_lo, (size_t)xr * a.lddres + c, r);
+          ld8s<SPLIT>(a.dres, a.dres_lo, (size_t)xr * a.lddres + c, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) dy[e] += r[e];
         }
@@ -139,25 +158,18 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - c1 - xh[i][e] * c2);
-        store8_split(a.dx, a.dx_lo, (size_t)xr * a.lddx + c, o);
+        st8s<SPLIT>(a.dx, a.dx_lo, (size_t)xr * a.lddx + c, o);
         if (a.dx_drop != nullptr) {
           if (a.drop_thr) {
             const unsigned km = tf_keep8((unsigned)xr * (unsigned)a.drop_ld + (unsigned)c, a.drop_key, a.drop_thr);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = ((km >> e) & 1u) ? o[e] * a.drop_scale : 0.f;
           }
-          store8_split(a.dx_drop, a.dx_drop_lo, (size_t)xr * a.lddxd + c, o);
+          st8s<SPLIT>(a.dx_drop, a.dx_drop_lo, (size_t)xr * a.lddxd + c, o);
         }
       } else {
-        const u32x4 z = {0, 0, 0, 0};
-        if (c < a.lddx) {
-          *(u32x4*)((u16*)a.dx + (size_t)xr * a.lddx + c) = z;
-          if (a.dx_lo != nullptr) *(u32x4*)((u16*)a.dx_lo + (size_t)xr * a.lddx + c) = z;
-        }
-        if (a.dx_drop != nullptr && c < a.lddxd) {
-          *(u32x4*)((u16*)a.dx_drop + (size_t)xr * a.lddxd + c) = z;
-          if (a.dx_drop_lo != nullptr) *(u32x4*)((u16*)a.dx_drop_lo + (size_t)xr * a.lddxd + c) = z;
-        }
+        if (c < a.lddx) zero8s<SPLIT>(a.dx, a.dx_lo, (size_t)xr * a.lddx + c);
+        if (a.dx_drop != nullptr && c < a.lddxd) zero8s<SPLIT>(a.dx_drop, a.dx_drop_lo, (size_t)xr * a.lddxd + c);
       }
     }
   }
@@ -755,10 +767,16 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   const dim3 grid((a->rows + 3) / 4);
   const int width = max(a->d, a->y_is_f32 ? a->d : a->ldy);      // columns a lane set must cover (payload + zeroed pad)
   if (width > 64 * MAXC_MAX * 8) return -2;
-  TfTraceScope tr("ln_fwd_kernel", st, 0.0, 4.0 * a->rows * a->d);
-  if (width <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, st, *a);
-  else if (width <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, st, *a);
-  else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, st, *a);
+  // fp32-accuracy mode: every bf16 tensor of the call carries its lo plane (x always; y unless it is fp32)
+  const bool split = a->x_lo != nullptr;
+  if (split && !a->y_is_f32 && a->y_lo == nullptr) return -6;
+  TfTraceScope tr("ln_fwd_kernel", st, 0.0, (split ? 8.0 : 4.0) * a->rows * a->d);
+#define TF_LNF(C) do { if (split) hipLaunchKernelGGL((ln_fwd_kernel<C, true>), grid, dim3(256), 0, st, *a); \
+                       else hipLaunchKernelGGL((ln_fwd_kernel<C, false>), grid, dim3(256), 0, st, *a); } while (0)
+  if (width <= 512) TF_LNF(1);
+  else if (width <= 1024) TF_LNF(2);
+  else TF_LNF(4);
+#undef TF_LNF
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
@@ -769,11 +787,17 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   static const int env_w = getenv("TF_LNB_WAVES") ? atoi(getenv("TF_LNB_WAVES")) : 8;     // experiment switch: 16 waves measured slower (39.9 vs 38.3 us)
   const int nw = (width <= 1024 && env_w == 16) ? 16 : 8;   // 16 waves where the reduction array fits the 64 KiB static LDS
   const dim3 grid(grid_for(a->rows, nw * 2, 512));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
-  TfTraceScope tr("ln_bwd_kernel", st, 0.0, (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
+  const bool split = a->x_lo != nullptr;
+  if (split && (a->dx_lo == nullptr || (!a->dy_is_f32 && a->dy_lo == nullptr) || (a->dx_drop != nullptr && a->dx_drop_lo == nullptr) ||
+                (a->dres != nullptr && a->dres_lo == nullptr))) return -6;
+  TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
-  if (width <= 512) { if (nw == 16) hipLaunchKernelGGL((ln_bwd_kernel<1, 16>), grid, block, 0, st, *a); else hipLaunchKernelGGL((ln_bwd_kernel<1, 8>), grid, block, 0, st, *a); }
-  else if (width <= 1024) { if (nw == 16) hipLaunchKernelGGL((ln_bwd_kernel<2, 16>), grid, block, 0, st, *a); else hipLaunchKernelGGL((ln_bwd_kernel<2, 8>), grid, block, 0, st, *a); }
-  else hipLaunchKernelGGL((ln_bwd_kernel<4, 8>), grid, block, 0, st, *a);
+#define TF_LNB(C, W) do { if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \
+                          else hipLaunchKernelGGL((ln_bwd_kernel<C, W, false>), grid, block, 0, st, *a); } while (0)
+  if (width <= 512) { if (nw == 16) TF_LNB(1, 16); else TF_LNB(1, 8); }
+  else if (width <= 1024) { if (nw == 16) TF_LNB(2, 16); else TF_LNB(2, 8); }
+  else TF_LNB(4, 8);
+#undef TF_LNB
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {

@@ -344,6 +344,12 @@ int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bw
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s) { TF_WRAP("tf_radam_step", tf_launch_radam(a, (hipStream_t)s)); }
+int tf_heads_loss_fwd(const TfHeadsLossArgs* a, tf_stream_t s) { TF_WRAP("tf_heads_loss_fwd", tf_launch_heads_loss_fwd(a, (hipStream_t)s)); }
+int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s) { TF_WRAP("tf_heads_loss_bwd", tf_launch_heads_loss_bwd(a, (hipStream_t)s)); }
+int tf_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, const float* dy, void* dx, void* dx_lo, int R, tf_stream_t s) {
+  TF_TRY(tf_launch_softplus_col(x, x_lo, ld, col, y, dy, dx, dx_lo, R, (hipStream_t)s), "tf_softplus_col");
+  return 0;
+}
 int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_fwd(a, (hipStream_t)s), "tf_lm_pool_fwd"); return 0; }
 int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_bwd(a, (hipStream_t)s), "tf_lm_pool_bwd"); return 0; }
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq(x, n, out, (hipStream_t)s), "tf_sumsq"); return 0; }

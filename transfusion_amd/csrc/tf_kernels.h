@@ -28,6 +28,9 @@ int tf_launch_cast_f32_bf16(const float* src, void* dst, long long n, hipStream_
 int tf_launch_cast_bf16_f32(const void* src, float* dst, long long n, hipStream_t stream);
 int tf_launch_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, hipStream_t stream);
 int tf_launch_radam(const TfRadamArgs* a, hipStream_t stream);
+int tf_launch_heads_loss_fwd(const TfHeadsLossArgs* a, hipStream_t stream);
+int tf_launch_heads_loss_bwd(const TfHeadsLossArgs* a, hipStream_t stream);
+int tf_launch_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, const float* dy, void* dx, void* dx_lo, int R, hipStream_t stream);
 int tf_launch_lm_pool_fwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_bwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);

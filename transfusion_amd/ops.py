@@ -379,6 +379,91 @@ def lm_pool(x, att_mask, pool_type: str, ln_w=None, ln_b=None, eps: float = 1e-5
     return _LmPoolFn.apply(x, m, 1 if pool_type == "max" else 0, ln_w, ln_b, float(eps), bool(gelu))
 
 
+# ------------------------------------------------------------------------------------------------------
+# RoI heads: softplus TTC output and the four losses (csrc/heads.hip)
+# ------------------------------------------------------------------------------------------------------
+class _SoftplusColFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls, col):
+        _require_cuda(cls)
+        if cls.dtype != torch.bfloat16 or cls.dim() != 2 or cls.stride(1) != 1:
+            raise L.TfError("softplus_col: a bf16 [R, N] tensor (row stride free) is expected")
+        R = cls.shape[0]
+        y = torch.empty(R, dtype=torch.float32, device=cls.device)
+        L.check(L.load().tf_softplus_col(cls.data_ptr(), None, cls.stride(0), col, y.data_ptr(), None, None, None, R, _stream()), "tf_softplus_col")
+        ctx.save_for_backward(cls)
+        ctx.col = col
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (cls,) = ctx.saved_tensors
+        R = cls.shape[0]
+        dcls = torch.zeros(R, cls.stride(0), dtype=torch.bfloat16, device=cls.device)
+        gy = gy.float().contiguous()
+        L.check(L.load().tf_softplus_col(cls.data_ptr(), None, cls.stride(0), ctx.col, None, gy.data_ptr(), dcls.data_ptr(), None, R, _stream()),
+                "tf_softplus_col")
+        return dcls[:, :cls.shape[1]], None
+
+
+def softplus_col(cls, col: int):
+    """ttcs = F.softplus(cls[:, col]) as fp32 [R] (roi_wrappers.py:228-229), cls the bf16 logits of the concatenated heads."""
+    return _SoftplusColFn.apply(cls, col)
+
+
+class _NaoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls, box, ttcs, Cn, Cv, noun, verb, ttc_t, reg_t, noun_w, verb_w, verb_ignore, verb_bg, ttc_bg, ttc_bg_val, ttc_beta):
+        _require_cuda(cls, box, noun)
+        for t in (cls, box):
+            if t is not None and (t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1):
+                raise L.TfError("nao_head_losses: logits must be bf16 [R, N] tensors (row stride free)")
+        R = cls.shape[0]
+        dev = cls.device
+        i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+        noun, verb, ttc_t, reg_t, noun_w, verb_w = i64(noun), i64(verb), f32(ttc_t), f32(reg_t), f32(noun_w), f32(verb_w)
+        ttcs = None if ttcs is None else ttcs.detach().float().contiguous()
+        if noun.numel() != R or (verb is not None and verb.numel() != R) or (reg_t is not None and tuple(reg_t.shape) != (R, 4)):
+            raise RuntimeError(f"labels / targets do not match the {R} RoIs")
+        if int(noun.min()) < 0 or int(noun.max()) >= Cn:
+            raise IndexError("Target out of bounds (noun labels)")          # what torch's cross_entropy raises
+        sums = torch.zeros(8, dtype=torch.float32, device=dev)
+        lse = torch.empty(2 * R, dtype=torch.float32, device=dev)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        a = L.TfHeadsLossArgs(cls=L.ptr(cls), ld_cls=cls.stride(0), box=L.ptr(box) if reg_t is not None else 0, ld_box=0 if box is None else box.stride(0),
+                              ttcs=L.ptr(ttcs) if ttc_t is not None else 0, R=R, Cn=Cn, Cv=Cv, noun_labels=L.ptr(noun), verb_labels=L.ptr(verb),
+                              ttc_targets=L.ptr(ttc_t), reg_targets=L.ptr(reg_t), noun_w=L.ptr(noun_w), verb_w=L.ptr(verb_w) if verb is not None else 0,
+                              verb_ignore=int(verb_ignore), verb_bg=int(bool(verb_bg)), ttc_bg=int(bool(ttc_bg)), ttc_bg_val=float(ttc_bg_val),
+                              ttc_beta=float(ttc_beta), box_beta=1.0 / 9, sums=L.ptr(sums), lse=L.ptr(lse), losses=L.ptr(losses))
+        L.call("tf_heads_loss_fwd", a, _stream())
+        ctx.args, ctx.keep = a, (cls, box, ttcs, noun, verb, ttc_t, reg_t, noun_w, verb_w, sums, lse)
+        ctx.shapes = (cls.shape, None if box is None else box.shape)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        a = ctx.args
+        cls, box, ttcs = ctx.keep[0], ctx.keep[1], ctx.keep[2]
+        R, dev = cls.shape[0], cls.device
+        gscale = g.float().contiguous()
+        d_cls = torch.empty(R, cls.stride(0), dtype=torch.bfloat16, device=dev)
+        d_box = None if box is None else torch.empty(R, box.stride(0), dtype=torch.bfloat16, device=dev)
+        d_ttcs = None if ttcs is None else torch.empty(R, dtype=torch.float32, device=dev)
+        a.gscale, a.d_cls, a.d_box, a.d_ttcs = L.ptr(gscale), L.ptr(d_cls), L.ptr(d_box), L.ptr(d_ttcs)
+        L.call("tf_heads_loss_bwd", a, _stream())
+        (cs, bs) = ctx.shapes
+        return (d_cls[:, :cs[1]], None if box is None else d_box[:, :bs[1]], d_ttcs) + (None,) * 13
+
+
+def nao_head_losses(cls, box, ttcs, Cn, Cv, noun, verb, ttc_targets, reg_targets, noun_w, verb_w, verb_ignore=999, verb_bg=False, ttc_bg=False,
+                    ttc_bg_val=0.0, ttc_beta=1.0):
+    """-> fp32 [4]: box, noun, verb, ttc losses (include/tfusion.h TfHeadsLossArgs).  cls = noun | verb | ttc logits [R, >= Cn + Cv (+1)],
+    box = box_regression [R, 4*Cn], ttcs = softplus outputs [R] (its gradient flows back through ``softplus_col``)."""
+    return _NaoLossFn.apply(cls, box, ttcs, Cn, Cv, noun, verb, ttc_targets, reg_targets, noun_w, verb_w, verb_ignore, verb_bg, ttc_bg,
+                            ttc_bg_val, ttc_beta)
+
+
 def attn_dropmask(B: int, H: int, S: int, p: float, seed: int, site: int, device) -> torch.Tensor:
     """Keep-bitmask of the attention-probability dropout site ([B*H*S, ceil(S/64)] u64, as int64 storage)."""
     lib = L.load()

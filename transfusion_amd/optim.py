@@ -91,5 +91,5 @@ class FusedRAdam(torch.optim.Optimizer):
                 L.call("tf_radam_step", a, st)
                 # the kernel wrote through a raw pointer: tell autograd / the encoders' bf16 weight-shadow cache
                 # (CrossTransformerModuleBox._wpack_dirty keys on (data_ptr, _version)) that the tensor changed
-                torch._C._increment_version(p)
+                torch._C._increment_version((p,))          # (takes an iterable of tensors)
         return loss
