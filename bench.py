@@ -88,6 +88,42 @@ def loss_fn(module, batch):
     return _MaskedSquareLoss.apply(vis, lo, valid, km)
 
 
+class _EncoderWithHeads(torch.nn.Module):
+    """bench --with-heads: the fusion encoder plus the RoI heads that consume the detector's box features (synthetic here: the
+    detector between them is out of scope), one parameter set for the trainer."""
+
+    def __init__(self, enc, heads, crit):
+        super().__init__()
+        self.enc, self.heads, self.crit = enc, heads, crit
+
+    def forward(self, x, lang, pad):
+        return self.enc(x, lang, pad)
+
+
+def make_heads_batch(B, device, rank, variant, rois_per_image=512, repr_size=1024, nouns=88, verbs=75):
+    g = torch.Generator().manual_seed(4242 + 1000 * rank + 77 * variant)
+    R = B * rois_per_image
+    feats = torch.randn(R, repr_size, generator=g).to(device=device, dtype=torch.bfloat16)
+    noun = torch.randint(1, nouns, (R,), generator=g)
+    noun[torch.rand(R, generator=g) < 0.75] = 0                      # RoI sampling keeps 25 % positives (torchvision's positive_fraction)
+    verb = torch.randint(0, verbs - 1, (R,), generator=g)
+    verb[noun == 0] = 999
+    ttc = torch.rand(R, generator=g) * 2
+    ttc[noun == 0] = 999.0
+    reg = torch.randn(R, 4, generator=g) * 0.1
+    return feats, noun.to(device), verb.to(device), ttc.to(device), reg.to(device)
+
+
+def loss_fn_heads(module, batch):
+    x, lang, pad, valid, km = batch[:5]
+    vis, lo, _, _ = module(x, lang, pad)
+    loss = _MaskedSquareLoss.apply(vis, lo, valid, km)
+    feats, noun, verb, ttc, reg = batch[6]
+    out = module.heads(feats)
+    l = module.crit(out, noun, verb, ttc, reg)
+    return loss + l["bbox_loss"] + l["noun_loss"] + l["verb_loss"] + l["ttc_loss"]
+
+
 def flops_per_sample_layer(S, d):
     return 16 * S * d * d + 4 * S * S * d       # forward, SURVEY.md 8(d)
 
@@ -366,6 +402,9 @@ def main():
     ap.add_argument("--trace-steps", type=int, default=5)
     ap.add_argument("--isolated-census", action="store_true", help="also time every kernel alone (back-to-back launches of one kernel)")
     ap.add_argument("--grad-clip", type=float, default=1.0)
+    ap.add_argument("--with-heads", action="store_true",
+                    help="variant: add the NAO RoI heads + losses (SURVEY.md 8f-2) on synthetic box features, 512 RoIs per image, repr 1024, "
+                         "Ego4Dv1 class counts (88 nouns / 75 verbs); not the headline line")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
@@ -399,15 +438,23 @@ def main():
     enc = make_encoder(device)
     enc.precision = args.precision
     enc.train()
-    trainer = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap)
+    module, step_loss = enc, loss_fn
+    if args.with_heads:
+        from transfusion_amd.modeling.obj_detection.nao_heads import NaoHeadLosses, NaoRoIHeads
+        heads = NaoRoIHeads(1024, 88, 75, box_2_dropout=0.0, classif_dropout=0.0).to(device)
+        crit = NaoHeadLosses(torch.ones(88), torch.ones(75)).to(device)
+        module, step_loss = _EncoderWithHeads(enc, heads, crit).train(), loss_fn_heads
+    trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap)
     # distinct batches (tensors, padding lengths) rotated through the steps: a real loader hands the encoder a new mask tensor
     # every step, so the padding-mask conversion cache never hits
     batches = [make_batch(args.batch, device, rank, variant=v) for v in range(max(1, args.batches))]
+    if args.with_heads:
+        batches = [b + (make_heads_batch(args.batch, device, rank, v),) for v, b in enumerate(batches)]
     comm = _Comm(world, device)
     last = {}
 
     def step(i):
-        last["loss"] = trainer.step([batches[i % len(batches)]], loss_fn)
+        last["loss"] = trainer.step([batches[i % len(batches)]], step_loss)
 
     elapsed, rows = run_schedule(step, comm, rank, args.warmup, args.steps, 0 if args.no_census else args.trace_steps, traced_kernels)
     final_loss = float(last["loss"].item())
@@ -439,7 +486,7 @@ def main():
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp32" if args.precision == "fp32" else ("fp8 projections + bf16" if os.environ.get("TF_FP8_PROJ") == "1" else "bf16"),
         "data": "synthetic",
-        "config": {"workload": f"fusion-encoder train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
+        "config": {"workload": f"fusion-encoder{' + RoI heads and losses (512 RoIs / image)' if args.with_heads else ''} train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
                                f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding",
                    "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}"},
         "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

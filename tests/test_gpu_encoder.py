@@ -2,8 +2,13 @@
 against (a) the committed golden fixtures produced by the reference itself and (b) the CPU oracle.
 
 Tolerance (BASELINE.json north_star): outputs within 1e-2 for bf16 compute.  Asserted as relative L2
-error <= 1e-2 for forward outputs (O(1) LayerNorm outputs, so abs ~= rel) and <= 3e-2 for gradients
-(bf16 activations in every GEMM of a 2x-deeper graph); max-abs bounds are written at each assert."""
+error <= 1e-2 for forward outputs (measured 4.9e-3 .. 6.9e-3 on the fixtures) and <= 2e-2 for gradients
+(measured: inputs <= 1.1e-2, worst parameter <= 1.2e-2).  Where that error comes from (tools/fp32_diag.py budget):
+against the oracle evaluated on bf16-ROUNDED parameters the numbers barely move (6.9e-3 -> 6.0e-3), i.e. it is
+the bf16 storage of every intermediate activation, not operand quantisation; an element of an O(1..4)
+output stored in bf16 carries up to 2^-8 * 4 = 1.6e-2 of rounding by itself, so the elementwise bound is 5e-2
+(measured 3.1e-2 .. 3.9e-2).  The elementwise 1e-3 statement of the north_star is the fp32-accuracy mode's:
+tests/test_gpu_fp32_mode.py asserts it, max-abs included, on the same fixtures."""
 import os
 
 import numpy as np
@@ -14,7 +19,7 @@ from cases import ENCODER_CASES, make_encoder_inputs, make_encoder_params
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL, GRAD_TOL = 1e-2, 3e-2
+FWD_TOL, GRAD_TOL = 1e-2, 2e-2
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +62,7 @@ def test_golden_small(dev, golden_dir, name):
     valid = np.ones(lang.shape[:2], bool) if mask is None else ~g["in_mask"]
     e_v, e_l = rel(vis, g["train_vis"]), rel(lo.detach().cpu().numpy()[valid], g["train_lang"][valid])
     assert e_v < FWD_TOL and e_l < FWD_TOL, (e_v, e_l)
-    assert (vis.detach().cpu() - torch.from_numpy(g["train_vis"])).abs().max() < 6e-2
+    assert (vis.detach().cpu() - torch.from_numpy(g["train_vis"])).abs().max() < 5e-2
     loss = (vis * torch.from_numpy(g["cot_vis"]).to(dev)).sum() + (lo * torch.from_numpy(g["cot_lang"]).to(dev)).sum()
     loss.backward()
     assert rel(x.grad, g["grad_x"]) < GRAD_TOL
@@ -340,6 +345,17 @@ def test_fp8_projections_against_bf16(dev):
     assert rel(outs[True][2], outs[False][2]) < 1e-1
     for k in ("t_encoder.layers.0.self_attn.in_proj_weight", "t_encoder.layers.1.linear2.weight", "t_encoder.layers.0.norm1.weight"):
         assert rel(outs[True][3][k], outs[False][3][k]) < 1e-1, k
+    # ... and against the fp32 oracle itself (not only against this library's own bf16 path)
+    from oracle import fusion_oracle as O
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+    xr, lr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+    v_ref, l_ref = O.encoder_forward(sd, xr, lr, torch.from_numpy(mask), cfg["h"], cfg["L"])
+    ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+    assert rel(outs[True][0], v_ref.detach()) < 6e-2 and rel(outs[True][1][valid], l_ref.detach()[valid]) < 6e-2
+    assert rel(outs[True][2], xr.grad) < 1e-1
+    for k in ("t_encoder.layers.0.self_attn.in_proj_weight", "t_encoder.layers.1.linear2.weight", "t_encoder.layers.0.norm1.weight"):
+        assert rel(outs[True][3][k], sd[k].grad) < 1e-1, k
 
 
 @pytest.mark.gpu

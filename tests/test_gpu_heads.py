@@ -40,12 +40,12 @@ def test_heads_and_losses_against_reference_fixture(dev, golden_dir, name):
     out = heads(x)
     for k in ("box_regression", "class_logits", "verb_logits"):
         assert tuple(out[k].shape) == g[k].shape and rel(out[k], g[k]) < 1e-2, k
-    assert (out["ttcs"].cpu() - torch.from_numpy(g["ttcs"])).abs().max() < 3e-2
+    assert (out["ttcs"].detach().cpu() - torch.from_numpy(g["ttcs"])).abs().max() < 3e-2
     h = cfg["R"] // 2
     t = lambda a: torch.from_numpy(a).to(dev)
     # per-image lists, as roi_heads.select_training_samples hands them over (two images)
     losses = crit(out, [t(noun[:h]), t(noun[h:])], [t(verb[:h]), t(verb[h:])], [t(ttc[:h]), t(ttc[h:])], [t(reg[:h]), t(reg[h:])])
-    got = torch.stack([losses["bbox_loss"], losses["noun_loss"], losses["verb_loss"], losses["ttc_loss"]]).cpu().double().numpy()
+    got = torch.stack([losses["bbox_loss"], losses["noun_loss"], losses["verb_loss"], losses["ttc_loss"]]).detach().cpu().double().numpy()
     assert np.abs(got - g["losses"]).max() < 1e-2 * (1 + np.abs(g["losses"]).max()), (got, g["losses"])
     if name == "heads_allbg":
         assert got[0] == 0 and got[2] == 0 and got[3] == 0       # no positive RoI: box / verb / TTC terms are exactly zero

@@ -126,7 +126,40 @@ def attention_sweep():
         print(f"attn hd={hd} S={S} p={p} H={H}: O {rel(joined(oh, ol), o.detach()):.1e}  dq {e[0]:.1e} dk {e[1]:.1e} dv {e[2]:.1e}")
 
 
+def bf16_error_budget(name):
+    """bf16 compute against (a) the fp32 oracle and (b) the oracle evaluated on bf16-ROUNDED parameters and inputs: (b) removes the
+    operand quantisation every bf16 implementation shares, what remains is this implementation's own rounding of intermediates."""
+    from test_gpu_fp32_mode import build
+    from oracle import fusion_oracle as O
+    dev = torch.device("cuda:0")
+    cfg = ENCODER_CASES[name]
+    enc, params = build(cfg, dev, "bf16")
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    xd, ld = torch.from_numpy(x).to(dev).requires_grad_(True), torch.from_numpy(lang).to(dev).requires_grad_(True)
+    md = None if mask is None else torch.from_numpy(mask).to(dev)
+    vis, lo, _, _ = enc(xd, ld, md)
+    ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+    rb = lambda t: t.to(torch.bfloat16).float()
+    for label, rnd in (("fp32 oracle", lambda t: t), ("bf16-rounded oracle", rb)):
+        sd = {k: rnd(torch.from_numpy(v)).clone().requires_grad_(True) for k, v in params.items()}
+        for k in list(sd):
+            if "norm" in k or "bias" in k or "kind" in k:            # fp32 inside the runtime as well
+                sd[k] = torch.from_numpy(params[k]).clone().requires_grad_(True)
+        sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+        xr, lr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+        mk = None if mask is None else torch.from_numpy(mask)
+        v_ref, l_ref = O.encoder_forward(sd, xr, lr, mk, cfg["h"], cfg["L"])
+        ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+        worst = max(rel(p.grad, sd[k].grad) for k, p in enc.named_parameters() if k in sd and sd[k].grad is not None and p.grad is not None)
+        print(f"{name} bf16 vs {label}: vis rel {rel(vis, v_ref):.2e} max-abs {(vis.detach().cpu() - v_ref.detach()).abs().max():.2e}  dX {rel(xd.grad, xr.grad):.2e}  worst param grad {worst:.2e}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["budget"]:
+        for n in ("enc_small", "enc_hd18", "enc_d768", "enc_d896"):
+            bf16_error_budget(n)
+        sys.exit(0)
     attention_sweep()
     for n in sys.argv[1:] or ["enc_d768", "enc_d896"]:
         encoder_stages(n)

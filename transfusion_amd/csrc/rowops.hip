@@ -30,23 +30,18 @@ __device__ __forceinline__ void store8_any(void* base, size_t off, int is_f32, c
 __device__ __forceinline__ int map_row(int r, int rpg, int stride) { return (r / rpg) * stride + (r % rpg); }
 // bf16 tensor with a lo plane only in the SPLIT instantiation (fp32-accuracy mode): the bf16 instantiation carries no extra pointer,
 // branch or register (ln_bwd_kernel<2, 8> must stay at 126 VGPRs = 4 waves per SIMD)
+// (in the SPLIT instantiation a tensor may still come without its lo plane -- a caller-owned bf16 output or cotangent: null-checked there)
 template <bool SPLIT> __device__ __forceinline__ void ld8s(const void* hi, const void* lo, size_t off, float (&f)[8]) {
-  if constexpr (SPLIT) join8(*(const u32x4*)((const u16*)hi + off), *(const u32x4*)((const u16*)lo + off), f);
+  if constexpr (SPLIT) load8_split(hi, lo, off, f);
   else unpack8(*(const u32x4*)((const u16*)hi + off), f);
 }
 template <bool SPLIT> __device__ __forceinline__ void st8s(void* hi, void* lo, size_t off, const float (&f)[8]) {
-  if constexpr (SPLIT) {
-    u32x4 h, l;
-    split8(f, h, l);
-    *(u32x4*)((u16*)hi + off) = h;
-    *(u32x4*)((u16*)lo + off) = l;
-  } else {
-    *(u32x4*)((u16*)hi + off) = pack8(f);
-  }
+  if constexpr (SPLIT) store8_split(hi, lo, off, f);
+  else *(u32x4*)((u16*)hi + off) = pack8(f);
 }
 template <bool SPLIT> __device__ __forceinline__ void zero8s(void* hi, void* lo, size_t off) {
   *(u32x4*)((u16*)hi + off) = u32x4{0, 0, 0, 0};
-  if constexpr (SPLIT) *(u32x4*)((u16*)lo + off) = u32x4{0, 0, 0, 0};
+  if constexpr (SPLIT) { if (lo != nullptr) *(u32x4*)((u16*)lo + off) = u32x4{0, 0, 0, 0}; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -768,8 +763,7 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   const int width = max(a->d, a->y_is_f32 ? a->d : a->ldy);      // columns a lane set must cover (payload + zeroed pad)
   if (width > 64 * MAXC_MAX * 8) return -2;
   // fp32-accuracy mode: every bf16 tensor of the call carries its lo plane (x always; y unless it is fp32)
-  const bool split = a->x_lo != nullptr;
-  if (split && !a->y_is_f32 && a->y_lo == nullptr) return -6;
+  const bool split = a->x_lo != nullptr || a->y_lo != nullptr;
   TfTraceScope tr("ln_fwd_kernel", st, 0.0, (split ? 8.0 : 4.0) * a->rows * a->d);
 #define TF_LNF(C) do { if (split) hipLaunchKernelGGL((ln_fwd_kernel<C, true>), grid, dim3(256), 0, st, *a); \
                        else hipLaunchKernelGGL((ln_fwd_kernel<C, false>), grid, dim3(256), 0, st, *a); } while (0)
@@ -787,9 +781,7 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   static const int env_w = getenv("TF_LNB_WAVES") ? atoi(getenv("TF_LNB_WAVES")) : 8;     // experiment switch: 16 waves measured slower (39.9 vs 38.3 us)
   const int nw = (width <= 1024 && env_w == 16) ? 16 : 8;   // 16 waves where the reduction array fits the 64 KiB static LDS
   const dim3 grid(grid_for(a->rows, nw * 2, 512));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
-  const bool split = a->x_lo != nullptr;
-  if (split && (a->dx_lo == nullptr || (!a->dy_is_f32 && a->dy_lo == nullptr) || (a->dx_drop != nullptr && a->dx_drop_lo == nullptr) ||
-                (a->dres != nullptr && a->dres_lo == nullptr))) return -6;
+  const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
 #define TF_LNB(C, W) do { if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \

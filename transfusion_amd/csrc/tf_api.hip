@@ -212,6 +212,8 @@ int wgrad(const Ctx& c, Side& sd, Buf dY, int N, Buf X, int K, float* dW, int ld
   TfWgradArgs w{};
   w.dY = dY.p; w.ldy = dY.ld; w.X = X.p; w.ldx = X.ld; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
   w.dY_lo = dY.lo; w.X_lo = X.lo;
+  static const int exp_skip = getenv("TF_EXP_SKIP_WGRAD") ? atoi(getenv("TF_EXP_SKIP_WGRAD")) : 0;   // timing experiment only: WRONG gradients
+  if (exp_skip) return 0;
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
   static const int tail_alone = getenv("TF_WGRAD_TAIL_ALONE") ? atoi(getenv("TF_WGRAD_TAIL_ALONE")) : 1;   // experiment switch
@@ -636,10 +638,17 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     const Buf dy2 = d2.thr ? dy : dz;
     TF_TRY(gemm(c, dy2, c.wgt(w + c.W.w2T, D.ffp, D.dp), du, nullptr, u, NOBUF, D.ffp, D.dp, TF_EPI_MUL, none),
            "dgrad ffn_down");                                 // dU = dH . G (G stored by the forward FFN-up epilogue)
-    TF_TRY(side_fork(c, sd, EV_FORK_A), "fork A");
-    TF_TRY(wgrad(c, sd, dy2, D.dp, hh, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff), "wgrad w2");
-    TF_TRY(wgrad(c, sd, du, D.ffp, x1, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d), "wgrad w1");
-    TF_TRY(side_done(sd, 0), "done A");
+    // where the side stream picks up its work (experiment switches; defaults = measured best)
+    static const int fork_a_pos = getenv("TF_FORK_A_POS") ? atoi(getenv("TF_FORK_A_POS")) : 0;   // 0 after dgrad ffn_down, 1 after LN1 bwd, 2 after dgrad out_proj
+    static const int fork_o_pos = getenv("TF_FORK_O_POS") ? atoi(getenv("TF_FORK_O_POS")) : 0;   // 0 before dgrad out_proj, 1 after it
+    auto fork_a = [&]() -> int {
+      int rc = side_fork(c, sd, EV_FORK_A);
+      if (rc == 0) rc = wgrad(c, sd, dy2, D.dp, hh, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff);
+      if (rc == 0) rc = wgrad(c, sd, du, D.ffp, x1, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d);
+      if (rc == 0) rc = side_done(sd, 0);
+      return rc;
+    };
+    if (fork_a_pos == 0) TF_TRY(fork_a(), "wgrad w2 / w1");
     TF_TRY(gemm(c, du, c.wgt(w + c.W.w1T, D.dp, D.ffp), dxb, nullptr, dz, NOBUF, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
     // ---- LN1 backward: dxb -> dzb (= d z1), dyb (= dropout1-masked) ----
     const Drop d1 = drop_for(e, e->p_token, site_of(l, SITE_DROP1));
@@ -653,9 +662,16 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln1_bwd");
     }
     const Buf dy1 = d1.thr ? dyb : dzb;
-    TF_TRY(side_fork(c, sd, EV_FORK_O), "fork O");
-    TF_TRY(wgrad(c, sd, dy1, D.dp, o, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d), "wgrad out_proj");
+    if (fork_a_pos == 1) TF_TRY(fork_a(), "wgrad w2 / w1");
+    auto fork_o = [&]() -> int {
+      int rc = side_fork(c, sd, EV_FORK_O);
+      if (rc == 0) rc = wgrad(c, sd, dy1, D.dp, o, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d);
+      return rc;
+    };
+    if (fork_o_pos == 0) TF_TRY(fork_o(), "wgrad out_proj");
     TF_TRY(gemm(c, dy1, c.wgt(w + c.W.woT, D.dp, D.dp), d_o, nullptr, NOBUF, NOBUF, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
+    if (fork_a_pos == 2) TF_TRY(fork_a(), "wgrad w2 / w1");
+    if (fork_o_pos == 1) TF_TRY(fork_o(), "wgrad out_proj");
     {
       TfAttnArgs a{};
       a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);

@@ -276,14 +276,37 @@ def regroup(patches, init_h, init_w, patch_h, patch_w, out_dtype=None):
 # ------------------------------------------------------------------------------------------------------
 # Linear (K1's conv-as-GEMM and K9's back-projection)
 # ------------------------------------------------------------------------------------------------------
+import weakref
+
+_shadow_cache = weakref.WeakKeyDictionary()      # parameter object -> ((data_ptr, _version, shape), W shadow, W^T shadow)
+
+
+def _weight_shadows(weight, N8, Kp, Np):
+    """bf16 shadows [N8, Kp] and [Kp, Np] of an fp32 weight, re-packed only when the parameter changed (its storage moved or its
+    version was bumped -- FusedRAdam does that for its raw-pointer updates).  Keyed on the parameter OBJECT (weakly), never on a
+    bare data_ptr: a freed tensor's address is reused by its successor."""
+    w2 = weight.reshape(weight.shape[0], -1)
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), N8, Kp, Np)
+    try:
+        hit = _shadow_cache.get(weight)
+    except TypeError:
+        hit = None
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np)
+    try:
+        _shadow_cache[weight] = (key, wsh, wsh_t)
+    except TypeError:
+        pass
+    return wsh, wsh_t
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, weight, bias, p_drop_in, seed):
+    def forward(ctx, x2d, weight, bias, p_drop_in, seed, wsh, wsh_t):
         _require_cuda(x2d, weight)
         M, K = x2d.shape
         N = weight.shape[0]
-        if K % 8:
-            raise L.TfError(f"linear: K={K} must be a multiple of 8")
         N8 = _up(N, 8)      # class-count heads (87 nouns, 74 verbs): zero weight rows up to the 16-B store width
         Kp, Np = _up(K, 64), _up(N, 64)
         xb = to_bf16_padded(x2d, Kp)
@@ -292,7 +315,6 @@ class _LinearFn(torch.autograd.Function):
             xd = torch.empty_like(xb)
             L.check(L.load().tf_dropout_apply(L.ptr(xb), L.ptr(xd), xb.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
             xb = xd
-        wsh, wsh_t = pack_weight(weight, N8, Kp, Kp, Np)
         y = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device) if Np != N else torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
         bf = None if bias is None else bias.detach().float().contiguous()
         if bf is not None and N8 != N:
@@ -310,22 +332,32 @@ class _LinearFn(torch.autograd.Function):
         if N8 != N:
             gy = torch.nn.functional.pad(gy, (0, N8 - N))
         gyb = to_bf16_padded(gy, Np)
-        dx = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
-        gemm(gyb, wsh_t, dx, Kp, Np, L.TF_EPI_NONE)
-        if drop[0]:
-            L.check(L.load().tf_dropout_apply(L.ptr(dx), L.ptr(dx), dx.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+            gemm(gyb, wsh_t, dx, Kp, Np, L.TF_EPI_NONE)
+            if drop[0]:
+                L.check(L.load().tf_dropout_apply(L.ptr(dx), L.ptr(dx), dx.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
+            dx = from_padded(dx, K, xdtype)
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
         wgrad(gyb, N8, xb, Kp, dW.view(N, -1), db)      # rows >= N are masked by n_src = N
-        return from_padded(dx, K, xdtype), dW, db, None, None
+        return dx, dW, db, None, None, None, None
 
 
 def linear(x, weight, bias=None, p_drop_in: float = 0.0):
-    """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N]."""
+    """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N].  ``weight`` may have any trailing shape (the k = s = p
+    Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)]."""
     lead = x.shape[:-1]
-    w2 = weight.reshape(weight.shape[0], -1)
-    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0)
-    return y.reshape(*lead, weight.shape[0])
+    K = x.shape[-1]
+    N = weight.shape[0]
+    if K % 8:
+        raise L.TfError(f"linear: K={K} must be a multiple of 8")
+    _require_cuda(x, weight)
+    wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64))
+    w2 = weight.reshape(N, -1)
+    y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0, wsh, wsh_t)
+    return y.reshape(*lead, N)
 
 
 # ------------------------------------------------------------------------------------------------------
