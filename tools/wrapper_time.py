@@ -21,7 +21,7 @@ shapes = [(14 * p, 14 * p) for p in ps]
 fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
 fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})       # run.narr_fusion.* keys of the experiment YAML
 fusion["args"].update({"input_f_size": D})
-run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0},
+run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": int(os.environ.get("PRECISION", 16)),
            "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": D,
                                                      "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
 model = get_fusion_model(StubDetector(shapes, chans), {}, run_cfg, None).to(dev).train()
@@ -43,8 +43,10 @@ n = 5
 t0 = time.perf_counter()
 for _ in range(n):
     loss = step()
+t_host = (time.perf_counter() - t0) / n * 1e3
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
+print(f"host enqueue {t_host:.2f} ms/step")
 print(f"wrapper fwd+bwd, B={B}, 4 levels x 4 layers: {ms:.2f} ms/step ({B / ms * 1e3:.1f} samples/s), loss {float(loss):.4f}")
 lib = Lb.load()
 Lb.check(lib.tf_trace_start(), "trace")

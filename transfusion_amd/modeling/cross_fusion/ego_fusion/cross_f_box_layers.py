@@ -216,6 +216,7 @@ class CrossTransformerModuleBox(nn.Module):
         # configs[2]): hi + lo bf16 planes, three MFMA passes per contraction (include/tfusion.h, TfEncoderDesc.precision)
         self.precision = os.environ.get("TF_PRECISION", "bf16")
         self.layer_grad_hook = None           # callable(module, layer): called as soon as that layer's gradients are enqueued
+        self._params_cache = None
         self._wpack = None
         self._wpack_versions = None
         self._work_pool = {}
@@ -223,12 +224,18 @@ class CrossTransformerModuleBox(nn.Module):
 
     # ---- parameter plumbing ----------------------------------------------------------------------------
     def _param_list(self):
-        ps = [self.image_kind_embedding, self.lang_kind_embedding]
-        for layer in self.t_encoder.layers:
-            sd = dict(layer.named_parameters())
-            ps += [sd[name] for _, name in _LAYER_FIELDS]
-        if self.final_norm == "ln":
-            ps += [self.final_norm_layer.weight, self.final_norm_layer.bias]
+        """[kind_v, kind_l, 12 tensors per layer in _LAYER_FIELDS order, (final norm w, b)] -- the Parameter OBJECTS, cached: the module
+        tree is fixed after construction (`.to()` / `load_state_dict` change `.data` in place), and walking `named_parameters()` of
+        every layer on every call was a visible part of the host time per step at small batches."""
+        ps = self._params_cache
+        if ps is None:
+            ps = [self.image_kind_embedding, self.lang_kind_embedding]
+            for layer in self.t_encoder.layers:
+                sd = dict(layer.named_parameters())
+                ps += [sd[name] for _, name in _LAYER_FIELDS]
+            if self.final_norm == "ln":
+                ps += [self.final_norm_layer.weight, self.final_norm_layer.bias]
+            self._params_cache = ps
         return ps
 
     def _wpack_dirty(self) -> bool:
@@ -262,7 +269,8 @@ class CrossTransformerModuleBox(nn.Module):
         Nl = lang.shape[1]
         if d != self.token_dim or lang.shape[2] != d or lang.shape[0] != B:
             raise RuntimeError(f"token shapes {tuple(x.shape)} / {tuple(lang.shape)} do not match input_f_size={self.token_dim}")
-        for p in self._param_list():
+        params = self._param_list()
+        for p in params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise L.TfError("parameters must be contiguous fp32 (bf16 shadows are derived inside the runtime)")
         if self.precision not in ("bf16", "fp32"):
@@ -287,13 +295,14 @@ class CrossTransformerModuleBox(nn.Module):
         e.p_token, e.p_patch = float(self.token_dropout), float(self.patch_dropout)
         self._last_seed = ops.next_seed() if self.training else 0
         e.seed = self._last_seed
-        for j, layer in enumerate(self.t_encoder.layers):
-            sd = dict(layer.named_parameters())
-            for field, name in _LAYER_FIELDS:
-                setattr(e.p[j], field, sd[name].data_ptr())
-        e.kind_v, e.kind_l = self.image_kind_embedding.data_ptr(), self.lang_kind_embedding.data_ptr()
+        it = iter(params)
+        e.kind_v, e.kind_l = next(it).data_ptr(), next(it).data_ptr()
+        for j in range(self.num_layers):
+            pj = e.p[j]
+            for field, _ in _LAYER_FIELDS:
+                setattr(pj, field, next(it).data_ptr())
         if e.final_norm:
-            e.fn_w, e.fn_b = self.final_norm_layer.weight.data_ptr(), self.final_norm_layer.bias.data_ptr()
+            e.fn_w, e.fn_b = next(it).data_ptr(), next(it).data_ptr()
         # positional tables: the sin1d BUFFERS are read by the assemble kernel; learned / zero tables are Parameters (utils.py:181-184)
         # whose gradient autograd needs, so forward() has already added those with a torch op and they are not passed here
         pe = self.pos_embedding_layer.pos_embedding

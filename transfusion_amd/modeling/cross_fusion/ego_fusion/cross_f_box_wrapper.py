@@ -10,6 +10,8 @@ bias=False, is exactly that GEMM), fused encoder, K9 back-projection GEMM + fold
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -64,6 +66,7 @@ class CrossFusionBoxWrapper(nn.Module):
             w_ln = cross_layer_args["args"].pop("final_ln")
             cross_layer_args["args"]["final_norm"] = "ln" if w_ln else False
 
+        self._level_streams = None
         self.cross_encoder_args = cross_layer_args
         self.forward_language_f = self.cross_encoder_args.get("forward_language_f", False)
         self.vis_mask_type = self.cross_encoder_args.get("vis_mask_type", "global")
@@ -157,17 +160,39 @@ class CrossFusionBoxWrapper(nn.Module):
         pad_mask = ~(att_mask.type(torch.bool))     # HF mask (1 = token) -> torch convention (True = ignore), reference :196
         fused_l_features = None
         mscale_l_features = []
+        # The feature levels are independent of each other unless language_f is forwarded from level to level (forward_language_f,
+        # False in the shipped configs): each level then runs on its own HIP stream.  At the reference's real per-GPU batch (4-8 samples)
+        # one level's kernels cover a fraction of the 256 CUs (grids of 50-150 workgroups); four levels side by side fill the chip.
+        # Autograd replays every node's backward on the stream its forward ran on, so the backward is level-parallel too.
+        main = torch.cuda.current_stream(language_f.device) if language_f.is_cuda else None
+        parallel = (main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
+                    and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
+        if parallel and (self._level_streams is None or self._level_streams[0].device != language_f.device):
+            self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
         for i, key in enumerate(self.fpn_features_idx):
             key = str(key)
             feat = features_dict["features"][key]
             self.tokens_to_features[i].init_h = feat.shape[2]
             self.tokens_to_features[i].init_w = feat.shape[3]
-            vis_tokens = self.patches_to_token[i](feat)
             hp, wp = feat.shape[2] // self.patches_to_token[i].patch_h, feat.shape[3] // self.patches_to_token[i].patch_w
             vis_tokens_mask = get_visual_token_mask((hp, wp), self.vis_mask_type)
-            fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
-                vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
-            )
+            if parallel:
+                st = self._level_streams[i]
+                st.wait_stream(main)                              # inputs (features, language tokens, masks) were produced on main
+                with torch.cuda.stream(st):
+                    vis_tokens = self.patches_to_token[i](feat)
+                    fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
+                        vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
+                    )
+                    out_i = self.tokens_to_features[i](fused_features)
+                for t in (out_i, fused_l_features):
+                    t.record_stream(main)                         # consumed on main below: keep the allocator from recycling them early
+            else:
+                vis_tokens = self.patches_to_token[i](feat)
+                fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
+                    vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
+                )
+                out_i = self.tokens_to_features[i](fused_features)
             if self.multi_lm:
                 mscale_l_features.append(fused_l_features)
             if self.forward_language_f:
@@ -177,7 +202,10 @@ class CrossFusionBoxWrapper(nn.Module):
                     language_f = language_f + fused_l_features
                 else:
                     raise NotImplementedError()
-            features_dict["features"][key] = self.tokens_to_features[i](fused_features)
+            features_dict["features"][key] = out_i
+        if parallel:
+            for st in self._level_streams:
+                main.wait_stream(st)
 
         features_dict = self.rcnn_model.apply_fpn(features_dict)
         if "hand_boxes" in x:

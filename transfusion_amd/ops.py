@@ -129,35 +129,40 @@ def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
     return q, sc
 
 
-_overlap_cache = {}
+_overlap_cache = {}      # (device index, stream handle) -> TfOverlap: every stream that runs encoders has its own side stream + events
+
+
+def _overlap_key(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return idx, torch.cuda.current_stream(idx).cuda_stream
 
 
 def overlap_handle(device):
-    """The device's ``TfOverlap`` ctypes object (None when disabled); see ``wgrad_overlap``."""
+    """The ``TfOverlap`` ctypes object of (device, current stream) (None when disabled); see ``wgrad_overlap``."""
     addr = wgrad_overlap(device)
     if addr is None:
         return None
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return _overlap_cache[idx]
+    return _overlap_cache[_overlap_key(device)]
 
 
 def wgrad_overlap(device):
-    """Address of this device's ``TfOverlap`` (side stream + events on which ``tf_encoder_bwd`` issues its weight-gradient
-    GEMMs), created on first use; ``TF_WGRAD_OVERLAP=0`` keeps everything on the caller's stream (A/B switch)."""
+    """Address of the ``TfOverlap`` (side stream + events on which ``tf_encoder_bwd`` issues its weight-gradient GEMMs) that belongs to
+    the CURRENT stream of ``device``, created on first use: encoders that run concurrently on different streams (the wrapper's feature
+    levels) must not share events.  ``TF_WGRAD_OVERLAP=0`` keeps everything on the caller's stream (A/B switch)."""
     if os.environ.get("TF_WGRAD_OVERLAP", "1") == "0":
         return None
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    o = _overlap_cache.get(idx)
+    key = _overlap_key(device)
+    o = _overlap_cache.get(key)
     if o is None:
         o = L.TfOverlap()
-        with torch.cuda.device(idx):
+        with torch.cuda.device(key[0]):
             L.check(L.load().tf_overlap_create(C.byref(o)), "tf_overlap_create")
-        _overlap_cache[idx] = o
+        _overlap_cache[key] = o
     return C.addressof(o)
 
 
 def join_overlap(device):
-    """Make the current stream wait for every weight-gradient GEMM the side stream still owes (tf_overlap_join)."""
+    """Make the current stream wait for every weight-gradient GEMM its side stream still owes (tf_overlap_join)."""
     o = overlap_handle(device)
     if o is not None:
         L.check(L.load().tf_overlap_join(C.byref(o), C.c_void_p(_stream())), "tf_overlap_join")
@@ -171,11 +176,11 @@ def side_stream(device):
     o = overlap_handle(device)
     if o is None:
         return None
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    s = _side_streams.get(idx)
+    key = _overlap_key(device)
+    s = _side_streams.get(key)
     if s is None:
-        s = torch.cuda.ExternalStream(o.stream, device=torch.device("cuda", idx))
-        _side_streams[idx] = s
+        s = torch.cuda.ExternalStream(o.stream, device=torch.device("cuda", key[0]))
+        _side_streams[key] = s
     return s
 
 
@@ -278,24 +283,24 @@ def regroup(patches, init_h, init_w, patch_h, patch_w, out_dtype=None):
 # ------------------------------------------------------------------------------------------------------
 import weakref
 
-_shadow_cache = weakref.WeakKeyDictionary()      # parameter object -> ((data_ptr, _version, shape), W shadow, W^T shadow)
+_shadow_cache = {}      # id(parameter) -> (weakref to the parameter, (data_ptr, _version, shape, pads), W shadow, W^T shadow)
 
 
 def _weight_shadows(weight, N8, Kp, Np):
     """bf16 shadows [N8, Kp] and [Kp, Np] of an fp32 weight, re-packed only when the parameter changed (its storage moved or its
-    version was bumped -- FusedRAdam does that for its raw-pointer updates).  Keyed on the parameter OBJECT (weakly), never on a
-    bare data_ptr: a freed tensor's address is reused by its successor."""
+    version was bumped -- FusedRAdam does that for its raw-pointer updates).  Keyed on the parameter OBJECT (id + a weak reference that
+    must still point at it), never on a bare data_ptr: a freed tensor's address is reused by its successor."""
     w2 = weight.reshape(weight.shape[0], -1)
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), N8, Kp, Np)
-    try:
-        hit = _shadow_cache.get(weight)
-    except TypeError:
-        hit = None
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+    hit = _shadow_cache.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2], hit[3]
     wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np)
+    if len(_shadow_cache) > 256:                                   # drop entries whose parameter is gone
+        for k in [k for k, v in _shadow_cache.items() if v[0]() is None]:
+            del _shadow_cache[k]
     try:
-        _shadow_cache[weight] = (key, wsh, wsh_t)
+        _shadow_cache[id(weight)] = (weakref.ref(weight), key, wsh, wsh_t)
     except TypeError:
         pass
     return wsh, wsh_t
