@@ -98,6 +98,12 @@ typedef struct TfAttnArgs {
   // fp32-accuracy mode (see TfGemmArgs): lo planes of qkv / out / dout / dqkv, same leading dimensions.  qkv_lo != null selects
   // the split kernels (attn_x3.hip): every S x S x hd product is three bf16 MFMA passes, probabilities are split in registers.
   const void* qkv_lo; void* out_lo; const void* dout_lo; void* dqkv_lo;
+  // Cross attention with its own query set (QKVEncoder, modeling/cross_fusion/cross_qkv_layers.py:51-81: queries from one modality,
+  // keys / values from the concatenation).  q != null: queries are q [B*Sq, ld_q] (column = head*HDP + e) instead of the Q third of
+  // qkv, whose K and V thirds [B*S, .] still hold the S keys; out / lse / delta / dout / the dropout bitmask rows then have Sq rows
+  // per (batch, head), and the query gradient goes to dq [B*Sq, ld_dq] (dqkv keeps dK, dV).  block_bits must be null.
+  const void* q; int ld_q; int Sq; void* dq; int ld_dq;
+  const void* q_lo; void* dq_lo;          // their lo planes in the fp32-accuracy mode
 } TfAttnArgs;
 
 
@@ -238,6 +244,8 @@ float tf_drop_scale(float p);          /* 1 / (1 - threshold/65536): the exact i
 /* bytes of the attention dropout bitmask for (B, H, S) */
 size_t tf_attn_dropmask_bytes(int B, int H, int S);
 int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr, tf_stream_t s);
+/* cross attention (TfAttnArgs.q): nrows = B * H * Sq query rows of S key bits, [nrows, ceil(S/64)] u64 */
+int tf_attn_dropmask_rows(void* bits, long long nrows, int S, uint32_t key, uint32_t thr, tf_stream_t s);
 
 /* ---- library ---- */
 int tf_version(void);

@@ -352,3 +352,56 @@ def nao_losses(out, noun_labels: torch.Tensor, verb_labels: Optional[torch.Tenso
         if t_logits.shape[0] > 0:                                                                   # :358-359
             res["ttc"] = _smooth_l1(t_logits - t_targets, ttc_beta).mean()
     return res
+
+
+# ----------------------------------------------------------------------------
+# asymmetric cross attention
+# ----------------------------------------------------------------------------
+def qkv_encoder_layer(sd: Dict[str, torch.Tensor], pre: str, q: torch.Tensor, kv: torch.Tensor, num_heads: int,
+                      key_padding_mask: Optional[torch.Tensor] = None, activation: str = "relu",
+                      masks: Optional[Dict[str, torch.Tensor]] = None, p: float = 0.0) -> torch.Tensor:
+    """QKVEncoder.forward, modeling/cross_fusion/cross_qkv_layers.py:73-81, with k = v = kv (how AsymmetricCrossFModuleBox calls it).
+    Attention: torch18_adapters.py:647-700 (_in_projection_packed with q is not k, k is v: w.split([E, 2E]); q from the first E rows of
+    in_proj_weight, k | v from the other 2E), :530-540 (heads), :578-597 (key padding), :788-799 (softmax(q/sqrt(hd) k^T) v), :606-608.
+    q [B,Nq,d], kv [B,Nk,d] -> [B,Nq,d]."""
+    B, Nq, d = q.shape
+    Nk = kv.shape[1]
+    hd = d // num_heads
+    w, b = sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"]
+    qp = q @ w[:d].t() + b[:d]
+    kp = kv @ w[d:2 * d].t() + b[d:2 * d]
+    vp = kv @ w[2 * d:].t() + b[2 * d:]
+    heads = lambda t, n: t.reshape(B, n, num_heads, hd).permute(0, 2, 1, 3)
+    scores = (heads(qp, Nq) / math.sqrt(hd)) @ heads(kp, Nk).transpose(-2, -1)             # [B,h,Nq,Nk]
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask.view(B, 1, 1, Nk), float("-inf"))
+    prob = torch.softmax(scores, dim=-1)
+    prob = _drop(prob, masks, pre + "attn", p)
+    o = (prob @ heads(vp, Nk)).permute(0, 2, 1, 3).reshape(B, Nq, d)
+    q2 = o @ sd[pre + "self_attn.out_proj.weight"].t() + sd[pre + "self_attn.out_proj.bias"]
+    x = layer_norm(q + _drop(q2, masks, pre + "dropout1", p), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])       # :76-77
+    u = x @ sd[pre + "linear1.weight"].t() + sd[pre + "linear1.bias"]
+    hdn = _drop(gelu(u) if activation == "gelu" else torch.clamp(u, min=0.0), masks, pre + "dropout", p)              # :78
+    y = hdn @ sd[pre + "linear2.weight"].t() + sd[pre + "linear2.bias"]
+    return layer_norm(x + _drop(y, masks, pre + "dropout2", p), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])     # :79-80
+
+
+def asymmetric_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch.Tensor, num_heads: int, vis_layers: int,
+                       lang_layers: int, activation: str = "relu", back_to_img_fn: str = "regroup"):
+    """AsymmetricCrossFModuleBox.forward, modeling/cross_fusion/ego_fusion/cross_f_box_asymm.py:72-120 (eval / p = 0).  The padding
+    mask the reference builds at :85-86 is never handed to a layer: no key is masked.  Returns (vis, lang)."""
+    n = x.shape[1]
+    x = x + sd["pos_embedding_layer.pos_embedding"][:, :n]                               # :75
+    x = x + sd["image_kind_embedding"]                                                   # :76
+    lang = lang + sd["lang_kind_embedding"]                                              # :80
+    v_k = torch.cat((x, lang), dim=1)                                                    # :87
+    lang = qkv_encoder_layer(sd, "cross_lang_layers.0.", lang, v_k, num_heads, None, activation)        # :88
+    x = qkv_encoder_layer(sd, "cross_vis_layers.0.", x, v_k, num_heads, None, activation)               # :93
+    for i in range(1, lang_layers):                                                      # :97-103
+        v_k = torch.cat((x, lang), dim=1)
+        x = qkv_encoder_layer(sd, f"cross_vis_layers.{i}.", x, v_k, num_heads, None, activation)
+        lang = qkv_encoder_layer(sd, f"cross_lang_layers.{i}.", lang, v_k, num_heads, None, activation)
+    for i in range(lang_layers, vis_layers):                                             # :106-110
+        v_k = torch.cat((x, lang), dim=1)
+        x = qkv_encoder_layer(sd, f"cross_vis_layers.{i}.", x, v_k, num_heads, None, activation)
+    return (x[:, 0] if back_to_img_fn == "token" else x[:, :n]), lang                    # :112-115

@@ -215,3 +215,64 @@ def make_heads_case(cfg):
     noun_w = (0.5 + rs.rand(Cn)).astype(np.float32)
     verb_w = (0.5 + rs.rand(Cv)).astype(np.float32)
     return params, feats, noun, verb, ttc, reg, noun_w, verb_w
+
+
+# asymmetric encoder (type: asymmetric): cross-attention layers with their own query set (cross_qkv_layers.py, cross_f_box_asymm.py)
+QKV_CASES = {
+    "qkv_layer": dict(B=2, Nq=9, Nk=14, d=32, h=2, ff=48, activ="relu", mask_lens=[14, 8], seed=601),        # with a key padding mask
+    "qkv_layer_gelu_hd18": dict(B=1, Nq=5, Nk=21, d=72, h=4, ff=72, activ="gelu", mask_lens=None, seed=602),  # head dim 18 -> padded 32
+}
+ASYM_CASES = {
+    "asym_small": dict(B=2, Nv=10, Nl=7, d=32, h=2, vis_layers=3, lang_layers=2, ff_mult=1, activ="relu", seed=611),
+}
+
+
+def qkv_param_shapes(d, ff, prefix=""):
+    return {prefix + "self_attn.in_proj_weight": (3 * d, d), prefix + "self_attn.in_proj_bias": (3 * d,),
+            prefix + "self_attn.out_proj.weight": (d, d), prefix + "self_attn.out_proj.bias": (d,),
+            prefix + "linear1.weight": (ff, d), prefix + "linear1.bias": (ff,), prefix + "linear2.weight": (d, ff), prefix + "linear2.bias": (d,),
+            prefix + "norm1.weight": (d,), prefix + "norm1.bias": (d,), prefix + "norm2.weight": (d,), prefix + "norm2.bias": (d,)}
+
+
+def _fill(rs, shapes):
+    out = {}
+    for name, shp in shapes.items():
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+            out[name] = (1.0 + 0.1 * rs.randn(*shp)).astype(np.float32)
+        elif len(shp) == 2:
+            out[name] = (rs.randn(*shp) / np.sqrt(shp[1])).astype(np.float32)
+        elif len(shp) == 3:
+            out[name] = rs.randn(*shp).astype(np.float32)
+        else:
+            out[name] = (0.1 * rs.randn(*shp)).astype(np.float32)
+    return out
+
+
+def make_qkv_case(cfg):
+    """-> (params, q [B,Nq,d], kv [B,Nk,d], key padding mask [B,Nk] bool | None, cotangent [B,Nq,d])"""
+    rs = np.random.RandomState(cfg["seed"])
+    params = _fill(rs, qkv_param_shapes(cfg["d"], cfg["ff"]))
+    q = rs.randn(cfg["B"], cfg["Nq"], cfg["d"]).astype(np.float32)
+    kv = rs.randn(cfg["B"], cfg["Nk"], cfg["d"]).astype(np.float32)
+    cot = rs.randn(cfg["B"], cfg["Nq"], cfg["d"]).astype(np.float32)
+    mask = None
+    if cfg["mask_lens"] is not None:
+        mask = np.zeros((cfg["B"], cfg["Nk"]), dtype=bool)
+        for b, n in enumerate(cfg["mask_lens"]):
+            mask[b, n:] = True
+    return params, q, kv, mask, cot
+
+
+def make_asym_case(cfg):
+    """-> (params, x [B,Nv,d], lang [B,Nl,d], cot_vis, cot_lang)"""
+    rs = np.random.RandomState(cfg["seed"])
+    d, ff = cfg["d"], int(cfg["d"] * cfg["ff_mult"])
+    shapes = {"image_kind_embedding": (1, 1, d), "lang_kind_embedding": (1, 1, d)}
+    for i in range(cfg["vis_layers"]):
+        shapes.update(qkv_param_shapes(d, ff, f"cross_vis_layers.{i}."))
+    for i in range(cfg["lang_layers"]):
+        shapes.update(qkv_param_shapes(d, ff, f"cross_lang_layers.{i}."))
+    params = _fill(rs, shapes)
+    x = rs.randn(cfg["B"], cfg["Nv"], d).astype(np.float32)
+    lang = rs.randn(cfg["B"], cfg["Nl"], d).astype(np.float32)
+    return params, x, lang, rs.randn(cfg["B"], cfg["Nv"], d).astype(np.float32), rs.randn(cfg["B"], cfg["Nl"], d).astype(np.float32)

@@ -24,8 +24,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, RADAM_CASES, make_encoder_inputs,  # noqa: E402
-                   make_encoder_params, make_heads_case, make_level_extras, make_lm_case, make_radam_case)
+from cases import (ASYM_CASES, ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, QKV_CASES, RADAM_CASES,  # noqa: E402
+                   make_asym_case, make_encoder_inputs, make_encoder_params, make_heads_case, make_level_extras, make_lm_case,
+                   make_qkv_case, make_radam_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -288,6 +289,98 @@ def run_heads_case(name, cfg):
     print(name, "ok", out["losses"])
 
 
+def _ref_qkv_forward(layer, q, k, v, key_padding_mask=None):
+    """``QKVEncoder.forward`` (cross_qkv_layers.py:73-81) executed statement by statement on a reference ``QKVEncoder`` INSTANCE -- its own
+    Linear / LayerNorm / Dropout submodules and its own parameters -- with ONE substitution: the call ``self.self_attn(q, k, v, ...)`` of
+    :73-75 unpacks three values, which on this torch raises (stock ``nn.MultiheadAttention`` returns two; checked: ValueError); the
+    three-value attention is the reference's vendored ``MultiheadAttentionBFirst`` (torch18_adapters.py:270-345), which cannot be
+    instantiated on torch 2.x (``_LinearWithBias``).  Its forward is therefore followed line by line here (batch_first transposes :300,
+    the vendored functional ``multi_head_attention_forward`` :322-339 on the instance's parameters, transpose back :341-343)."""
+    from modeling.cross_fusion.ego_fusion.torch18_adapters import multi_head_attention_forward
+    a = layer.self_attn
+    qt, kt, vt = [t.transpose(1, 0) for t in (q, k, v)]                                   # torch18_adapters.py:300
+    attn_output, attentions, vs = multi_head_attention_forward(                          # :322-339
+        qt, kt, vt, a.embed_dim, a.num_heads, a.in_proj_weight, a.in_proj_bias, a.bias_k, a.bias_v, a.add_zero_attn, a.dropout,
+        a.out_proj.weight, a.out_proj.bias, training=layer.training, key_padding_mask=key_padding_mask, need_weights=False, attn_mask=None)
+    q2 = attn_output.transpose(1, 0)                                                      # :341
+    q = q + layer.dropout1(q2)                                                            # cross_qkv_layers.py:76
+    q = layer.norm1(q)                                                                    # :77
+    q2 = layer.linear2(layer.dropout(layer.activation(layer.linear1(q))))                 # :78
+    q = q + layer.dropout2(q2)                                                            # :79
+    q = layer.norm2(q)                                                                    # :80
+    return q, attentions, vs
+
+
+def _load_qkv(layer, params, prefix=""):
+    missing, unexpected = layer.load_state_dict({k[len(prefix):]: torch.from_numpy(v) for k, v in params.items() if k.startswith(prefix)}, strict=True)
+    assert not missing and not unexpected
+
+
+def run_qkv_case(name, cfg):
+    from modeling.cross_fusion.cross_qkv_layers import QKVEncoder
+    params, q, kv, mask, cot = make_qkv_case(cfg)
+    layer = QKVEncoder(cfg["d"], cfg["d"], cfg["h"], dim_feedforward=cfg["ff"], dropout=0.0, activation=cfg["activ"])
+    _load_qkv(layer, params)
+    layer.train()
+    tq, tkv = torch.from_numpy(q).requires_grad_(True), torch.from_numpy(kv).requires_grad_(True)
+    out, att, vs = _ref_qkv_forward(layer, tq, tkv, tkv, None if mask is None else torch.from_numpy(mask))
+    assert att is None and vs is None
+    (out * torch.from_numpy(cot)).sum().backward()
+    res = {"out": out.detach().numpy(), "grad_q": tq.grad.numpy(), "grad_kv": tkv.grad.numpy(),
+           "state_dict_keys": np.array(sorted(layer.state_dict().keys()))}
+    for k, p_ in layer.named_parameters():
+        res["gradp/" + k] = p_.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "ok", res["out"].shape)
+
+
+def run_asym_case(name, cfg, ref_utils):
+    """``AsymmetricCrossFModuleBox.forward`` (cross_f_box_asymm.py:72-120) executed statement by statement: the class itself cannot be
+    constructed (its ``super().__init__`` call passes ``pos_embedding=`` / ``final_ln=``, TypeError -- checked), so the pieces it would
+    hold are built as its constructor builds them (:48-71: two reference ``QKVEncoder`` prototypes cloned with torch's ``_get_clones``, the
+    reference ``PositionalEmbeddingLayer``, the kind embeddings) and its forward's statements are executed on them in order."""
+    from modeling.cross_fusion.cross_qkv_layers import QKVEncoder
+    from torch.nn.modules.transformer import _get_clones
+    params, x, lang, cv, cl = make_asym_case(cfg)
+    d, ff = cfg["d"], int(cfg["d"] * cfg["ff_mult"])
+    vis = _get_clones(QKVEncoder(d, d, cfg["h"], dim_feedforward=ff, dropout=0.0, activation=cfg["activ"]), cfg["vis_layers"])      # :53-60, :70
+    lng = _get_clones(QKVEncoder(d, d, cfg["h"], dim_feedforward=ff, dropout=0.0, activation=cfg["activ"]), cfg["lang_layers"])     # :61-68, :71
+    for i, l_ in enumerate(vis):
+        _load_qkv(l_, params, f"cross_vis_layers.{i}.")
+    for i, l_ in enumerate(lng):
+        _load_qkv(l_, params, f"cross_lang_layers.{i}.")
+    pe = ref_utils.PositionalEmbeddingLayer("sin1d", 8192, d)
+    kind_v = torch.from_numpy(params["image_kind_embedding"]).requires_grad_(True)
+    kind_l = torch.from_numpy(params["lang_kind_embedding"]).requires_grad_(True)
+    tx, tl = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+    n = tx.shape[1]
+    xx = pe(tx)                                                                          # :75
+    xx = xx + kind_v                                                                     # :76
+    language_f = tl + kind_l                                                             # :80
+    v_k = torch.cat((xx, language_f), dim=1)                                             # :87
+    language_f, _, _ = _ref_qkv_forward(lng[0], language_f, v_k, v_k)                    # :88
+    xx, _, _ = _ref_qkv_forward(vis[0], xx, v_k, v_k)                                    # :93
+    for i in range(1, cfg["lang_layers"]):                                               # :97-103
+        v_k = torch.cat((xx, language_f), dim=1)
+        xx, _, _ = _ref_qkv_forward(vis[i], xx, v_k, v_k)
+        language_f, _, _ = _ref_qkv_forward(lng[i], language_f, v_k, v_k)
+    for i in range(cfg["lang_layers"], cfg["vis_layers"]):                               # :106-110
+        v_k = torch.cat((xx, language_f), dim=1)
+        xx, _, _ = _ref_qkv_forward(vis[i], xx, v_k, v_k)
+    hmap_token = xx[:, :n]                                                               # :115 (back_to_img_fn != "token")
+    ((hmap_token * torch.from_numpy(cv)).sum() + (language_f * torch.from_numpy(cl)).sum()).backward()
+    res = {"vis": hmap_token.detach().numpy(), "lang": language_f.detach().numpy(), "grad_x": tx.grad.numpy(), "grad_lang": tl.grad.numpy(),
+           "gradp/image_kind_embedding": kind_v.grad.numpy(), "gradp/lang_kind_embedding": kind_l.grad.numpy()}
+    for i, l_ in enumerate(vis):
+        for k, p_ in l_.named_parameters():
+            res[f"gradp/cross_vis_layers.{i}.{k}"] = p_.grad.numpy()
+    for i, l_ in enumerate(lng):
+        for k, p_ in l_.named_parameters():
+            res[f"gradp/cross_lang_layers.{i}.{k}"] = np.zeros_like(params[f"cross_lang_layers.{i}.{k}"]) if p_.grad is None else p_.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "ok", res["vis"].shape, res["lang"].shape)
+
+
 def main():
     """python tests/golden/make_golden.py [case-name ...]   (no names: every fixture)"""
     only = set(sys.argv[1:])
@@ -310,6 +403,12 @@ def main():
     for name, cfg in HEADS_CASES.items():
         if want(name):
             run_heads_case(name, cfg)
+    for name, cfg in QKV_CASES.items():
+        if want(name):
+            run_qkv_case(name, cfg)
+    for name, cfg in ASYM_CASES.items():
+        if want(name):
+            run_asym_case(name, cfg, ref_utils)
     if want("sin1d_768"):
         # sin1d table spot values (utils.py:267-273) at the real width
         pe = ref_utils.get_sin1d_embed(8192, 768)

@@ -35,23 +35,26 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   unsigned char* vt = smem + 64 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   // 1-D grid, XCD-aware: all query blocks of one (batch, head) -- which share K and V -- run on the same XCD / L2
-  const int S = a.S;
-  const int nqb = (S + 127) / 128;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries (their own tensor for cross attention, TfAttnArgs.q)
+  const int nqb = (Sq + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const u16* __restrict__ qkv = (const u16*)a.qkv;
   const size_t ld = a.ld_qkv;
-  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
+                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
   const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
   const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
 
   // Q^T B-operand fragments, resident in registers
   bf16x8 qf[G::KSTEPS];
   {
-    const int qr = min(q0 + (lane & 31), S - 1);
+    const int qr = min(q0 + (lane & 31), Sq - 1);
 #pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ld + ks * 16 + 8 * h));
+    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ldq + ks * 16 + 8 * h));
   }
   f32x16 o[G::DBLK];
 #pragma unroll
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
-  const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, S - 1) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sq - 1)) * SW : nullptr;
+  const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sq - 1) * SW : nullptr;
 
   const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   for (int t = 0; t < ntiles; ++t) {
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
-  if (qrow < S) {
-    u16* orow = (u16*)a.out + ((size_t)b * S + qrow) * a.ld_out + (size_t)head * HDP;
+  if (qrow < Sq) {
+    u16* orow = (u16*)a.out + ((size_t)b * Sq + qrow) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
         v[1] = pack2bf(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
         *(u32x2*)(orow + d * 32 + 8 * g4 + 4 * h) = v;
       }
-    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * S + qrow] = m_run + log2f(l_tot);
+    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
   }
 }
 
@@ -174,32 +177,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   unsigned char* vt = smem + 64 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   // 1-D grid, XCD-aware: all query blocks of one (batch, head) -- which share K and V -- run on the same XCD / L2
-  const int S = a.S;
-  const int nqb = (S + 127) / 128;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries
+  const int nqb = (Sq + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
-  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
+                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
   const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
   const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
 
   const int qrow = q0 + (lane & 31);
-  const int qr = min(qrow, S - 1);
+  const int qr = min(qrow, Sq - 1);
   bf16x8 qf[G::KSTEPS], dof[G::KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < G::KSTEPS; ++ks) {
-    qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ld + ks * 16 + 8 * h));
+    qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ldq + ks * 16 + 8 * h));
     dof[ks] = as_bf16x8(*(const u32x4*)(dobase + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
   }
-  const float lse = a.lse[(size_t)bh * S + qr];
+  const float lse = a.lse[(size_t)bh * Sq + qr];
   // delta[q] = rowsum(dO . O): this wave already holds dO in B-operand layout (lane half h owns hd elements 16ks+8h..+7),
   // so read O the same way, reduce in registers + one cross-half exchange, and publish it for the dK/dV kernel
   float delta = 0.f;
   {
-    const u16* orow = (const u16*)a.out + ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+    const u16* orow = (const u16*)a.out + ((size_t)b * Sq + qr) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       float of[8], df[8];
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
     }
     delta += __shfl_xor(delta, 32, 64);
-    if (h == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+    if (h == 0 && qrow < Sq) a.delta[(size_t)bh * Sq + qrow] = delta;
   }
   f32x16 dq[G::DBLK];
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
   const float sc = a.scale * LOG2E;
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + qr) * SW : nullptr;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
   const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
@@ -324,8 +330,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       }
     }
   }
-  if (qrow < S) {
-    u16* orow = (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+  if (qrow < Sq) {
+    u16* orow = a.q != nullptr ? (u16*)a.dq + ((size_t)b * Sq + qrow) * a.ld_dq + (size_t)head * HDP
+                               : (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -586,17 +593,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   unsigned* dw_s = (unsigned*)(del_s + 32);                       // [4 waves][32 query rows] keep-bit words of the wave's 32 keys
   unsigned* bw_s = dw_s + 128;                                    // [4 waves][32 query rows] block-bit words (BLK only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int S = a.S;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries
   const int nkb = (S + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);          // key blocks of one (batch, head) share Q and dO: same XCD
   const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int key0 = (logical % nkb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
-  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
+  const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
+                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
   const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
   const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const u16* dobase = (const u16*)a.dout + (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
 
   const int key = key0 + (lane & 31);
   const int kr_ = min(key, S - 1);
@@ -618,13 +628,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
   // a key block that holds only padding receives exactly-zero dK / dV: skip its query loop
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (Sq + 31) / 32;
   TileRegs<32, HDP> qr, dr;
   // per-tile row scalars travel with the tile prefetch (one tile ahead, in registers): LSE / delta of row q0 + tid
   // (threads 0..31) and the keep-bit word of (row q0 + (lane & 31), this wave's 32 keys).  Loaded inside the loop body
   // they sat between the two barriers with their global latency fully exposed, once per tile.
   const int dw_ld = 2 * ((S + 63) / 64);
-  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
   const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
   float lse_n = 1.0e30f, del_n = 0.f;
   unsigned dw_n = 0xffffffffu, bw_n = 0u;
@@ -632,16 +642,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   // LDS one iteration later -- arithmetic on them here would pull their vmcnt wait up to this point)
   auto prefetch_rows = [&](int q0n) {
     if (tid < 32) {
-      const int q = min(q0n + tid, S - 1);
-      lse_n = a.lse[(size_t)bh * S + q];
-      del_n = a.delta[(size_t)bh * S + q];
+      const int q = min(q0n + tid, Sq - 1);
+      lse_n = a.lse[(size_t)bh * Sq + q];
+      del_n = a.delta[(size_t)bh * Sq + q];
     }
-    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
-    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), S - 1) * dw_ld];
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), Sq - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), Sq - 1) * dw_ld];
   };
   if (ntiles > 0) {
-    qr.load(qbase, ld, 0, S - 1, false, tid);
-    dr.load(dobase, a.ld_dout, 0, S - 1, true, tid);       // rows >= S contribute nothing
+    qr.load(qbase, ldq, 0, Sq - 1, false, tid);
+    dr.load(dobase, a.ld_dout, 0, Sq - 1, true, tid);       // rows >= Sq contribute nothing
     prefetch_rows(0);
   }
   for (int t = 0; t < ntiles; ++t) {
@@ -650,16 +660,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
     qr.store(qt, tid);
     dr.store(dot, tid);
     if (tid < 32) {
-      const bool in = q0 + tid < S;
+      const bool in = q0 + tid < Sq;
       lse_s[tid] = in ? lse_n : 1.0e30f;                     // P = 0 for rows past the end
       del_s[tid] = in ? del_n : 0.f;
     }
-    if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < S) ? dw_n : 0u;
+    if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < Sq) ? dw_n : 0u;
     if (BLK && lane < 32) bw_s[wave * 32 + lane] = bw_n;
     __syncthreads();
     if (t + 1 < ntiles) {
-      qr.load(qbase, ld, q0 + 32, S - 1, false, tid);
-      dr.load(dobase, a.ld_dout, q0 + 32, S - 1, true, tid);
+      qr.load(qbase, ldq, q0 + 32, Sq - 1, false, tid);
+      dr.load(dobase, a.ld_dout, q0 + 32, Sq - 1, true, tid);
       prefetch_rows(q0 + 32);
     }
     f32x16 st, dp;
@@ -948,8 +958,9 @@ template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   (void)once; (void)onceb;
   char nm[56];
   snprintf(nm, sizeof(nm), "attn_fwd_kernel<%d>", HDP);
-  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)a->S * a->S * HDP);
-  const dim3 grid(((a->S + 127) / 128) * a->B * a->H);
+  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)(a->q != nullptr ? a->Sq : a->S) * a->S * HDP);
+  const int Sq = a->q != nullptr ? a->Sq : a->S;
+  const dim3 grid(((Sq + 127) / 128) * a->B * a->H);
   if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<HDP, true>), grid, dim3(256), lds, st, *a);
   else hipLaunchKernelGGL((attn_fwd_kernel<HDP, false>), grid, dim3(256), lds, st, *a);
   return (int)hipGetLastError();
@@ -960,22 +971,24 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   static const hipError_t once_kv = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   static const hipError_t once_kvb = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   (void)once_q; (void)once_kv; (void)once_kvb;
-  dim3 grid(((a->S + 127) / 128) * a->B * a->H);
+  const bool cross = a->q != nullptr;                    // own query set: the 32-row kernels (the 16-row ones assume the packed layout)
+  const int Sq = cross ? a->Sq : a->S;
+  const dim3 grid_q(((Sq + 127) / 128) * a->B * a->H), grid(((a->S + 127) / 128) * a->B * a->H);
   // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
-  const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;
+  const double fl = 4.0 * a->B * a->H * (double)Sq * a->S * HDP;
   char nm[56];
   const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
   static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
   (void)once_q16;
   static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
-  if (dq16 && HDP <= 192) {
+  if (dq16 && HDP <= 192 && !cross) {
     snprintf(nm, sizeof(nm), "attn_bwd_dq16_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 8>), grid, dim3(512), lds_q16, st, *a);
   } else {
     snprintf(nm, sizeof(nm), "attn_bwd_dq_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
   }
   static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
   constexpr int QT = TF_DKV16_QT;
@@ -983,7 +996,7 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
   static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
   (void)once_kv16; (void)once_kv16b;
-  if (dkv16 && HDP <= 192) {
+  if (dkv16 && HDP <= 192 && !cross) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT>), grid, dim3(512), lds_kv16, st, *a);
@@ -1002,6 +1015,7 @@ int check(const TfAttnArgs* a) {
   if ((a->ld_qkv % 8) || (a->ld_out % 8)) return -2;
   if ((long long)a->B * a->H * a->S * a->S >= (1ll << 32) && a->drop_thr) return -5;   // 32-bit dropout index space
   if (a->drop_thr && a->drop_bits == nullptr) return -6;
+  if (a->q != nullptr && (a->Sq <= 0 || (a->ld_q % 8) || a->block_bits != nullptr)) return -7;   // cross attention: own query rows, no block mask
   return 0;
 }
 
@@ -1030,6 +1044,7 @@ extern "C" int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t st) {
   const int c = check(a);
   if (c) return c > 0 ? 0 : c;
   if ((a->ld_dout % 8) || (a->ld_dqkv % 8) || a->delta == nullptr || a->lse == nullptr) return -2;
+  if (a->q != nullptr && (a->dq == nullptr || (a->ld_dq % 8))) return -7;
   if (a->qkv_lo != nullptr) return tf_launch_attn_bwd_x3(a, st);
   TF_ATTN_DISPATCH(launch_bwd)
 }

@@ -67,24 +67,28 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   unsigned char* vt_h = smem + 128 * G::TSTR;
   unsigned char* vt_l = smem + 192 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int S = a.S;
-  const int nqb = (S + 127) / 128;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries
+  const int nqb = (Sq + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const size_t boff = (size_t)b * S * ld;
-  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const size_t ldq = cross ? (size_t)a.ld_q : ld;
+  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
 
   bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS];
   {
-    const int qr = min(q0 + (lane & 31), S - 1);
+    const int qr = min(q0 + (lane & 31), Sq - 1);
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
-      qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ld + ks * 16 + 8 * h));
-      qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ld + ks * 16 + 8 * h));
+      qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ldq + ks * 16 + 8 * h));
+      qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ldq + ks * 16 + 8 * h));
     }
   }
   f32x16 o[G::DBLK];
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + min(qrow, S - 1)) * SW : nullptr;
-  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, S - 1) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sq - 1)) * SW : nullptr;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sq - 1) * SW : nullptr;
 
   const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
   for (int t = 0; t < ntiles; ++t) {
@@ -165,8 +169,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
-  if (qrow < S) {
-    const size_t off = ((size_t)b * S + qrow) * a.ld_out + (size_t)head * HDP;
+  if (qrow < Sq) {
+    const size_t off = ((size_t)b * Sq + qrow) * a.ld_out + (size_t)head * HDP;
     u16* orow_h = (u16*)a.out + off;
     u16* orow_l = (u16*)a.out_lo + off;
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
         const int c = d * 32 + 8 * g4 + 4 * h;
         store4_split(orow_h + c, orow_l + c, o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv, o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
       }
-    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * S + qrow] = m_run + log2f(l_tot);
+    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
   }
 }
 
@@ -192,33 +196,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
   unsigned char* vt_h = smem + 128 * G::TSTR;
   unsigned char* vt_l = smem + 192 * G::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int S = a.S;
-  const int nqb = (S + 127) / 128;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries
+  const int nqb = (Sq + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const size_t boff = (size_t)b * S * ld;
-  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const size_t ldq = cross ? (size_t)a.ld_q : ld;
+  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
-  const size_t dooff = (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const size_t dooff = (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
   cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
 
   const int qrow = q0 + (lane & 31);
-  const int qr = min(qrow, S - 1);
+  const int qr = min(qrow, Sq - 1);
   bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS], dof_h[G::KSTEPS], dof_l[G::KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < G::KSTEPS; ++ks) {
-    qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ld + ks * 16 + 8 * h));
-    qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ld + ks * 16 + 8 * h));
+    qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ldq + ks * 16 + 8 * h));
+    qf_l[ks] = as_bf16x8(*(const u32x4*)(q_l + (size_t)qr * ldq + ks * 16 + 8 * h));
     dof_h[ks] = as_bf16x8(*(const u32x4*)(do_h + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
     dof_l[ks] = as_bf16x8(*(const u32x4*)(do_l + (size_t)qr * a.ld_dout + ks * 16 + 8 * h));
   }
-  const float lse = a.lse[(size_t)bh * S + qr];
+  const float lse = a.lse[(size_t)bh * Sq + qr];
   float delta = 0.f;                       // rowsum(dO . O) in fp32 from both planes of both tensors
   {
-    const size_t ooff = ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+    const size_t ooff = ((size_t)b * Sq + qr) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       float of[8], df[8];
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
       for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
     }
     delta += __shfl_xor(delta, 32, 64);
-    if (h == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+    if (h == 0 && qrow < Sq) a.delta[(size_t)bh * Sq + qrow] = delta;
   }
   f32x16 dq[G::DBLK];
 #pragma unroll
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
   const float sc = a.scale * LOG2E;
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * S + qr) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + qr) * SW : nullptr;
   const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
@@ -280,10 +288,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
       }
     }
   }
-  if (qrow < S) {
-    const size_t off = ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
-    u16* r_h = (u16*)a.dqkv + off;
-    u16* r_l = (u16*)a.dqkv_lo + off;
+  if (qrow < Sq) {
+    const size_t off = cross ? ((size_t)b * Sq + qrow) * a.ld_dq + (size_t)head * HDP : ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+    u16* r_h = (cross ? (u16*)a.dq : (u16*)a.dqkv) + off;
+    u16* r_l = (cross ? (u16*)a.dq_lo : (u16*)a.dqkv_lo) + off;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -312,17 +320,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   unsigned* dw_s = (unsigned*)(del_s + 32);                       // [4 waves][32 query rows] keep-bit words of the wave's 32 keys
   unsigned* bw_s = dw_s + 128;                                    // [4 waves][32 query rows] block-bit words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int S = a.S;
+  const int S = a.S;                                   // keys
+  const int Sq = a.q != nullptr ? a.Sq : S;            // queries
   const int nkb = (S + 127) / 128;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int key0 = (logical % nkb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
   const size_t boff = (size_t)b * S * ld;
-  cu16p q_h = (const u16*)a.qkv + boff + (size_t)(0 * a.H + head) * HDP, q_l = (const u16*)a.qkv_lo + boff + (size_t)(0 * a.H + head) * HDP;
+  const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const size_t ldq = cross ? (size_t)a.ld_q : ld;
+  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
-  const size_t dooff = (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const size_t dooff = (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
   cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
 
   const int key = key0 + (lane & 31);
@@ -349,24 +361,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const bool blk = a.block_bits != nullptr;
 
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + 31) / 32;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (Sq + 31) / 32;
   const int dw_ld = 2 * ((S + 63) / 64);
-  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
   const unsigned* bbits = blk ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = t * 32;
     __syncthreads();
-    stage_pair<32, HDP>(q_h, q_l, ld, q0, S - 1, false, qt_h, qt_l, tid);
-    stage_pair<32, HDP>(do_h, do_l, a.ld_dout, q0, S - 1, true, dot_h, dot_l, tid);       // rows >= S contribute nothing
+    stage_pair<32, HDP>(q_h, q_l, ldq, q0, Sq - 1, false, qt_h, qt_l, tid);
+    stage_pair<32, HDP>(do_h, do_l, a.ld_dout, q0, Sq - 1, true, dot_h, dot_l, tid);       // rows >= Sq contribute nothing
     if (tid < 32) {
-      const bool in = q0 + tid < S;
-      const int q = min(q0 + tid, S - 1);
-      lse_s[tid] = in ? a.lse[(size_t)bh * S + q] : 1.0e30f;      // P = 0 for rows past the end
-      del_s[tid] = in ? a.delta[(size_t)bh * S + q] : 0.f;
+      const bool in = q0 + tid < Sq;
+      const int q = min(q0 + tid, Sq - 1);
+      lse_s[tid] = in ? a.lse[(size_t)bh * Sq + q] : 1.0e30f;      // P = 0 for rows past the end
+      del_s[tid] = in ? a.delta[(size_t)bh * Sq + q] : 0.f;
     }
     if (lane < 32) {
-      const int q = min(q0 + lane, S - 1);
-      dw_s[wave * 32 + lane] = a.drop_thr ? (q0 + lane < S ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
+      const int q = min(q0 + lane, Sq - 1);
+      dw_s[wave * 32 + lane] = a.drop_thr ? (q0 + lane < Sq ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
       bw_s[wave * 32 + lane] = blk ? bbits[(size_t)q * dw_ld] : 0u;
     }
     __syncthreads();
@@ -430,8 +442,9 @@ template <int HDP> int launch_fwd_x3(const TfAttnArgs* a, hipStream_t st) {
   (void)once;
   char nm[56];
   snprintf(nm, sizeof(nm), "attn_fwd_x3_kernel<%d>", HDP);
-  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)a->S * a->S * HDP);
-  hipLaunchKernelGGL(attn_fwd_x3_kernel<HDP>, dim3(((a->S + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
+  const int Sq = a->q != nullptr ? a->Sq : a->S;
+  TfTraceScope tr(nm, st, 4.0 * a->B * a->H * (double)Sq * a->S * HDP);
+  hipLaunchKernelGGL(attn_fwd_x3_kernel<HDP>, dim3(((Sq + 127) / 128) * a->B * a->H), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
@@ -440,13 +453,14 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
   static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_x3_kernel<HDP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   static const hipError_t o3 = hipFuncSetAttribute((const void*)attn_bwd_dkv_x3_kernel<HDP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
   (void)o1; (void)o2; (void)o3;
-  const dim3 grid(((a->S + 127) / 128) * a->B * a->H);
-  const double fl = 4.0 * a->B * a->H * (double)a->S * a->S * HDP;       // credited as in attn_bf16.hip: backward = 2x forward over dq + dkv
+  const int Sq = a->q != nullptr ? a->Sq : a->S;
+  const dim3 grid(((a->S + 127) / 128) * a->B * a->H), grid_q(((Sq + 127) / 128) * a->B * a->H);
+  const double fl = 4.0 * a->B * a->H * (double)Sq * a->S * HDP;       // credited as in attn_bf16.hip: backward = 2x forward over dq + dkv
   char nm[56];
   {
     snprintf(nm, sizeof(nm), "attn_bwd_dq_x3_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
-    hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<HDP>, grid, dim3(256), lds_q, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
   }
   {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dV>", HDP);
@@ -477,10 +491,11 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
   }
 
 extern "C" int tf_launch_attn_fwd_x3(const TfAttnArgs* a, hipStream_t st) {
-  if (a->qkv_lo == nullptr || a->out_lo == nullptr) return -6;
+  if (a->qkv_lo == nullptr || a->out_lo == nullptr || (a->q != nullptr && a->q_lo == nullptr)) return -6;
   TF_ATTN_X3_DISPATCH(launch_fwd_x3)
 }
 extern "C" int tf_launch_attn_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
   if (a->qkv_lo == nullptr || a->out_lo == nullptr || a->dout_lo == nullptr || a->dqkv_lo == nullptr) return -6;
+  if (a->q != nullptr && (a->q_lo == nullptr || a->dq_lo == nullptr)) return -6;
   TF_ATTN_X3_DISPATCH(launch_bwd_x3)
 }

@@ -852,7 +852,10 @@ extern "C" int tf_launch_dropout_apply(const void* x, void* y, long long n, unsi
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t st) {
-  const long long nrows = (long long)B * H * S;
+  return tf_launch_attn_dropmask_rows(bits, (long long)B * H * S, S, key, thr, st);
+}
+// nrows query rows (batch x head x query) of S key bits each; element index = row * S + key
+extern "C" int tf_launch_attn_dropmask_rows(void* bits, long long nrows, int S, unsigned key, unsigned thr, hipStream_t st) {
   const int SW32 = 2 * ((S + 63) / 64);
   if (nrows <= 0) return 0;
   if (nrows * S >= (1ll << 32)) return -5;

@@ -321,6 +321,12 @@ int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr
   return 0;
 }
 
+int tf_attn_dropmask_rows(void* bits, long long nrows, int S, uint32_t key, uint32_t thr, tf_stream_t s) {
+  if (bits == nullptr || nrows < 0 || S <= 0) return fail(-1, "tf_attn_dropmask_rows");
+  TF_TRY(tf_launch_attn_dropmask_rows(bits, nrows, S, key, thr, (hipStream_t)s), "tf_attn_dropmask_rows");
+  return 0;
+}
+
 #define TF_WRAP(name, call) do { if (a == nullptr) return fail(-1, name); TF_TRY(call, name); return 0; } while (0)
 int tf_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float* scale, int rows, int cols, tf_stream_t s) {
   if (src == nullptr || dst == nullptr || scale == nullptr) return fail(-1, "tf_quant_rows_fp8");

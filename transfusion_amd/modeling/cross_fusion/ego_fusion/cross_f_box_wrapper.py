@@ -32,8 +32,13 @@ def get_cross_box_encoder(cross_type, class_token_only):
             raise NotImplementedError("narr_out_mode: embedding (CrossTransformerTokenModule) is broken in the reference "
                                       "(cross_f_box_layers.py:143) and out of scope")
         return CrossTransformerModuleBox
-    elif cross_type in ("space_time", "asymmetric"):
-        raise NotImplementedError(f"type: {cross_type} is not selected by the shipped configs (SURVEY.md 8f-4)")
+    elif cross_type == "asymmetric":
+        if class_token_only:
+            raise NotImplementedError("AsymmetricCrossFTokenModuleBox is an empty class in the reference (cross_f_box_asymm.py:123-124)")
+        from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_asymm import AsymmetricCrossFModuleBox
+        return AsymmetricCrossFModuleBox
+    elif cross_type == "space_time":
+        raise NotImplementedError(f"type: {cross_type} is not selected by the shipped configs (SURVEY.md 2 #1: out of scope)")
     else:
         raise ValueError(f"{cross_type=} not implemented")
 

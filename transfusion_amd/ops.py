@@ -81,16 +81,43 @@ def from_padded(x2d: torch.Tensor, cols: int, dtype) -> torch.Tensor:
     return out
 
 
-def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True):
-    """fp32 [N,K] parameter -> bf16 shadow [rows_p, ld] and transpose [cols_p, ld_t]."""
+def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG):
+    """fp32 [N,K] parameter -> bf16 shadow [rows_p, ld] and transpose [cols_p, ld_t]; rows / columns may be regrouped (source index
+    (p // gp) * g + p % gp, valid iff p % gp < g): heads of width hd padded to hdp."""
     N, K = w.shape
     w = w.detach().contiguous().float()
     dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
     dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
     a = L.TfPackArgs(src=L.ptr(w), rows=N, cols=K, dst=L.ptr(dst), ld_dst=ld, dst_t=L.ptr(dst_t), ld_dst_t=ld_t,
-                     rows_p=rows_p, cols_p=cols_p, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG, dst_is_f32=0)
+                     rows_p=rows_p, cols_p=cols_p, rg=rg, rgp=rgp, cg=cg, cgp=cgp, dst_is_f32=0)
     L.call("tf_pack_weight", a, _stream())
     return dst, dst_t
+
+
+def pack_bias(b: torch.Tensor, cols_p: int, cg=BIG, cgp=BIG):
+    """fp32 [N] bias -> fp32 [cols_p] with the same column regrouping as its weight's rows."""
+    b = b.detach().contiguous().float()
+    dst = torch.zeros(cols_p, dtype=torch.float32, device=b.device)
+    a = L.TfPackArgs(src=L.ptr(b), rows=1, cols=b.numel(), dst=L.ptr(dst), ld_dst=cols_p, dst_t=0, ld_dst_t=0, rows_p=1, cols_p=cols_p,
+                     rg=BIG, rgp=BIG, cg=cg, cgp=cgp, dst_is_f32=1)
+    L.call("tf_pack_weight", a, _stream())
+    return dst
+
+
+def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, d, eps=1e-5):
+    """y = LN(x[:, :d]) per row; x bf16 [rows, ldx]; y bf16 [rows, ldy] (pad zeroed) or fp32 [rows, d]; mean / rstd fp32 [rows]."""
+    a = L.TfLnArgs(x=L.ptr(x), ldx=x.stride(0), y=L.ptr(y), ldy=y.stride(0), y_is_f32=_is_f32(y), gamma=L.ptr(gamma), beta=L.ptr(beta),
+                   mean=L.ptr(mean), rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=eps)
+    L.call("tf_layernorm_fwd", a, _stream())
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, d, dx_drop=None, drop=(0, 0, 1.0), eps=1e-5):
+    """dx (bf16 [rows, lddx]) and optionally dx_drop = dx * keep / (1 - p); dgamma / dbeta accumulated (fp32 atomics)."""
+    a = L.TfLnArgs(x=L.ptr(x), ldx=x.stride(0), gamma=L.ptr(gamma), mean=L.ptr(mean), rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows,
+                   x_group_stride=rows, y_group_stride=rows, eps=eps, dy=L.ptr(dy), lddy=dy.stride(0), dy_is_f32=_is_f32(dy), dx=L.ptr(dx),
+                   lddx=dx.stride(0), dx_drop=L.ptr(dx_drop), lddxd=0 if dx_drop is None else dx_drop.stride(0), drop_thr=drop[0], drop_key=drop[1],
+                   drop_scale=drop[2], drop_ld=dx.stride(0), dgamma=L.ptr(dgamma), dbeta=L.ptr(dbeta))
+    L.call("tf_layernorm_bwd", a, _stream())
 
 
 def split_planes(x: torch.Tensor):
