@@ -1,0 +1,131 @@
+"""The N > 1 code paths on ONE MI355X: two ranks share the device over gloo (no second GPU is available to these tests; RCCL itself is
+exercised only by the driver's multi-GPU run).  What this does cover is everything around the collective that differs from the CPU tests:
+the real encoder's per-layer backward with `defer_join`, `LayerwiseReducer.hook` on its CUDA branch (communication stream behind one
+event of the chain and one of the side stream, asynchronous all-reduce), `finish()`, the fused optimiser on the flat buffer -- and
+bench.py's own N = 2 control flow end to end under a timeout."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from cases import make_encoder_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
+from cases import make_encoder_inputs
+from test_gpu_encoder import build
+from transfusion_amd.optim import FusedRAdam
+from transfusion_amd.runner.trainer import FusionTrainStep
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
+enc, _ = build(cfg, dev)
+enc.train()
+sgd = lambda ps, lr, weight_decay: FusedRAdam(ps, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+tr = FusionTrainStep(enc, lr=5e-2, weight_decay=0.0, grad_clip=None, accumulate={acc}, optimizer_cls=sgd)
+assert tr.layerwise is not None and enc.layer_grad_hook is not None, "the default N > 1 path must be the layer-wise reducer"
+x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], [30, 11, 22, 30])
+t = lambda a: torch.from_numpy(a).to(dev)
+mine = slice(rank * 2, rank * 2 + 2)                       # this rank's two samples
+def loss_fn(m, b):
+    sl = b
+    v, l_, _, _ = m(t(x[sl]), t(lang[sl]), t(mask[sl]))
+    return (v * t(gv[sl])).sum() + (l_ * t(gl[sl])).sum()
+mbs = [mine] if {acc} == 1 else [slice(rank * 2, rank * 2 + 1), slice(rank * 2 + 1, rank * 2 + 2)]
+before = tr.flat.flat.clone()
+tr.step(mbs, loss_fn)
+torch.cuda.synchronize()
+# every rank must hold bit-identical parameters afterwards
+chk = tr.flat.flat.double().sum().reshape(1).cpu()
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert lo.item() == hi.item(), (lo.item(), hi.item())
+if rank == 0:
+    torch.save({{"grad": tr.flat.grad.cpu(), "param": tr.flat.flat.cpu(), "before": before.cpu(), "collectives": tr.layerwise.collectives}}, {out!r})
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("acc", [1, 2])
+def test_two_ranks_one_gpu_layerwise_reducer_on_the_real_encoder(tmp_path, acc):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = str(tmp_path / "ddp.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, out=out, acc=acc))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank run hung (a rank issued a different number of collectives?)")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    got = torch.load(out)
+    assert got["collectives"] == 3                               # one all-reduce per layer per optimiser step (also with accumulation)
+    # single process, all four samples, same starting parameters
+    from test_gpu_encoder import build
+    from transfusion_amd.runner.trainer import FlatParams
+    dev = torch.device("cuda:0")
+    cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    flat = FlatParams(enc)
+    assert torch.equal(flat.flat.cpu(), got["before"])
+    enc.accumulate_into_grad = True
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], [30, 11, 22, 30])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    v, l_, _, _ = enc(t(x), t(lang), t(mask))
+    ((v * t(gv)).sum() + (l_ * t(gl)).sum()).backward()
+    torch.cuda.synchronize()
+    ref = flat.grad.cpu() / acc                                   # micro-batch losses are scaled by 1 / accumulate
+    err = ((got["grad"] - ref).norm() / ref.norm()).item()
+    assert err < 2e-3, err                                        # same products, different fp32 summation order (atomics, ranks)
+    # SGD-degenerated first RAdam step: p -= lr * step_size * m, m = (1 - beta1) * g / world -- the parameters moved by the mean gradient
+    moved = got["param"] - got["before"]
+    want = -5e-2 * (1.0 / (1 - 0.9)) * (1 - 0.9) * (ref / 2)
+    assert ((moved - want).norm() / want.norm()).item() < 2e-3
+
+
+def test_bench_two_ranks_on_one_gpu_does_not_hang(tmp_path):
+    """bench.py --gpus 2 through torch.distributed.run, both ranks on cuda:0 over gloo (the rehearsal hooks TF_FORCE_DEVICE /
+    TF_DIST_BACKEND): warm-up, timed steps, traced steps on EVERY rank, the all-reduce bandwidth probe, one JSON line from rank 0."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    env = dict(os.environ, TF_FORCE_DEVICE="0", TF_DIST_BACKEND="gloo", TF_CHECK_SYNC="1", TF_BENCH_WATCHDOG_S="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--trace-steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert res["allreduce"]["collectives_per_step"] == 4 and res["allreduce"]["bytes"] > 7e7
+    assert "parameter checksum identical on 2 ranks" in r.stderr
