@@ -13,6 +13,7 @@
 // columns; the tile is then passed through LDS once so that the epilogue (bias / GELU / dropout /
 // residual) works on 16-B row chunks and HBM sees full 256-B row segments.
 #include <cstdlib>
+#include <type_traits>
 #include "tf_common.h"
 #include <cstdio>
 #include "tf_kernels.h"
@@ -28,18 +29,37 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds(TF_GLB_PTR(gsrc), TF_LDS_PTR(lds_dst), 16, 0, 0);
 }
 
-// FFN activation (TfGemmArgs.act): h = act(u), dh = act'(u); 0 = exact GELU, 1 = ReLU
-__device__ __forceinline__ void act_parts(int act, float u, float& h, float& dh) {
-  if (act == 1) { h = fmaxf(u, 0.f); dh = u > 0.f ? 1.f : 0.f; return; }
+// FFN activation (TfGemmArgs.act): h = act(u), dh = act'(u); 0 = exact GELU, 1 = ReLU.  The choice is uniform over a launch:
+// act_loop8 branches ONCE per 8-element chunk (a per-element branch splits the chunk into basic blocks and serialises it).
+template <bool RELU>
+__device__ __forceinline__ void act_parts(float u, float& h, float& dh) {
+  if constexpr (RELU) { h = fmaxf(u, 0.f); dh = u > 0.f ? 1.f : 0.f; return; }
   float cdf, ex;
   gelu_parts(u, cdf, ex);
   h = u * cdf;
   dh = cdf + u * 0.39894228040143268f * ex;
 }
+template <typename F>
+__device__ __forceinline__ void act_loop8(int act, F&& body) {      // body(e, relu_tag) for e = 0..7
+  if (act == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) body(e, std::true_type{});
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) body(e, std::false_type{});
+  }
+}
+#define TF_ACT(tag, u, h, dh) act_parts<decltype(tag)::value>(u, h, dh)
 
 // elementwise epilogue of one 16-B chunk (8 consecutive columns of one output row) -- shared by both GEMM kernels
+// rpre: the chunk of R already in registers (the large-tile kernel fetches every R chunk of its tile before the C tile goes
+// through LDS, so the HBM latency is paid once per tile instead of once per chunk), or null = load it here
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __restrict__ C, u32x4 v, int gm, int gn) {
+__device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __restrict__ C, u32x4 v, int gm, int gn,
+                                                    const u32x4* rpre = nullptr) {
+  [[maybe_unused]] auto load_r = [&]() -> u32x4 {
+    return rpre != nullptr ? *rpre : *(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn);
+  };
   if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
     *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;
   } else {
@@ -48,56 +68,53 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
     if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) {
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      act_loop8(g.act, [&](int e, auto relu) {
         float hh, dh;
-        act_parts(g.act, f[e], hh, dh);
+        TF_ACT(relu, f[e], hh, dh);
         f[e] = ((km >> e) & 1u) ? hh * g.drop_scale : 0.f;
-      }
+      });
       *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP_G) {
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
       float gd[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      act_loop8(g.act, [&](int e, auto relu) {
         float hh, dh;
-        act_parts(g.act, f[e], hh, dh);
+        TF_ACT(relu, f[e], hh, dh);
         const float keep = ((km >> e) & 1u) ? g.drop_scale : 0.f;
         gd[e] = keep * dh;                                           // d dropout(act(u)) / du
         f[e] = keep * hh;
-      }
+      });
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(gd);
       *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_MUL) {
       float r[8];
-      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+      unpack8(load_r(), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] *= r[e];
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
       float r[8];
-      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+      unpack8(load_r(), r);
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_ADD) {
       float r[8];
-      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), r);
+      unpack8(load_r(), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] += r[e];
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
       // dU = dH . mask/(1-p) . gelu'(U); R = U, dropout index space = that of H (ldr == ld of H)
       float u[8];
-      unpack8(*(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn), u);
+      unpack8(load_r(), u);
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      act_loop8(g.act, [&](int e, auto relu) {
         float hh, dh;
-        act_parts(g.act, u[e], hh, dh);
+        TF_ACT(relu, u[e], hh, dh);
         f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
-      }
+      });
       *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
     }
   }
@@ -112,14 +129,13 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
   } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP || EPI == TF_EPI_BIAS_GELU_DROP_G) {
     const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
     float gd[8], hv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    act_loop8(g.act, [&](int e, auto relu) {
       float hh, dh;
-      act_parts(g.act, f[e], hh, dh);
+      TF_ACT(relu, f[e], hh, dh);
       const float keep = ((km >> e) & 1u) ? g.drop_scale : 0.f;
       gd[e] = keep * dh;
       hv[e] = keep * hh;
-    }
+    });
     if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) store8_split(g.C, g.C_lo, oc, f);      // pre-activation U
     else store8_split(g.C, g.C_lo, oc, gd);                                             // G = d h / d u
     store8_split(g.C2, g.C2_lo, (size_t)gm * g.ldc2 + gn, hv);
@@ -138,12 +154,11 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
       for (int e = 0; e < 8; ++e) f[e] += r[e];
     } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldr + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      act_loop8(g.act, [&](int e, auto relu) {
         float hh, dh;
-        act_parts(g.act, r[e], hh, dh);
+        TF_ACT(relu, r[e], hh, dh);
         f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
-      }
+      });
     }
     store8_split(g.C, g.C_lo, oc, f);
   }
@@ -445,6 +460,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     split_epilogue<EPI, MF, 3, BIG_BN, 512>(g, acc, smem, m0, n0, BM / 2, wr, wc, lane, tid);
     return;
   }
+  // every chunk of R this thread will need in phase 2 is fetched half-way through phase 1: the loads fly while the C tile
+  // passes through LDS, so HBM latency is paid once per tile, not once per chunk (half of the accumulators are dead by then:
+  // 2*MF*4 registers of R next to 2*MF*4 of accumulators)
+  constexpr bool HAS_R = EPI == TF_EPI_MUL || EPI == TF_EPI_ADD || EPI == TF_EPI_BIAS_DROP_RES || EPI == TF_EPI_DGELU_DROP;
+  u32x4 rpre[HAS_R ? 2 * MF : 1];
   // ---- epilogue phase 1: (acc + bias) -> bf16 -> LDS C tile [BM][BIG_CT_STRIDE] ----
   unsigned char* ct = smem;
 #pragma unroll
@@ -454,6 +474,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     if (g.bias != nullptr && n0 + nl < g.N) b = *(const f32x4*)(g.bias + n0 + nl);
     f32x4 sw = {1.f, 1.f, 1.f, 1.f};
     if constexpr (FP8) { if (g.scale_w != nullptr && n0 + nl < g.N) sw = *(const f32x4*)(g.scale_w + n0 + nl); }
+    if constexpr (HAS_R) {
+      if (ni == 2) {
+#pragma unroll
+        for (int i = 0; i < 2 * MF; ++i) {
+          const int id = i * 512 + tid;
+          const int gm = min(m0 + (id >> 5), g.M - 1), gn = min(n0 + (id & 31) * 8, g.N - 8);     // clamped: never used out of range
+          rpre[i] = *(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn);
+        }
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
       const int ml = wr * (BM / 2) + mi * 16 + (lane & 15);
@@ -472,14 +502,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
   __syncthreads();
   // ---- phase 2: row-contiguous 16-B chunks (32 per row), elementwise epilogue, coalesced stores ----
   u16* __restrict__ C = (u16*)g.C;
-#pragma unroll 2
+  constexpr int UNR = HAS_R ? 2 * MF : 2;          // rpre[] must stay in registers; the long activation bodies stay rolled
+#pragma unroll UNR
   for (int i = 0; i < 2 * MF; ++i) {
     const int id = i * 512 + tid;
     const int row = id >> 5, c = id & 31;
     const int gm = m0 + row, gn = n0 + c * 8;
     if (gm >= g.M || gn >= g.N) continue;
     u32x4 v = *(const u32x4*)(ct + row * BIG_CT_STRIDE + c * 16);
-    gemm_epilogue_chunk<EPI>(g, C, v, gm, gn);
+    gemm_epilogue_chunk<EPI>(g, C, v, gm, gn, HAS_R ? &rpre[i] : nullptr);
   }
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned tf_keep8(unsigned base, unsigned key, unsign
 // exp(-(x/sqrt2)^2) = exp(-x^2/2).
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 12-instruction IEEE divide
   ex = __expf(-ax * ax);                                   // = exp(-x^2 / 2)
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   const float erf_abs = 1.0f - poly * ex;
