@@ -31,6 +31,7 @@ lens = torch.randint(NL // 4, NL + 1, (B,), generator=g).tolist()
 lang = [torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1).to(dev) for n in lens]
 
 def step():
+    model.zero_grad(set_to_none=True)                # as a training loop does (optimizer.zero_grad)
     out = model({"image": feats, "language_f": lang})
     loss = sum(f.float().square().mean() for f in out["features"].values())
     loss.backward()

@@ -351,13 +351,25 @@ class CrossTransformerModuleBox(nn.Module):
         params = self._param_list()
         direct = self.accumulate_into_grad
         grads = []
-        for p in params:
-            if direct:
+        if direct:
+            for p in params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 grads.append(p.grad)
-            else:
-                grads.append(torch.zeros_like(p, memory_format=torch.contiguous_format) if p.requires_grad else None)
+        else:
+            # ONE zero fill for all gradients of the call (a zeros_like per parameter is ~50 launches per backward); each
+            # gradient is a 256-B aligned view, and no reference is kept here, so AccumulateGrad can adopt the view as p.grad
+            sizes = [((p.numel() + 63) // 64) * 64 if p.requires_grad else 0 for p in params]
+            flat = torch.zeros(max(sum(sizes), 1), dtype=torch.float32, device=device)
+            off = 0
+            for p, n in zip(params, sizes):
+                if not p.requires_grad:
+                    grads.append(None)
+                elif p.dtype != torch.float32:
+                    grads.append(torch.zeros_like(p, memory_format=torch.contiguous_format))
+                else:
+                    grads.append(flat[off:off + p.numel()].view(p.shape))
+                off += n
         scratch = None
 
         def gp(t, ref):
@@ -378,7 +390,7 @@ class CrossTransformerModuleBox(nn.Module):
         if desc.final_norm:
             g, p = next(it); desc.g_fn_w = gp(g, p)
             g, p = next(it); desc.g_fn_b = gp(g, p)
-        self._grad_keepalive = (grads, scratch)
+        self._grad_keepalive = scratch             # (the returned gradients are owned by autograd; the kernels are stream-ordered)
         return grads, direct
 
     # ---- reference forward contract (cross_f_box_layers.py:69-108) --------------------------------------

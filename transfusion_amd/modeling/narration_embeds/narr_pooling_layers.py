@@ -42,7 +42,12 @@ class SlowFastPooling(nn.Module):
             tensor = [F.pad(t, (0, 0, 0, T - t.shape[0])) for t in tensor]
         tensor = torch.stack(tensor, dim=0)
         # HF style: 1 = keep, 0 = cancelled; built on the host in one piece (no per-sample device writes)
-        att_mask = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)).to(device=tensor.device, dtype=torch.float32)
+        # (on a GPU the lengths travel through pinned memory without blocking: a pageable copy would stall the host until the
+        # stream has drained, once per step)
+        lens_t = torch.tensor(lens, dtype=torch.int32)
+        if tensor.is_cuda:
+            lens_t = lens_t.pin_memory().to(tensor.device, non_blocking=True)
+        att_mask = (torch.arange(T, device=tensor.device, dtype=torch.int32).unsqueeze(0) < lens_t.unsqueeze(1)).to(torch.float32)
         if self.out_mlp:
             tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias).float()
         if self.use_out_tanh:
