@@ -380,7 +380,10 @@ def allreduce_busbw(trainer, comm, reps=10):
     t0 = time.perf_counter()
     for _ in range(reps):
         for lo, hi in ranges:
-            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+            if trainer.bucket_comm is not None:
+                trainer.bucket_comm.all_reduce_(g[lo:hi])
+            else:
+                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
     comm.sync()
     dt = comm.max(time.perf_counter() - t0) / reps
     nbytes = g.numel() * 4
@@ -408,6 +411,9 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
+    ap.add_argument("--comm", choices=["torch", "rccl"], default=os.environ.get("TF_COMM", "torch"),
+                    help="N > 1: gradient exchange through torch.distributed's process group (default) or the C ABI's own RCCL "
+                         "communicator (tf_allreduce_bucket)")
     args = ap.parse_args()
 
     # a hang must end with a Python stack on stderr, not with the driver's silence timeout
@@ -444,7 +450,7 @@ def main():
         heads = NaoRoIHeads(1024, 88, 75, box_2_dropout=0.0, classif_dropout=0.0).to(device)
         crit = NaoHeadLosses(torch.ones(88), torch.ones(75)).to(device)
         module, step_loss = _EncoderWithHeads(enc, heads, crit).train(), loss_fn_heads
-    trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap)
+    trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap, comm=args.comm)
     # distinct batches (tensors, padding lengths) rotated through the steps: a real loader hands the encoder a new mask tensor
     # every step, so the padding-mask conversion cache never hits
     batches = [make_batch(args.batch, device, rank, variant=v) for v in range(max(1, args.batches))]
@@ -488,7 +494,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"fusion-encoder{' + RoI heads and losses (512 RoIs / image)' if args.with_heads else ''} train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
                                f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding",
-                   "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}"},
+                   "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "comm": args.comm if world > 1 else None},
         "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "block_tflops_per_gpu": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
         "block_mfma_util_valid_tokens": round(train_flops_valid / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

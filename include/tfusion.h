@@ -380,6 +380,26 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);
  * "z2_<l>", "dqkv", ...) as fp32 [rows, cols] into dst; returns rows*cols (cols = padded width) or < 0 */
 long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s);
 
+/* ---- data-parallel gradient exchange (SURVEY.md 8(b) `tf_allreduce_bucket`, 8(e)) ---------------------------------------
+ * What the reference gets from Lightning's strategy="ddp" (runner/run_experiment.py:452: torch DDP's bucketed gradient
+ * all-reduce over NCCL): one RCCL communicator per process (one process per GPU, created on the calling thread's current
+ * HIP device), and an in-place SUM all-reduce of a contiguous fp32 slice of the flat gradient buffer, enqueued on the
+ * stream the caller names (the host side puts it behind events of the backward's two streams, so a layer's exchange
+ * overlaps the layers below it; the 1 / world average is folded into tf_radam_step's grad_scale).
+ * RCCL is bound at run time (dlopen of librccl.so.1): without it every entry returns TF_ERR_NO_RCCL.
+ * Bootstrap: rank 0 calls tf_comm_unique_id, the host broadcasts the 128 bytes (torch.distributed store, MPI, a file ...),
+ * every rank calls tf_comm_create (collective: returns when all `world` ranks have joined). */
+#define TF_COMM_ID_BYTES 128
+#define TF_ERR_NO_RCCL (-100)   /* librccl.so.1 not loadable in this process */
+#define TF_ERR_RCCL (-101)      /* an RCCL call failed; tf_last_error() carries ncclGetErrorString */
+typedef struct TfComm TfComm;
+int tf_comm_unique_id(void* id /* TF_COMM_ID_BYTES, host memory */);
+int tf_comm_create(TfComm** comm, const void* id, int world, int rank);
+int tf_allreduce_bucket(TfComm* comm, float* buf, long long n, tf_stream_t s);    /* buf[0..n) <- sum over ranks, in place */
+/* collectives issued / fp32 elements reduced so far on this rank (all ranks must agree); any out pointer may be null */
+int tf_comm_stats(const TfComm* comm, int* world, int* rank, long long* calls, long long* elems);
+int tf_comm_destroy(TfComm* comm);
+
 /* ---- launch tracer (measurement only) ----
  * Between tf_trace_start and tf_trace_stop every kernel launch of this library is bracketed by a HIP event pair on
  * the stream it is launched on, so durations are the kernels' own, in situ (side-stream overlap included) -- the same

@@ -98,3 +98,26 @@ def test_integration_md_stub_matches_header(lib, tmp_path):
     exe = tmp_path / "g"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(csrc), "-o", str(exe)])
     assert int(subprocess.check_output([str(exe)], text=True)) == C.sizeof(stub)
+
+
+def test_comm_entries_validate_arguments_without_a_gpu(lib):
+    """tf_comm_* / tf_allreduce_bucket: argument errors come back as -1 with a message, and drawing a unique id
+    either works (RCCL resident: torch ships it) or reports TF_ERR_NO_RCCL -- no compute, no device needed."""
+    import ctypes as C
+    from transfusion_amd import _lib as L
+    lib.tf_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.tf_allreduce_bucket.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    handle = C.c_void_p()
+    ident = bytes(L.CONSTS["TF_COMM_ID_BYTES"])
+    assert lib.tf_comm_create(C.byref(handle), ident, 2, 2) == -1          # rank outside [0, world)
+    assert b"tf_comm_create" in lib.tf_last_error()
+    assert lib.tf_comm_create(C.byref(handle), None, 1, 0) == -1           # no id
+    assert lib.tf_allreduce_bucket(None, None, 16, None) == -1
+    assert lib.tf_comm_destroy(None) == -1
+    buf = C.create_string_buffer(L.CONSTS["TF_COMM_ID_BYTES"])
+    rc = lib.tf_comm_unique_id(buf)
+    assert rc in (0, L.CONSTS["TF_ERR_NO_RCCL"])
+    if rc == 0:
+        assert any(buf.raw)                                                # an id was drawn
+    else:
+        assert b"librccl" in lib.tf_last_error()

@@ -1,0 +1,46 @@
+"""tf_comm_* / tf_allreduce_bucket on the device: a one-rank RCCL communicator behind the C ABI (the one GPU these tests get; RCCL
+refuses two ranks on one device, so N > 1 through this entry is covered by construction and by the gloo tests of the code around it).
+One rank still exercises everything on this side of the wire: the run-time binding of librccl, communicator creation on the current
+device, the in-place all-reduce enqueued on a stream that is NOT the current one, ordering against work on that stream, the counters."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_allreduce_is_in_place_identity_and_stream_ordered():
+    from transfusion_amd.comm import BucketComm
+    dev = torch.device("cuda", 0)
+    comm = BucketComm(1, 0, BucketComm.new_unique_id(), dev)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        g = torch.zeros(3_000_000, device=dev)
+        want = torch.randn(3_000_000, generator=torch.Generator().manual_seed(5)).to(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            g.copy_(want)                                    # producer on the side stream ...
+        comm.all_reduce_(g[1024:2_000_000], stream=side)     # ... the collective behind it on the same stream
+        comm.all_reduce_(g[:1024], stream=side)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        assert torch.equal(g, want)                          # sum over one rank
+        st = comm.stats()
+        assert st == {"world": 1, "rank": 0, "calls": 2, "elems": 2_000_000}
+        with pytest.raises(Exception):
+            comm.all_reduce_(g.to(torch.bfloat16))           # fp32 only
+    finally:
+        comm.close()
+
+
+def test_train_step_accepts_comm_choice_at_world_one():
+    from cases import make_encoder_inputs  # noqa: F401  (path set up by conftest)
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    dev = torch.device("cuda", 0)
+    enc = CrossTransformerModuleBox(no_patches=64, pos_embedding_layer=PositionalEmbeddingLayer("sin1d", 64, 64), num_layers=1,
+                                    patch_dropout=0.0, num_heads=2, token_dropout=0.0, activ_f="gelu", final_norm="ln",
+                                    input_f_size=64).to(dev).train()
+    tr = FusionTrainStep(enc, comm="rccl")                   # no process group: the choice is accepted, nothing to create
+    assert tr.bucket_comm is None
+    with pytest.raises(ValueError):
+        FusionTrainStep(enc, comm="mpi")

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtfusion_hip.so")
-SOURCES = ["gemm_bf16.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "heads.hip", "tf_api.hip"]
+SOURCES = ["gemm_bf16.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "heads.hip", "comm.hip", "tf_api.hip"]
 HEADERS = ["tf_common.h", "tf_kernels.h", "attn_common.h", os.path.join("..", "..", "include", "tfusion.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -58,7 +58,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                     print(f"[transfusion_amd.build] compiled {os.path.basename(done)}", file=sys.stderr)
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

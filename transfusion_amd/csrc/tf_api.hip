@@ -301,6 +301,7 @@ int tf_overlap_destroy(TfOverlap* o) {
   return 0;
 }
 const char* tf_last_error(void) { return g_err; }
+void tf_set_error_msg(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
 
 uint32_t tf_drop_key(uint64_t seed, uint32_t site) { return (uint32_t)(splitmix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(site + 1))) >> 32); }
 uint32_t tf_drop_threshold(float p) {

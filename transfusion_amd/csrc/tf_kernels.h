@@ -6,6 +6,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+void tf_set_error_msg(const char* msg);                             // sets this thread's tf_last_error() text (tf_api.hip)
 int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream);
 int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
 int tf_wgrad_tiles(int N, int K, int caller_sized);                // output tiles of the wgrad kernel that will run

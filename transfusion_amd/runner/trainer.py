@@ -58,9 +58,10 @@ class DataParallelReducer:
     """Sum all-reduce of the flat gradient buffer in a few large buckets (xGMI rings are per-link bound: fewer,
     larger messages).  Works with any initialised torch.distributed backend; a no-op at world size 1."""
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_mb: float = 64.0, group=None):
+    def __init__(self, flat_grad: torch.Tensor, bucket_mb: float = 64.0, group=None, bucket_comm=None):
         self.grad = flat_grad
         self.group = group
+        self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm: the C ABI's tf_allreduce_bucket instead of torch's
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         n = flat_grad.numel()
         per = max(1, int(bucket_mb * (1 << 20) // 4))
@@ -71,6 +72,10 @@ class DataParallelReducer:
         if self.world == 1:
             return []
         handles = []
+        if self.bucket_comm is not None:              # stream-ordered: nothing to wait for on the host
+            for s, e in self.buckets:
+                self.bucket_comm.all_reduce_(self.grad[s:e])
+            return handles
         for s, e in self.buckets:
             h = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
@@ -85,8 +90,9 @@ class LayerwiseReducer:
     group orders the collective after the kernels already enqueued and runs it on its own stream, so it overlaps the
     remaining backward.  ``finish()`` joins before the optimiser."""
 
-    def __init__(self, flat: FlatParams, group=None):
+    def __init__(self, flat: FlatParams, group=None, bucket_comm=None):
         self.flat, self.group = flat, group
+        self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm or None (torch.distributed's process group)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.bytes_per_step = flat.grad.numel() * 4
         self.handles = []
@@ -143,6 +149,9 @@ class LayerwiseReducer:
             self.comm = torch.cuda.Stream(device=g.device)
         self.comm.wait_event(main.record_event())
         self.comm.wait_event(side.record_event())
+        if self.bucket_comm is not None:
+            self.bucket_comm.all_reduce_(g[lo:hi], stream=self.comm)         # tf_allreduce_bucket, enqueued on the communication stream
+            return
         with torch.cuda.stream(self.comm):
             self.handles.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -161,20 +170,31 @@ class FusionTrainStep:
     """One optimiser step over ``accumulate`` micro-batches for a module that writes into ``p.grad`` directly."""
 
     def __init__(self, module: nn.Module, lr=1e-4, weight_decay=2e-4, grad_clip: Optional[float] = 1.0, accumulate: int = 1,
-                 bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True):
+                 bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True, comm: Optional[str] = None):
+        """``comm``: "torch" (default; torch.distributed's process group) or "rccl" (the C ABI's own communicator,
+        tf_allreduce_bucket; also selected by TF_COMM=rccl) -- both are RCCL on a GPU."""
         from transfusion_amd.optim import FusedRAdam
+        comm = comm or os.environ.get("TF_COMM", "torch")
+        if comm not in ("torch", "rccl"):
+            raise ValueError(f"comm must be 'torch' or 'rccl', not {comm!r}")
         self.module = module
         self.flat = FlatParams(module)
         for m in module.modules():
             if hasattr(m, "accumulate_into_grad"):
                 m.accumulate_into_grad = True
-        self.reducer = DataParallelReducer(self.flat.grad, bucket_mb)
+        self.bucket_comm = None
+        if comm == "rccl" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if not self.flat.grad.is_cuda:
+                raise ValueError("comm='rccl' needs the parameters on a GPU")
+            from transfusion_amd.comm import BucketComm
+            self.bucket_comm = BucketComm.from_process_group(self.flat.grad.device)
+        self.reducer = DataParallelReducer(self.flat.grad, bucket_mb, bucket_comm=self.bucket_comm)
         self.world = self.reducer.world
         self.layerwise = None
         encoders = [m for m in module.modules() if hasattr(m, "layer_grad_hook")]
         force = os.environ.get("TF_FORCE_LAYERWISE") == "1"      # measurement hook: the per-layer call path on one GPU (no-op reduce)
         if overlap and (self.world > 1 or force) and len(encoders) == 1 and encoders[0] is module:
-            self.layerwise = LayerwiseReducer(self.flat)
+            self.layerwise = LayerwiseReducer(self.flat, bucket_comm=self.bucket_comm)
             module.layer_grad_hook = self.layerwise.hook
         self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
