@@ -350,18 +350,35 @@ __device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmc
 // FP8: operands are OCP e4m3 bytes.  The byte geometry is unchanged (64-B tile rows = 64 values, one K-step = 64 values): a
 // 16-B fragment feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes; both operands use the same k <-> byte map,
 // so every k is multiplied exactly once), and the per-row / per-output-channel scales are applied with the bias.
-template <int EPI, int MF, bool FP8 = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g) {
+// NWR = 1 ("duo"): half the rows -- (16*MF) x 256, 256 threads = 4 waves of the same 144 x 64 wave tile, 3-slot ring (76.8 KB), TWO
+// workgroups per CU.  Costs 47 % more DMA bytes per MFMA (the W tile is staged once per 144 rows instead of once per 288) and is no
+// faster with the chip to itself (N = 1536, K = 768: 70 vs 66 us), but inside the step the launches of two or more rounds gain 2-4 %
+// and so do the kernels that follow them (finer-grained tail; a 256-thread / 77 KB workgroup can share a CU with a weight-gradient
+// workgroup of the side stream, a 512-thread / 139 KB one cannot): 5.46 -> 5.36 ms per step, same box.  Single-round launches lose.
+// Experiment switch kept: the workgroups with blockIdx in [stagger_lo, stagger_hi) (the second slot of each CU in the first round)
+// can start `stagger_ticks` (100 MHz) late, to put one workgroup's store burst under the other's K loop -- measured neutral to
+// negative at 5 / 15 / 30 us, alone and in the step, so the default is 0.
+template <int EPI, int MF, bool FP8 = false, bool SPLIT = false, int NWR = 2>
+__global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmArgs g, int stagger_lo, int stagger_hi, int stagger_ticks) {
   static_assert(!(FP8 && SPLIT), "fp8 operands have no lo plane");
+  static_assert(NWR == 2 || !(FP8 || SPLIT), "the two-per-CU form exists for bf16 operands only");
   constexpr int ES = FP8 ? 1 : 2;                                  // bytes per operand element
-  constexpr int BM = 32 * MF;
+  constexpr int NT = 256 * NWR, NWAVES = 4 * NWR;
+  constexpr int NSLOT = NWR == 2 ? 4 : 3, DIST = NSLOT - 1;        // ring slots; the DMA of step i + DIST is issued in phase i
+  constexpr int BM = 16 * MF * NWR;
   constexpr int A_BYTES = BM * BIG_ROWB, W_BYTES = BIG_BN * BIG_ROWB, SLOT = A_BYTES + W_BYTES;
-  constexpr int NA = BM / 16, NW = BIG_BN / 16, NINST = NA + NW;   // DMA instructions per K-step (34 / 36 / 36)
-  constexpr int PER_WAVE = (NINST + 7) / 8;                        // <= 5
+  constexpr int NA = BM / 16, NW = BIG_BN / 16, NINST = NA + NW;   // DMA instructions per K-step (34 / 36 / 36; duo 25)
+  constexpr int PER_WAVE = (NINST + NWAVES - 1) / NWAVES;          // <= 5 (duo: 7)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = NWR == 2 ? wave >> 2 : 0, wc = wave & 3;
+  if constexpr (NWR == 1) {
+    if (stagger_ticks > 0 && (int)blockIdx.x >= stagger_lo && (int)blockIdx.x < stagger_hi) {
+      const unsigned long long r0 = wall_clock64();                 // s_memrealtime: 100 MHz, independent of the core clock
+      while ((long long)(wall_clock64() - r0) < (long long)stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BIG_BN;
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
   size_t src_off[PER_WAVE];
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
-    const int j = min(i * 8 + wave, NINST - 1);               // surplus slots repeat the last transfer (same bytes, same place)
+    const int j = min(i * NWAVES + wave, NINST - 1);          // surplus slots repeat the last transfer (same bytes, same place)
     const bool isW = j >= NA;
     const int r = (isW ? j - NA : j) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ swz<32>(r);
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     }
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-      const int j = min(i * 8 + wave, NINST - 1);               // wave-uniform, branch-free (keeps the K loop one basic block)
+      const int j = min(i * NWAVES + wave, NINST - 1);          // wave-uniform, branch-free (keeps the K loop one basic block)
       const bool isW = j >= NA;
       const unsigned char* base = (isW ? Wp : Ap) + (size_t)kstep * (BIG_BK * 2);
       unsigned char* dst = sl + (isW ? A_BYTES + (j - NA) * 1024 : j * 1024);
@@ -410,26 +427,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
   const int nk = SPLIT ? 3 * nk0 : nk0;
   const int frow = lane & 15, fch = lane >> 4;
   // fragment j sits 16 rows = 1024 B after fragment 0 with the SAME swizzle: one base register each plus immediates
-  const int rn0 = wc * 64 + frow, rm0 = wr * (BM / 2) + frow;
+  const int rn0 = wc * 64 + frow, rm0 = wr * (16 * MF) + frow;
   const int woff0 = A_BYTES + rn0 * BIG_ROWB + ((fch ^ swz<32>(rn0)) << 4);
   const int xoff0 = rm0 * BIG_ROWB + ((fch ^ swz<32>(rm0)) << 4);
   // prologue: steps 0, 1, 2 in flight (past the end the last step is re-fetched: the loop body is branch-free, and
   // every phase always has exactly two younger steps' transfers in flight, so one counted wait fits all phases)
-  stage(0, 0);
-  stage(1, min(1, nk - 1));
-  stage(2, min(2, nk - 1));
+#pragma unroll
+  for (int d = 0; d < DIST; ++d) stage(d, min(d, nk - 1));
+  int cur = 0;                                                     // ring slot of step i
   for (int i = 0; i < nk; ++i) {
-    // retire step i's transfers (issued three phases ago) on every wave, then make them visible
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PER_WAVE) : "memory");
-    const unsigned char* slw = smem + (i & 3) * SLOT + woff0;
-    const unsigned char* slx = smem + (i & 3) * SLOT + xoff0;
+    // retire step i's transfers (issued DIST phases ago) on every wave, then make them visible
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * PER_WAVE) : "memory");
+    const unsigned char* slw = smem + cur * SLOT + woff0;
+    const unsigned char* slx = smem + cur * SLOT + xoff0;
     bf16x8 wf[4], xf[MF];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(slw + j * 1024);
 #pragma unroll
     for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(slx + j * 1024);
     // (after the reads in program order: the compiler cannot tell the DMA's LDS destination from the slot being read)
-    stage((i + 3) & 3, min(i + 3, nk - 1));     // slot (i+3)&3 == (i-1)&3: every wave finished reading it before this barrier
+    // slot of step i + DIST == slot of step i - 1: every wave finished reading it before this barrier
+    stage(cur == 0 ? NSLOT - 1 : cur - 1, min(i + DIST, nk - 1));
+    cur = cur == NSLOT - 1 ? 0 : cur + 1;
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
@@ -447,17 +466,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
     constexpr int MM = FP8 ? 2 : 1;
     __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+    constexpr int GAP = NWR == 2 ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 7 * MM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, GAP * MM, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MF - 7 * PER_WAVE) * MM, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MF - GAP * PER_WAVE) * MM, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers must land before LDS is reused
 
   if constexpr (SPLIT) {
-    split_epilogue<EPI, MF, 3, BIG_BN, 512>(g, acc, smem, m0, n0, BM / 2, wr, wc, lane, tid);
+    split_epilogue<EPI, MF, 3, BIG_BN, 512>(g, acc, smem, m0, n0, 16 * MF, wr, wc, lane, tid);
     return;
   }
   // every chunk of R this thread will need in phase 2 is fetched half-way through phase 1: the loads fly while the C tile
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
       if (ni == 2) {
 #pragma unroll
         for (int i = 0; i < 2 * MF; ++i) {
-          const int id = i * 512 + tid;
+          const int id = i * NT + tid;
           const int gm = min(m0 + (id >> 5), g.M - 1), gn = min(n0 + (id & 31) * 8, g.N - 8);     // clamped: never used out of range
           rpre[i] = *(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn);
         }
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
     }
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
-      const int ml = wr * (BM / 2) + mi * 16 + (lane & 15);
+      const int ml = wr * (16 * MF) + mi * 16 + (lane & 15);
       f32x4 c4 = acc[ni][mi];
       if constexpr (FP8) {
         const float sa = g.scale_a != nullptr ? g.scale_a[min(m0 + ml, g.M - 1)] : 1.f;
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(const TfGemmArgs g)
   constexpr int UNR = HAS_R ? 2 * MF : 2;          // rpre[] must stay in registers; the long activation bodies stay rolled
 #pragma unroll UNR
   for (int i = 0; i < 2 * MF; ++i) {
-    const int id = i * 512 + tid;
+    const int id = i * NT + tid;
     const int row = id >> 5, c = id & 31;
     const int gm = m0 + row, gn = n0 + c * 8;
     if (gm >= g.M || gn >= g.N) continue;
@@ -934,13 +954,13 @@ template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, h
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
-    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, false, SPLIT>), grid, block, lds, stream, *a);                  \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, false, SPLIT>), grid, block, lds, stream, *a, 0, 0, 0);         \
   } break;
 #define TF_GEMM_CASE8(E)                                                                                          \
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
-    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a);                          \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a, 0, 0, 0);                 \
   } break;
   if constexpr (!SPLIT) if (a->fp8) {
     switch (a->epilogue) {
@@ -953,6 +973,35 @@ template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, h
     return (int)hipGetLastError();
   }
 #undef TF_GEMM_CASE8
+  switch (a->epilogue) {
+    TF_GEMM_CASE(TF_EPI_NONE)
+    TF_GEMM_CASE(TF_EPI_BIAS)
+    TF_GEMM_CASE(TF_EPI_BIAS_GELU_DROP)
+    TF_GEMM_CASE(TF_EPI_BIAS_DROP_RES)
+    TF_GEMM_CASE(TF_EPI_ADD)
+    TF_GEMM_CASE(TF_EPI_DGELU_DROP)
+    TF_GEMM_CASE(TF_EPI_BIAS_GELU_DROP_G)
+    TF_GEMM_CASE(TF_EPI_MUL)
+    default: return -4;
+  }
+#undef TF_GEMM_CASE
+  return (int)hipGetLastError();
+}
+int num_cus();
+// two-per-CU form (NWR = 1): 144 x 256 tiles (MF = 9), 3-slot ring; the second-slot workgroups of the first round start late
+int launch_gemm_duo(const TfGemmArgs* a, hipStream_t stream, int stagger_ticks) {
+  constexpr int MF = 9, BM = 16 * MF;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BIG_BN - 1) / BIG_BN);
+  size_t lds = 3 * (size_t)(BM + BIG_BN) * BIG_ROWB;               // 76.8 KB: two workgroups per CU
+  static_assert((size_t)BM * BIG_CT_STRIDE <= 3 * (size_t)(BM + BIG_BN) * BIG_ROWB, "the C tile must fit the ring");
+  dim3 grid(tiles), block(256);
+  const int ncu = num_cus();
+#define TF_GEMM_CASE(E)                                                                                           \
+  case E: {                                                                                                       \
+    static bool attr_set = false;                                                                                 \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, false, false, 1>), grid, block, lds, stream, *a, ncu, 2 * ncu, stagger_ticks); \
+  } break;
   switch (a->epilogue) {
     TF_GEMM_CASE(TF_EPI_NONE)
     TF_GEMM_CASE(TF_EPI_BIAS)
@@ -1026,6 +1075,22 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     const double t_small = (double)((ts + 2 * num_cus() - 1) / (2 * num_cus())) * (8.0 + 0.021 * a->K) * (mi / 4.0);
     static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
     if (model && t_small < t_big) use_big = false;
+  }
+  // Two workgroups per CU (144 x 256 tiles) for launches of two or more rounds (QKV, FFN-up, FFN-down dgrad at the benchmark shape):
+  // see the kernel's header.  TF_GEMM_DUO=0 turns it off, TF_GEMM_DUO_MIN sets the tile threshold, TF_GEMM_DUO_US the stagger.
+  static const int duo = getenv("TF_GEMM_DUO") ? atoi(getenv("TF_GEMM_DUO")) : 1;
+  static const int duo_min = getenv("TF_GEMM_DUO_MIN") ? atoi(getenv("TF_GEMM_DUO_MIN")) : 0;
+  static const double duo_us = getenv("TF_GEMM_DUO_US") ? atof(getenv("TF_GEMM_DUO_US")) : -1.0;
+  if (use_big && duo && !split) {
+    const long td = (long)((a->M + 143) / 144) * ((a->N + BIG_BN - 1) / BIG_BN);
+    const long need = duo_min > 0 ? duo_min : 2L * num_cus() + 1;
+    if (td >= need) {
+      const double us = duo_us >= 0 ? duo_us : 0.0;
+      char nm[56];
+      snprintf(nm, sizeof(nm), "gemm_nt_duo_kernel<%d, 9>", a->epilogue);
+      TfTraceScope tr(nm, stream, fl);
+      return launch_gemm_duo(a, stream, (int)(us * 100.0));
+    }
   }
   if (use_big) {
     const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
