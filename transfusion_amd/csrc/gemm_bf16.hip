@@ -703,7 +703,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 // Bias grad: ONE extra accumulator for all four n-blocks -- D += SEL_nb . dYfrag_nb with SEL_nb[i][m] = (i >> 3 == nb),
 // so rows 8nb..8nb+7 of the 32x32 result (= accumulator registers 4nb..4nb+3) hold the column sums of n-block nb.
 // ------------------------------------------------------------------------------------------------
-template <bool SPLIT>        // see wgrad_tn_kernel
+// NS = ring slots (3; 2 = 48 KiB: the workgroup then fits on a CU next to an attention-backward workgroup of the chain -- experiment)
+template <bool SPLIT, int NS = 3>        // see wgrad_tn_kernel
 __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) {
   constexpr int STEP = 32, YB = STEP * 512, XB = STEP * 256, SLOT = YB + XB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -817,12 +818,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
   const unsigned lds_base = lds_addr_of(smem);
   if (nsteps > 0) {
     stage(0, 0);
-    stage(1, min(1, nsteps - 1));
+    if constexpr (NS == 3) stage(1, min(1, nsteps - 1));
   }
   int slot = 0;
   for (int st = 0; st < nsteps; ++st) {
-    // retire step st's transfers (issued two phases ago; 6 per wave per step), make them visible, recycle slot (st+2)%3
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    // retire step st's transfers (issued NS - 1 phases ago; 6 per wave per step), make them visible, recycle slot (st+NS-1)%NS
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * 6) : "memory");
     const unsigned sl = lds_base + slot * SLOT;
     u64 y0[4][2], x0[2][2], y1[4][2], x1[2][2];               // [block][row half] of substep 0 / 1
 #define TF_RD(Y, Xv, MS)                                                                                  \
@@ -836,9 +837,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
     TF_RD(y1, x1, 1)
 #undef TF_RD
     // (after the reads: hipcc orders an LDS-DMA before any LATER LDS read with a vmcnt(0), it cannot tell the slots apart)
-    const int nslot = slot == 0 ? 2 : slot - 1;                // (st + 2) % 3 given slot = st % 3
-    stage(nslot, min(st + 2, nsteps - 1));
-    slot = slot == 2 ? 0 : slot + 1;
+    const int nslot = slot == 0 ? NS - 1 : slot - 1;           // (st + NS - 1) % NS given slot = st % NS
+    stage(nslot, min(st + NS - 1, nsteps - 1));
+    slot = slot == NS - 1 ? 0 : slot + 1;
     auto substep = [&](u64 (&Y)[4][2], u64 (&Xv)[2][2]) {
       bf16x8 af[4], bfr[2];
 #pragma unroll
@@ -1083,7 +1084,8 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   static const double duo_us = getenv("TF_GEMM_DUO_US") ? atof(getenv("TF_GEMM_DUO_US")) : -1.0;
   if (use_big && duo && !split) {
     const long td = (long)((a->M + 143) / 144) * ((a->N + BIG_BN - 1) / BIG_BN);
-    const long need = duo_min > 0 ? duo_min : 2L * num_cus() + 1;
+    static const int duo_1r = getenv("TF_GEMM_DUO_1R") ? atoi(getenv("TF_GEMM_DUO_1R")) : 0;   // experiment: epilogue bitmask -> also single-round launches
+    const long need = duo_min > 0 ? duo_min : (((duo_1r >> a->epilogue) & 1) ? num_cus() + 1 : 2L * num_cus() + 1);
     if (td >= need) {
       const double us = duo_us >= 0 ? duo_us : 0.0;
       char nm[56];
@@ -1164,7 +1166,9 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
     static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     static const hipError_t once3 = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     (void)once; (void)once3;
+    static const int ring = getenv("TF_WGRAD_RING") ? atoi(getenv("TF_WGRAD_RING")) : 3;      // experiment switch (2: 48 KiB)
     if (split) hipLaunchKernelGGL(wgrad_tn2_kernel<true>, grid, block, LDS2, stream, a);
+    else if (ring == 2) hipLaunchKernelGGL((wgrad_tn2_kernel<false, 2>), grid, block, LDS2 / 3 * 2, stream, a);
     else hipLaunchKernelGGL(wgrad_tn2_kernel<false>, grid, block, LDS2, stream, a);
   } else {
     if (split) hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, block, 4 * TILE_BYTES, stream, a);
