@@ -259,6 +259,29 @@ def test_pack_and_patch_permutations(dev):
     assert torch.equal(img.cpu(), expect)
 
 
+@pytest.mark.parametrize("B,C,H,W,p", [(2, 256, 56, 56, 4), (3, 40, 15, 17, 2), (2, 2048, 14, 14, 1), (1, 12, 7, 300, 3), (2, 520, 29, 28, 2)])
+def test_patch_permutations_tiled_kernels(dev, B, C, H, W, p):
+    """K1 / K9 permutations at the wrapper's level shapes and at ragged ones (channel tails, maps that are not a multiple of the patch,
+    several channel chunks per patch row): im2col rows and the fold must be EXACT permutations of the bf16-rounded input."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + H + W + p)
+    feat = torch.randn(B, C, H, W, generator=g).to(dev)
+    Hp, Wp = H // p, W // p
+    rows = ops.patchify(feat, p, p)
+    x = feat.cpu()[:, :, : Hp * p, : Wp * p].reshape(B, C, Hp, p, Wp, p).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * p * p)
+    assert rows.shape[-1] >= C * p * p
+    assert torch.equal(rows.float().cpu()[..., : C * p * p], bf(x).float())
+    assert rows.float().cpu()[..., C * p * p:].abs().sum() == 0                 # row padding is zero
+    for out_dtype in (torch.float32, torch.bfloat16):
+        img = ops.regroup(rows, H, W, p, p, out_dtype=out_dtype)
+        expect = torch.zeros(B, C, H, W)
+        expect[:, :, : Hp * p, : Wp * p] = bf(feat.cpu()[:, :, : Hp * p, : Wp * p]).float()
+        assert torch.equal(img.float().cpu(), expect)
+    # bf16 feature map in (regroup's backward path: d(feat) -> d(token rows))
+    rows16 = ops.patchify(feat.to(torch.bfloat16), p, p)
+    assert torch.equal(rows16.float().cpu(), rows.float().cpu())
+
+
 def test_linear_fn_fwd_bwd(dev):
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(11)

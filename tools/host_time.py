@@ -9,7 +9,7 @@ from transfusion_amd.runner.trainer import FusionTrainStep
 dev = torch.device("cuda", 0)
 enc = b.make_encoder(dev); enc.train()
 tr = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=1.0)
-batch = b.make_batch(32, dev, 0)
+batch = b.make_batch(int(os.environ.get("B", 32)), dev, 0)
 for _ in range(5): tr.step([batch], b.loss_fn)
 torch.cuda.synchronize()
 n = 30

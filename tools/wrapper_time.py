@@ -62,6 +62,6 @@ for i in range(min(nrec, cap)):
     a = agg.setdefault(r.name.decode(), [0.0, 0])
     a[0] += r.us; a[1] += 1
 tot = sum(v[0] for v in agg.values()) / 2
-for name, (us, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+for name, (us, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TOP", 14))]:
     print(f"  {name:36s} {us / cnt:9.1f} us x{cnt / 2:6.1f} = {us / 2:8.1f} us/step")
 print(f"  library kernels (sum of durations) {tot:.0f} us/step")

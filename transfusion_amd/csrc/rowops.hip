@@ -537,6 +537,69 @@ __global__ void col2im_kernel(const TfPatchArgs a, int out_is_f32) {
   }
 }
 
+// Tiled form of the gather above (the element-per-thread kernel reads 4-16 B pieces at a stride of one image row).  One workgroup =
+// one (sample, patch row hp, channel chunk): the ph image rows of CC channels pass through LDS as bf16, so the image side moves in
+// whole rows and the token side in contiguous CC*ph*pw-element slices (1 KiB) of each of the Wp tokens: 51 -> 42 us per call inside the
+// wrapper step.  (The same tiling of the fold, col2im, measured SLOWER than its element-per-thread kernel, 48 vs 43 us, and was dropped.)
+// This pass is also the fp32 -> bf16 conversion of the detector's feature map, which is why K1 keeps a materialised im2col: a GEMM
+// that gathered patches itself (LDS-DMA cannot convert) would need the same pass to produce bf16 first.
+constexpr int PATCH_TILE = 8192;                       // elements per workgroup (16 KiB of bf16)
+template <bool F32>
+__global__ __launch_bounds__(256) void im2col_tiled_kernel(const TfPatchArgs a, int CC, int nchunks) {
+  __shared__ __attribute__((aligned(16))) u16 tile[PATCH_TILE];
+  const int tid = threadIdx.x;
+  const int Hp = a.H / a.ph, Wp = a.W / a.pw, Wx = Wp * a.pw, pp = a.ph * a.pw, Kc = a.C * pp;
+  int blk = blockIdx.x;
+  const int ch = blk % nchunks; blk /= nchunks;
+  const int hp = blk % Hp, b = blk / Hp;
+  const int c0 = ch * CC, cn = min(CC, a.C - c0);
+  const int rowlen = a.ph * Wx, n = cn * rowlen;
+  for (int idx = tid; idx < n; idx += 256) {           // (cc, i, x), x fastest: whole image rows
+    const int cc = idx / rowlen, r = idx - cc * rowlen, i = r / Wx, x = r - i * Wx;
+    const size_t src = (((size_t)b * a.C + c0 + cc) * a.H + hp * a.ph + i) * a.W + x;
+    tile[idx] = F32 ? f2bf(((const float*)a.feat)[src]) : ((const u16*)a.feat)[src];
+  }
+  __syncthreads();
+  const int per_tok = cn * pp, groups = (per_tok + 7) / 8;
+  u16* __restrict__ cols = (u16*)a.cols;
+  for (int g = tid; g < Wp * groups; g += 256) {       // (wp, 8 consecutive k): 16-B stores, contiguous per token
+    const int wp = g / groups, e0 = (g - wp * groups) * 8;
+    u16 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = min(e0 + t, per_tok - 1);
+      const int cc = e / pp, r = e - cc * pp, i = r / a.pw, j = r - i * a.pw;
+      v[t] = tile[cc * rowlen + i * Wx + wp * a.pw + j];
+    }
+    u16* dst = cols + ((size_t)(b * Hp + hp) * Wp + wp) * a.ld_cols + (size_t)c0 * pp + e0;
+    if (e0 + 8 <= per_tok) {
+      u32x4 w;
+      w[0] = v[0] | ((unsigned)v[1] << 16); w[1] = v[2] | ((unsigned)v[3] << 16);
+      w[2] = v[4] | ((unsigned)v[5] << 16); w[3] = v[6] | ((unsigned)v[7] << 16);
+      *(u32x4*)dst = w;
+    } else {
+      for (int t = 0; e0 + t < per_tok; ++t) dst[t] = v[t];
+    }
+  }
+  if (ch == 0 && a.ld_cols > Kc) {                     // zero the row padding once
+    const int padw = a.ld_cols - Kc;
+    for (int idx = tid; idx < Wp * padw; idx += 256) {
+      const int wp = idx / padw, q = idx - wp * padw;
+      cols[((size_t)(b * Hp + hp) * Wp + wp) * a.ld_cols + Kc + q] = 0;
+    }
+  }
+}
+// channels per workgroup of the tiled kernel (0: shape not served -> element-per-thread kernel)
+static int patch_chunk(const TfPatchArgs* a) {
+  const int Hp = a->H / a->ph, Wp = a->W / a->pw;
+  if (Hp <= 0 || Wp <= 0 || (a->ld_cols % 8) != 0) return 0;
+  const int rowlen = a->ph * Wp * a->pw;
+  int cc = (PATCH_TILE / rowlen) / 8 * 8;
+  if (cc < 8) return 0;
+  const int cpad = (a->C + 7) / 8 * 8;
+  return cc < cpad ? cc : cpad;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row-wise fp8 (OCP e4m3) quantisation: one wave per row, 16-B lanes; scale[r] = max|row| / 448.
 // Feeds the fp8 operand variant of the large-tile GEMM (activations per token, weights per output channel).
@@ -909,6 +972,16 @@ extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStrea
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
   if (total <= 0) return 0;
+  static const int tiled = getenv("TF_PATCH_TILED") ? atoi(getenv("TF_PATCH_TILED")) : 1;
+  const int cc = tiled ? patch_chunk(a) : 0;
+  if (cc > 0) {
+    const int nch = (a->C + cc - 1) / cc;
+    const dim3 grid((unsigned)((long long)a->B * (a->H / a->ph) * nch));
+    TfTraceScope tr("im2col_tiled_kernel", st);
+    if (a->feat_is_f32) hipLaunchKernelGGL(im2col_tiled_kernel<true>, grid, dim3(256), 0, st, *a, cc, nch);
+    else hipLaunchKernelGGL(im2col_tiled_kernel<false>, grid, dim3(256), 0, st, *a, cc, nch);
+    return (int)hipGetLastError();
+  }
   TfTraceScope tr("im2col_kernel", st);
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a);
   return (int)hipGetLastError();

@@ -276,7 +276,15 @@ int tf_overlap_create(TfOverlap* o) {
   if (o == nullptr) return fail(-1, "tf_overlap_create");
   memset(o, 0, sizeof(*o));
   hipStream_t st = nullptr;
-  TF_TRY((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "tf_overlap_create(stream)");
+  // TF_SIDE_PRIORITY (experiment): -1 = the device's highest stream priority, 1 = its lowest, unset / 0 = default
+  static const int prio_sel = getenv("TF_SIDE_PRIORITY") ? atoi(getenv("TF_SIDE_PRIORITY")) : 0;
+  if (prio_sel != 0) {
+    int least = 0, greatest = 0;
+    TF_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest), "tf_overlap_create(priority range)");
+    TF_TRY((int)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_sel < 0 ? greatest : least), "tf_overlap_create(stream)");
+  } else {
+    TF_TRY((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "tf_overlap_create(stream)");
+  }
   o->stream = st;
   tf_trace_mark_side(st);
   for (int i = 0; i < 8; ++i) {
