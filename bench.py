@@ -531,7 +531,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, measured offline
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+            table = json.load(open(tpath))
+            base = dom["kernel"].split("<")[0]                   # rocprofv3 prints template arguments the tracer's short names omit
+            hit = table.get(dom["kernel"]) or next((v for k, v in table.items() if isinstance(v, dict) and k.split("<")[0] == base), {})
+            traffic = hit.get("hbm_bytes_per_launch")
         if dom["tflops"] is not None:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": round(peak, 1),
                                   "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
