@@ -506,6 +506,44 @@ def test_two_forwards_before_their_backwards(dev):
 
 
 @pytest.mark.gpu
+def test_workspace_pool_is_bounded_under_changing_token_counts(dev):
+    """A loader that pads the language tokens to the longest sample of each batch changes Nl almost every step: the encoder must not keep
+    one workspace per length ever seen, a forward whose workspace was evicted before its backward must still be correct, and coming back
+    to an earlier length (fresh workspace) must reproduce its first result bit for bit."""
+    from oracle import fusion_oracle as O
+    cfg = dict(B=2, Nv=16, d=64, h=4, L=2, seed=67)
+    enc, params = build(dict(cfg, Nl=24), dev)
+    enc.eval()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    first = {}
+    pending = None
+    for step, nl in enumerate([24, 40, 17, 33, 64, 24, 9, 40]):
+        x, l, m, gv, gl = make_encoder_inputs(700 + nl, cfg["B"], cfg["Nv"], nl, cfg["d"], [nl, max(1, nl // 3)])
+        xd = t(x).requires_grad_(True)
+        v, lo, _, _ = enc(xd, t(l), t(m))
+        assert len(enc._work_pool) <= enc.MAX_WORK_SHAPES
+        assert sum(len(p) for p in enc._work_pool.values()) <= enc.MAX_WORK_SHAPES * 4
+        if nl in first:
+            assert torch.equal(v, first[nl][0]) and torch.equal(lo, first[nl][1])
+        else:
+            first[nl] = (v.detach().clone(), lo.detach().clone())
+        if step == 0:
+            pending = (xd, x, l, m, gv, gl, v, lo)        # its backward runs after its workspace has left the pool
+    xd, x, l, m, gv, gl, v, lo = pending
+    assert (cfg["B"], cfg["Nv"], 24, enc.precision) in enc._work_pool      # came back at step 5 -- with a NEW workspace
+    ((v * t(gv)).sum() + (lo * t(gl)).sum()).backward()
+    sd = {k: torch.from_numpy(p).clone().requires_grad_(True) for k, p in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, cfg["d"])
+    xr = torch.from_numpy(x).requires_grad_(True)
+    vr, lr = O.encoder_forward(sd, xr, torch.from_numpy(l), torch.from_numpy(m), cfg["h"], cfg["L"])
+    ((vr * torch.from_numpy(gv)).sum() + (lr * torch.from_numpy(gl)).sum()).backward()
+    assert rel(v, vr.detach()) < FWD_TOL and rel(xd.grad, xr.grad) < GRAD_TOL
+    for k, p in enc.named_parameters():
+        if k in sd and sd[k].grad is not None:
+            assert rel(p.grad, sd[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.gpu
 def test_standalone_optimizer_step_refreshes_weight_shadows(dev):
     """FusedRAdam used the way the reference uses RAdam (opt = cls(model.parameters()); loss.backward(); opt.step()): the raw-pointer
     update bumps the parameter versions, so the next forward re-packs the bf16 weight shadows and its output changes."""

@@ -248,8 +248,18 @@ class CrossTransformerModuleBox(nn.Module):
     def mark_weights_updated(self):
         self._wpack_versions = None
 
+    MAX_WORK_SHAPES = 3       # workspaces are kept for this many distinct (B, Nv, Nl, precision) shapes, least recently used first out
+
     def _get_work(self, key, plan, device):
-        pool = self._work_pool.setdefault(key, [])
+        # a loader that pads the language tokens to the longest sample of each batch hands over a new Nl almost every step: without a
+        # bound the pool would keep one multi-GB workspace per length ever seen.  An evicted workspace that still awaits its backward stays
+        # alive through that backward's ctx; it just is not reused afterwards.
+        pool = self._work_pool.pop(key, None)
+        if pool is None:
+            pool = []
+            while len(self._work_pool) >= self.MAX_WORK_SHAPES:
+                self._work_pool.pop(next(iter(self._work_pool)))
+        self._work_pool[key] = pool           # (re)inserted last: dict order is the recency order
         for item in pool:
             if not item["busy"]:
                 item["gen"] += 1
