@@ -843,7 +843,8 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (width > 64 * MAXC_MAX * 8) return -2;
   static const int env_w = getenv("TF_LNB_WAVES") ? atoi(getenv("TF_LNB_WAVES")) : 8;     // experiment switch: 16 waves measured slower (39.9 vs 38.3 us)
   const int nw = (width <= 1024 && env_w == 16) ? 16 : 8;   // 16 waves where the reduction array fits the 64 KiB static LDS
-  const dim3 grid(grid_for(a->rows, nw * 2, 512));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
+  static const int env_g = getenv("TF_LNB_GRID") ? atoi(getenv("TF_LNB_GRID")) : 512;     // experiment switch
+  const dim3 grid(grid_for(a->rows, nw * 2, env_g));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
   const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
