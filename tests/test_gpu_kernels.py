@@ -36,7 +36,8 @@ def gelu_grad(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 768), (1000, 2304, 768), (77, 8, 64),
-                                   (5000, 776, 192), (4100, 2304, 64), (22656, 768, 768)])   # the last three take the large-tile kernel
+                                   (5000, 776, 192), (4100, 2304, 64), (22656, 768, 768),    # these three take the large-tile kernel
+                                   (9000, 2304, 128)])   # 63 x 9 = 567 tiles of 144 x 256: the two-workgroups-per-CU form, ragged last row tile
 def test_gemm_epilogues(dev, M, N, K):
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)
