@@ -121,8 +121,10 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
 }
 
 // ---- fp32-accuracy mode (TfGemmArgs.A_lo != null): the same epilogues on fp32 values, every bf16 tensor a hi + lo plane pair ----
+// rhi / rlo: the chunk's R planes already in registers (split_epilogue fetches a whole group's before its LDS pass), or null
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, float (&f)[8], int gm, int gn) {
+__device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, float (&f)[8], int gm, int gn,
+                                                        const u32x4* rhi = nullptr, const u32x4* rlo = nullptr) {
   const size_t oc = (size_t)gm * g.ldc + gn;
   if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
     store8_split(g.C, g.C_lo, oc, f);
@@ -141,7 +143,8 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
     store8_split(g.C2, g.C2_lo, (size_t)gm * g.ldc2 + gn, hv);
   } else {
     float r[8];
-    load8_split(g.R, g.R_lo, (size_t)gm * g.ldr + gn, r);
+    if (rhi != nullptr) join8(*rhi, *rlo, r);
+    else load8_split(g.R, g.R_lo, (size_t)gm * g.ldr + gn, r);
     if constexpr (EPI == TF_EPI_MUL) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] *= r[e];
@@ -171,8 +174,25 @@ template <int EPI, int MBLK, int PM, int TBN, int NT>
 __device__ __forceinline__ void split_epilogue(const TfGemmArgs& g, f32x4 (&acc)[4][MBLK], unsigned char* ct, int m0, int n0, int wave_rows,
                                                int wr, int wc, int lane, int tid) {
   constexpr int RS = TBN * 4 + 16, CH = TBN / 8;
+  constexpr bool HAS_R = EPI == TF_EPI_MUL || EPI == TF_EPI_ADD || EPI == TF_EPI_BIAS_DROP_RES || EPI == TF_EPI_DGELU_DROP;
+  constexpr int PER = (2 * PM * 16 * CH + NT - 1) / NT;              // chunks of a group per thread
 #pragma unroll
   for (int p0 = 0; p0 < MBLK; p0 += PM) {
+    // this thread's R chunks of the group, both planes, fetched before the group passes through LDS (one HBM latency per group
+    // instead of one per chunk)
+    u32x4 rhi[HAS_R ? PER : 1], rlo[HAS_R ? PER : 1];
+    if constexpr (HAS_R) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int id = min(k * NT + tid, 2 * PM * 16 * CH - 1);
+        const int row_l = id / CH, c = id - row_l * CH;
+        const int w = row_l / (PM * 16), rem = row_l - w * (PM * 16);
+        const int gm = min(m0 + w * wave_rows + p0 * 16 + rem, g.M - 1), gn = min(n0 + c * 8, g.N - 8);   // clamped: unused when out of range
+        const size_t off = (size_t)gm * g.ldr + gn;
+        rhi[k] = *(const u32x4*)((const u16*)g.R + off);
+        rlo[k] = *(const u32x4*)((const u16*)g.R_lo + off);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int nl = wc * 64 + ni * 16 + (lane >> 4) * 4;
@@ -187,7 +207,10 @@ __device__ __forceinline__ void split_epilogue(const TfGemmArgs& g, f32x4 (&acc)
       }
     }
     __syncthreads();
-    for (int id = tid; id < 2 * PM * 16 * CH; id += NT) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int id = k * NT + tid;
+      if (id >= 2 * PM * 16 * CH) continue;
       const int row_l = id / CH, c = id - row_l * CH;
       const int w = row_l / (PM * 16), rem = row_l - w * (PM * 16);
       if (p0 + rem / 16 >= MBLK) continue;
@@ -195,7 +218,7 @@ __device__ __forceinline__ void split_epilogue(const TfGemmArgs& g, f32x4 (&acc)
       if (gm >= g.M || gn >= g.N) continue;
       const f32x4 lo4 = *(const f32x4*)(ct + row_l * RS + c * 32), hi4 = *(const f32x4*)(ct + row_l * RS + c * 32 + 16);
       float f[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-      gemm_epilogue_chunk_f32<EPI>(g, f, gm, gn);
+      gemm_epilogue_chunk_f32<EPI>(g, f, gm, gn, HAS_R ? &rhi[k] : nullptr, HAS_R ? &rlo[k] : nullptr);
     }
     __syncthreads();
   }
