@@ -351,3 +351,32 @@ def test_fp32_mode_dropout_replay_and_full_size_slice(dev):
         v_ref, l_ref = O.encoder_forward(sd, x[:2], lang[:2], mask[:2], full["h"], full["L"])
     assert rel(v_full[:2], v_ref) < TOL and (v_full[:2].cpu() - v_ref).abs().max() < TOL
     assert rel(l_full[:2].cpu()[~mask[:2]], l_ref[~mask[:2]]) < TOL
+
+
+@pytest.mark.parametrize("M,K,N", [(150, 40, 72), (5000, 200, 87), (1568, 4096, 768)])   # class-count head (padded rows), K1 at level 0
+def test_linear_fp32_mode(dev, M, K, N):
+    """``ops.linear(..., precision="fp32")`` (K1 / K9 / out_mlp when run.precision is 32): hi + lo planes of the input, the weight and
+    the upstream gradient, fp32 out -- output and all three gradients against fp64, with and without input dropout (statistics only:
+    the keep mask is drawn inside)."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(M, N, generator=g).to(dev)
+    y = ops.linear(x, w, b, precision="fp32")
+    assert y.dtype == torch.float32 and y.shape == (M, N)
+    (y * gy).sum().backward()
+    xr, wr, br = (t.detach().double().cpu().requires_grad_(True) for t in (x, w, b))
+    yr = xr @ wr.t() + br
+    (yr * gy.double().cpu()).sum().backward()
+    assert rel(y, yr.detach()) < 2e-5
+    assert rel(x.grad, xr.grad) < 2e-5 and rel(w.grad, wr.grad) < 2e-5 and rel(b.grad, br.grad) < 2e-5
+    # input dropout: E[y] is unchanged, a dropped input column contributes nothing, kept ones are scaled by 1 / (1 - p)
+    x2 = torch.ones(M, K, device=dev)
+    w2 = torch.eye(K, device=dev)[: min(N, K)].contiguous() if K >= 8 else None
+    if w2 is not None and w2.shape[0] % 1 == 0:
+        y2 = ops.linear(x2, w2, None, p_drop_in=0.25, precision="fp32")
+        kept = y2 > 0
+        assert (y2[~kept] == 0).all() and (y2[kept] - 1 / 0.75).abs().max().item() < 5e-5        # 16 significant bits of 4/3, not bf16(4/3)
+        assert 0.6 < kept.float().mean().item() < 0.9

@@ -60,7 +60,7 @@ def test_level_golden_through_wrapper(golden_dir, name):
     fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
     fusion.update({"fpn_features": [0], "replace_fpn_features": True, "patch_h": [p], "patch_w": [p], "backproj_dropout": 0.0})
     fusion["args"].update({"num_layers": [cfg["L"]], "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
-    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0},
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 16,      # bf16 compute (the fp32 mode: next test)
                "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
                                                          "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
     det = StubDetector([(H, W)], [C])
@@ -115,6 +115,77 @@ def test_level_golden_through_wrapper(golden_dir, name):
     assert rel(model.tokens_to_features[0].linear.weight.grad, rw.grad) < 3e-2
     assert rel(model.tokens_to_features[0].linear.bias.grad, rb.grad) < 3e-2
     assert rel(model.cross_fusion_encoders[0].t_encoder.layers[0].linear1.weight.grad, sd["t_encoder.layers.0.linear1.weight"].grad) < 3e-2
+
+
+@pytest.mark.parametrize("name", list(LEVEL_CASES))
+def test_level_golden_through_wrapper_fp32_mode(golden_dir, name):
+    """BASELINE configs[2] (run.precision: 32) at the WRAPPER boundary: with ``precision: 32`` the patch-embedding GEMM (K1), the encoder
+    and the back-projection GEMM + fold (K9) all run in the fp32-accuracy mode -- fused feature map and every gradient within the
+    north_star's 1e-3 of the fp32 fixture / oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    from oracle import fusion_oracle as O
+    dev = torch.device("cuda:0")
+    cfg = LEVEL_CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    B, C, H, W, p, d = cfg["B"], cfg["C"], cfg["H"], cfg["W"], cfg["p"], cfg["d"]
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": [0], "replace_fpn_features": True, "patch_h": [p], "patch_w": [p], "backproj_dropout": 0.0})
+    fusion["args"].update({"num_layers": [cfg["L"]], "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 32,
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    model = get_fusion_model(StubDetector([(H, W)], [C]), {}, run_cfg, None).to(dev).train()
+    assert model.cross_fusion_encoders[0].precision == "fp32" and model.patches_to_token[0].precision == "fp32"
+    assert model.tokens_to_features[0].precision == "fp32"
+    enc_sd = {k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}
+    model.cross_fusion_encoders[0].load_state_dict(enc_sd, strict=False)
+    model.patches_to_token[0].weight.data.copy_(torch.from_numpy(g["conv_w"]))
+    model.tokens_to_features[0].linear.weight.data.copy_(torch.from_numpy(g["reg_w"]))
+    model.tokens_to_features[0].linear.bias.data.copy_(torch.from_numpy(g["reg_b"]))
+    feat = torch.from_numpy(g["in_feat"]).to(dev).requires_grad_(True)
+    lang_full = torch.from_numpy(g["in_lang"])
+    lens = [int((~g["in_mask"][b]).sum()) for b in range(B)]
+
+    class PassThroughPooling(torch.nn.Module):
+        precision = "bf16"
+
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, n in enumerate(lens):
+                m[b, n:] = 0
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    lang_dev = lang_full.to(dev)
+    out = model({"image": [feat], "language_f": [lang_dev[b] for b in range(B)]})
+    fused = out["features"]["0"]
+    assert fused.dtype == torch.float32 and fused.shape == (B, C, H, W)
+    assert rel(fused, g["fused"]) < 1e-3
+    if H % p:
+        assert fused[:, :, H // p * p:].abs().max().item() == 0.0
+    (fused * torch.from_numpy(g["cot_out"]).to(dev)).sum().backward()
+    sd = {k: v.clone().requires_grad_(True) for k, v in enc_sd.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+    fr = torch.from_numpy(g["in_feat"]).requires_grad_(True)
+    cw = torch.from_numpy(g["conv_w"]).requires_grad_(True)
+    rw = torch.from_numpy(g["reg_w"]).requires_grad_(True)
+    rb = torch.from_numpy(g["reg_b"]).requires_grad_(True)
+    f_ref, _ = O.fusion_level_forward(fr, cw, sd, lang_full, torch.from_numpy(g["in_mask"]), cfg["h"], cfg["L"], rw, rb, p, p)
+    (f_ref * torch.from_numpy(g["cot_out"])).sum().backward()
+    assert rel(feat.grad, fr.grad) < 1e-3
+    assert rel(model.patches_to_token[0].weight.grad, cw.grad) < 1e-3
+    assert rel(model.tokens_to_features[0].linear.weight.grad, rw.grad) < 1e-3
+    assert rel(model.tokens_to_features[0].linear.bias.grad, rb.grad) < 1e-3
+    for k, prm in model.cross_fusion_encoders[0].named_parameters():
+        if k in sd and sd[k].grad is not None:
+            assert rel(prm.grad, sd[k].grad) < 1e-3, k
 
 
 def test_slowfast_pooling_contract():

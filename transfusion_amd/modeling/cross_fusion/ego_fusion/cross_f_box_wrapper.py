@@ -52,11 +52,18 @@ class PatchToToken(nn.Module):
         holder = nn.Conv2d(in_channels, token_dim, kernel_size=(patch_h, patch_w), stride=(patch_h, patch_w), bias=False)
         self.weight = nn.Parameter(holder.weight.detach().clone())      # same init family as the reference
         self.patch_h, self.patch_w = patch_h, patch_w
+        self.precision = "bf16"          # "fp32": run.precision 32 (set_precision)
 
     def forward(self, feat):
         """[B,C,H,W] -> tokens [B, H'*W', d] (already token-major: the reference's patchify_image(.,1,1) is fused)."""
         B, Cc, H, W = feat.shape
         K = Cc * self.patch_h * self.patch_w
+        if self.precision == "fp32":
+            # the gather stays in fp32 (an exact permutation, done by torch); the GEMM takes hi + lo planes of it
+            ph, pw = self.patch_h, self.patch_w
+            Hp, Wp = H // ph, W // pw
+            rows = feat[:, :, : Hp * ph, : Wp * pw].float().reshape(B, Cc, Hp, ph, Wp, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * Hp * Wp, K)
+            return ops.linear(rows, self.weight, None, precision="fp32").view(B, Hp * Wp, -1)
         rows = ops.patchify(feat, self.patch_h, self.patch_w, ld=(K + 63) // 64 * 64)
         tok = ops.linear(rows[:, :K] if rows.shape[1] != K else rows, self.weight, None)
         return tok.view(B, (H // self.patch_h) * (W // self.patch_w), -1)
@@ -105,8 +112,9 @@ class CrossFusionBoxWrapper(nn.Module):
         """``run.precision`` of the reference's run YAML (run_experiment.py:450): 32 -> the fp32-accuracy mode of the fusion encoders
         (Ego4Dv2 YAML), 16 / "bf16" -> bf16 compute (the Ego4Dv1 YAML's 16 is fp16 autocast in the reference)."""
         mode = "fp32" if str(precision) in ("32", "32-true", "fp32") else "bf16"
-        for enc in self.cross_fusion_encoders:
-            enc.precision = mode
+        for m in self.modules():               # the encoders, the patch-embedding / back-projection GEMMs (K1 / K9), the pooling layer's out_mlp
+            if m is not self and isinstance(getattr(m, "precision", None), str):
+                m.precision = mode
         return mode
 
     def setup_cross_fusion_encoders(self, cross_encoder_args):

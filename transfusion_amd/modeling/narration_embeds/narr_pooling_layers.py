@@ -31,6 +31,7 @@ class SlowFastPooling(nn.Module):
         self.out_dropout = nn.Dropout(cfg["out_dropout"])
         self.use_out_tanh = cfg["out_tanh"]
         self.out_mlp = nn.Linear(self.size, out_mlp) if out_mlp else None
+        self.precision = "bf16"          # "fp32": run.precision 32 (CrossFusionBoxWrapper.set_precision)
 
     def unfreeze_embeddings(self):
         pass
@@ -49,7 +50,7 @@ class SlowFastPooling(nn.Module):
             lens_t = lens_t.pin_memory().to(tensor.device, non_blocking=True)
         att_mask = (torch.arange(T, device=tensor.device, dtype=torch.int32).unsqueeze(0) < lens_t.unsqueeze(1)).to(torch.float32)
         if self.out_mlp:
-            tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias).float()
+            tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias, precision=self.precision).float()
         if self.use_out_tanh:
             tensor = torch.tanh(tensor)
         if min(lens) != T:

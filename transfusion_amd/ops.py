@@ -313,24 +313,93 @@ import weakref
 _shadow_cache = {}      # id(parameter) -> (weakref to the parameter, (data_ptr, _version, shape, pads), W shadow, W^T shadow)
 
 
-def _weight_shadows(weight, N8, Kp, Np):
+def _weight_shadows(weight, N8, Kp, Np, planes=False):
     """bf16 shadows [N8, Kp] and [Kp, Np] of an fp32 weight, re-packed only when the parameter changed (its storage moved or its
     version was bumped -- FusedRAdam does that for its raw-pointer updates).  Keyed on the parameter OBJECT (id + a weak reference that
-    must still point at it), never on a bare data_ptr: a freed tensor's address is reused by its successor."""
+    must still point at it), never on a bare data_ptr: a freed tensor's address is reused by its successor.
+    ``planes``: also the lo planes (w - bf16(w), the fp32-accuracy mode's second operand plane) -> (W, W^T, W_lo, W^T_lo)."""
     w2 = weight.reshape(weight.shape[0], -1)
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), N8, Kp, Np)
-    hit = _shadow_cache.get(id(weight))
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), N8, Kp, Np, bool(planes))
+    hit = _shadow_cache.get((id(weight), bool(planes)))
     if hit is not None and hit[0]() is weight and hit[1] == key:
-        return hit[2], hit[3]
+        return hit[2]
     wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np)
+    out = (wsh, wsh_t)
+    if planes:
+        wf = w2.detach().float()
+        lo = wf - wf.to(torch.bfloat16).float()                    # exact in fp32; the pack kernel rounds to nearest even as torch does
+        out = out + pack_weight(lo, N8, Kp, Kp, Np)
     if len(_shadow_cache) > 256:                                   # drop entries whose parameter is gone
         for k in [k for k, v in _shadow_cache.items() if v[0]() is None]:
             del _shadow_cache[k]
     try:
-        _shadow_cache[id(weight)] = (weakref.ref(weight), key, wsh, wsh_t)
+        _shadow_cache[(id(weight), bool(planes))] = (weakref.ref(weight), key, out)
     except TypeError:
         pass
-    return wsh, wsh_t
+    return out
+
+
+def _planes_padded(x2d: torch.Tensor, ld: int):
+    """[M, K] (fp32 or bf16) -> (hi, lo) bf16 [M, ld], zero padded: hi + lo == x to 16 significant bits."""
+    xf = x2d.float()
+    hi = xf.to(torch.bfloat16)
+    lo = (xf - hi.float()).to(torch.bfloat16)
+    K = x2d.shape[1]
+    if ld != K:
+        hi, lo = torch.nn.functional.pad(hi, (0, ld - K)), torch.nn.functional.pad(lo, (0, ld - K))
+    return hi.contiguous(), lo.contiguous()
+
+
+class _LinearX3Fn(torch.autograd.Function):
+    """``_LinearFn`` in the fp32-accuracy mode (include/tfusion.h, TfGemmArgs.A_lo): operands as hi + lo bf16 planes, three MFMA passes,
+    fp32 results -- K1 / K9 / the RoI heads when ``run.precision`` is 32."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, p_drop_in, seed, wsh, wsh_t, wsh_lo, wsh_t_lo):
+        _require_cuda(x2d, weight)
+        M, K = x2d.shape
+        N = weight.shape[0]
+        N8, Kp, Np = _up(N, 8), _up(K, 64), _up(N, 64)
+        drop = drop_params(p_drop_in, seed, 7)
+        keep = None
+        if drop[0]:
+            # dropout BEFORE the split (scaling each plane separately would round hi * 1/(1-p) to bf16 and lose the 16-bit property);
+            # the keep mask is the same function of the element index (row * Kp + col) the bf16 path's tf_dropout_apply uses
+            mask = torch.empty(M * Kp, dtype=torch.uint8, device=x2d.device)
+            L.check(L.load().tf_dropout_mask(L.ptr(mask), M * Kp, drop[1], drop[0], _stream()), "tf_dropout_mask")
+            keep = mask.view(M, Kp)[:, :K].float() * drop[2]
+            x2d = x2d.float() * keep
+        xh, xl = _planes_padded(x2d, Kp)
+        yh = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device)
+        yl = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device)
+        bf = None if bias is None else bias.detach().float().contiguous()
+        if bf is not None and N8 != N:
+            bf = torch.nn.functional.pad(bf, (0, N8 - N))
+        gemm(xh, wsh, yh, N8, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf, A_lo=xl, W_lo=wsh_lo, C_lo=yl)
+        ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo, keep)
+        ctx.meta = (M, K, N, N8, Kp, Np, bias is not None, weight.shape)
+        return yh[:, :N].float() + yl[:, :N].float()
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, xl, wsh_t, wsh_t_lo, keep = ctx.saved_tensors
+        M, K, N, N8, Kp, Np, has_bias, wshape = ctx.meta
+        gy = gy.reshape(M, N)
+        if N8 != N:
+            gy = torch.nn.functional.pad(gy, (0, N8 - N))
+        gh, gl = _planes_padded(gy, Np)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+            dl = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+            gemm(gh, wsh_t, dh, Kp, Np, L.TF_EPI_NONE, A_lo=gl, W_lo=wsh_t_lo, C_lo=dl)
+            dx = dh[:, :K].float() + dl[:, :K].float()
+            if keep is not None:
+                dx = dx * keep
+        dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
+        db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
+        wgrad(gh, N8, xh, Kp, dW.view(N, -1), db, dY_lo=gl, X_lo=xl)
+        return dx, dW, db, None, None, None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -377,18 +446,25 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None
 
 
-def linear(x, weight, bias=None, p_drop_in: float = 0.0):
-    """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N].  ``weight`` may have any trailing shape (the k = s = p
-    Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)]."""
+def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16"):
+    """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N] (``precision="fp32"``: the fp32-accuracy mode, fp32 out).
+    ``weight`` may have any trailing shape (the k = s = p Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)]."""
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = weight.shape[0]
     if K % 8:
         raise L.TfError(f"linear: K={K} must be a multiple of 8")
+    if precision not in ("bf16", "fp32"):
+        raise ValueError(f"precision={precision!r}: 'bf16' or 'fp32'")
     _require_cuda(x, weight)
-    wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64))
     w2 = weight.reshape(N, -1)
-    y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), next_seed() if p_drop_in > 0 else 0, wsh, wsh_t)
+    seed = next_seed() if p_drop_in > 0 else 0
+    if precision == "fp32":
+        wsh, wsh_t, wsh_lo, wsh_t_lo = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), planes=True)
+        y = _LinearX3Fn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t, wsh_lo, wsh_t_lo)
+    else:
+        wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64))
+        y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t)
     return y.reshape(*lead, N)
 
 
