@@ -448,6 +448,7 @@ def main():
     if args.with_heads:
         from transfusion_amd.modeling.obj_detection.nao_heads import NaoHeadLosses, NaoRoIHeads
         heads = NaoRoIHeads(1024, 88, 75, box_2_dropout=0.0, classif_dropout=0.0).to(device)
+        heads.precision = args.precision
         crit = NaoHeadLosses(torch.ones(88), torch.ones(75)).to(device)
         module, step_loss = _EncoderWithHeads(enc, heads, crit).train(), loss_fn_heads
     trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap, comm=args.comm)

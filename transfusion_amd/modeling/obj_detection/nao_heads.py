@@ -38,6 +38,7 @@ class NaoRoIHeads(nn.Module):
         self.ttc_pred = ttc_pred
         if ttc_pred:
             self.ttc_pred_layer = nn.Linear(representation_size, 1)
+        self.precision = "bf16"          # "fp32": run.precision 32 -- the fp32-accuracy mode of the GEMMs, fp32 logits
 
     def forward(self, box_features):
         """box_features [R, repr] (or [R, repr, 1, 1], flattened as roi_wrappers.py:205-207 does) -> the reference's dict."""
@@ -47,7 +48,7 @@ class NaoRoIHeads(nn.Module):
         p_box = self.box_dropout.p if self.training and isinstance(self.box_dropout, nn.Dropout) else 0.0
         p_cls = self.classif_dropout.p if self.training and isinstance(self.classif_dropout, nn.Dropout) else 0.0
         lin = self.box_regressor[1]
-        box_regression = ops.linear(box_features, lin.weight, lin.bias, p_drop_in=p_box)
+        box_regression = ops.linear(box_features, lin.weight, lin.bias, p_drop_in=p_box, precision=self.precision)
         ws, bs = [self.noun_classifier.weight], [self.noun_classifier.bias]
         Cn, Cv = self.noun_classifier.out_features, 0
         if self.verb_classifier is not None:
@@ -55,7 +56,7 @@ class NaoRoIHeads(nn.Module):
             Cv = self.verb_classifier.out_features
         if self.ttc_pred:
             ws.append(self.ttc_pred_layer.weight); bs.append(self.ttc_pred_layer.bias)
-        cls = ops.linear(box_features, torch.cat(ws, 0), torch.cat(bs, 0), p_drop_in=p_cls)       # one GEMM: noun | verb | ttc
+        cls = ops.linear(box_features, torch.cat(ws, 0), torch.cat(bs, 0), p_drop_in=p_cls, precision=self.precision)   # one GEMM: noun | verb | ttc
         ttcs = ops.softplus_col(cls, Cn + Cv) if self.ttc_pred else None
         return {"class_logits": cls[:, :Cn], "verb_logits": cls[:, Cn:Cn + Cv] if Cv else None, "ttcs": ttcs,
                 "box_regression": box_regression, "box_features": box_features, "_cls": cls, "_dims": (Cn, Cv)}

@@ -523,27 +523,33 @@ def lm_pool(x, att_mask, pool_type: str, ln_w=None, ln_b=None, eps: float = 1e-5
 # RoI heads: softplus TTC output and the four losses (csrc/heads.hip)
 # ------------------------------------------------------------------------------------------------------
 class _SoftplusColFn(torch.autograd.Function):
+    """bf16 logits, or fp32 logits (fp32-accuracy mode): those go to the kernel as hi + lo bf16 planes."""
+
     @staticmethod
     def forward(ctx, cls, col):
         _require_cuda(cls)
-        if cls.dtype != torch.bfloat16 or cls.dim() != 2 or cls.stride(1) != 1:
-            raise L.TfError("softplus_col: a bf16 [R, N] tensor (row stride free) is expected")
+        if cls.dtype not in (torch.bfloat16, torch.float32) or cls.dim() != 2 or cls.stride(1) != 1:
+            raise L.TfError("softplus_col: a bf16 or fp32 [R, N] tensor (row stride free) is expected")
         R = cls.shape[0]
+        hi, lo = (cls, None) if cls.dtype == torch.bfloat16 else _planes_padded(cls, cls.shape[1])
         y = torch.empty(R, dtype=torch.float32, device=cls.device)
-        L.check(L.load().tf_softplus_col(cls.data_ptr(), None, cls.stride(0), col, y.data_ptr(), None, None, None, R, _stream()), "tf_softplus_col")
-        ctx.save_for_backward(cls)
-        ctx.col = col
+        L.check(L.load().tf_softplus_col(hi.data_ptr(), L.ptr(lo), hi.stride(0), col, y.data_ptr(), None, None, None, R, _stream()), "tf_softplus_col")
+        ctx.save_for_backward(hi, lo)
+        ctx.col, ctx.ncols = col, cls.shape[1]
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (cls,) = ctx.saved_tensors
-        R = cls.shape[0]
-        dcls = torch.zeros(R, cls.stride(0), dtype=torch.bfloat16, device=cls.device)
+        hi, lo = ctx.saved_tensors
+        R = hi.shape[0]
+        dh = torch.zeros(R, hi.stride(0), dtype=torch.bfloat16, device=hi.device)
+        dl = None if lo is None else torch.zeros(R, hi.stride(0), dtype=torch.bfloat16, device=hi.device)
         gy = gy.float().contiguous()
-        L.check(L.load().tf_softplus_col(cls.data_ptr(), None, cls.stride(0), ctx.col, None, gy.data_ptr(), dcls.data_ptr(), None, R, _stream()),
+        L.check(L.load().tf_softplus_col(hi.data_ptr(), L.ptr(lo), hi.stride(0), ctx.col, None, gy.data_ptr(), dh.data_ptr(), L.ptr(dl), R, _stream()),
                 "tf_softplus_col")
-        return dcls[:, :cls.shape[1]], None
+        if lo is None:
+            return dh[:, :ctx.ncols], None
+        return dh[:, :ctx.ncols].float() + dl[:, :ctx.ncols].float(), None
 
 
 def softplus_col(cls, col: int):
@@ -556,8 +562,15 @@ class _NaoLossFn(torch.autograd.Function):
     def forward(ctx, cls, box, ttcs, Cn, Cv, noun, verb, ttc_t, reg_t, noun_w, verb_w, verb_ignore, verb_bg, ttc_bg, ttc_bg_val, ttc_beta):
         _require_cuda(cls, box, noun)
         for t in (cls, box):
-            if t is not None and (t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1):
-                raise L.TfError("nao_head_losses: logits must be bf16 [R, N] tensors (row stride free)")
+            if t is not None and (t.dtype not in (torch.bfloat16, torch.float32) or t.dim() != 2 or t.stride(1) != 1):
+                raise L.TfError("nao_head_losses: logits must be bf16 or fp32 [R, N] tensors (row stride free)")
+        # fp32 logits (fp32-accuracy mode) reach the kernels as hi + lo bf16 planes (TfHeadsLossArgs.cls_lo / box_lo)
+        cls_shape, box_shape = cls.shape, None if box is None else box.shape
+        cls_lo = box_lo = None
+        if cls.dtype == torch.float32:
+            cls, cls_lo = _planes_padded(cls, cls.shape[1])
+        if box is not None and box.dtype == torch.float32:
+            box, box_lo = _planes_padded(box, box.shape[1])
         R = cls.shape[0]
         dev = cls.device
         i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
@@ -571,14 +584,15 @@ class _NaoLossFn(torch.autograd.Function):
         sums = torch.zeros(8, dtype=torch.float32, device=dev)
         lse = torch.empty(2 * R, dtype=torch.float32, device=dev)
         losses = torch.empty(4, dtype=torch.float32, device=dev)
-        a = L.TfHeadsLossArgs(cls=L.ptr(cls), ld_cls=cls.stride(0), box=L.ptr(box) if reg_t is not None else 0, ld_box=0 if box is None else box.stride(0),
+        a = L.TfHeadsLossArgs(cls=L.ptr(cls), cls_lo=L.ptr(cls_lo), ld_cls=cls.stride(0), box=L.ptr(box) if reg_t is not None else 0,
+                              box_lo=L.ptr(box_lo) if reg_t is not None else 0, ld_box=0 if box is None else box.stride(0),
                               ttcs=L.ptr(ttcs) if ttc_t is not None else 0, R=R, Cn=Cn, Cv=Cv, noun_labels=L.ptr(noun), verb_labels=L.ptr(verb),
                               ttc_targets=L.ptr(ttc_t), reg_targets=L.ptr(reg_t), noun_w=L.ptr(noun_w), verb_w=L.ptr(verb_w) if verb is not None else 0,
                               verb_ignore=int(verb_ignore), verb_bg=int(bool(verb_bg)), ttc_bg=int(bool(ttc_bg)), ttc_bg_val=float(ttc_bg_val),
                               ttc_beta=float(ttc_beta), box_beta=1.0 / 9, sums=L.ptr(sums), lse=L.ptr(lse), losses=L.ptr(losses))
         L.call("tf_heads_loss_fwd", a, _stream())
-        ctx.args, ctx.keep = a, (cls, box, ttcs, noun, verb, ttc_t, reg_t, noun_w, verb_w, sums, lse)
-        ctx.shapes = (cls.shape, None if box is None else box.shape)
+        ctx.args, ctx.keep = a, (cls, box, ttcs, noun, verb, ttc_t, reg_t, noun_w, verb_w, sums, lse, cls_lo, box_lo)
+        ctx.shapes = (cls_shape, box_shape)
         return losses
 
     @staticmethod
@@ -587,13 +601,19 @@ class _NaoLossFn(torch.autograd.Function):
         cls, box, ttcs = ctx.keep[0], ctx.keep[1], ctx.keep[2]
         R, dev = cls.shape[0], cls.device
         gscale = g.float().contiguous()
+        cls_lo, box_lo = ctx.keep[11], ctx.keep[12]
         d_cls = torch.empty(R, cls.stride(0), dtype=torch.bfloat16, device=dev)
         d_box = None if box is None else torch.empty(R, box.stride(0), dtype=torch.bfloat16, device=dev)
+        d_cls_lo = None if cls_lo is None else torch.empty_like(d_cls)
+        d_box_lo = None if box_lo is None else torch.empty_like(d_box)
         d_ttcs = None if ttcs is None else torch.empty(R, dtype=torch.float32, device=dev)
         a.gscale, a.d_cls, a.d_box, a.d_ttcs = L.ptr(gscale), L.ptr(d_cls), L.ptr(d_box), L.ptr(d_ttcs)
+        a.d_cls_lo, a.d_box_lo = L.ptr(d_cls_lo), L.ptr(d_box_lo)
         L.call("tf_heads_loss_bwd", a, _stream())
         (cs, bs) = ctx.shapes
-        return (d_cls[:, :cs[1]], None if box is None else d_box[:, :bs[1]], d_ttcs) + (None,) * 13
+        g_cls = d_cls[:, :cs[1]] if d_cls_lo is None else d_cls[:, :cs[1]].float() + d_cls_lo[:, :cs[1]].float()
+        g_box = None if box is None else (d_box[:, :bs[1]] if d_box_lo is None else d_box[:, :bs[1]].float() + d_box_lo[:, :bs[1]].float())
+        return (g_cls, g_box, d_ttcs) + (None,) * 13
 
 
 def nao_head_losses(cls, box, ttcs, Cn, Cv, noun, verb, ttc_targets, reg_targets, noun_w, verb_w, verb_ignore=999, verb_bg=False, ttc_bg=False,
