@@ -26,31 +26,36 @@ def _build(cfg, params, dev):
     return head.to(dev).train()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", list(LM_CASES))
-def test_lm_head_golden(golden_dir, name):
+def test_lm_head_golden(golden_dir, name, precision):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     dev = torch.device("cuda:0")
+    TOL, GTOL = (1e-2, 3e-2) if precision == "bf16" else (1e-3, 1e-3)      # fp32 mode: the Linears take hi + lo planes
     cfg = LM_CASES[name]
     g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     params, tokens, att, cot_noun, cot_verb = make_lm_case(cfg)
     head = _build(cfg, params, dev)
+    for m in head.modules():
+        if hasattr(m, "precision"):
+            m.precision = precision
     toks = [torch.from_numpy(t).to(dev).requires_grad_(True) for t in tokens]
     out = head(toks if cfg["multi"] else toks[0], torch.from_numpy(att).to(dev))
     assert out["noun_logits"].shape == g["noun_logits"].shape
-    assert rel(out["noun_logits"], g["noun_logits"]) < 1e-2
+    assert rel(out["noun_logits"], g["noun_logits"]) < TOL
     loss = (out["noun_logits"].float() * torch.from_numpy(cot_noun).to(dev)).sum()
     if cfg["verbs"]:
-        assert rel(out["verb_logits"], g["verb_logits"]) < 1e-2
+        assert rel(out["verb_logits"], g["verb_logits"]) < TOL
         loss = loss + (out["verb_logits"].float() * torch.from_numpy(cot_verb).to(dev)).sum()
     else:
         assert out["verb_logits"] is None
     loss.backward()
     for i, t in enumerate(toks):
-        assert rel(t.grad, g[f"grad_tokens/{i}"]) < 3e-2, i
+        assert rel(t.grad, g[f"grad_tokens/{i}"]) < GTOL, i
         assert t.grad[~torch.from_numpy(att).to(dev)].abs().max().item() == 0.0       # padded rows: exactly zero
     for k, p in head.named_parameters():
-        assert rel(p.grad, g["gradp/" + k]) < 3e-2, k
+        assert rel(p.grad, g["gradp/" + k]) < GTOL, k
 
 
 @pytest.mark.parametrize("pool", ["mean", "max"])

@@ -55,6 +55,7 @@ class PoolPredictor(nn.Module):
         self.mlp_noun = nn.Linear(self.repr_size, no_nouns)
         if no_verbs:
             self.mlp_verb = nn.Linear(self.repr_size, no_verbs)
+        self.precision = "bf16"          # "fp32": run.precision 32 (CrossFusionBoxWrapper.set_precision); the pooling kernel is fp32 either way
 
     def forward(self, fused_l_tokens, att_mask=None):
         ln_w = ln_b = None
@@ -64,11 +65,11 @@ class PoolPredictor(nn.Module):
         features = ops.lm_pool(fused_l_tokens, att_mask, self.pooling_args["type"], ln_w, ln_b, eps,
                                gelu=self.repr_mlp is not None)
         if self.repr_mlp is not None:
-            features = ops.linear(features, self.repr_mlp[1].weight, self.repr_mlp[1].bias)
-        noun_logits = ops.linear(features, self.mlp_noun.weight, self.mlp_noun.bias)
+            features = ops.linear(features, self.repr_mlp[1].weight, self.repr_mlp[1].bias, precision=self.precision)
+        noun_logits = ops.linear(features, self.mlp_noun.weight, self.mlp_noun.bias, precision=self.precision)
         verb_logits = None
         if self.mlp_verb is not None:
-            verb_logits = ops.linear(features, self.mlp_verb.weight, self.mlp_verb.bias)
+            verb_logits = ops.linear(features, self.mlp_verb.weight, self.mlp_verb.bias, precision=self.precision)
         return {"noun_logits": noun_logits, "verb_logits": verb_logits}
 
 
