@@ -220,6 +220,7 @@ class CrossTransformerModuleBox(nn.Module):
         self._wpack = None
         self._wpack_versions = None
         self._work_pool = {}
+        self._grad_layout = None
         self._last_seed = 0
 
     # ---- parameter plumbing ----------------------------------------------------------------------------
@@ -368,18 +369,28 @@ class CrossTransformerModuleBox(nn.Module):
                 grads.append(p.grad)
         else:
             # ONE zero fill for all gradients of the call (a zeros_like per parameter is ~50 launches per backward); each
-            # gradient is a 256-B aligned view, and no reference is kept here, so AccumulateGrad can adopt the view as p.grad
-            sizes = [((p.numel() + 63) // 64) * 64 if p.requires_grad else 0 for p in params]
-            flat = torch.zeros(max(sum(sizes), 1), dtype=torch.float32, device=device)
-            off = 0
-            for p, n in zip(params, sizes):
+            # gradient is a 256-B aligned view, and no reference is kept here, so AccumulateGrad can adopt the view as p.grad.
+            # The layout is computed once per parameter set: one split + one view per parameter (host time counts: the wrapper
+            # path is host-bound at the reference's batch sizes).
+            lay = self._grad_layout
+            sig = tuple((p.requires_grad, p.dtype == torch.float32) for p in params)
+            if lay is None or lay[0] != sig:
+                sizes = [((p.numel() + 63) // 64) * 64 if (p.requires_grad and p.dtype == torch.float32) else 0 for p in params]
+                exact = [p.numel() == n for p, n in zip(params, sizes)]
+                lay = self._grad_layout = (sig, sizes, exact, [tuple(p.shape) for p in params], max(sum(sizes), 1))
+            _, sizes, exact, shapes, total = lay
+            flat = torch.zeros(total, dtype=torch.float32, device=device)
+            pieces = flat.split([n for n in sizes if n]) if total > 1 or any(sizes) else ()
+            k = 0
+            for p, n, ex, shp in zip(params, sizes, exact, shapes):
                 if not p.requires_grad:
                     grads.append(None)
-                elif p.dtype != torch.float32:
+                elif n == 0:
                     grads.append(torch.zeros_like(p, memory_format=torch.contiguous_format))
                 else:
-                    grads.append(flat[off:off + p.numel()].view(p.shape))
-                off += n
+                    piece = pieces[k]
+                    k += 1
+                    grads.append(piece.view(shp) if ex else piece[:p.numel()].view(shp))
         scratch = None
 
         def gp(t, ref):
