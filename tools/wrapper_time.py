@@ -37,6 +37,20 @@ def step():
     loss.backward()
     return loss
 
+if os.environ.get("TRAINER") == "1":
+    # the library's own training step around the whole wrapper: flat parameter / gradient buffers, the encoders accumulate straight
+    # into .grad (no AccumulateGrad node per parameter), bucketed reduce (no-op on one GPU), clip + fused RAdam -- MORE work per step
+    # than the bare forward + backward above, on fewer host operations
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    trainer = FusionTrainStep(model, lr=1e-4, weight_decay=2e-4, grad_clip=1.0)
+
+    def _loss(m, batch):
+        out = m({"image": feats, "language_f": lang})
+        return sum(f.float().square().mean() for f in out["features"].values())
+
+    def step():
+        return trainer.step([None], _loss)
+
 for _ in range(3):
     step()
 torch.cuda.synchronize()
