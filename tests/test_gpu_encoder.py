@@ -3,7 +3,7 @@ against (a) the committed golden fixtures produced by the reference itself and (
 
 Tolerance (BASELINE.json north_star): outputs within 1e-2 for bf16 compute.  Asserted as relative L2
 error <= 1e-2 for forward outputs (measured 4.9e-3 .. 6.9e-3 on the fixtures) and <= 2e-2 for gradients
-(measured: inputs <= 1.1e-2, worst parameter <= 1.2e-2).  Where that error comes from (tools/fp32_diag.py budget):
+(measured: inputs <= 1.1e-2, worst parameter <= 1.2e-2).  Where that error comes from (tests/diag_fp32.py budget):
 against the oracle evaluated on bf16-ROUNDED parameters the numbers barely move (6.9e-3 -> 6.0e-3), i.e. it is
 the bf16 storage of every intermediate activation, not operand quantisation; an element of an O(1..4)
 output stored in bf16 carries up to 2^-8 * 4 = 1.6e-2 of rounding by itself, so the elementwise bound is 5e-2
