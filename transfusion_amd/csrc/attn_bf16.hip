@@ -965,7 +965,8 @@ template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   else hipLaunchKernelGGL((attn_fwd_kernel<HDP, false>), grid, dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
-template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
+// part: 0 = dQ then dK / dV, 1 = dQ only (also fills `delta`), 2 = dK / dV only (after a part-1 launch on the same stream)
+template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part) {
   const size_t lds_q = 128 * Geo<HDP>::TSTR, lds_kv = 64 * Geo<HDP>::TSTR + 256 + 1024;
   static const hipError_t once_q = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
   static const hipError_t once_kv = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
@@ -981,7 +982,8 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
   (void)once_q16;
   static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
-  if (dq16 && HDP <= 192 && !cross) {
+  if (part == 2) {
+  } else if (dq16 && HDP <= 192 && !cross) {
     snprintf(nm, sizeof(nm), "attn_bwd_dq16_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 8>), grid, dim3(512), lds_q16, st, *a);
@@ -996,6 +998,7 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st) {
   static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
   static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
   (void)once_kv16; (void)once_kv16b;
+  if (part == 1) return (int)hipGetLastError();
   if (dkv16 && HDP <= 192 && !cross) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
@@ -1034,6 +1037,20 @@ int check(const TfAttnArgs* a) {
     default: return -3;                          \
   }
 
+#define TF_ATTN_DISPATCH_PART(FN, P)                     \
+  switch (a->HDP) {                              \
+    case 32: return FN<32>(a, st, P);               \
+    case 64: return FN<64>(a, st, P);               \
+    case 96: return FN<96>(a, st, P);               \
+    case 128: return FN<128>(a, st, P);             \
+    case 160: return FN<160>(a, st, P);             \
+    case 192: return FN<192>(a, st, P);             \
+    case 224: return FN<224>(a, st, P);             \
+    case 256: return FN<256>(a, st, P);             \
+    default: return -3;                          \
+  }
+
+
 extern "C" int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t st) {
   const int c = check(a);
   if (c) return c > 0 ? 0 : c;
@@ -1046,5 +1063,16 @@ extern "C" int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t st) {
   if ((a->ld_dout % 8) || (a->ld_dqkv % 8) || a->delta == nullptr || a->lse == nullptr) return -2;
   if (a->q != nullptr && (a->dq == nullptr || (a->ld_dq % 8))) return -7;
   if (a->qkv_lo != nullptr) return tf_launch_attn_bwd_x3(a, st);
-  TF_ATTN_DISPATCH(launch_bwd)
+  TF_ATTN_DISPATCH_PART(launch_bwd, 0)
+}
+// the two halves of tf_launch_attn_bwd as separate launches (the encoder runtime starts the Q rows of the in-proj weight gradient
+// between them); the fp32-accuracy kernels run whole in part 1
+extern "C" int tf_launch_attn_bwd_part(const TfAttnArgs* a, int part, hipStream_t st) {
+  if (part != 1 && part != 2) return -2;
+  const int c = check(a);
+  if (c) return c > 0 ? 0 : c;
+  if ((a->ld_dout % 8) || (a->ld_dqkv % 8) || a->delta == nullptr || a->lse == nullptr) return -2;
+  if (a->q != nullptr && (a->dq == nullptr || (a->ld_dq % 8))) return -7;
+  if (a->qkv_lo != nullptr) return part == 1 ? tf_launch_attn_bwd_x3(a, st) : 0;
+  TF_ATTN_DISPATCH_PART(launch_bwd, part)
 }

@@ -188,7 +188,7 @@ int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const 
 //   fork O = {out_proj}         after the LN1 backward       (reads dyb/dzb, o)
 //   fork I = {in_proj}          after the attention backward (reads dqkv, x)
 //   guard A at the top of the next layer, guard I (FIFO: covers O) before its LN1 backward.
-enum { EV_FORK_A = 0, EV_FORK_O = 1, EV_FORK_I = 2, EV_DONE_A = 4, EV_DONE_I = 5 };
+enum { EV_FORK_A = 0, EV_FORK_O = 1, EV_FORK_I = 2, EV_FORK_Q = 3, EV_DONE_A = 4, EV_DONE_I = 5 };
 struct Side {
   hipStream_t st = nullptr; hipEvent_t* ev = nullptr; bool pending[2] = {false, false};
 };
@@ -694,11 +694,32 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
-      TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
+      // TF_SPLIT_INPROJ (0 off, 1 last layer of the backward only, 2 every layer): the Q third of the in-proj weight gradient needs dQ
+      // only, so it can start under the dK / dV kernel instead of after it -- which shortens the un-overlapped tail behind layer 0
+      static const int split_inproj = getenv("TF_SPLIT_INPROJ") ? atoi(getenv("TF_SPLIT_INPROJ")) : 0;
+      const bool split_q = sd.st != nullptr && (split_inproj == 2 || (split_inproj == 1 && l == 0));
+      if (split_q) {
+        const int hq = D.nqkv / 3;
+        TF_TRY(tf_launch_attn_bwd_part(&a, 1, c.st), "attn_bwd dq");
+        TF_TRY(side_fork(c, sd, EV_FORK_Q), "fork Q");
+        TF_TRY(wgrad(c, sd, dqkv, hq, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, D.d, BIG, BIG, D.d), "wgrad in_proj (Q)");
+        TF_TRY(tf_launch_attn_bwd_part(&a, 2, c.st), "attn_bwd dkv");
+        TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
+        Buf dkv = dqkv;
+        dkv.p = (const unsigned char*)dqkv.p + (size_t)hq * 2;
+        if (dqkv.lo != nullptr) dkv.lo = (const unsigned char*)dqkv.lo + (size_t)hq * 2;
+        TF_TRY(wgrad(c, sd, dkv, 2 * hq, x, D.dp, g.in_w + (size_t)D.d * D.d, D.d, g.in_b + D.d, D.hd, D.hdp, 2 * D.d, BIG, BIG, D.d, l == 0),
+               "wgrad in_proj (K, V)");
+        TF_TRY(side_done(sd, 1), "done I");
+      } else {
+        TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
+      }
+      if (!split_q) {
+        TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
+        TF_TRY(wgrad(c, sd, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
+        TF_TRY(side_done(sd, 1), "done I");
+      }
     }
-    TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
-    TF_TRY(wgrad(c, sd, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
-    TF_TRY(side_done(sd, 1), "done I");
     TF_TRY(gemm(c, dqkv, c.wgt(w + c.W.winT, D.dp, D.ldq), dxa, nullptr, dzb, NOBUF, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
   if (tail) {

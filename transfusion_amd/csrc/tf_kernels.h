@@ -12,6 +12,7 @@ int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
 int tf_wgrad_tiles(int N, int K, int caller_sized);                // output tiles of the wgrad kernel that will run
 int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t stream);
+int tf_launch_attn_bwd_part(const TfAttnArgs* a, int part, hipStream_t stream);   // 1: dQ (+ delta), 2: dK / dV
 int tf_launch_attn_fwd_x3(const TfAttnArgs* a, hipStream_t stream);    // fp32-accuracy mode (attn_x3.hip); reached through the two above
 int tf_launch_attn_bwd_x3(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t stream);
