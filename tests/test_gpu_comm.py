@@ -44,3 +44,53 @@ def test_train_step_accepts_comm_choice_at_world_one():
     assert tr.bucket_comm is None
     with pytest.raises(ValueError):
         FusionTrainStep(enc, comm="mpi")
+
+
+def test_layerwise_reducer_drives_the_own_communicator(monkeypatch):
+    """The layer-wise reducer's CUDA branch with ``bucket_comm`` set: per-layer ``tf_allreduce_bucket`` calls on the communication stream,
+    behind one event of the chain and one of the side stream, joined by ``finish()``.  One rank (sum over one rank = identity), so the
+    step must end bit-identical to the same step without any exchange -- what is exercised is the ordering code, with real RCCL launches."""
+    import os
+    from cases import make_encoder_inputs, make_encoder_params
+    from transfusion_amd.comm import BucketComm
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    monkeypatch.setenv("TF_FORCE_LAYERWISE", "1")
+    dev = torch.device("cuda", 0)
+    d, L, h, B, Nv, Nl = 64, 3, 4, 2, 20, 12
+    params = make_encoder_params(77, d, L)
+    x, lang, mask, gv, gl = make_encoder_inputs(77, B, Nv, Nl, d, [12, 5])
+    t = lambda a: torch.from_numpy(a).to(dev)
+
+    def run(with_comm):
+        enc = CrossTransformerModuleBox(no_patches=8192, pos_embedding_layer=PositionalEmbeddingLayer("sin1d", 8192, d), num_layers=L,
+                                        patch_dropout=0.0, num_heads=h, token_dropout=0.0, activ_f="gelu", final_norm="ln", input_f_size=d)
+        enc.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+        enc = enc.to(dev).train()
+        tr = FusionTrainStep(enc, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+        assert tr.layerwise is not None
+        comm = None
+        if with_comm:
+            comm = BucketComm(1, 0, BucketComm.new_unique_id(), dev)
+            tr.layerwise.world = 2                       # take the exchange branch (the optimiser's 1 / world stays 1)
+            tr.layerwise.bucket_comm = comm
+
+        def loss_fn(m, batch):
+            v, lo, _, _ = m(t(x), t(lang), t(mask))
+            return (v.float() * t(gv)).sum() + (lo.float() * t(gl)).sum()
+
+        for _ in range(3):
+            tr.step([None], loss_fn)
+        torch.cuda.synchronize()
+        out = tr.flat.flat.clone()
+        stats = None
+        if comm is not None:
+            stats = comm.stats()
+            comm.close()
+        return out, stats, tr
+
+    ref, _, _ = run(False)
+    got, stats, tr = run(True)
+    assert stats["calls"] == 3 * L and stats["elems"] == 3 * tr.flat.grad.numel()     # every layer range, every step, nothing twice
+    assert torch.equal(got, ref)
