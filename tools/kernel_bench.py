@@ -115,3 +115,13 @@ if which in ("ksweep",):
                 Y = rnd(M, N)
                 timeit(f"gemm N={N} K={K} (bias)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_BIAS, bias=b1), 2.0 * M * N * K)
                 timeit(f"gemm N={N} K={K} (drop+res)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_BIAS_DROP_RES, bias=b1, R=Y, drop=drop), 2.0 * M * N * K)
+if which in ("small",):
+    # the 128x128 kernel at the per-level sizes of the wrapper path / the reference's batch (M = B * 708 for B = 4, 8)
+    for Ms in (2832, 5664):
+        for N in (768, 1536, 2304):
+            for K in (768, 1536, 2304):
+                if N != 768 and K != 768:
+                    continue
+                Xk, Wk = rnd(Ms, K), rnd(N, K) * 0.03
+                O = torch.empty(Ms, N, device=dev, dtype=bf)
+                timeit(f"gemm M={Ms} N={N} K={K} (none)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_NONE), 2.0 * Ms * N * K)
