@@ -277,3 +277,82 @@ def test_wrapper_language_head(golden_dir, mode):
     assert rel(lang_dev.grad, lang_ref.grad) < 3e-2                 # through the encoder in the fused / multi modes
     if mode != "use_lm_f":
         assert model.cross_fusion_encoders[0].t_encoder.layers[0].linear1.weight.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("precision", [16, 32])
+@pytest.mark.parametrize("streams", ["1", "0"])
+def test_three_levels_in_one_forward_against_oracle(monkeypatch, precision, streams):
+    """The per-level loop with SEVERAL levels in one forward (cross_f_box_wrapper.py:177-212): each level has its own patch size, encoder,
+    back-projection and feature-map shape; the levels run on their own HIP streams (TF_LEVEL_STREAMS, default) or one after the other.
+    Every level's fused map and the gradients of every level's input map and parameters against the oracle -- a race between the level
+    streams (shared language tokens / masks / allocator reuse) or between their side streams would show up here."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    monkeypatch.setenv("TF_LEVEL_STREAMS", streams)
+    from oracle import fusion_oracle as O
+    from cases import make_encoder_params, make_level_extras
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    dev = torch.device("cuda:0")
+    d, h, L, B, Nl = 64, 4, 2, 3, 11
+    levels = [dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3), dict(C=24, H=5, W=7, p=1)]
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": [0, 1, 2], "replace_fpn_features": True, "patch_h": [l["p"] for l in levels], "patch_w": [l["p"] for l in levels],
+                   "backproj_dropout": 0.0})
+    fusion["args"].update({"num_layers": [L] * 3, "num_heads": h, "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": precision,
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in levels], [l["C"] for l in levels]), {}, run_cfg, None).to(dev).train()
+    rs = np.random.RandomState(4242)
+    lens = [11, 4, 7]
+    lang = rs.randn(B, Nl, d).astype(np.float32)
+    mask = np.zeros((B, Nl), dtype=bool)
+    for b, n in enumerate(lens):
+        mask[b, n:] = True
+    lang_t = torch.from_numpy(lang)
+
+    class PassThroughPooling(torch.nn.Module):
+        precision = "bf16"
+
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, n in enumerate(lens):
+                m[b, n:] = 0
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    feats, refs = [], []
+    for i, l in enumerate(levels):
+        params = make_encoder_params(500 + i, d, L)
+        feat, conv_w, reg_w, reg_b, gout = make_level_extras(600 + i, B, l["C"], l["H"], l["W"], l["p"], d)
+        model.cross_fusion_encoders[i].load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+        model.patches_to_token[i].weight.data.copy_(torch.from_numpy(conv_w))
+        model.tokens_to_features[i].linear.weight.data.copy_(torch.from_numpy(reg_w))
+        model.tokens_to_features[i].linear.bias.data.copy_(torch.from_numpy(reg_b))
+        feats.append(torch.from_numpy(feat).to(dev).requires_grad_(True))
+        refs.append((params, feat, conv_w, reg_w, reg_b, gout))
+    lang_dev = lang_t.to(dev)
+    out = model({"image": feats, "language_f": [lang_dev[b] for b in range(B)]})
+    loss = sum((out["features"][str(i)] * torch.from_numpy(refs[i][5]).to(dev)).sum() for i in range(3))
+    loss.backward()
+    ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
+    for i, l in enumerate(levels):
+        params, feat, conv_w, reg_w, reg_b, gout = refs[i]
+        sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+        sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+        fr = torch.from_numpy(feat).requires_grad_(True)
+        cw, rw, rb = (torch.from_numpy(a).requires_grad_(True) for a in (conv_w, reg_w, reg_b))
+        f_ref, _ = O.fusion_level_forward(fr, cw, sd, lang_t, torch.from_numpy(mask), h, L, rw, rb, l["p"], l["p"])
+        (f_ref * torch.from_numpy(gout)).sum().backward()
+        assert rel(out["features"][str(i)], f_ref.detach()) < ftol, i
+        assert rel(feats[i].grad, fr.grad) < gtol, i
+        assert rel(model.patches_to_token[i].weight.grad, cw.grad) < gtol, i
+        assert rel(model.tokens_to_features[i].linear.weight.grad, rw.grad) < gtol, i
+        for k, prm in model.cross_fusion_encoders[i].named_parameters():
+            if k in sd and sd[k].grad is not None:
+                assert rel(prm.grad, sd[k].grad) < gtol, (i, k)
