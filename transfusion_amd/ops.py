@@ -360,6 +360,7 @@ class _LinearX3Fn(torch.autograd.Function):
         M, K = x2d.shape
         N = weight.shape[0]
         N8, Kp, Np = _up(N, 8), _up(K, 64), _up(N, 64)
+        xdtype = x2d.dtype
         drop = drop_params(p_drop_in, seed, 7)
         keep = None
         if drop[0]:
@@ -377,13 +378,13 @@ class _LinearX3Fn(torch.autograd.Function):
             bf = torch.nn.functional.pad(bf, (0, N8 - N))
         gemm(xh, wsh, yh, N8, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf, A_lo=xl, W_lo=wsh_lo, C_lo=yl)
         ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo, keep)
-        ctx.meta = (M, K, N, N8, Kp, Np, bias is not None, weight.shape)
+        ctx.meta = (M, K, N, N8, Kp, Np, bias is not None, weight.shape, xdtype)
         return yh[:, :N].float() + yl[:, :N].float()
 
     @staticmethod
     def backward(ctx, gy):
         xh, xl, wsh_t, wsh_t_lo, keep = ctx.saved_tensors
-        M, K, N, N8, Kp, Np, has_bias, wshape = ctx.meta
+        M, K, N, N8, Kp, Np, has_bias, wshape, xdtype = ctx.meta
         gy = gy.reshape(M, N)
         if N8 != N:
             gy = torch.nn.functional.pad(gy, (0, N8 - N))
@@ -396,6 +397,7 @@ class _LinearX3Fn(torch.autograd.Function):
             dx = dh[:, :K].float() + dl[:, :K].float()
             if keep is not None:
                 dx = dx * keep
+            dx = dx.to(xdtype)
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
         wgrad(gh, N8, xh, Kp, dW.view(N, -1), db, dY_lo=gl, X_lo=xl)
