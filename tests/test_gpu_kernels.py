@@ -122,7 +122,11 @@ def _attn_ref(qkv, B, S, H, hd, hdp, key_mask, keep=None, p=0.0):
     return o, P
 
 
-@pytest.mark.parametrize("B,S,H,hd", [(2, 150, 2, 32), (1, 708, 4, 192), (2, 70, 4, 18), (1, 300, 2, 64), (1, 130, 1, 224)])
+@pytest.mark.parametrize("B,S,H,hd", [(2, 150, 2, 32), (1, 708, 4, 192), (2, 70, 4, 18), (1, 300, 2, 64), (1, 130, 1, 224),
+                                      # tile edges and the other head widths: one key, exactly one / two tiles and one more, 8 heads of 8,
+                                      # the padded 178 of Ego4Dv1, 160, 256 (one wave per SIMD forms), a batch of single-tile samples
+                                      (3, 1, 2, 64), (2, 64, 1, 96), (1, 65, 2, 128), (2, 128, 3, 40), (1, 129, 8, 8), (1, 257, 4, 178),
+                                      (2, 200, 1, 160), (1, 321, 2, 256), (5, 33, 4, 32)])
 def test_attention_fwd_bwd(dev, B, S, H, hd):
     from transfusion_amd import _lib as L, ops
     hdp = (hd + 31) // 32 * 32
@@ -181,7 +185,11 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
         o.backward(do[:, : H * hdp].double().cpu().view(B, S, H, hdp)[..., :hd])
         g_hip = dqkv[:, : 3 * H * hdp].float().cpu().view(B, S, 3, H, hdp)
         for which, nm in enumerate("qkv"):
-            assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm} p={p}"
+            got, want = g_hip[:, :, which, :, :hd].double(), xr.grad[:, :, which]
+            # S = 1: softmax over one key has EXACTLY zero gradient w.r.t. q and k; the kernels form dS = P (dP - delta) with delta from
+            # the bf16-rounded forward output, which leaves its rounding (2^-9 of |dO . v|) there -- an absolute floor for that case
+            floor = (5e-3 if S == 1 else 1e-6) * want.numel() ** 0.5
+            assert (got - want).norm().item() < 1.5e-2 * want.norm().item() + floor, f"d{nm} p={p}"
         if hdp > hd:
             assert g_hip[..., hd:].abs().max().item() == 0.0
 
