@@ -76,7 +76,9 @@ def test_gemm_epilogues(dev, M, N, K):
     assert rel(C, bf(ref).float() * keep / (1 - p) * gelu_grad(R.float())) < 5e-3
 
 
-@pytest.mark.parametrize("M,N,K,grouped", [(200, 136, 72, False), (708 * 2, 768, 768, False), (1000, 384, 128, True)])
+@pytest.mark.parametrize("M,N,K,grouped", [(200, 136, 72, False), (708 * 2, 768, 768, False), (1000, 384, 128, True),
+                                           # one ragged 32-row step, tile tails in both directions, the benchmark's largest launch
+                                           (33, 8, 8, False), (5000, 520, 264, False), (22656, 2304, 768, False)])
 def test_wgrad(dev, M, N, K, grouped):
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(7)
@@ -215,7 +217,8 @@ def test_attention_online_softmax_rescale(dev):
     assert (out.float().cpu()[10] - o_ref[0, 10, 0].float()).abs().max() < 5e-2
 
 
-@pytest.mark.parametrize("rows,d,ld", [(37, 64, 64), (500, 768, 768), (64, 72, 128), (10, 712, 768)])
+@pytest.mark.parametrize("rows,d,ld", [(37, 64, 64), (500, 768, 768), (64, 72, 128), (10, 712, 768),
+                                       (1, 8, 8), (22656, 768, 768), (300, 1024, 1024), (129, 896, 896), (77, 1536, 1536)])
 def test_layernorm_fwd_bwd(dev, rows, d, ld):
     from transfusion_amd import _lib as L, ops
     from oracle import fusion_oracle as O
