@@ -336,18 +336,19 @@ def test_three_levels_in_one_forward_against_oracle(monkeypatch, precision, stre
         model.tokens_to_features[i].linear.bias.data.copy_(torch.from_numpy(reg_b))
         feats.append(torch.from_numpy(feat).to(dev).requires_grad_(True))
         refs.append((params, feat, conv_w, reg_w, reg_b, gout))
-    lang_dev = lang_t.to(dev)
+    lang_dev = lang_t.to(dev).requires_grad_(True)      # shared by the three levels: its gradient is summed ACROSS their streams
     out = model({"image": feats, "language_f": [lang_dev[b] for b in range(B)]})
     loss = sum((out["features"][str(i)] * torch.from_numpy(refs[i][5]).to(dev)).sum() for i in range(3))
     loss.backward()
     ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
+    lang_ref = lang_t.clone().requires_grad_(True)
     for i, l in enumerate(levels):
         params, feat, conv_w, reg_w, reg_b, gout = refs[i]
         sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
         sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
         fr = torch.from_numpy(feat).requires_grad_(True)
         cw, rw, rb = (torch.from_numpy(a).requires_grad_(True) for a in (conv_w, reg_w, reg_b))
-        f_ref, _ = O.fusion_level_forward(fr, cw, sd, lang_t, torch.from_numpy(mask), h, L, rw, rb, l["p"], l["p"])
+        f_ref, _ = O.fusion_level_forward(fr, cw, sd, lang_ref, torch.from_numpy(mask), h, L, rw, rb, l["p"], l["p"])
         (f_ref * torch.from_numpy(gout)).sum().backward()
         assert rel(out["features"][str(i)], f_ref.detach()) < ftol, i
         assert rel(feats[i].grad, fr.grad) < gtol, i
@@ -356,3 +357,5 @@ def test_three_levels_in_one_forward_against_oracle(monkeypatch, precision, stre
         for k, prm in model.cross_fusion_encoders[i].named_parameters():
             if k in sd and sd[k].grad is not None:
                 assert rel(prm.grad, sd[k].grad) < gtol, (i, k)
+    valid = ~torch.from_numpy(mask)
+    assert rel(lang_dev.grad.cpu()[valid], lang_ref.grad[valid]) < gtol          # sum over the three levels (valid rows; padded rows get none)
