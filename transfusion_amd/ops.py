@@ -104,19 +104,23 @@ def pack_bias(b: torch.Tensor, cols_p: int, cg=BIG, cgp=BIG):
     return dst
 
 
-def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, d, eps=1e-5):
-    """y = LN(x[:, :d]) per row; x bf16 [rows, ldx]; y bf16 [rows, ldy] (pad zeroed) or fp32 [rows, d]; mean / rstd fp32 [rows]."""
+def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, d, eps=1e-5, x_lo=None, y_lo=None):
+    """y = LN(x[:, :d]) per row; x bf16 [rows, ldx]; y bf16 [rows, ldy] (pad zeroed) or fp32 [rows, d]; mean / rstd fp32 [rows].
+    ``*_lo``: the lo planes of the fp32-accuracy mode (value = hi + lo)."""
     a = L.TfLnArgs(x=L.ptr(x), ldx=x.stride(0), y=L.ptr(y), ldy=y.stride(0), y_is_f32=_is_f32(y), gamma=L.ptr(gamma), beta=L.ptr(beta),
-                   mean=L.ptr(mean), rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=eps)
+                   mean=L.ptr(mean), rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=eps,
+                   x_lo=L.ptr(x_lo), y_lo=L.ptr(y_lo))
     L.call("tf_layernorm_fwd", a, _stream())
 
 
-def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, d, dx_drop=None, drop=(0, 0, 1.0), eps=1e-5):
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, d, dx_drop=None, drop=(0, 0, 1.0), eps=1e-5, x_lo=None, dy_lo=None,
+                  dx_lo=None, dx_drop_lo=None):
     """dx (bf16 [rows, lddx]) and optionally dx_drop = dx * keep / (1 - p); dgamma / dbeta accumulated (fp32 atomics)."""
     a = L.TfLnArgs(x=L.ptr(x), ldx=x.stride(0), gamma=L.ptr(gamma), mean=L.ptr(mean), rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows,
                    x_group_stride=rows, y_group_stride=rows, eps=eps, dy=L.ptr(dy), lddy=dy.stride(0), dy_is_f32=_is_f32(dy), dx=L.ptr(dx),
                    lddx=dx.stride(0), dx_drop=L.ptr(dx_drop), lddxd=0 if dx_drop is None else dx_drop.stride(0), drop_thr=drop[0], drop_key=drop[1],
-                   drop_scale=drop[2], drop_ld=dx.stride(0), dgamma=L.ptr(dgamma), dbeta=L.ptr(dbeta))
+                   drop_scale=drop[2], drop_ld=dx.stride(0), dgamma=L.ptr(dgamma), dbeta=L.ptr(dbeta),
+                   x_lo=L.ptr(x_lo), dy_lo=L.ptr(dy_lo), dx_lo=L.ptr(dx_lo), dx_drop_lo=L.ptr(dx_drop_lo))
     L.call("tf_layernorm_bwd", a, _stream())
 
 
