@@ -391,21 +391,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const int dw_ld = 2 * ((S + 63) / 64);
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
   const unsigned* bbits = blk ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  // the per-row scalars of a query block (LSE, delta, keep / block bit words) are fetched ONE BLOCK AHEAD into four registers: read
+  // in place they were a dependent global load between the two barriers of every block
+  auto row_scalars = [&](int q0, float& r_lse, float& r_del, unsigned& r_dw, unsigned& r_bw) {
+    const int row = q0 + (lane & 31);
+    const bool in = row < Sq;
+    const int q = min(row, Sq - 1);
+    r_lse = in ? a.lse[(size_t)bh * Sq + q] : 1.0e30f;             // P = 0 for rows past the end
+    r_del = in ? a.delta[(size_t)bh * Sq + q] : 0.f;
+    r_dw = a.drop_thr ? (in ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
+    r_bw = blk ? bbits[(size_t)q * dw_ld] : 0u;
+  };
+  float n_lse = 0.f, n_del = 0.f;
+  unsigned n_dw = 0u, n_bw = 0u;
+  if (ntiles > 0) row_scalars(0, n_lse, n_del, n_dw, n_bw);
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = t * 32;
     __syncthreads();
     stage_quad<32, HDP>(q_h, q_l, ldq, false, qt_h, qt_l, do_h, do_l, a.ld_dout, true, dot_h, dot_l, q0, Sq - 1, tid);   // dO rows >= Sq: zero
-    if (tid < 32) {
-      const bool in = q0 + tid < Sq;
-      const int q = min(q0 + tid, Sq - 1);
-      lse_s[tid] = in ? a.lse[(size_t)bh * Sq + q] : 1.0e30f;      // P = 0 for rows past the end
-      del_s[tid] = in ? a.delta[(size_t)bh * Sq + q] : 0.f;
-    }
-    if (lane < 32) {
-      const int q = min(q0 + lane, Sq - 1);
-      dw_s[wave * 32 + lane] = a.drop_thr ? (q0 + lane < Sq ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
-      bw_s[wave * 32 + lane] = blk ? bbits[(size_t)q * dw_ld] : 0u;
-    }
+    if (tid < 32) { lse_s[tid] = n_lse; del_s[tid] = n_del; }
+    if (lane < 32) { dw_s[wave * 32 + lane] = n_dw; bw_s[wave * 32 + lane] = n_bw; }
+    if (t + 1 < ntiles) row_scalars(q0 + 32, n_lse, n_del, n_dw, n_bw);
     __syncthreads();
     f32x16 st, dp;
 #pragma unroll
