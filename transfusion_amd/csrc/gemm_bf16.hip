@@ -228,7 +228,7 @@ __device__ __forceinline__ void split_epilogue(const TfGemmArgs& g, f32x4 (&acc)
 // span one 256-B bank row): ^ g[(r>>2)&3], g = {0,2,3,1}.  Both make the 16 rows of a ds_read_b128 lane group hit 16 distinct slots.
 template <int BK> __device__ __forceinline__ int swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((0x78 >> ((r >> 1) & 6)) & 3); }
 
-// SPLIT (fp32-accuracy mode): the K loop runs three times over the operands' planes -- (A_hi, W_hi), (A_lo, W_hi), (A_hi, W_lo) -- into
+// SPLIT (fp32-accuracy mode), this 128x128 kernel: the K loop runs three times over the operands' planes -- (A_hi, W_hi), (A_lo, W_hi), (A_hi, W_lo) -- into
 // the same fp32 accumulators; the epilogue works on fp32 values and writes hi + lo planes.
 template <int EPI, int MI, int BK, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
@@ -425,11 +425,10 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
     int kstep = step;
     const unsigned char* Ap = A;
     const unsigned char* Wp = W;
-    if constexpr (SPLIT) {                                        // pass 0: A_hi.W_hi, pass 1: A_lo.W_hi, pass 2: A_hi.W_lo (wave-uniform)
-      const int seg = step >= 2 * nk0 ? 2 : (step >= nk0 ? 1 : 0);
-      kstep = step - seg * nk0;
-      Ap = seg == 1 ? (const unsigned char*)g.A_lo : A;
-      Wp = seg == 2 ? (const unsigned char*)g.W_lo : W;
+    if constexpr (SPLIT) {                                        // phase 2k: the hi planes of K-step k, phase 2k+1: its lo planes (wave-uniform)
+      kstep = step >> 1;
+      Ap = (step & 1) ? (const unsigned char*)g.A_lo : A;
+      Wp = (step & 1) ? (const unsigned char*)g.W_lo : W;
     }
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
@@ -447,56 +446,102 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
 #pragma unroll
     for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = SPLIT ? 3 * nk0 : nk0;
+  const int nk = SPLIT ? 2 * nk0 : nk0;
   const int frow = lane & 15, fch = lane >> 4;
   // fragment j sits 16 rows = 1024 B after fragment 0 with the SAME swizzle: one base register each plus immediates
   const int rn0 = wc * 64 + frow, rm0 = wr * (16 * MF) + frow;
   const int woff0 = A_BYTES + rn0 * BIG_ROWB + ((fch ^ swz<32>(rn0)) << 4);
   const int xoff0 = rm0 * BIG_ROWB + ((fch ^ swz<32>(rm0)) << 4);
-  // prologue: steps 0, 1, 2 in flight (past the end the last step is re-fetched: the loop body is branch-free, and
-  // every phase always has exactly two younger steps' transfers in flight, so one counted wait fits all phases)
+  if constexpr (SPLIT) {
+    // fp32-accuracy mode: A_hi.W_hi + A_lo.W_hi + A_hi.W_lo per K-step in TWO ring phases instead of three passes over K.  Phase 2k
+    // stages (A_hi, W_hi) of K-step k and multiplies them; phase 2k+1 stages (A_lo, W_lo) and forms A_lo.W_hi and A_hi.W_lo with the hi
+    // planes still sitting in the previous slot -- a third fewer DMA bytes and barriers for the same matrix work.  Four slots, the DMA
+    // of phase p+2 issued in phase p: slot (p+2)%4 == (p-2)%4 was last read in phase p-1, which every wave has left behind the barrier.
+    // In an odd phase the second fragment set is read BEFORE the DMA issue in program order (hipcc would otherwise put a vmcnt(0)
+    // between an LDS-DMA and any later LDS read).
+    stage(0, 0);
+    stage(1, min(1, nk - 1));
+    auto product = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[MF]) {
 #pragma unroll
-  for (int d = 0; d < DIST; ++d) stage(d, min(d, nk - 1));
-  int cur = 0;                                                     // ring slot of step i
-  for (int i = 0; i < nk; ++i) {
-    // retire step i's transfers (issued DIST phases ago) on every wave, then make them visible
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * PER_WAVE) : "memory");
-    const unsigned char* slw = smem + cur * SLOT + woff0;
-    const unsigned char* slx = smem + cur * SLOT + xoff0;
-    bf16x8 wf[4], xf[MF];
+      for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(slw + j * 1024);
+        for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    };
+    for (int p = 0; p < nk; p += 2) {
+      const int s0 = p & 3, s1 = (p + 1) & 3;                       // slots of the hi and the lo phase of this K-step
+      {                                                             // ---- even phase: hi x hi ----
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_WAVE) : "memory");
+        bf16x8 wf[4], xf[MF];
 #pragma unroll
-    for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(slx + j * 1024);
-    // (after the reads in program order: the compiler cannot tell the DMA's LDS destination from the slot being read)
-    // slot of step i + DIST == slot of step i - 1: every wave finished reading it before this barrier
-    stage(cur == 0 ? NSLOT - 1 : cur - 1, min(i + DIST, nk - 1));
-    cur = cur == NSLOT - 1 ? 0 : cur + 1;
+        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(smem + s0 * SLOT + woff0 + j * 1024);
 #pragma unroll
-    for (int mi = 0; mi < MF; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        if constexpr (FP8) {
-          typedef long long2_t __attribute__((ext_vector_type(2)));
-          const long2_t w2 = __builtin_bit_cast(long2_t, wf[ni]), x2 = __builtin_bit_cast(long2_t, xf[mi]);
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], acc[ni][mi], 0, 0, 0);
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], acc[ni][mi], 0, 0, 0);
-        } else {
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        }
+        for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(smem + s0 * SLOT + xoff0 + j * 1024);
+        stage((p + 2) & 3, min(p + 2, nk - 1));
+        product(wf, xf);
       }
-    // schedule: fragment reads first, then the step's DMA instructions spread one per 7 MFMAs, so that a wave's DMA
-    // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
-    constexpr int MM = FP8 ? 2 : 1;
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
-    constexpr int GAP = NWR == 2 ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
+      {                                                             // ---- odd phase: lo x hi, then hi x lo ----
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_WAVE) : "memory");
+        bf16x8 wf[4], xf[MF];
 #pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, GAP * MM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(smem + s0 * SLOT + woff0 + j * 1024);      // W_hi (previous slot)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(smem + s1 * SLOT + xoff0 + j * 1024);     // A_lo
+        product(wf, xf);
+        bf16x8 wl[4], xh[MF];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[j] = *(const bf16x8*)(smem + s1 * SLOT + woff0 + j * 1024);      // W_lo
+#pragma unroll
+        for (int j = 0; j < MF; ++j) xh[j] = *(const bf16x8*)(smem + s0 * SLOT + xoff0 + j * 1024);     // A_hi (previous slot)
+        stage((p + 3) & 3, min(p + 3, nk - 1));
+        product(wl, xh);
+      }
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MF - GAP * PER_WAVE) * MM, 0);
-  }
+  } else {
+  // prologue: steps 0, 1, 2 in flight (past the end the last step is re-fetched: the loop body is branch-free, and
+    // every phase always has exactly two younger steps' transfers in flight, so one counted wait fits all phases)
+  #pragma unroll
+    for (int d = 0; d < DIST; ++d) stage(d, min(d, nk - 1));
+    int cur = 0;                                                     // ring slot of step i
+    for (int i = 0; i < nk; ++i) {
+      // retire step i's transfers (issued DIST phases ago) on every wave, then make them visible
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * PER_WAVE) : "memory");
+      const unsigned char* slw = smem + cur * SLOT + woff0;
+      const unsigned char* slx = smem + cur * SLOT + xoff0;
+      bf16x8 wf[4], xf[MF];
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(slw + j * 1024);
+  #pragma unroll
+      for (int j = 0; j < MF; ++j) xf[j] = *(const bf16x8*)(slx + j * 1024);
+      // (after the reads in program order: the compiler cannot tell the DMA's LDS destination from the slot being read)
+      // slot of step i + DIST == slot of step i - 1: every wave finished reading it before this barrier
+      stage(cur == 0 ? NSLOT - 1 : cur - 1, min(i + DIST, nk - 1));
+      cur = cur == NSLOT - 1 ? 0 : cur + 1;
+  #pragma unroll
+      for (int mi = 0; mi < MF; ++mi)
+  #pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          if constexpr (FP8) {
+            typedef long long2_t __attribute__((ext_vector_type(2)));
+            const long2_t w2 = __builtin_bit_cast(long2_t, wf[ni]), x2 = __builtin_bit_cast(long2_t, xf[mi]);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], acc[ni][mi], 0, 0, 0);
+          } else {
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+          }
+        }
+      // schedule: fragment reads first, then the step's DMA instructions spread one per 7 MFMAs, so that a wave's DMA
+      // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
+      constexpr int MM = FP8 ? 2 : 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
+      constexpr int GAP = NWR == 2 ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
+  #pragma unroll
+      for (int q = 0; q < PER_WAVE; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GAP * MM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, (4 * MF - GAP * PER_WAVE) * MM, 0);
+    }
+}
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers must land before LDS is reused
 
   if constexpr (SPLIT) {
