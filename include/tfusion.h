@@ -219,8 +219,11 @@ typedef struct TfHeadsLossArgs {
   const float* ttc_targets;                              // [R] fp32
   const float* reg_targets;                              // [R, 4] fp32
   const float* noun_w; const float* verb_w;              // class weights [Cn] / [Cv]; null switches that head's loss off
+  // Labels are range-checked on the device: a noun label outside [0, Cn) or a verb label that is neither verb_ignore nor in [0, Cv)
+  // contributes nothing (no memory is read through it); unless it equals -100 (torch's ignore_index) it is counted in sums[7].
   long long verb_ignore; int verb_bg; int ttc_bg; float ttc_bg_val; float ttc_beta; float box_beta;
-  float* sums;                                           // [8] fp32, zeroed by the caller: numerators / normalisers, kept for the backward
+  float* sums;                                           // [8] fp32, zeroed by the caller: numerators / normalisers, kept for the backward;
+                                                         // [7] = number of out-of-range labels seen (error flag for the host, read lazily)
   float* lse;                                            // [2, R] fp32 work: log-sum-exp of the noun / verb rows, kept for the backward
   float* losses;                                         // forward out [4]: box, noun, verb, ttc
   const float* gscale;                                   // backward in [4]: d(total) / d(box, noun, verb, ttc loss)

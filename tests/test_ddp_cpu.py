@@ -235,3 +235,21 @@ def test_gloo_world2_layerwise_hook_path(tmp_path, accumulate):
         # and the update used grad / world (FusionTrainStep's mean over ranks)
         want = named[n].data.reshape(-1) - 0.1 * named[n].grad.reshape(-1) / accumulate / world
         torch.testing.assert_close(got["param"][off:off + k], want, rtol=1e-4, atol=1e-5)
+
+
+def test_train_step_bumps_version_of_rehomed_parameters():
+    """A re-homed parameter (``p.data = flat[off:off+n]``) has a version counter of its own, and the fused optimiser only writes the
+    flat buffer: FusionTrainStep must bump every parameter's version after the step, or the bf16 weight-shadow caches keyed on
+    ``(data_ptr, _version)`` (ops._weight_shadows, QKVEncoder._shadows) keep serving the step-0 weights."""
+    from transfusion_amd.runner import trainer as T
+    model = Toy()
+    tr = T.FusionTrainStep(model, lr=0.1, weight_decay=0.0, grad_clip=None, optimizer_cls=_PlainSGD)
+    ps = [p for _, p, _, _ in tr.flat.slices]
+    ptrs = [p.data_ptr() for p in ps]
+    for it in range(3):
+        before = [p._version for p in ps]
+        w0 = model.a.weight.detach().clone()
+        tr.step([torch.randn(4, 6)], lambda m, b: m(b).pow(2).sum())
+        assert all(p._version > v for p, v in zip(ps, before)), it
+        assert not torch.equal(w0, model.a.weight)                     # the step did move the weights ...
+    assert ptrs == [p.data_ptr() for p in ps]                          # ... in place: data_ptr alone would never have told

@@ -45,6 +45,10 @@ def test_heads_and_losses_against_reference_fixture(dev, golden_dir, name, preci
     out = heads(x)
     for k in ("box_regression", "class_logits", "verb_logits"):
         assert tuple(out[k].shape) == g[k].shape and rel(out[k], g[k]) < TOL, k
+        # the north_star names these outputs element by element ("noun/verb logits, bbox and TTC outputs ... within 1e-3 fp32 / 1e-2
+        # bf16"): max-abs against the largest reference magnitude as well, not only the relative L2 norm
+        ref_k = torch.from_numpy(g[k]).double()
+        assert (out[k].detach().double().cpu() - ref_k).abs().max() < TOL * max(1.0, float(ref_k.abs().max())), k
     assert (out["ttcs"].detach().cpu() - torch.from_numpy(g["ttcs"])).abs().max() < TTC_TOL
     h = cfg["R"] // 2
     t = lambda a: torch.from_numpy(a).to(dev)
@@ -101,3 +105,53 @@ def test_heads_loss_kernel_against_oracle_on_given_logits(dev):
         (refv * cot.double()).sum().backward()
         assert rel(cd.grad, c64.grad) < 2e-2 and rel(bd.grad, b64.grad) < 2e-2
         assert (ttcs.cpu().double() - out["ttcs"].detach()).abs().max() < 1e-5
+
+
+def test_out_of_range_labels_select_nothing_and_are_reported(dev):
+    """Labels are range-checked by the kernel, not by host-side min / max syncs: an out-of-range noun or verb label reads no class
+    weight / logit / box slot (the result equals the same call with that RoI's terms removed), -100 (torch's ignore_index) is skipped
+    silently, anything else is counted and ``ops.check_label_errors()`` raises torch's IndexError for it afterwards."""
+    from transfusion_amd import ops
+    cfg = HEADS_CASES["heads_v2_bg"]
+    _, _, noun, verb, ttc, reg, noun_w, verb_w = make_heads_case(cfg)
+    R, Cn, Cv = cfg["R"], cfg["nouns"], cfg["verbs"]
+    g = torch.Generator().manual_seed(3)
+    cls = (2 * torch.randn(R, Cn + Cv + 1, generator=g)).to(torch.bfloat16).to(dev)
+    box = torch.randn(R, 4 * Cn, generator=g).to(torch.bfloat16).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def run(noun_l, verb_l):
+        c = cls.clone().requires_grad_(True)
+        b = box.clone().requires_grad_(True)
+        ttcs = ops.softplus_col(c, Cn + Cv)
+        losses = ops.nao_head_losses(c, b, ttcs, Cn, Cv, t(noun_l), t(verb_l), t(ttc), t(reg), t(noun_w), t(verb_w), IGNORE_VERB_IDX_BG, False, False,
+                                     0.0, 1.0)
+        losses.sum().backward()
+        return losses.detach().cpu(), c.grad.detach().cpu().float(), b.grad.detach().cpu().float()
+
+    ops.check_label_errors(sync=True)                       # nothing pending from earlier tests
+    base = run(noun, verb)
+    ops.check_label_errors(sync=True)                       # in-range labels: no error
+    assert all(torch.isfinite(x).all() for x in base)
+    # torch's ignore_index: silently skipped
+    n2, v2 = noun.copy(), verb.copy()
+    rows = [i for i in range(R) if noun[i] > 0 and verb[i] != IGNORE_VERB_IDX_BG][:2]
+    n2[rows[0]] = -100
+    v2[rows[1]] = -100
+    ign = run(n2, v2)
+    ops.check_label_errors(sync=True)
+    assert all(torch.isfinite(x).all() for x in ign)
+    assert float(ign[1][rows[0], :Cn].abs().max()) == 0 and float(ign[2][rows[0]].abs().max()) == 0      # no noun / box gradient for that RoI
+    assert float(ign[1][rows[1], Cn:Cn + Cv].abs().max()) == 0
+    # far out of range (would be a wild read): same values as the ignored case, plus the error afterwards
+    n3, v3 = noun.copy(), verb.copy()
+    n3[rows[0]] = 1 << 40
+    v3[rows[1]] = Cv + 12345
+    bad = run(n3, v3)
+    for a, b in zip(bad, ign):
+        assert torch.equal(a, b)
+    with pytest.raises(IndexError):
+        ops.check_label_errors(sync=True)
+    ops.check_label_errors(sync=True)                       # reported once
+    with pytest.raises(RuntimeError):                       # class-weight vector shorter than the class count
+        ops.nao_head_losses(cls, box, None, Cn, Cv, t(noun), t(verb), None, t(reg), t(noun_w[:-1]), t(verb_w), IGNORE_VERB_IDX_BG)

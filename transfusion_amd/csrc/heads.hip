@@ -47,7 +47,14 @@ __device__ __forceinline__ float row_lse(const u16* hi, const u16* lo, size_t ba
   return m + __logf(wave_sum(s));
 }
 
-// sums: [0] noun num  [1] noun den  [2] verb num  [3] verb den  [4] ttc num  [5] ttc count  [6] box num  [7] unused
+// Labels are range-checked HERE, not by host-side min / max reductions (two blocking syncs per step): a noun label outside [0, Cn) or
+// a verb label that is neither verb_ignore nor inside [0, Cv) selects nothing -- no class weight, no logit, no box slot is read
+// through it -- and, unless it is torch's ignore_index (-100, which nn.CrossEntropyLoss skips silently), raises sums[7], which the
+// host reads lazily and turns into the IndexError torch would have raised.
+constexpr long long kTorchIgnoreIndex = -100;
+__device__ __forceinline__ bool label_ok(long long y, int C) { return y >= 0 && y < (long long)C; }
+
+// sums: [0] noun num  [1] noun den  [2] verb num  [3] verb den  [4] ttc num  [5] ttc count  [6] box num  [7] count of out-of-range labels
 __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const TfHeadsLossArgs a) {
   __shared__ float red[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -57,23 +64,29 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const TfHeadsLossAr
     const u16* cls = (const u16*)a.cls; const u16* cls_lo = (const u16*)a.cls_lo;
     const size_t rb = (size_t)r * a.ld_cls;
     const long long yn = a.noun_labels[r];
+    const bool yn_ok = label_ok(yn, a.Cn);
+    if (!yn_ok && yn != kTorchIgnoreIndex && lane == 0) acc[7] += 1.f;
     float v[MAXK];
     if (a.noun_w != nullptr) {                       // noun head (criterion.noun > 0)
       const float lse = row_lse(cls, cls_lo, rb, a.Cn, lane, v);
       if (lane == 0) {
-        const float w = a.noun_w[yn];
-        acc[0] = w * (lse - (ld_logit(cls, cls_lo, rb + yn) + 1e-6f));
-        acc[1] = w;
         a.lse[r] = lse;
+        if (yn_ok) {
+          const float w = a.noun_w[yn];
+          acc[0] = w * (lse - (ld_logit(cls, cls_lo, rb + yn) + 1e-6f));
+          acc[1] = w;
+        }
       }
     }
     const long long tv = a.verb_labels != nullptr ? a.verb_labels[r] : 0;
     const bool bg = a.verb_labels != nullptr && tv == a.verb_ignore;
+    const bool tv_ok = bg || label_ok(tv, a.Cv);
     if (a.verb_w != nullptr && a.Cv > 0) {           // verb head; background RoIs: last class (verb_bg) or dropped (:316-320)
       const float lse = row_lse(cls, cls_lo, rb + a.Cn, a.Cv, lane, v);
+      if (!tv_ok && tv != kTorchIgnoreIndex && lane == 0) acc[7] += 1.f;
       if (lane == 0) {
         a.lse[a.R + r] = lse;
-        if (a.verb_bg || !bg) {
+        if (tv_ok && (a.verb_bg || !bg)) {
           const long long yv = bg ? a.Cv - 1 : tv;
           const float w = a.verb_w[yv];
           acc[2] = w * (lse - (ld_logit(cls, cls_lo, rb + a.Cn + yv) + 1e-6f));
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const TfHeadsLossAr
       else if (tt == (float)a.verb_ignore) tt = a.ttc_bg_val;
       if (sel) { acc[4] = smooth_l1(a.ttcs[r] - tt, a.ttc_beta); acc[5] = 1.f; }
     }
-    if (a.box != nullptr && yn > 0 && lane < 4) {    // box regression of the label's class, positives only (losses.py:119-131)
+    if (a.box != nullptr && yn > 0 && yn_ok && lane < 4) {    // box regression of the label's class, positives only (losses.py:119-131)
       const float d = ld_logit((const u16*)a.box, (const u16*)a.box_lo, (size_t)r * a.ld_box + 4 * yn + lane) - a.reg_targets[(size_t)r * 4 + lane];
       float l = smooth_l1(d, a.box_beta);
       l += __shfl_xor(l, 1, 64);
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const TfHeadsLossAr
     for (int i = 0; i < 8; ++i) red[wave][i] = acc[i];
   }
   __syncthreads();
-  if (threadIdx.x < 7) {
+  if (threadIdx.x < 8) {
     const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (t != 0.f) atomicAdd(a.sums + threadIdx.x, t);
   }
@@ -130,9 +143,10 @@ __global__ __launch_bounds__(256) void heads_loss_bwd_kernel(const TfHeadsLossAr
     hi[i] = hb;
     if (lo != nullptr) lo[i] = f2bf(g - bf2f(hb));
   };
+  const bool yn_ok = label_ok(yn, a.Cn);
   // noun columns
   {
-    const float coef = (a.noun_w != nullptr && a.sums[1] > 0.f) ? g_noun * a.noun_w[yn] / a.sums[1] : 0.f;
+    const float coef = (a.noun_w != nullptr && yn_ok && a.sums[1] > 0.f) ? g_noun * a.noun_w[yn] / a.sums[1] : 0.f;
     const float lse = a.noun_w != nullptr ? a.lse[r] : 0.f;
     for (int c = lane; c < a.Cn; c += 64) {
       float g = 0.f;
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(256) void heads_loss_bwd_kernel(const TfHeadsLossAr
   const long long tv = a.verb_labels != nullptr ? a.verb_labels[r] : 0;
   const bool bg = a.verb_labels != nullptr && tv == a.verb_ignore;
   {
-    const bool on = a.verb_w != nullptr && a.Cv > 0 && (a.verb_bg || !bg) && a.sums[3] > 0.f;
+    const bool on = a.verb_w != nullptr && a.Cv > 0 && (a.verb_bg || !bg) && (bg || label_ok(tv, a.Cv)) && a.sums[3] > 0.f;
     const long long yv = bg ? a.Cv - 1 : tv;
     const float coef = on ? g_verb * a.verb_w[yv] / a.sums[3] : 0.f;
     const float lse = on ? a.lse[a.R + r] : 0.f;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void heads_loss_bwd_kernel(const TfHeadsLossAr
     const float coef = g_box / (float)(a.R > 1 ? a.R : 1);
     for (int c = lane; c < a.ld_box; c += 64) {
       float g = 0.f;
-      if (a.box != nullptr && yn > 0 && c >= 4 * yn && c < 4 * yn + 4) {
+      if (a.box != nullptr && yn > 0 && yn_ok && c >= 4 * yn && c < 4 * yn + 4) {
         const float d = ld_logit((const u16*)a.box, (const u16*)a.box_lo, bb + c) - a.reg_targets[(size_t)r * 4 + (c - 4 * yn)];
         g = coef * smooth_l1_grad(d, a.box_beta);
       }

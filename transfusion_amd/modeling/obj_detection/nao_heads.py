@@ -56,7 +56,8 @@ class NaoRoIHeads(nn.Module):
             Cv = self.verb_classifier.out_features
         if self.ttc_pred:
             ws.append(self.ttc_pred_layer.weight); bs.append(self.ttc_pred_layer.bias)
-        cls = ops.linear(box_features, torch.cat(ws, 0), torch.cat(bs, 0), p_drop_in=p_cls, precision=self.precision)   # one GEMM: noun | verb | ttc
+        cls = ops.linear(box_features, torch.cat(ws, 0), torch.cat(bs, 0), p_drop_in=p_cls, precision=self.precision,
+                         weight_sources=ws)   # one GEMM: noun | verb | ttc; bf16 shadows cached on the three Parameters
         ttcs = ops.softplus_col(cls, Cn + Cv) if self.ttc_pred else None
         return {"class_logits": cls[:, :Cn], "verb_logits": cls[:, Cn:Cn + Cv] if Cv else None, "ttcs": ttcs,
                 "box_regression": box_regression, "box_features": box_features, "_cls": cls, "_dims": (Cn, Cv)}

@@ -314,18 +314,24 @@ def regroup(patches, init_h, init_w, patch_h, patch_w, out_dtype=None):
 # ------------------------------------------------------------------------------------------------------
 import weakref
 
-_shadow_cache = {}      # id(parameter) -> (weakref to the parameter, (data_ptr, _version, shape, pads), W shadow, W^T shadow)
+_shadow_cache = {}      # (id(first owner), #owners, planes) -> (weakrefs to the owning Parameters, key, shadows)
 
 
-def _weight_shadows(weight, N8, Kp, Np, planes=False):
+def _weight_shadows(weight, N8, Kp, Np, planes=False, sources=None):
     """bf16 shadows [N8, Kp] and [Kp, Np] of an fp32 weight, re-packed only when the parameter changed (its storage moved or its
-    version was bumped -- FusedRAdam does that for its raw-pointer updates).  Keyed on the parameter OBJECT (id + a weak reference that
-    must still point at it), never on a bare data_ptr: a freed tensor's address is reused by its successor.
+    version was bumped -- FusedRAdam / FusionTrainStep do that for their raw-pointer updates).  Keyed on the parameter OBJECT (id + a
+    weak reference that must still point at it), never on a bare data_ptr: a freed tensor's address is reused by its successor.
+    ``sources``: the Parameters a derived ``weight`` (e.g. the noun | verb | ttc concatenation of the RoI heads) was built from -- the
+    cache entry is then keyed on THEM, so the temporary is packed once per optimiser step, not once per forward; a derived tensor
+    without ``sources`` is packed every call and never cached (it would only leave a dead entry behind).
     ``planes``: also the lo planes (w - bf16(w), the fp32-accuracy mode's second operand plane) -> (W, W^T, W_lo, W^T_lo)."""
     w2 = weight.reshape(weight.shape[0], -1)
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), N8, Kp, Np, bool(planes))
-    hit = _shadow_cache.get((id(weight), bool(planes)))
-    if hit is not None and hit[0]() is weight and hit[1] == key:
+    owners = list(sources) if sources else [weight]
+    cacheable = all(isinstance(o, torch.nn.Parameter) for o in owners)
+    key = tuple((id(o), o.data_ptr(), o._version) for o in owners) + (tuple(weight.shape), N8, Kp, Np, bool(planes))
+    slot = (id(owners[0]), len(owners), bool(planes))
+    hit = _shadow_cache.get(slot) if cacheable else None
+    if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == key:
         return hit[2]
     wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np)
     out = (wsh, wsh_t)
@@ -333,13 +339,12 @@ def _weight_shadows(weight, N8, Kp, Np, planes=False):
         wf = w2.detach().float()
         lo = wf - wf.to(torch.bfloat16).float()                    # exact in fp32; the pack kernel rounds to nearest even as torch does
         out = out + pack_weight(lo, N8, Kp, Kp, Np)
+    if not cacheable:
+        return out
     if len(_shadow_cache) > 256:                                   # drop entries whose parameter is gone
-        for k in [k for k, v in _shadow_cache.items() if v[0]() is None]:
+        for k in [k for k, v in _shadow_cache.items() if any(r() is None for r in v[0])]:
             del _shadow_cache[k]
-    try:
-        _shadow_cache[(id(weight), bool(planes))] = (weakref.ref(weight), key, out)
-    except TypeError:
-        pass
+    _shadow_cache[slot] = (tuple(weakref.ref(o) for o in owners), key, out)
     return out
 
 
@@ -452,9 +457,10 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None
 
 
-def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16"):
+def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16", weight_sources=None):
     """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N] (``precision="fp32"``: the fp32-accuracy mode, fp32 out).
-    ``weight`` may have any trailing shape (the k = s = p Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)]."""
+    ``weight`` may have any trailing shape (the k = s = p Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)].
+    ``weight_sources``: the Parameters a derived ``weight`` (a concatenation) was built from -- see ``_weight_shadows``."""
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = weight.shape[0]
@@ -466,10 +472,10 @@ def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16"
     w2 = weight.reshape(N, -1)
     seed = next_seed() if p_drop_in > 0 else 0
     if precision == "fp32":
-        wsh, wsh_t, wsh_lo, wsh_t_lo = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), planes=True)
+        wsh, wsh_t, wsh_lo, wsh_t_lo = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), planes=True, sources=weight_sources)
         y = _LinearX3Fn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t, wsh_lo, wsh_t_lo)
     else:
-        wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64))
+        wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), sources=weight_sources)
         y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t)
     return y.reshape(*lead, N)
 
@@ -585,8 +591,15 @@ class _NaoLossFn(torch.autograd.Function):
         ttcs = None if ttcs is None else ttcs.detach().float().contiguous()
         if noun.numel() != R or (verb is not None and verb.numel() != R) or (reg_t is not None and tuple(reg_t.shape) != (R, 4)):
             raise RuntimeError(f"labels / targets do not match the {R} RoIs")
-        if int(noun.min()) < 0 or int(noun.max()) >= Cn:
-            raise IndexError("Target out of bounds (noun labels)")          # what torch's cross_entropy raises
+        if ttc_t is not None and ttc_t.numel() != R:
+            raise RuntimeError(f"ttc_targets has {ttc_t.numel()} entries for {R} RoIs")
+        if noun_w is not None and noun_w.numel() < Cn:
+            raise RuntimeError(f"noun class weights: {noun_w.numel()} entries for {Cn} classes")
+        if verb is not None and verb_w is not None and verb_w.numel() < Cv:
+            raise RuntimeError(f"verb class weights: {verb_w.numel()} entries for {Cv} classes")
+        # label ranges are checked by the kernel (out-of-range labels select nothing and raise sums[7]); the flag of an EARLIER call is
+        # turned into torch's IndexError here, once its copy has landed -- no host synchronisation in the step (csrc/heads.hip)
+        check_label_errors(sync=False)
         sums = torch.zeros(8, dtype=torch.float32, device=dev)
         lse = torch.empty(2 * R, dtype=torch.float32, device=dev)
         losses = torch.empty(4, dtype=torch.float32, device=dev)
@@ -597,6 +610,7 @@ class _NaoLossFn(torch.autograd.Function):
                               verb_ignore=int(verb_ignore), verb_bg=int(bool(verb_bg)), ttc_bg=int(bool(ttc_bg)), ttc_bg_val=float(ttc_bg_val),
                               ttc_beta=float(ttc_beta), box_beta=1.0 / 9, sums=L.ptr(sums), lse=L.ptr(lse), losses=L.ptr(losses))
         L.call("tf_heads_loss_fwd", a, _stream())
+        _watch_label_flag(sums)
         ctx.args, ctx.keep = a, (cls, box, ttcs, noun, verb, ttc_t, reg_t, noun_w, verb_w, sums, lse, cls_lo, box_lo)
         ctx.shapes = (cls_shape, box_shape)
         return losses
@@ -620,6 +634,37 @@ class _NaoLossFn(torch.autograd.Function):
         g_cls = d_cls[:, :cs[1]] if d_cls_lo is None else d_cls[:, :cs[1]].float() + d_cls_lo[:, :cs[1]].float()
         g_box = None if box is None else (d_box[:, :bs[1]] if d_box_lo is None else d_box[:, :bs[1]].float() + d_box_lo[:, :bs[1]].float())
         return (g_cls, g_box, d_ttcs) + (None,) * 13
+
+
+_label_flags = []        # (pinned host copy of sums[7], event recorded behind the copy) of recent loss calls
+
+
+def _watch_label_flag(sums):
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(sums[7:8], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(sums.device))
+    _label_flags.append((host, ev))
+    if len(_label_flags) > 64:            # nobody ever asked: keep the queue bounded (the oldest copies have long landed)
+        check_label_errors(sync=False)
+        del _label_flags[:-64]
+
+
+def check_label_errors(sync: bool = True):
+    """Raises the IndexError torch's cross_entropy raises for a target outside [0, C) -- for any earlier ``nao_head_losses`` call whose
+    labels the kernel found out of range (such labels contributed nothing to that call's losses and gradients).  ``sync=False`` looks
+    only at calls whose flag has already reached the host; ``sync=True`` waits for all of them (end of an epoch, tests)."""
+    bad = 0.0
+    while _label_flags:
+        host, ev = _label_flags[0]
+        if not sync and not ev.query():
+            break
+        if sync:
+            ev.synchronize()
+        _label_flags.pop(0)
+        bad += float(host[0])
+    if bad:
+        raise IndexError(f"Target out of bounds: {int(bad)} noun / verb labels outside their class range in an earlier nao_head_losses call")
 
 
 def nao_head_losses(cls, box, ttcs, Cn, Cv, noun, verb, ttc_targets, reg_targets, noun_w, verb_w, verb_ignore=999, verb_bg=False, ttc_bg=False,

@@ -232,7 +232,16 @@ class FusionTrainStep:
             self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip)
         else:
             self.opt.step(grad_scale=scale)
+        self.mark_parameters_updated()
+        return loss.detach()
+
+    def mark_parameters_updated(self):
+        """The fused optimiser wrote through the FLAT buffer: it bumped that tensor's version counter, but a re-homed parameter
+        (``p.data = flat[off:off+n]``) keeps a version counter of its own, and every bf16 weight-shadow cache of the library keys on
+        ``(p.data_ptr(), p._version)`` (ops._weight_shadows, QKVEncoder._shadows, CrossTransformerModuleBox._wpack_dirty).  Without
+        this bump PatchToToken / RegroupPatchesLayerBox / the heads / the asymmetric layers would keep multiplying by their step-0
+        weights."""
+        torch._C._increment_version([p for _, p, _, _ in self.flat.slices])
         for m in self.module.modules():
             if hasattr(m, "mark_weights_updated"):
                 m.mark_weights_updated()
-        return loss.detach()
