@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 2
+#define TF_ABI_VERSION 3
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -104,6 +104,10 @@ typedef struct TfAttnArgs {
   // per (batch, head), and the query gradient goes to dq [B*Sq, ld_dq] (dqkv keeps dK, dV).  block_bits must be null.
   const void* q; int ld_q; int Sq; void* dq; int ld_dq;
   const void* q_lo; void* dq_lo;          // their lo planes in the fp32-accuracy mode
+  // Packed (ragged) batches: cu_rows != null -> sample b owns rows cu_rows[b] .. cu_rows[b+1]-1 of qkv / out / dout / dqkv (its length
+  // S_b = cu_rows[b+1] - cu_rows[b] <= S keys and queries, all of them attended: key_mask and q must be null); lse / delta / drop_bits
+  // keep their dense [B,H,S] row indexing with sample-local row numbers.  S stays the maximum length (grid and bitmask geometry).
+  const int* cu_rows;                     // [B+1] int32 device array, or null: every sample has S rows starting at b*S
 } TfAttnArgs;
 
 
@@ -127,6 +131,8 @@ typedef struct TfLnArgs {
   const void* dres; int lddres;  // optional bf16 tensor added to dy before the backward (residual-path gradient)
   // fp32-accuracy mode: lo planes of the bf16 tensors above (value = hi + lo); each is used iff its hi plane is bf16 and it is non-null
   const void* x_lo; void* y_lo; const void* dy_lo; void* dx_lo; void* dx_drop_lo; const void* dres_lo;
+  // packed batches: group g of the x side (x, dx, dx_drop, dres) starts at row x_group_row0[g] instead of g * x_group_stride
+  const int* x_group_row0;       // [ceil(rows / rows_per_group)] int32 device array or null
 } TfLnArgs;
 
 typedef struct TfAssembleArgs {
@@ -144,6 +150,9 @@ typedef struct TfAssembleArgs {
   void* dlang; int dlang_is_f32; int ld_dlang;
   float* dkind_v; float* dkind_l;
   void* out_lo; const void* dout_lo;             // fp32-accuracy mode: lo planes of out / dout
+  // packed batches (padded language tokens dropped): out / dout hold `rows` token rows and row_map[m] = b * (Nv + Nl) + s names the
+  // (sample, position) row m was gathered from; dlang rows of dropped tokens are NOT written (the caller zero-fills dlang).
+  const int* row_map; int rows;                  // null / 0: dense, row m = b * S + s
 } TfAssembleArgs;
 
 // rowsum(dO . O) per (b, head, s)
@@ -166,6 +175,11 @@ typedef struct TfCopyRowsArgs {
   void* dst; int dst_is_f32; int ld_dst; int dst_rpg, dst_gstride;
   int rows, cols;
   const void* src_lo; void* dst_lo;      // fp32-accuracy mode: lo plane of a bf16 src (added) / of a bf16 dst (residual written)
+  // optional per-row indirections (int32 [rows], device): row r reads src row src_row_map[r] (< 0: zeros) instead of its group-mapped
+  // row, and writes dst row dst_row_map[r] (< 0: nothing is written)
+  const int* src_row_map; const int* dst_row_map;
+  // or per-GROUP starts (packed batches): group g of src / dst begins at row src_group_row0[g] / dst_group_row0[g] instead of g * gstride
+  const int* src_group_row0; const int* dst_group_row0;
 } TfCopyRowsArgs;
 // key_mask[b, s] = s < Nv ? 0 : lang_pad_mask[b, s - Nv]
 
@@ -372,6 +386,16 @@ typedef struct TfEncoderDesc {
                                  * (results within 1e-3 of the fp32 reference; ~1e-5 measured).  wpack / work sizes: tf_encoder_plan_ex */
   int act;                      /* FFN activation: 0 = GELU (activ_f: "gelu"), 1 = ReLU (the reference constructor's default) */
   const float* pe_lang;         /* lang_pos_embedding table [>=Nl, d] fp32 or null (cross_f_box_layers.py:77-78) */
+  int packed_rows;              /* > 0: run on the PACKED token rows only.  The value is the number of rows that take part: B * Nv plus the
+                                 * number of language tokens lang_pad_mask leaves un-masked, counted by the host (the tokeniser / the
+                                 * length list that built the mask knows it; no device read-back).  Masked language tokens are then never
+                                 * gathered: they are attended by nobody (key padding) and, in every use the reference makes of the
+                                 * fused language tokens (lm_layers.py:59-61 multiplies them by the mask), their outputs are discarded --
+                                 * so this mode writes ZEROS to their lang_out rows, ignores their d_lang_out rows and returns zero d_lang
+                                 * rows for them; every other output and every parameter gradient is what the dense mode computes.
+                                 * All row-wise work (GEMMs, LayerNorm, attention queries, weight gradients) shrinks to the real tokens.
+                                 * 0: dense (bit-for-bit the reference's semantics, padded rows included).  A count that disagrees with
+                                 * the mask is reported through tf_encoder_packed_error. */
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);   /* precision 0 */
@@ -379,6 +403,10 @@ int tf_encoder_plan_ex(const TfEncoderDesc* e, TfEncoderPlan* out);   /* reads B
 int tf_encoder_pack(const TfEncoderDesc* e, tf_stream_t s);   /* fp32 parameters -> bf16 shadows in wpack */
 int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s);
 int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s);
+/* packed mode self-check: copies the device-side count mismatch word of the workspace of *e (0 = the host's packed_rows agreed with
+ * the mask in every forward run on this workspace so far; otherwise the row count the mask gave) into host memory *out.  Enqueues a
+ * 4-byte device-to-host copy on s; the caller synchronises s before reading (tests, debugging; not needed per step). */
+int tf_encoder_packed_error(const TfEncoderDesc* e, int* out, tf_stream_t s);
 /* test hook: copies an internal activation by name ("x<l>", "qkv<l>", "o<l>", "z1_<l>", "x1_<l>", "u<l>" (holds G = d h / d u), "h<l>",
  * "z2_<l>", "dqkv", ...) as fp32 [rows, cols] into dst; returns rows*cols (cols = padded width) or < 0 */
 long long tf_encoder_peek(const TfEncoderDesc* e, const char* name, float* dst, long long cap, tf_stream_t s);

@@ -149,7 +149,8 @@ def test_out_of_range_labels_select_nothing_and_are_reported(dev):
     v3[rows[1]] = Cv + 12345
     bad = run(n3, v3)
     for a, b in zip(bad, ign):
-        assert torch.equal(a, b)
+        # (equal up to the order of the fp32 atomics behind the normalisers; gradients are stored in bf16)
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()) and torch.allclose(bad[0], ign[0], rtol=1e-5, atol=1e-6)
     with pytest.raises(IndexError):
         ops.check_label_errors(sync=True)
     ops.check_label_errors(sync=True)                       # reported once

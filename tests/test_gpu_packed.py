@@ -1,0 +1,246 @@
+"""Packed batches (TfEncoderDesc.packed_rows / ``forward(..., lang_valid_rows=...)``): the language tokens the padding mask removes
+are dropped from every row-wise kernel instead of travelling through the GEMMs, LayerNorms and attention as dead rows.  What must hold:
+every visual output, every un-masked language output, every input gradient and every parameter gradient equals the dense computation
+(the reference's semantics, pinned by the golden fixtures and the oracle elsewhere); masked tokens come back as zero rows with zero
+gradient.  Right padding, masks with holes, a fully masked sample, head-dim padding, the block (local_k) mask, both arithmetic modes,
+dropout replayed against the oracle, the benchmark's full size, and the count self-check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import ENCODER_CASES, make_encoder_inputs, make_encoder_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def build(cfg, dev, p_tok=0.0, p_patch=0.0, precision="bf16"):
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    pe = PositionalEmbeddingLayer("sin1d", 8192, cfg["d"])
+    enc = CrossTransformerModuleBox(no_patches=8192, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=cfg["L"],
+                                    patch_dropout=p_patch, num_heads=cfg["h"], fforward_multiplier=2, token_dropout=p_tok,
+                                    back_to_img_fn="regroup", activ_f="gelu", final_norm="ln", input_f_size=cfg["d"])
+    params = make_encoder_params(cfg["seed"], cfg["d"], cfg["L"])
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    enc.precision = precision
+    return enc.to(dev), params
+
+
+def run(enc, x, lang, mask, gv, gl, dev, packed, vis_tokens_mask=None):
+    enc.zero_grad(set_to_none=True)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+    md = torch.from_numpy(mask).to(dev)
+    kw = dict(lang_valid_rows=int((~mask).sum())) if packed else {}
+    vis, lo, _, _ = enc(xd, ld, md, vis_tokens_mask=vis_tokens_mask, **kw)
+    assert (enc._last_desc.packed_rows > 0) == packed
+    ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+    grads = {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}
+    return vis.detach(), lo.detach(), xd.grad.detach(), ld.grad.detach(), grads
+
+
+def masks_for(kind, B, Nl, seed):
+    rs = np.random.RandomState(seed)
+    if kind == "right":
+        lens = rs.randint(1, Nl + 1, size=B)
+        lens[0] = Nl                                          # one sample without padding
+        return np.arange(Nl)[None, :] >= lens[:, None]
+    if kind == "holes":                                       # an arbitrary key-padding mask: the packed rows are gathered, not a prefix
+        m = rs.rand(B, Nl) < 0.4
+        m[0] = False
+        return m
+    if kind == "empty_sample":                                # one sample whose language tokens are ALL masked
+        lens = rs.randint(1, Nl + 1, size=B)
+        lens[1 % B] = 0
+        return np.arange(Nl)[None, :] >= lens[:, None]
+    raise ValueError(kind)
+
+
+SHAPES = {
+    "small": dict(B=3, Nv=36, Nl=50, d=64, h=4, L=2, seed=51),
+    "hd18": dict(B=2, Nv=20, Nl=33, d=72, h=4, L=2, seed=52),          # head dim 18 -> padded to 32 inside the shadows
+    "tiles": dict(B=4, Nv=196, Nl=300, d=256, h=4, L=2, seed=53),      # several key / query tiles per sample, ragged tile tails
+}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("kind", ["right", "holes", "empty_sample"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_packed_equals_dense(dev, shape, kind, precision):
+    cfg = SHAPES[shape]
+    enc, _ = build(cfg, dev, precision=precision)
+    enc.train()
+    x, lang, _, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], None)
+    mask = masks_for(kind, cfg["B"], cfg["Nl"], cfg["seed"])
+    gl = gl * (~mask)[..., None]                               # cotangents on masked tokens are dropped by the packed mode (documented)
+    dense = run(enc, x, lang, mask, gv, gl, dev, packed=False)
+    packed = run(enc, x, lang, mask, gv, gl, dev, packed=True)
+    assert enc.packed_row_error() == 0
+    valid = torch.from_numpy(~mask)
+    tol = 2e-3 if precision == "bf16" else 1e-5                # same arithmetic per row; only tile shapes / atomic orders differ
+    assert rel(packed[0], dense[0]) < tol
+    assert rel(packed[1].cpu()[valid], dense[1].cpu()[valid]) < tol
+    assert float(packed[1].cpu()[~valid].abs().max() if (~valid).any() else 0.0) == 0.0       # masked tokens: zero rows
+    assert rel(packed[2], dense[2]) < 5 * tol
+    assert rel(packed[3].cpu()[valid], dense[3].cpu()[valid]) < 5 * tol
+    assert float(packed[3].cpu()[~valid].abs().max() if (~valid).any() else 0.0) == 0.0       # ... and zero input gradient
+    for k in dense[4]:
+        assert rel(packed[4][k], dense[4][k]) < 5 * tol, k
+
+
+def test_packed_with_block_mask(dev):
+    """vis_mask_type: local_k (a block-bit matrix over the joint sequence) on packed batches: only visual-visual pairs are ever
+    blocked and the visual rows keep their positions, so the same bit matrix serves both layouts."""
+    from transfusion_amd.modeling.cross_fusion.utils import get_visual_token_mask
+    cfg = dict(B=3, Nv=49, Nl=70, d=64, h=2, L=2, seed=55)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    x, lang, _, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], None)
+    mask = masks_for("right", cfg["B"], cfg["Nl"], 5)
+    gl = gl * (~mask)[..., None]
+    vm = get_visual_token_mask((7, 7), "local_1")
+    dense = run(enc, x, lang, mask, gv, gl, dev, packed=False, vis_tokens_mask=vm)
+    packed = run(enc, x, lang, mask, gv, gl, dev, packed=True, vis_tokens_mask=vm)
+    valid = torch.from_numpy(~mask)
+    assert rel(packed[0], dense[0]) < 2e-3 and rel(packed[1].cpu()[valid], dense[1].cpu()[valid]) < 2e-3
+    assert rel(packed[2], dense[2]) < 1e-2
+    for k in dense[4]:
+        assert rel(packed[4][k], dense[4][k]) < 1e-2, k
+    nomask = run(enc, x, lang, mask, gv, gl, dev, packed=True)
+    assert rel(nomask[0], dense[0]) > 1e-2                    # (the block mask does change the result)
+
+
+def test_packed_golden_fixture(dev, golden_dir):
+    """The reference-generated ``enc_small`` fixture (right-padded mask) through the packed path: the un-masked outputs and
+    every gradient against the reference's own values."""
+    cfg = ENCODER_CASES["enc_small"]
+    g = dict(np.load(os.path.join(golden_dir, "enc_small.npz")))
+    enc, _ = build(cfg, dev)
+    enc.train()
+    x = torch.from_numpy(g["in_x"]).to(dev).requires_grad_(True)
+    lang = torch.from_numpy(g["in_lang"]).to(dev).requires_grad_(True)
+    valid = ~g["in_mask"]
+    vis, lo, _, _ = enc(x, lang, torch.from_numpy(g["in_mask"]).to(dev), lang_valid_rows=int(valid.sum()))
+    assert enc._last_desc.packed_rows == cfg["B"] * cfg["Nv"] + int(valid.sum())
+    assert rel(vis, g["train_vis"]) < 1e-2 and rel(lo.detach().cpu().numpy()[valid], g["train_lang"][valid]) < 1e-2
+    ((vis * torch.from_numpy(g["cot_vis"]).to(dev)).sum() + (lo * torch.from_numpy(g["cot_lang"]).to(dev)).sum()).backward()
+    assert rel(x.grad, g["grad_x"]) < 2e-2 and rel(lang.grad, g["grad_lang"]) < 2e-2
+    for k, p in enc.named_parameters():
+        if "gradp/" + k in g:
+            assert rel(p.grad, g["gradp/" + k]) < 2e-2, k
+
+
+def test_packed_dropout_replay_against_oracle(dev):
+    """Dropout ON in the packed layout: row-indexed sites (patch, dropout1, FFN, dropout2) hash the PACKED row index, so their exported
+    masks are scattered back to the dense positions before the oracle replays them; the attention bitmask keeps sample-local
+    indices, which equal the dense ones under right padding."""
+    from oracle import fusion_oracle as O
+    from transfusion_amd import ops
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import SITE_PATCH, site_of
+    cfg = dict(B=3, Nv=24, Nl=40, d=64, h=4, L=2, mask_lens=[25, 40, 3], seed=78)
+    p_tok, p_patch = 0.15, 0.1
+    enc, params = build(cfg, dev, p_tok, p_patch)
+    enc.train()
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["mask_lens"])
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ld = torch.from_numpy(lang).to(dev).requires_grad_(True)
+    nvalid = int((~mask).sum())
+    vis, lo, _, _ = enc(xd, ld, torch.from_numpy(mask).to(dev), lang_valid_rows=nvalid)
+    ((vis * torch.from_numpy(gv).to(dev)).sum() + (lo * torch.from_numpy(gl).to(dev)).sum()).backward()
+    seed = enc._last_seed
+    B, Nv, Nl, d, H, L = cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], cfg["h"], cfg["L"]
+    S = Nv + Nl
+    Mp = B * Nv + nvalid
+    dp, ffp = 128, 128
+    # packed row -> (b, s): the visual rows, then the first len_b language tokens of each sample
+    rows = [(b, s) for b in range(B) for s in list(range(Nv)) + [Nv + j for j in range(cfg["mask_lens"][b])]]
+    assert len(rows) == Mp
+    bi = torch.tensor([r[0] for r in rows]); si = torch.tensor([r[1] for r in rows])
+
+    def scatter(flat, width, cols):
+        dense = torch.ones(B, S, cols)
+        dense[bi, si] = flat.view(Mp, width)[:, :cols].float()
+        return dense
+
+    mk = lambda n, p, site: ops.dropout_mask(n, p, seed, site, dev).cpu()
+    masks = {"patch": scatter(mk(Mp * dp, p_patch, SITE_PATCH), dp, d)[:, :Nv]}
+    for l in range(L):
+        pre = f"t_encoder.layers.{l}."
+        masks[pre + "attn"] = mk(B * H * S * S, p_tok, site_of(l, 1)).view(B, H, S, S).float()
+        masks[pre + "dropout1"] = scatter(mk(Mp * dp, p_tok, site_of(l, 2)), dp, d)
+        masks[pre + "dropout"] = scatter(mk(Mp * ffp, p_tok, site_of(l, 3)), ffp, 2 * d)
+        masks[pre + "dropout2"] = scatter(mk(Mp * dp, p_tok, site_of(l, 4)), dp, d)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    sd["pos_embedding_layer.pos_embedding"] = O.sin1d_table(8192, d)
+    xr, lr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(lang).requires_grad_(True)
+    v_ref, l_ref = O.encoder_forward(sd, xr, lr, torch.from_numpy(mask), H, L, masks=masks, token_dropout=p_tok, patch_dropout=p_patch)
+    ((v_ref * torch.from_numpy(gv)).sum() + (l_ref * torch.from_numpy(gl)).sum()).backward()
+    valid = ~mask
+    assert rel(vis, v_ref.detach()) < 1e-2
+    assert rel(lo.detach().cpu()[valid], l_ref.detach()[valid]) < 1e-2
+    assert rel(xd.grad, xr.grad) < 2e-2 and rel(ld.grad.cpu()[valid], lr.grad[valid]) < 2e-2
+    for k, p in enc.named_parameters():
+        if k in sd and sd[k].grad is not None:
+            assert rel(p.grad, sd[k].grad) < 2e-2, k
+
+
+def test_wrong_count_is_reported_and_harmless(dev):
+    """A ``lang_valid_rows`` that disagrees with the mask cannot fault (every address stays inside the dense-sized workspace); the
+    device-side self-check reports the mask's true row total."""
+    cfg = SHAPES["small"]
+    enc, _ = build(cfg, dev)
+    enc.eval()
+    x, lang, _, _, _ = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], None)
+    mask = masks_for("right", cfg["B"], cfg["Nl"], 3)
+    true_rows = cfg["B"] * cfg["Nv"] + int((~mask).sum())
+    t = lambda a: torch.from_numpy(a).to(dev)
+    with torch.no_grad():
+        enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()))
+        assert enc.packed_row_error() == 0
+        enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()) - 3)
+        assert enc.packed_row_error() == true_rows
+    with pytest.raises(ValueError):
+        enc(t(x), t(lang), t(mask), lang_valid_rows=cfg["B"] * cfg["Nl"] + 1)
+    enc.pack_tokens = False                                    # the switch: the count is then ignored
+    with torch.no_grad():
+        enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()))
+    assert enc._last_desc.packed_rows == 0
+
+
+def test_packed_full_size(dev):
+    """The benchmark's shape (B = 32 x [196 + 512] tokens, d = 768, 4 layers, lengths U{128..512}): packed == dense on the outputs
+    and on the gradients of one step, in training mode without dropout."""
+    cfg = dict(B=32, Nv=196, Nl=512, d=768, h=4, L=4, seed=5)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(cfg["B"], cfg["Nv"], cfg["d"], generator=g).numpy()
+    lang = torch.nn.functional.normalize(torch.randn(cfg["B"], cfg["Nl"], cfg["d"], generator=g), dim=-1).numpy()
+    lens = torch.randint(cfg["Nl"] // 4, cfg["Nl"] + 1, (cfg["B"],), generator=g)
+    mask = (torch.arange(cfg["Nl"]).view(1, -1) >= lens.view(-1, 1)).numpy()
+    gv = torch.randn(cfg["B"], cfg["Nv"], cfg["d"], generator=g).numpy()
+    gl = (torch.randn(cfg["B"], cfg["Nl"], cfg["d"], generator=g) * torch.from_numpy(~mask)[..., None]).numpy()
+    dense = run(enc, x, lang, mask, gv, gl, dev, packed=False)
+    packed = run(enc, x, lang, mask, gv, gl, dev, packed=True)
+    assert enc.packed_row_error() == 0
+    valid = torch.from_numpy(~mask)
+    assert rel(packed[0], dense[0]) < 2e-3 and rel(packed[1].cpu()[valid], dense[1].cpu()[valid]) < 2e-3
+    assert float(packed[1].cpu()[~valid].abs().max()) == 0.0
+    assert rel(packed[2], dense[2]) < 1e-2 and rel(packed[3].cpu()[valid], dense[3].cpu()[valid]) < 1e-2
+    for k in dense[4]:
+        assert rel(packed[4][k], dense[4][k]) < 1e-2, k

@@ -41,18 +41,23 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
+  // S / Sq stay the (maximum) lengths that index lse / the dropout rows and shape the grid; Sb / Sqb are THIS sample's row counts
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len, Sqb = a.q != nullptr ? Sq : Sb;
+  if ((logical % nqb) * 128 >= Sqb) return;            // packed batches: query blocks past the sample's end (workgroup-uniform)
   const u16* __restrict__ qkv = (const u16*)a.qkv;
   const size_t ld = a.ld_qkv;
   const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
-  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
-                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
-  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
-  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
+  const size_t qrow0 = a.q != nullptr ? (size_t)b * Sq : sr.row0;      // first row of this sample's queries (out / dout rows follow it)
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + qrow0 * ldq + (size_t)head * HDP
+                                    : qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + sr.row0 * ld + (size_t)(2 * a.H + head) * HDP;
 
   // Q^T B-operand fragments, resident in registers
   bf16x8 qf[G::KSTEPS];
   {
-    const int qr = min(q0 + (lane & 31), Sq - 1);
+    const int qr = min(q0 + (lane & 31), Sqb - 1);
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) qf[ks] = as_bf16x8(*(const u32x4*)(qbase + (size_t)qr * ldq + ks * 16 + 8 * h));
   }
@@ -65,27 +70,27 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sq - 1)) * SW : nullptr;
-  const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sq - 1) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sqb - 1)) * SW : nullptr;
+  const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sqb - 1) * SW : nullptr;
 
-  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
     // No register prefetch: the kernel stays under 256 VGPRs so that TWO workgroups share a CU (2 waves per SIMD)
     // and one's K/V staging overlaps the other's MFMA / softmax work.
     {
       TileRegs<64, HDP> kr;
-      kr.load(kbase, ld, kv0, S - 1, false, tid);
+      kr.load(kbase, ld, kv0, Sb - 1, false, tid);
       __syncthreads();                     // previous tile fully consumed
       kr.store(kt, tid);
-      kr.load(vbase, ld, kv0, S - 1, false, tid);
+      kr.load(vbase, ld, kv0, Sb - 1, false, tid);
       kr.store(vt, tid);
     }
     __syncthreads();
     const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
     // keys this lane's query may attend: not padded / out of range (wave-uniform ballot) and, with a block mask, not
     // blocked for this query (per lane).  Without a block mask nothing per-lane is computed outside the rare masked tile.
-    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long vall = key_bits(a.key_mask, b, Sb, kv0, lane);
     const unsigned long long blk = BLK ? brow[t] : 0ull;
     const bool masked_tile = vall != ~0ull || (BLK && __any(blk != 0ull));
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
-  if (qrow < Sq) {
-    u16* orow = (u16*)a.out + ((size_t)b * Sq + qrow) * a.ld_out + (size_t)head * HDP;
+  if (qrow < Sqb) {
+    u16* orow = (u16*)a.out + (qrow0 + qrow) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -183,17 +188,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);            // packed batches: see attn_fwd_kernel
+  const int Sb = sr.len, Sqb = a.q != nullptr ? Sq : Sb;
+  if ((logical % nqb) * 128 >= Sqb) return;
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
   const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
-  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
-                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
-  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
-  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
+  const size_t qrow0 = a.q != nullptr ? (size_t)b * Sq : sr.row0;
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + qrow0 * ldq + (size_t)head * HDP
+                                    : qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + sr.row0 * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + qrow0 * a.ld_dout + (size_t)head * HDP;
 
   const int qrow = q0 + (lane & 31);
-  const int qr = min(qrow, Sq - 1);
+  const int qr = min(qrow, Sqb - 1);
   bf16x8 qf[G::KSTEPS], dof[G::KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < G::KSTEPS; ++ks) {
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   // so read O the same way, reduce in registers + one cross-half exchange, and publish it for the dK/dV kernel
   float delta = 0.f;
   {
-    const u16* orow = (const u16*)a.out + ((size_t)b * Sq + qr) * a.ld_out + (size_t)head * HDP;
+    const u16* orow = (const u16*)a.out + (qrow0 + qr) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       float of[8], df[8];
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
     }
     delta += __shfl_xor(delta, 32, 64);
-    if (h == 0 && qrow < Sq) a.delta[(size_t)bh * Sq + qrow] = delta;
+    if (h == 0 && qrow < Sqb) a.delta[(size_t)bh * Sq + qrow] = delta;
   }
   f32x16 dq[G::DBLK];
 #pragma unroll
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + qr) * SW : nullptr;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
-  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
   // dQ needs Q, dO (B operands) and the dQ^T accumulator resident: > 256 registers, so this kernel runs one wave per
   // SIMD with the full 512-entry file and prefetches the next K/V tile into registers under the MFMA work instead.
   TileRegs<64, HDP> kr, vr;
@@ -240,11 +249,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
   unsigned long long dm_n = ~0ull, blk_n = 0ull;
   uint8_t km_n = 0;
   if (ntiles > 0) {
-    kr.load(kbase, ld, 0, S - 1, false, tid);
-    vr.load(vbase, ld, 0, S - 1, false, tid);
+    kr.load(kbase, ld, 0, Sb - 1, false, tid);
+    vr.load(vbase, ld, 0, Sb - 1, false, tid);
     if (a.drop_thr) dm_n = drow[0];
     if (brow) blk_n = brow[0];
-    if (kmrow) km_n = kmrow[min(lane, S - 1)];
+    if (kmrow) km_n = kmrow[min(lane, Sb - 1)];
   }
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
@@ -252,16 +261,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
     kr.store(kt, tid);
     vr.store(vt, tid);
     const unsigned long long dm = dm_n >> (4 * h);
-    const unsigned long long vlane = __ballot(kv0 + lane < S && km_n == 0) & ~blk_n;     // per query: valid and not blocked
+    const unsigned long long vlane = __ballot(kv0 + lane < Sb && km_n == 0) & ~blk_n;     // per query: valid and not blocked
     const bool all_valid = __all(vlane == ~0ull);
     const unsigned long long vbits = vlane >> (4 * h);
     __syncthreads();
     if (t + 1 < ntiles) {
-      kr.load(kbase, ld, kv0 + 64, S - 1, false, tid);
-      vr.load(vbase, ld, kv0 + 64, S - 1, false, tid);
+      kr.load(kbase, ld, kv0 + 64, Sb - 1, false, tid);
+      vr.load(vbase, ld, kv0 + 64, Sb - 1, false, tid);
       if (a.drop_thr) dm_n = drow[t + 1];
       if (brow) blk_n = brow[t + 1];
-      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, S - 1)];
+      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, Sb - 1)];
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -330,9 +339,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const TfAttnArgs a) {
       }
     }
   }
-  if (qrow < Sq) {
-    u16* orow = a.q != nullptr ? (u16*)a.dq + ((size_t)b * Sq + qrow) * a.ld_dq + (size_t)head * HDP
-                               : (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+  if (qrow < Sqb) {
+    u16* orow = a.q != nullptr ? (u16*)a.dq + (qrow0 + qrow) * a.ld_dq + (size_t)head * HDP
+                               : (u16*)a.dqkv + (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -404,20 +413,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * QB + wave * 16;
+  // S indexes lse / delta / the dropout rows and shapes the grid; Sb is THIS sample's row count (packed batches: TfAttnArgs.cu_rows)
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len;
+  if ((logical % nqb) * QB >= Sb) return;              // query blocks past the sample's end (workgroup-uniform)
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
-  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
-  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
-  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const u16* qbase = qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + sr.row0 * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + sr.row0 * a.ld_dout + (size_t)head * HDP;
 
   // the first K/V tile is requested before anything else: with one workgroup per CU nothing but this workgroup's own
   // instruction order overlaps the prologue's global round trips (tile, Q / dO / O rows, key-mask scan)
   TileRegs16<64, HDP, NT> kr, vr;
-  kr.load(kbase, ld, 0, S - 1, tid);
-  vr.load(vbase, ld, 0, S - 1, tid);
+  kr.load(kbase, ld, 0, Sb - 1, tid);
+  vr.load(vbase, ld, 0, Sb - 1, tid);
   const int qrow = q0 + n;
-  const int qr = min(qrow, S - 1);
+  const int qr = min(qrow, Sb - 1);
   bf16x8 qf[KS], dof[KS];          // B operands: query n, hd elements 32ks + 8g .. +7
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
   const float lse = a.lse[(size_t)bh * S + qr];
   float delta = 0.f;               // rowsum(dO . O): each lane group owns a quarter of the row
   {
-    const u16* orow = (const u16*)a.out + ((size_t)b * S + qr) * a.ld_out + (size_t)head * HDP;
+    const u16* orow = (const u16*)a.out + (sr.row0 + qr) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       float of[8], df[8];
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
-    if (g == 0 && qrow < S) a.delta[(size_t)bh * S + qrow] = delta;
+    if (g == 0 && qrow < Sb) a.delta[(size_t)bh * S + qrow] = delta;
   }
   f32x4 dq[DB];
 #pragma unroll
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
   const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + (32kb + 16t) * TSTR + 64 * (db>>1) + xe|xo
   const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
 
-  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
   const uint8_t* kmrow = a.key_mask ? a.key_mask + (size_t)b * S : nullptr;
   const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
   unsigned long long dm_n = ~0ull, blk_n = 0ull;
@@ -465,12 +478,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
   if (ntiles > 0) {
     if (a.drop_thr) dm_n = drow[0];
     if (brow) blk_n = brow[0];
-    if (kmrow) km_n = kmrow[min(lane, S - 1)];
+    if (kmrow) km_n = kmrow[min(lane, Sb - 1)];
     kr.store(smem, tid);
     vr.store(smem + 64 * TSTR, tid);
     if (ntiles > 1) {
-      kr.load(kbase, ld, 64, S - 1, tid);
-      vr.load(vbase, ld, 64, S - 1, tid);
+      kr.load(kbase, ld, 64, Sb - 1, tid);
+      vr.load(vbase, ld, 64, Sb - 1, tid);
     }
   }
   __syncthreads();
@@ -479,13 +492,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
     const unsigned char* kt = smem + (t & 1) * PAIR;
     const unsigned char* vt = kt + 64 * TSTR;
     const unsigned long long dm = dm_n >> (4 * g);
-    const unsigned long long vlane = __ballot(kv0 + lane < S && km_n == 0) & ~blk_n;
+    const unsigned long long vlane = __ballot(kv0 + lane < Sb && km_n == 0) & ~blk_n;
     const bool all_valid = __all(vlane == ~0ull);
     const unsigned long long vbits = vlane >> (4 * g);
     if (t + 1 < ntiles) {
       if (a.drop_thr) dm_n = drow[t + 1];
       if (brow) blk_n = brow[t + 1];
-      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, S - 1)];
+      if (kmrow) km_n = kmrow[min(kv0 + 64 + lane, Sb - 1)];
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -558,15 +571,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq16_kernel(const TfAttnA
         kr.store(nk, tid);
         vr.store(nk + 64 * TSTR, tid);
         if (t + 2 < ntiles) {
-          kr.load(kbase, ld, kv0 + 128, S - 1, tid);
-          vr.load(vbase, ld, kv0 + 128, S - 1, tid);
+          kr.load(kbase, ld, kv0 + 128, Sb - 1, tid);
+          vr.load(vbase, ld, kv0 + 128, Sb - 1, tid);
         }
       }
     }
     __syncthreads();
   }
-  if (qrow < S) {
-    u16* orow = (u16*)a.dqkv + ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+  if (qrow < Sb) {
+    u16* orow = (u16*)a.dqkv + (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
       u32x2 v;
@@ -599,18 +612,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   const int logical = xcd_remap(blockIdx.x, gridDim.x);          // key blocks of one (batch, head) share Q and dO: same XCD
   const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int key0 = (logical % nkb) * 128 + wave * 32;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);            // packed batches: see attn_fwd_kernel
+  const int Sb = sr.len, Sqb = a.q != nullptr ? Sq : Sb;
+  if ((logical % nkb) * 128 >= Sb) return;             // key blocks past the sample's end (workgroup-uniform)
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
   const size_t ldq = a.q != nullptr ? (size_t)a.ld_q : ld;
-  const u16* qbase = a.q != nullptr ? (const u16*)a.q + (size_t)b * Sq * ldq + (size_t)head * HDP
-                                    : qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
-  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
-  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
+  const size_t qrow0 = a.q != nullptr ? (size_t)b * Sq : sr.row0;
+  const u16* qbase = a.q != nullptr ? (const u16*)a.q + qrow0 * ldq + (size_t)head * HDP
+                                    : qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + sr.row0 * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + qrow0 * a.ld_dout + (size_t)head * HDP;
 
   const int key = key0 + (lane & 31);
-  const int kr_ = min(key, S - 1);
-  bool key_ok = key < S;
+  const int kr_ = min(key, Sb - 1);
+  bool key_ok = key < Sb;
   if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
   // K^T / V^T B-operand fragments (B[k = hd][col = key]) resident in registers
   bf16x8 kf[G::KSTEPS], vf[G::KSTEPS];
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
   // a key block that holds only padding receives exactly-zero dK / dV: skip its query loop
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (Sq + 31) / 32;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sqb + 31) / 32;
   TileRegs<32, HDP> qr, dr;
   // per-tile row scalars travel with the tile prefetch (one tile ahead, in registers): LSE / delta of row q0 + tid
   // (threads 0..31) and the keep-bit word of (row q0 + (lane & 31), this wave's 32 keys).  Loaded inside the loop body
@@ -642,16 +659,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   // LDS one iteration later -- arithmetic on them here would pull their vmcnt wait up to this point)
   auto prefetch_rows = [&](int q0n) {
     if (tid < 32) {
-      const int q = min(q0n + tid, Sq - 1);
+      const int q = min(q0n + tid, Sqb - 1);
       lse_n = a.lse[(size_t)bh * Sq + q];
       del_n = a.delta[(size_t)bh * Sq + q];
     }
-    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), Sq - 1) * dw_ld];
-    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), Sq - 1) * dw_ld];
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & 31), Sqb - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & 31), Sqb - 1) * dw_ld];
   };
   if (ntiles > 0) {
-    qr.load(qbase, ldq, 0, Sq - 1, false, tid);
-    dr.load(dobase, a.ld_dout, 0, Sq - 1, true, tid);       // rows >= Sq contribute nothing
+    qr.load(qbase, ldq, 0, Sqb - 1, false, tid);
+    dr.load(dobase, a.ld_dout, 0, Sqb - 1, true, tid);       // rows >= Sqb contribute nothing
     prefetch_rows(0);
   }
   for (int t = 0; t < ntiles; ++t) {
@@ -660,16 +677,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
     qr.store(qt, tid);
     dr.store(dot, tid);
     if (tid < 32) {
-      const bool in = q0 + tid < Sq;
+      const bool in = q0 + tid < Sqb;
       lse_s[tid] = in ? lse_n : 1.0e30f;                     // P = 0 for rows past the end
       del_s[tid] = in ? del_n : 0.f;
     }
-    if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < Sq) ? dw_n : 0u;
+    if (lane < 32) dw_s[wave * 32 + lane] = (!a.drop_thr || q0 + lane < Sqb) ? dw_n : 0u;
     if (BLK && lane < 32) bw_s[wave * 32 + lane] = bw_n;
     __syncthreads();
     if (t + 1 < ntiles) {
-      qr.load(qbase, ldq, q0 + 32, Sq - 1, false, tid);
-      dr.load(dobase, a.ld_dout, q0 + 32, Sq - 1, true, tid);
+      qr.load(qbase, ldq, q0 + 32, Sqb - 1, false, tid);
+      dr.load(dobase, a.ld_dout, q0 + 32, Sqb - 1, true, tid);
       prefetch_rows(q0 + 32);
     }
     f32x16 st, dp;
@@ -732,9 +749,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
     }
   }
-  if (key < S) {
-    u16* krow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
-    u16* vrow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+  if (key < Sb) {
+    u16* krow = (u16*)a.dqkv + (sr.row0 + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
+    u16* vrow = (u16*)a.dqkv + (sr.row0 + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
 #pragma unroll
     for (int d = 0; d < G::DBLK; ++d)
 #pragma unroll
@@ -772,19 +789,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int key0 = (logical % nkb) * 128 + wave * 16;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);            // packed batches: see attn_bwd_dq16_kernel
+  const int Sb = sr.len;
+  if ((logical % nkb) * 128 >= Sb) return;             // key blocks past the sample's end (workgroup-uniform)
   const size_t ld = a.ld_qkv;
   const u16* qkv = (const u16*)a.qkv;
-  const u16* qbase = qkv + (size_t)b * S * ld + (size_t)(0 * a.H + head) * HDP;
-  const u16* kbase = qkv + (size_t)b * S * ld + (size_t)(1 * a.H + head) * HDP;
-  const u16* vbase = qkv + (size_t)b * S * ld + (size_t)(2 * a.H + head) * HDP;
-  const u16* dobase = (const u16*)a.dout + (size_t)b * S * a.ld_dout + (size_t)head * HDP;
+  const u16* qbase = qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kbase = qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const u16* vbase = qkv + sr.row0 * ld + (size_t)(2 * a.H + head) * HDP;
+  const u16* dobase = (const u16*)a.dout + sr.row0 * a.ld_dout + (size_t)head * HDP;
 
   TileRegs16<QT, HDP, NT> qr, dr;
-  qr.load(qbase, ld, 0, S - 1, tid);
-  dr.load(dobase, a.ld_dout, 0, S - 1, tid, true);       // rows >= S contribute nothing
+  qr.load(qbase, ld, 0, Sb - 1, tid);
+  dr.load(dobase, a.ld_dout, 0, Sb - 1, tid, true);       // rows >= Sb contribute nothing
   const int key = key0 + n;
-  const int kr_ = min(key, S - 1);
-  bool key_ok = key < S;
+  const int kr_ = min(key, Sb - 1);
+  bool key_ok = key < Sb;
   if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
   bf16x8 kf[KS], vf[KS];           // B operands: key n, hd elements 32ks + 8g .. +7
 #pragma unroll
@@ -804,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + 16t * TSTR + 64 * (db>>1) + xe|xo
   const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
 
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (S + QT - 1) / QT;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sb + QT - 1) / QT;
   const int dw_ld = 2 * ((S + 63) / 64);
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
   const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
@@ -813,12 +833,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   // (RAW loaded values are carried; the row-validity selects happen when they are stored)
   auto prefetch_rows = [&](int q0n) {
     if (tid < QT) {
-      const int q = min(q0n + tid, S - 1);
+      const int q = min(q0n + tid, Sb - 1);
       lse_n = a.lse[(size_t)bh * S + q];
       del_n = a.delta[(size_t)bh * S + q];
     }
-    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & (QT - 1)), S - 1) * dw_ld];
-    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & (QT - 1)), S - 1) * dw_ld];
+    if (a.drop_thr) dw_n = dbits[(size_t)min(q0n + (lane & (QT - 1)), Sb - 1) * dw_ld];
+    if (BLK) bw_n = bbits[(size_t)min(q0n + (lane & (QT - 1)), Sb - 1) * dw_ld];
   };
   auto store_tile = [&](int q0s, int buf) {
     unsigned char* qt_w = smem + buf * PAIR;
@@ -827,19 +847,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     float* lse_w = (float*)(smem + 2 * PAIR + buf * ROWS_BYTES);
     unsigned* dw_w = (unsigned*)(lse_w + 2 * QT);
     if (tid < QT) {
-      const bool in = q0s + tid < S;
+      const bool in = q0s + tid < Sb;
       lse_w[tid] = in ? lse_n : 1.0e30f;                   // P = 0 for rows past the end
       lse_w[QT + tid] = in ? del_n : 0.f;
     }
-    if (lane < QT) dw_w[wave * QT + lane] = (!a.drop_thr || q0s + lane < S) ? dw_n : 0u;
+    if (lane < QT) dw_w[wave * QT + lane] = (!a.drop_thr || q0s + lane < Sb) ? dw_n : 0u;
     if (BLK && lane < QT) dw_w[8 * QT + wave * QT + lane] = bw_n;
   };
   if (ntiles > 0) {
     prefetch_rows(0);
     store_tile(0, 0);
     if (ntiles > 1) {
-      qr.load(qbase, ld, QT, S - 1, tid);
-      dr.load(dobase, a.ld_dout, QT, S - 1, tid, true);
+      qr.load(qbase, ld, QT, Sb - 1, tid);
+      dr.load(dobase, a.ld_dout, QT, Sb - 1, tid, true);
       prefetch_rows(QT);
     }
   }
@@ -886,8 +906,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     if (u == 0 && t + 1 < ntiles) {
       store_tile(q0 + QT, (t + 1) & 1);
       if (t + 2 < ntiles) {
-        qr.load(qbase, ld, q0 + 2 * QT, S - 1, tid);
-        dr.load(dobase, a.ld_dout, q0 + 2 * QT, S - 1, tid, true);
+        qr.load(qbase, ld, q0 + 2 * QT, Sb - 1, tid);
+        dr.load(dobase, a.ld_dout, q0 + 2 * QT, Sb - 1, tid, true);
         prefetch_rows(q0 + 2 * QT);
       }
     }
@@ -935,9 +955,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     }
     __syncthreads();
   }
-  if (key < S) {
-    u16* krow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
-    u16* vrow = (u16*)a.dqkv + ((size_t)b * S + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+  if (key < Sb) {
+    u16* krow = (u16*)a.dqkv + (sr.row0 + key) * a.ld_dqkv + (size_t)(1 * a.H + head) * HDP;
+    u16* vrow = (u16*)a.dqkv + (sr.row0 + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
       u32x2 v;
@@ -978,33 +998,48 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
   // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
   const double fl = 4.0 * a->B * a->H * (double)Sq * a->S * HDP;
   char nm[56];
-  const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
-  static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
-  (void)once_q16;
+  // The 16-row (two waves per SIMD) kernels exist for head dims <= 192 only: at 224 / 256 their resident fragments do not fit 256
+  // registers (70-177 spilled VGPRs), so those widths are not even instantiated and take the 32-row kernels (one wave per SIMD).
+  constexpr bool HAS16 = HDP <= 192;
   static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
-  if (part == 2) {
-  } else if (dq16 && HDP <= 192 && !cross) {
-    snprintf(nm, sizeof(nm), "attn_bwd_dq16_kernel<%d>", HDP);
-    TfTraceScope tr(nm, st, fl);
-    hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 8>), grid, dim3(512), lds_q16, st, *a);
-  } else {
+  static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
+  bool done_q = part == 2, done_kv = part == 1;
+  if constexpr (HAS16) {
+    constexpr int QT = TF_DKV16_QT;
+    const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
+    const size_t lds_kv16 = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT);
+    static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
+    static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+    static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
+    (void)once_q16; (void)once_kv16; (void)once_kv16b;
+    if (!done_q && dq16 && !cross) {
+      snprintf(nm, sizeof(nm), "attn_bwd_dq16_kernel<%d>", HDP);
+      TfTraceScope tr(nm, st, fl);
+      hipLaunchKernelGGL((attn_bwd_dq16_kernel<HDP, 8>), grid, dim3(512), lds_q16, st, *a);
+      done_q = true;
+    }
+    if (part == 1) return (int)hipGetLastError();
+    if (!done_kv && dkv16 && !cross) {
+      if (!done_q) {                                       // TF_ATTN_DQ16=0 with the 16-row dK / dV kernel: dQ (and delta) first
+        snprintf(nm, sizeof(nm), "attn_bwd_dq_kernel<%d>", HDP);
+        TfTraceScope tr(nm, st, fl);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
+        done_q = true;
+      }
+      snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
+      TfTraceScope tr(nm, st, fl);
+      if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT>), grid, dim3(512), lds_kv16, st, *a);
+      else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT>), grid, dim3(512), lds_kv16, st, *a);
+      done_kv = true;
+    }
+  }
+  if (!done_q) {
     snprintf(nm, sizeof(nm), "attn_bwd_dq_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
   }
-  static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
-  constexpr int QT = TF_DKV16_QT;
-  const size_t lds_kv16 = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT);
-  static const hipError_t once_kv16 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
-  static const hipError_t once_kv16b = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16);
-  (void)once_kv16; (void)once_kv16b;
   if (part == 1) return (int)hipGetLastError();
-  if (dkv16 && HDP <= 192 && !cross) {
-    snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d>", HDP);
-    TfTraceScope tr(nm, st, fl);
-    if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT>), grid, dim3(512), lds_kv16, st, *a);
-    else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT>), grid, dim3(512), lds_kv16, st, *a);
-  } else {
+  if (!done_kv) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, true>), grid, dim3(256), lds_kv, st, *a);
@@ -1019,6 +1054,7 @@ int check(const TfAttnArgs* a) {
   if ((long long)a->B * a->H * a->S * a->S >= (1ll << 32) && a->drop_thr) return -5;   // 32-bit dropout index space
   if (a->drop_thr && a->drop_bits == nullptr) return -6;
   if (a->q != nullptr && (a->Sq <= 0 || (a->ld_q % 8) || a->block_bits != nullptr)) return -7;   // cross attention: own query rows, no block mask
+  if (a->cu_rows != nullptr && (a->key_mask != nullptr || a->q != nullptr)) return -8;           // packed batches hold real tokens only
   return 0;
 }
 

@@ -75,6 +75,15 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Rows of sample b in the token-major tensors (qkv / out / dout / dqkv): the dense layout gives every sample S rows starting at
+// b * S; with packed batches (TfAttnArgs.cu_rows) sample b owns rows cu[b] .. cu[b+1]-1 and all of them are real tokens.
+struct SampleRows { size_t row0; int len; };
+__device__ __forceinline__ SampleRows sample_rows(const int* __restrict__ cu, int b, int S) {
+  if (cu == nullptr) return SampleRows{(size_t)b * S, S};
+  const int r0 = cu[b];
+  return SampleRows{(size_t)r0, cu[b + 1] - r0};
+}
+
 // 64-bit validity mask of keys kv0 .. kv0+63 (bit = key may be attended)
 __device__ __forceinline__ unsigned long long key_bits(const uint8_t* __restrict__ km, int b, int S, int kv0, int lane) {
   const int key = kv0 + lane;

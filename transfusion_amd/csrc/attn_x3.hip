@@ -92,17 +92,23 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
-  const size_t boff = (size_t)b * S * ld;
+  // S / Sq keep indexing lse / delta / the dropout rows and shaping the grid; Sb / Sqb are THIS sample's row counts and row0 its first
+  // row (packed batches: TfAttnArgs.cu_rows; dense: b * S and S)
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
   const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const int Sb = sr.len, Sqb = cross ? Sq : Sb;
+  if ((logical % nqb) * 128 >= Sqb) return;                     // query blocks past the sample's end (workgroup-uniform)
+  const size_t boff = sr.row0 * ld;
+  const size_t qrow0 = cross ? (size_t)b * Sq : sr.row0;        // first query row of this sample in q / out / dout / dq
   const size_t ldq = cross ? (size_t)a.ld_q : ld;
-  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  const size_t qoff = cross ? qrow0 * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
   cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
 
   bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS];
   {
-    const int qr = min(q0 + (lane & 31), Sq - 1);
+    const int qr = min(q0 + (lane & 31), Sqb - 1);
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       qf_h[ks] = as_bf16x8(*(const u32x4*)(q_h + (size_t)qr * ldq + ks * 16 + 8 * h));
@@ -118,22 +124,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
   const int SW = (S + 63) / 64;
-  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sq - 1)) * SW : nullptr;
-  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sq - 1) * SW : nullptr;
+  const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sqb - 1)) * SW : nullptr;
+  const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sqb - 1) * SW : nullptr;
 
-  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
     __syncthreads();                       // previous tile fully consumed
     if constexpr (HDP <= 192) {
-      stage_quad<64, HDP>(k_h, k_l, ld, false, kt_h, kt_l, v_h, v_l, ld, false, vt_h, vt_l, kv0, S - 1, tid);
+      stage_quad<64, HDP>(k_h, k_l, ld, false, kt_h, kt_l, v_h, v_l, ld, false, vt_h, vt_l, kv0, Sb - 1, tid);
     } else {                                 // head dim 224: four 64-row tiles in flight at once do not fit the register file
-      stage_pair<64, HDP>(k_h, k_l, ld, kv0, S - 1, false, kt_h, kt_l, tid);
-      stage_pair<64, HDP>(v_h, v_l, ld, kv0, S - 1, false, vt_h, vt_l, tid);
+      stage_pair<64, HDP>(k_h, k_l, ld, kv0, Sb - 1, false, kt_h, kt_l, tid);
+      stage_pair<64, HDP>(v_h, v_l, ld, kv0, Sb - 1, false, vt_h, vt_l, tid);
     }
     __syncthreads();
     const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
-    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long vall = key_bits(a.key_mask, b, Sb, kv0, lane);
     const unsigned long long blk = brow ? brow[t] : 0ull;
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
 
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
-  if (qrow < Sq) {
-    const size_t off = ((size_t)b * Sq + qrow) * a.ld_out + (size_t)head * HDP;
+  if (qrow < Sqb) {
+    const size_t off = (qrow0 + qrow) * a.ld_out + (size_t)head * HDP;
     u16* orow_h = (u16*)a.out + off;
     u16* orow_l = (u16*)a.out_lo + off;
 #pragma unroll
@@ -225,18 +231,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
   const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int q0 = (logical % nqb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
-  const size_t boff = (size_t)b * S * ld;
+  // S / Sq keep indexing lse / delta / the dropout rows and shaping the grid; Sb / Sqb are THIS sample's row counts and row0 its first
+  // row (packed batches: TfAttnArgs.cu_rows; dense: b * S and S)
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
   const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const int Sb = sr.len, Sqb = cross ? Sq : Sb;
+  if ((logical % nqb) * 128 >= Sqb) return;                     // query blocks past the sample's end (workgroup-uniform)
+  const size_t boff = sr.row0 * ld;
+  const size_t qrow0 = cross ? (size_t)b * Sq : sr.row0;        // first query row of this sample in q / out / dout / dq
   const size_t ldq = cross ? (size_t)a.ld_q : ld;
-  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  const size_t qoff = cross ? qrow0 * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
   cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
-  const size_t dooff = (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
+  const size_t dooff = qrow0 * a.ld_dout + (size_t)head * HDP;
   cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
 
   const int qrow = q0 + (lane & 31);
-  const int qr = min(qrow, Sq - 1);
+  const int qr = min(qrow, Sqb - 1);
   bf16x8 qf_h[G::KSTEPS], qf_l[G::KSTEPS], dof_h[G::KSTEPS], dof_l[G::KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < G::KSTEPS; ++ks) {
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
   const float lse = a.lse[(size_t)bh * Sq + qr];
   float delta = 0.f;                       // rowsum(dO . O) in fp32 from both planes of both tensors
   {
-    const size_t ooff = ((size_t)b * Sq + qr) * a.ld_out + (size_t)head * HDP;
+    const size_t ooff = (qrow0 + qr) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       float of[8], df[8];
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
       for (int e = 0; e < 8; ++e) delta = fmaf(of[e], df[e], delta);
     }
     delta += __shfl_xor(delta, 32, 64);
-    if (h == 0 && qrow < Sq) a.delta[(size_t)bh * Sq + qrow] = delta;
+    if (h == 0 && qrow < Sqb) a.delta[(size_t)bh * Sq + qrow] = delta;
   }
   f32x16 dq[G::DBLK];
 #pragma unroll
@@ -271,19 +283,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
   const unsigned long long* brow = a.block_bits ? (const unsigned long long*)a.block_bits + (size_t)qr * SW : nullptr;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
 
-  const int ntiles = (valid_key_limit(a.key_mask, b, S, lane) + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
     __syncthreads();
     if constexpr (HDP <= 192) {
-      stage_quad<64, HDP>(k_h, k_l, ld, false, kt_h, kt_l, v_h, v_l, ld, false, vt_h, vt_l, kv0, S - 1, tid);
+      stage_quad<64, HDP>(k_h, k_l, ld, false, kt_h, kt_l, v_h, v_l, ld, false, vt_h, vt_l, kv0, Sb - 1, tid);
     } else {                                 // head dim 224: four 64-row tiles in flight at once do not fit the register file
-      stage_pair<64, HDP>(k_h, k_l, ld, kv0, S - 1, false, kt_h, kt_l, tid);
-      stage_pair<64, HDP>(v_h, v_l, ld, kv0, S - 1, false, vt_h, vt_l, tid);
+      stage_pair<64, HDP>(k_h, k_l, ld, kv0, Sb - 1, false, kt_h, kt_l, tid);
+      stage_pair<64, HDP>(v_h, v_l, ld, kv0, Sb - 1, false, vt_h, vt_l, tid);
     }
     __syncthreads();
     const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
-    const unsigned long long vall = key_bits(a.key_mask, b, S, kv0, lane);
+    const unsigned long long vall = key_bits(a.key_mask, b, Sb, kv0, lane);
     const unsigned long long blk = brow ? brow[t] : 0ull;
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
 #pragma unroll 1                     // the two 32-key halves one after the other: interleaved by the unroller the kernel spills at head dim 192
@@ -314,8 +326,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
       }
     }
   }
-  if (qrow < Sq) {
-    const size_t off = cross ? ((size_t)b * Sq + qrow) * a.ld_dq + (size_t)head * HDP : ((size_t)b * S + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+  if (qrow < Sqb) {
+    const size_t off = cross ? (qrow0 + qrow) * a.ld_dq + (size_t)head * HDP : (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
     u16* r_h = (cross ? (u16*)a.dq : (u16*)a.dqkv) + off;
     u16* r_l = (cross ? (u16*)a.dq_lo : (u16*)a.dqkv_lo) + off;
 #pragma unroll
@@ -353,19 +365,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
   const int key0 = (logical % nkb) * 128 + wave * 32;
   const size_t ld = a.ld_qkv;
-  const size_t boff = (size_t)b * S * ld;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);            // packed batches: see attn_fwd_x3_kernel
   const bool cross = a.q != nullptr;                            // own query set (TfAttnArgs.q): Sq rows per (batch, head)
+  const int Sb = sr.len, Sqb = cross ? Sq : Sb;
+  if ((logical % nkb) * 128 >= Sb) return;                      // key blocks past the sample's end (workgroup-uniform)
+  const size_t boff = sr.row0 * ld;
+  const size_t qrow0 = cross ? (size_t)b * Sq : sr.row0;
   const size_t ldq = cross ? (size_t)a.ld_q : ld;
-  const size_t qoff = cross ? (size_t)b * Sq * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
+  const size_t qoff = cross ? qrow0 * ldq + (size_t)head * HDP : boff + (size_t)(0 * a.H + head) * HDP;
   cu16p q_h = (cross ? (const u16*)a.q : (const u16*)a.qkv) + qoff, q_l = (cross ? (const u16*)a.q_lo : (const u16*)a.qkv_lo) + qoff;
   cu16p k_h = (const u16*)a.qkv + boff + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + boff + (size_t)(1 * a.H + head) * HDP;
   cu16p v_h = (const u16*)a.qkv + boff + (size_t)(2 * a.H + head) * HDP, v_l = (const u16*)a.qkv_lo + boff + (size_t)(2 * a.H + head) * HDP;
-  const size_t dooff = (size_t)b * Sq * a.ld_dout + (size_t)head * HDP;
+  const size_t dooff = qrow0 * a.ld_dout + (size_t)head * HDP;
   cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
 
   const int key = key0 + (lane & 31);
-  const int kr_ = min(key, S - 1);
-  bool key_ok = key < S;
+  const int kr_ = min(key, Sb - 1);
+  bool key_ok = key < Sb;
   if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
   constexpr int NV = WHICH == 1 ? G::KSTEPS : 1;                  // V fragments are resident only in the dK launch
   bf16x8 kf_h[G::KSTEPS], kf_l[G::KSTEPS], vf_h[NV], vf_l[NV];
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const bool blk = a.block_bits != nullptr;
 
-  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, S, lane)) ? 0 : (Sq + 31) / 32;
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sqb + 31) / 32;
   const int dw_ld = 2 * ((S + 63) / 64);
   const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
   const unsigned* bbits = blk ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
@@ -395,8 +411,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   // in place they were a dependent global load between the two barriers of every block
   auto row_scalars = [&](int q0, float& r_lse, float& r_del, unsigned& r_dw, unsigned& r_bw) {
     const int row = q0 + (lane & 31);
-    const bool in = row < Sq;
-    const int q = min(row, Sq - 1);
+    const bool in = row < Sqb;
+    const int q = min(row, Sqb - 1);
     r_lse = in ? a.lse[(size_t)bh * Sq + q] : 1.0e30f;             // P = 0 for rows past the end
     r_del = in ? a.delta[(size_t)bh * Sq + q] : 0.f;
     r_dw = a.drop_thr ? (in ? dbits[(size_t)q * dw_ld] : 0u) : 0xffffffffu;
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = t * 32;
     __syncthreads();
-    stage_quad<32, HDP>(q_h, q_l, ldq, false, qt_h, qt_l, do_h, do_l, a.ld_dout, true, dot_h, dot_l, q0, Sq - 1, tid);   // dO rows >= Sq: zero
+    stage_quad<32, HDP>(q_h, q_l, ldq, false, qt_h, qt_l, do_h, do_l, a.ld_dout, true, dot_h, dot_l, q0, Sqb - 1, tid);   // dO rows >= Sqb: zero
     if (tid < 32) { lse_s[tid] = n_lse; del_s[tid] = n_del; }
     if (lane < 32) { dw_s[wave * 32 + lane] = n_dw; bw_s[wave * 32 + lane] = n_bw; }
     if (t + 1 < ntiles) row_scalars(q0 + 32, n_lse, n_del, n_dw, n_bw);
@@ -452,8 +468,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
         acc[d] = mfma3(tr_frag<HDP>(th, 16 * s2, d * 32, lane), tr_frag<HDP>(tl, 16 * s2, d * 32, lane), f_h, f_l, acc[d]);
     }
   }
-  if (key < S) {
-    const size_t off = ((size_t)b * S + key) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
+  if (key < Sb) {
+    const size_t off = (sr.row0 + key) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
     u16* r_h = (u16*)a.dqkv + off;
     u16* r_l = (u16*)a.dqkv_lo + off;
     const float osc = WHICH == 0 ? 1.0f : a.scale;

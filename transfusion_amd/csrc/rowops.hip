@@ -28,6 +28,12 @@ __device__ __forceinline__ void store8_any(void* base, size_t off, int is_f32, c
   else *(u32x4*)((u16*)base + off) = pack8(f);
 }
 __device__ __forceinline__ int map_row(int r, int rpg, int stride) { return (r / rpg) * stride + (r % rpg); }
+// x-side row of a LayerNorm launch: group g starts at row0[g] (packed batches: the visual rows of sample g) or at g * stride
+__device__ __forceinline__ int map_row_x(int r, int rpg, int stride, const int* __restrict__ row0) {
+  if (row0 == nullptr) return map_row(r, rpg, stride);
+  const int g = r / rpg;
+  return row0[g] + (r - g * rpg);
+}
 // bf16 tensor with a lo plane only in the SPLIT instantiation (fp32-accuracy mode): the bf16 instantiation carries no extra pointer,
 // branch or register (ln_bwd_kernel<2, 8> must stay at 126 VGPRs = 4 waves per SIMD)
 // (in the SPLIT instantiation a tensor may still come without its lo plane -- a caller-owned bf16 output or cotangent: null-checked there)
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.rows) return;
-  const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
+  const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
   const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
   float v[MAXC][8];
   float s = 0.f;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
 
   for (int row = blockIdx.x * LNB_WAVES + wave; row < a.rows; row += gridDim.x * LNB_WAVES) {
-    const int xr = map_row(row, a.rows_per_group, a.x_group_stride);
+    const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
     const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
     const float mean = a.mean[row], rstd = a.rstd[row];
     float xh[MAXC][8], g[MAXC][8];
@@ -194,8 +200,9 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.Nv + a.Nl;
   const int row = blockIdx.x * 4 + wave;
-  if (row >= a.B * S) return;
-  const int b = row / S, s = row - b * S;
+  if (row >= (a.row_map != nullptr ? a.rows : a.B * S)) return;
+  const int dense = a.row_map != nullptr ? a.row_map[row] : row;       // packed batches: the (sample, position) this row is gathered from
+  const int b = dense / S, s = dense - b * S;
   u16* out = (u16*)a.out + (size_t)row * a.ld_out;
   for (int c = lane * 8; c < a.ld_out; c += 512) {
     if (c >= a.d) {
@@ -238,8 +245,10 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
   for (int i = 0; i < MAXC; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kv[i][e] = 0.f; kl[i][e] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < a.B * S; row += gridDim.x * 4) {
-    const int b = row / S, s = row - b * S;
+  const int nrows = a.row_map != nullptr ? a.rows : a.B * S;
+  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+    const int dense = a.row_map != nullptr ? a.row_map[row] : row;
+    const int b = dense / S, s = dense - b * S;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = (lane + 64 * i) * 8;
@@ -375,14 +384,17 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const TfCopyRowsArgs a) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.rows) return;
-  const size_t sr = (size_t)map_row(row, a.src_rpg, a.src_gstride) * a.ld_src;
-  const size_t dr = (size_t)map_row(row, a.dst_rpg, a.dst_gstride) * a.ld_dst;
+  const int srow = a.src_row_map != nullptr ? a.src_row_map[row] : map_row_x(row, a.src_rpg, a.src_gstride, a.src_group_row0);
+  const int drow = a.dst_row_map != nullptr ? a.dst_row_map[row] : map_row_x(row, a.dst_rpg, a.dst_gstride, a.dst_group_row0);
+  if (drow < 0) return;                                       // wave-uniform: this row has no destination
+  const size_t sr = (size_t)(srow < 0 ? 0 : srow) * a.ld_src;
+  const size_t dr = (size_t)drow * a.ld_dst;
   const int width = a.dst_is_f32 ? a.cols : a.ld_dst;
   for (int c = lane * 8; c < width; c += 512) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (c < a.cols && a.src != nullptr) {
+    if (c < a.cols && a.src != nullptr && srow >= 0) {
       if (a.src_is_f32) load8_f32((const float*)a.src + sr + c, v);
       else load8_split(a.src, a.src_lo, sr + c, v);
     }
@@ -395,6 +407,51 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
     const int b = i / S, s = i - b * S;
     km[i] = (s < Nv || lm == nullptr) ? 0 : lm[b * Nl + s - Nv];
+  }
+}
+
+// Packed batches: which token rows take part.  lm [B, Nl] (1 = masked language token) ->
+//   cu[b]            first packed row of sample b (cu[B] = total): the Nv visual rows, then the un-masked language tokens in order
+//   dense_of[m]      b * S + s of packed row m
+//   packed_of_lang[b * Nl + j]   packed row of language token j of sample b, or -1 when it is masked
+// One workgroup (B is a few dozen samples of a few hundred tokens): a wave per sample counts, thread 0 scans the counts, a wave
+// per sample fills.  err[0] is set to the mask's total when it differs from the host's `expected` (tf_encoder_packed_error).
+__global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
+                                                       int* __restrict__ dense_of, int* __restrict__ packed_of_lang, int expected,
+                                                       int* __restrict__ err) {
+  extern __shared__ int cnt[];                                    // [B + 1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int S = Nv + Nl;
+  for (int b = wave; b < B; b += nw) {
+    int c = 0;
+    for (int j0 = 0; j0 < Nl; j0 += 64) {
+      const int j = j0 + lane;
+      const bool ok = j < Nl && (lm == nullptr || lm[(size_t)b * Nl + j] == 0);
+      c += __popcll(__ballot(ok));
+    }
+    if (lane == 0) cnt[b] = Nv + c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < B; ++b) { const int c = cnt[b]; cnt[b] = run; cu[b] = run; run += c; }
+    cnt[B] = run; cu[B] = run;
+    if (run != expected) err[0] = run;
+  }
+  __syncthreads();
+  for (int b = wave; b < B; b += nw) {
+    const int base = cnt[b];
+    for (int i = lane; i < Nv; i += 64) dense_of[base + i] = b * S + i;
+    int run = base + Nv;
+    for (int j0 = 0; j0 < Nl; j0 += 64) {
+      const int j = j0 + lane;
+      const bool ok = j < Nl && (lm == nullptr || lm[(size_t)b * Nl + j] == 0);
+      const unsigned long long m = __ballot(ok);
+      const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
+      if (ok) dense_of[pos] = b * S + Nv + j;
+      if (j < Nl) packed_of_lang[(size_t)b * Nl + j] = ok ? pos : -1;
+      run += __popcll(m);
+    }
   }
 }
 
@@ -857,16 +914,18 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
-  const int rows = a->B * (a->Nv + a->Nl);
+  const int rows = a->row_map != nullptr ? a->rows : a->B * (a->Nv + a->Nl);
   if (rows <= 0) return 0;
+  if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if ((a->d % 8) || (a->ld_out % 8) || (a->ld_vis % 8) || (a->ld_lang % 8)) return -2;
   TfTraceScope tr("assemble_fwd_kernel", st);
   hipLaunchKernelGGL(assemble_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
-  const int rows = a->B * (a->Nv + a->Nl);
+  const int rows = a->row_map != nullptr ? a->rows : a->B * (a->Nv + a->Nl);
   if (rows <= 0) return 0;
+  if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
   const dim3 grid(grid_for(rows, 4 * 8, 512));
   TfTraceScope tr("assemble_bwd_kernel", st, 0.0, 0.0);
@@ -899,6 +958,14 @@ extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   if ((a->cols % 8) || (a->ld_src % 8) || (a->ld_dst % 8)) return -2;
   TfTraceScope tr("copy_rows_kernel", st);
   hipLaunchKernelGGL(copy_rows_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* dense_of, int* packed_of_lang, int expected,
+                                 int* err, hipStream_t st) {
+  if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
+  if ((size_t)(B + 1) * sizeof(int) > 60000) return -2;          // the per-sample counts live in LDS
+  TfTraceScope tr("row_map_kernel", st);
+  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), (size_t)(B + 1) * sizeof(int), st, lm, B, Nv, Nl, cu, dense_of, packed_of_lang, expected, err);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {

@@ -42,14 +42,19 @@ uint64_t splitmix64(uint64_t x) {
 struct Dims {
   int B, Nv, Nl, d, H, L, ff;
   int S, M, hd, hdp, dp, ffp, nqkv, ldq;
+  int Md;           // B * S: token rows of the dense layout.  M = rows that take part: Md, or TfEncoderDesc.packed_rows (packed batches)
   int split;        // fp32-accuracy mode: every bf16 tensor of the workspace and of the weight shadows is a hi + lo plane pair
 };
-bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0) {
+bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0, int packed_rows = 0) {
   o->split = split ? 1 : 0;
   if (B <= 0 || Nv < 0 || Nl < 0 || Nv + Nl <= 0 || d <= 0 || H <= 0 || L <= 0 || L > TF_MAX_LAYERS || ff <= 0) return false;
   if (d % H != 0 || d % 8 != 0) return false;
   o->B = B; o->Nv = Nv; o->Nl = Nl; o->d = d; o->H = H; o->L = L; o->ff = ff;
-  o->S = Nv + Nl; o->M = B * o->S;
+  o->S = Nv + Nl; o->Md = B * o->S; o->M = o->Md;
+  if (packed_rows != 0) {                              // packed batches: every visual row and the un-masked language tokens
+    if (packed_rows < B * Nv || packed_rows > o->Md || packed_rows <= 0) return false;
+    o->M = packed_rows;
+  }
   o->hd = d / H;
   o->hdp = (int)up(o->hd, 32);
   if (o->hdp > 256) return false;
@@ -84,6 +89,7 @@ WOff make_woff(const Dims& D) {
 }
 struct AOff {   // byte offsets inside work
   size_t keymask, zeros, x0, x_stride;            // X[l] = x0 + l * x_stride, l = 0..L
+  size_t perr, cu, dense_of, pol;                 // packed batches: mismatch word, cu[B+1], dense_of[Md], packed_of_lang[B*Nl] (int32)
   size_t layer0, layer_stride;                    // per-layer block
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
@@ -97,8 +103,11 @@ AOff make_aoff(const Dims& D) {
   auto take2 = [&](size_t bytes) { size_t r = o; o += plane(bytes) * (size_t)(1 + D.split); return r; };      // bf16 tensor (+ lo plane)
   const size_t md = (size_t)D.M * D.dp * 2, mf = (size_t)D.M * D.ffp * 2, mq = (size_t)D.M * D.ldq * 2;
   const size_t st = (size_t)D.B * D.H * D.S * 4, mr = (size_t)D.M * 4;
+  // (everything up to x0 is sized by the DENSE shape: these offsets do not move with the packed row count)
   a.zeros = take(256);
-  a.keymask = take((size_t)D.M);
+  a.perr = take(256);
+  a.cu = take((size_t)(D.B + 1) * 4); a.dense_of = take((size_t)D.Md * 4); a.pol = take((size_t)D.B * (D.Nl > 0 ? D.Nl : 1) * 4);
+  a.keymask = take((size_t)D.Md);
   a.x0 = o; a.x_stride = plane(md) * (size_t)(1 + D.split); o += a.x_stride * (D.L + 1);
   a.layer0 = o;
   {
@@ -135,12 +144,16 @@ struct Ctx {
   // weight shadow [rows, ld] bf16 inside a layer's wpack block
   Buf wgt(const unsigned char* p, int rows, int ld) const { return Buf{p, lo(p, plane((size_t)rows * ld * 2)), ld}; }
   void* X(int l) const { return wk + A.x0 + (size_t)l * A.x_stride; }
+  bool packed() const { return e->packed_rows > 0; }
+  const int* cu() const { return packed() ? (const int*)(wk + A.cu) : nullptr; }                // first packed row of every sample
+  const int* dense_of() const { return packed() ? (const int*)(wk + A.dense_of) : nullptr; }    // packed row -> b * S + s
+  const int* pol() const { return packed() ? (const int*)(wk + A.pol) : nullptr; }              // language token (b, j) -> packed row or -1
   unsigned char* LB(int l) const { return wk + A.layer0 + (size_t)l * A.layer_stride; }
   unsigned char* WB(int l) const { return wp + (size_t)l * W.stride; }
 };
 bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
   if (e == nullptr || e->wpack == nullptr || e->work == nullptr) return false;
-  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision)) return false;
+  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision, e->packed_rows)) return false;
   if (e->precision != 0 && e->precision != 1) return false;
   if (e->precision && e->fp8_proj) return false;      // fp8 operands have no lo plane
   if (e->act != 0 && e->act != 1) return false;
@@ -479,13 +492,21 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   const Dims& D = c.D;
   if (e->vis == nullptr || e->lang == nullptr || e->vis_out == nullptr) return fail(-1, "tf_encoder_fwd(null io)");
   uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
-  TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
+  if (c.packed()) {
+    // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
+    TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
+                             e->packed_rows, (int*)(c.wk + c.A.perr), c.st), "row_map");
+    km = nullptr;
+  } else {
+    TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
+  }
   {
     TfAssembleArgs a{};
     const Buf x0 = c.act_d(c.X(0));
     a.vis = e->vis; a.vis_is_f32 = e->vis_is_f32; a.ld_vis = D.d; a.lang = e->lang; a.lang_is_f32 = e->lang_is_f32; a.ld_lang = D.d;
     a.pe = e->pe; a.pe_lang = e->pe_lang; a.kind_v = e->kind_v; a.kind_l = e->kind_l; a.out = (void*)x0.p; a.out_lo = (void*)x0.lo; a.ld_out = D.dp;
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
+    a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
@@ -528,7 +549,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     {
       TfAttnArgs a{};
       a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);
-      a.key_mask = km; a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      a.key_mask = km; a.cu_rows = c.cu(); a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
@@ -568,11 +589,11 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       TfLnArgs n{};
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
       n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
-      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
+      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f; n.x_group_row0 = c.cu();
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
     } else {
       TfCopyRowsArgs r{};
-      r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S;
+      r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S; r.src_group_row0 = c.cu();
       r.dst = e->vis_out; r.dst_is_f32 = e->vis_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nv; r.dst_gstride = D.Nv; r.rows = D.B * D.Nv; r.cols = D.d;
       TF_TRY(tf_launch_copy_rows(&r, c.st), "vis_copy");
     }
@@ -582,6 +603,9 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     const size_t lang_off = (size_t)D.Nv * D.dp * 2;
     r.src = (const unsigned char*)xl.p + lang_off; r.src_lo = xl.lo ? (const unsigned char*)xl.lo + lang_off : nullptr;
     r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nl; r.src_gstride = D.S;
+    if (c.packed()) {                   // language token (b, j) sits in packed row pol[b * Nl + j]; masked tokens (-1) get zero rows
+      r.src = xl.p; r.src_lo = xl.lo; r.src_row_map = c.pol();
+    }
     r.dst = e->lang_out; r.dst_is_f32 = e->lang_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nl; r.dst_gstride = D.Nl; r.rows = D.B * D.Nl; r.cols = D.d;
     TF_TRY(tf_launch_copy_rows(&r, c.st), "lang_copy");
   }
@@ -597,7 +621,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   const Buf dzb = c.act_d(c.wk + c.A.dzb), dyb = c.act_d(c.wk + c.A.dyb), du = c.act_f(c.wk + c.A.du), d_o = c.act_d(c.wk + c.A.d_o);
   const Buf dqkv = c.act_q(c.wk + c.A.dqkv);
   float* delta = (float*)(c.wk + c.A.delta);
-  const uint8_t* km = (const uint8_t*)(c.wk + c.A.keymask);
+  const uint8_t* km = c.packed() ? nullptr : (const uint8_t*)(c.wk + c.A.keymask);
   const int l_hi = e->bwd_nlayers > 0 ? e->bwd_hi : D.L - 1;
   const int l_lo = e->bwd_nlayers > 0 ? e->bwd_hi - e->bwd_nlayers + 1 : 0;
   if (l_hi >= D.L || l_lo < 0 || l_lo > l_hi) return fail(-1, "tf_encoder_bwd(layer range)");
@@ -614,6 +638,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Buf xl = c.act_d(c.X(D.L));
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
       n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
+      n.x_group_row0 = c.cu();
       n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = (void*)dxa.p; n.dx_lo = (void*)dxa.lo; n.lddx = D.dp;
       n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
@@ -621,6 +646,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TfCopyRowsArgs r{};
       r.src = e->d_vis_out; r.src_is_f32 = e->d_vis_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nv; r.src_gstride = D.Nv;
       r.dst = (void*)dxa.p; r.dst_lo = (void*)dxa.lo; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
+      r.dst_group_row0 = c.cu();
       TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
     }
   }
@@ -630,6 +656,9 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     r.src = e->d_lang_out; r.src_is_f32 = e->d_lang_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nl; r.src_gstride = D.Nl;
     r.dst = (unsigned char*)dxa.p + lang_off; r.dst_lo = dxa.lo ? (unsigned char*)dxa.lo + lang_off : nullptr;
     r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nl; r.dst_gstride = D.S; r.rows = D.B * D.Nl; r.cols = D.d;
+    if (c.packed()) {                   // the cotangents of masked tokens are dropped with their rows (TfEncoderDesc.packed_rows)
+      r.dst = (void*)dxa.p; r.dst_lo = (void*)dxa.lo; r.dst_row_map = c.pol();
+    }
     TF_TRY(tf_launch_copy_rows(&r, c.st), "dlang_copy");
   }
   const float scale = 1.0f / sqrtf((float)D.hd);
@@ -690,7 +719,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     {
       TfAttnArgs a{};
       a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);
-      a.key_mask = km; a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
+      a.key_mask = km; a.cu_rows = c.cu(); a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
@@ -727,6 +756,9 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa.p; a.dout_lo = dxa.lo; a.ld_dout = D.dp;
     a.dvis = e->d_vis; a.dvis_is_f32 = e->d_vis_is_f32; a.ld_dvis = D.d; a.dlang = e->d_lang; a.dlang_is_f32 = e->d_lang_is_f32; a.ld_dlang = D.d;
     a.dkind_v = e->g_kind_v; a.dkind_l = e->g_kind_l;
+    a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
+    if (c.packed() && e->d_lang != nullptr)          // rows of masked language tokens are not visited: their gradient is zero
+      TF_TRY((int)hipMemsetAsync(e->d_lang, 0, (size_t)D.B * D.Nl * D.d * (e->d_lang_is_f32 ? 4 : 2), c.st), "d_lang zero fill");
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_bwd(&a, c.st), "assemble_bwd");
@@ -739,6 +771,13 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (sd.pending[1]) { sd.pending[0] = false; TF_TRY(guard(c, sd, 1), "join"); }
   TF_TRY(guard(c, sd, 0), "join");
   if (sd.st != nullptr) e->overlap->pending = 0u;
+  return 0;
+}
+
+int tf_encoder_packed_error(const TfEncoderDesc* e, int* out, tf_stream_t s) {
+  Ctx c;
+  if (out == nullptr || !make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_packed_error");
+  TF_TRY((int)hipMemcpyAsync(out, c.wk + c.A.perr, sizeof(int), hipMemcpyDeviceToHost, c.st), "tf_encoder_packed_error");
   return 0;
 }
 

@@ -101,6 +101,7 @@ class _EncoderFn(torch.autograd.Function):
         L.call("tf_encoder_fwd", desc, st)
         desc.repack = 0
         ctx.mod, ctx.desc, ctx.keep, ctx.gen = mod, desc, keep, keep["gen"]
+        mod._last_desc = desc               # debug / test hooks (packed_row_error, peek)
         # per-call tensors the descriptor points at live on ctx (the workspace item may be recycled by a later forward)
         ctx.held = (keep["inputs"], keep.get("mask"), keep.get("block_bits"))
         ctx.io = (x.dtype, lang.dtype, x.requires_grad, lang.requires_grad)
@@ -216,6 +217,13 @@ class CrossTransformerModuleBox(nn.Module):
         # configs[2]): hi + lo bf16 planes, three MFMA passes per contraction (include/tfusion.h, TfEncoderDesc.precision)
         self.precision = os.environ.get("TF_PRECISION", "bf16")
         self.layer_grad_hook = None           # callable(module, layer): called as soon as that layer's gradients are enqueued
+        # Packed batches (TfEncoderDesc.packed_rows): when forward() is told how many language tokens the padding mask leaves
+        # (``lang_valid_rows``, a HOST integer -- the tokeniser / the length list that built the mask knows it), the masked tokens are
+        # dropped from every row-wise kernel instead of being carried through the GEMMs, LayerNorms and attention as dead rows.
+        # Their fused outputs come back as zeros (the reference multiplies them by the mask wherever it uses them, lm_layers.py:59-61)
+        # and cotangents on them are ignored; everything else equals the dense computation.  False: always dense.
+        self.pack_tokens = os.environ.get("TF_PACK_TOKENS", "1") != "0"
+        self._packed_rows = 0
         self._params_cache = None
         self._wpack = None
         self._wpack_versions = None
@@ -293,6 +301,7 @@ class CrossTransformerModuleBox(nn.Module):
         e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = B, Nv, Nl, d, self.num_heads, self.num_layers, self.dim_feedforward
         e.precision = 1 if self.precision == "fp32" else 0
         e.act = 1 if self.activ_f == "relu" else 0
+        e.packed_rows = 0                   # the plan is the dense one (an upper bound for every packed layout of this shape)
         plan = L.TfEncoderPlan()
         L.check(lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(plan)), "tf_encoder_plan_ex")
         if self._wpack is None or self._wpack.numel() != plan.wpack_bytes or self._wpack.device != x.device:
@@ -346,6 +355,11 @@ class CrossTransformerModuleBox(nn.Module):
                 self._pad_u8_cache = (pad_mask, pad_mask._version, m8)
             keep["mask"] = m8
             e.lang_pad_mask = m8.data_ptr()
+            pr = int(self._packed_rows)
+            if pr:
+                if not (B * Nv <= pr <= B * (Nv + Nl)):
+                    raise ValueError(f"lang_valid_rows: {pr - B * Nv} un-masked language tokens do not fit a [{B}, {Nl}] mask")
+                e.packed_rows = pr
         return e, keep
 
     @staticmethod
@@ -415,7 +429,10 @@ class CrossTransformerModuleBox(nn.Module):
         return grads, direct
 
     # ---- reference forward contract (cross_f_box_layers.py:69-108) --------------------------------------
-    def forward(self, x, language_tokens, language_tokens_att_maks, vis_tokens_mask=None):
+    def forward(self, x, language_tokens, language_tokens_att_maks, vis_tokens_mask=None, lang_valid_rows=None):
+        """Reference signature (cross_f_box_layers.py:69) plus one optional keyword: ``lang_valid_rows``, the number of language tokens
+        ``language_tokens_att_maks`` leaves un-masked in the whole batch, as a host integer.  When given (and ``pack_tokens``), the masked
+        tokens are dropped from the computation (see ``pack_tokens``); when absent the call is the reference's dense computation."""
         # learned / zero positional tables are Parameters: added here by torch so that autograd produces their gradient (the
         # kernel then adds nothing for that table); the default sin1d buffers go into the assemble kernel
         if isinstance(self.pos_embedding_layer.pos_embedding, nn.Parameter):
@@ -423,6 +440,9 @@ class CrossTransformerModuleBox(nn.Module):
         if self.lang_pos_embedding and isinstance(self.lang_pos_embedding.pos_embedding, nn.Parameter):
             # reference order (:76-78): (lang + kind) + pe; here (lang + pe) + kind -- the same sum up to fp32 rounding
             language_tokens = self.lang_pos_embedding(language_tokens)
+        self._packed_rows = 0
+        if lang_valid_rows is not None and language_tokens_att_maks is not None and self.pack_tokens:
+            self._packed_rows = x.shape[0] * x.shape[1] + int(lang_valid_rows)
         self._block_bits = None
         if vis_tokens_mask is not None:
             self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)
@@ -449,6 +469,15 @@ class CrossTransformerModuleBox(nn.Module):
         bits = words.contiguous().to(device)
         self._block_bits_cache = (vis_tokens_mask, key, bits)
         return bits
+
+    def packed_row_error(self, desc=None):
+        """Test / debug hook: 0 when the ``lang_valid_rows`` of every forward run on this descriptor's workspace (default: the last
+        forward's) agreed with its mask, otherwise the row total the mask gave (host sync)."""
+        desc = self._last_desc if desc is None else desc
+        out = (C.c_int * 1)(0)
+        L.check(L.load().tf_encoder_packed_error(C.byref(desc), out, C.c_void_p(ops._stream())), "tf_encoder_packed_error")
+        torch.cuda.current_stream().synchronize()
+        return int(out[0])
 
     def peek(self, desc_keep, name):
         """Test hook: copy an internal activation of the last forward out of the workspace (fp32)."""
