@@ -81,10 +81,19 @@ class _MaskedSquareLoss(torch.autograd.Function):
         return vis * (g * (2.0 * ctx.kv)), m * (g * (2.0 * km)), None, None      # valid is 0/1: d/dlo = 2 km lo valid^2 = 2 km m
 
 
+PACK_TOKENS = True      # --dense-rows turns it off: the masked language tokens then travel through every kernel as dead rows
+
+
+def _valid_rows(batch):
+    """Host-side count of un-masked language tokens of a batch (the lengths that built the mask): with it the encoder drops the masked
+    tokens from the computation (CrossTransformerModuleBox.pack_tokens)."""
+    return sum(batch[5]) if PACK_TOKENS else None
+
+
 def loss_fn(module, batch):
     """mean(vis^2) + mean(lang[valid]^2)."""
     x, lang, pad, valid, km = batch[:5]
-    vis, lo, _, _ = module(x, lang, pad)
+    vis, lo, _, _ = module(x, lang, pad, lang_valid_rows=_valid_rows(batch))
     return _MaskedSquareLoss.apply(vis, lo, valid, km)
 
 
@@ -96,8 +105,8 @@ class _EncoderWithHeads(torch.nn.Module):
         super().__init__()
         self.enc, self.heads, self.crit = enc, heads, crit
 
-    def forward(self, x, lang, pad):
-        return self.enc(x, lang, pad)
+    def forward(self, x, lang, pad, lang_valid_rows=None):
+        return self.enc(x, lang, pad, lang_valid_rows=lang_valid_rows)
 
 
 def make_heads_batch(B, device, rank, variant, rois_per_image=512, repr_size=1024, nouns=88, verbs=75):
@@ -116,7 +125,7 @@ def make_heads_batch(B, device, rank, variant, rois_per_image=512, repr_size=102
 
 def loss_fn_heads(module, batch):
     x, lang, pad, valid, km = batch[:5]
-    vis, lo, _, _ = module(x, lang, pad)
+    vis, lo, _, _ = module(x, lang, pad, lang_valid_rows=_valid_rows(batch))
     loss = _MaskedSquareLoss.apply(vis, lo, valid, km)
     feats, noun, verb, ttc, reg = batch[6]
     out = module.heads(feats)
@@ -411,10 +420,15 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
+    ap.add_argument("--dense-rows", action="store_true",
+                    help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
+                         "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
     ap.add_argument("--comm", choices=["torch", "rccl"], default=os.environ.get("TF_COMM", "torch"),
                     help="N > 1: gradient exchange through torch.distributed's process group (default) or the C ABI's own RCCL "
                          "communicator (tf_allreduce_bucket)")
     args = ap.parse_args()
+    global PACK_TOKENS
+    PACK_TOKENS = not args.dense_rows
 
     # a hang must end with a Python stack on stderr, not with the driver's silence timeout
     import faulthandler
@@ -482,8 +496,8 @@ def main():
     S = NV + NL
     train_flops_step = 3 * L * flops_per_sample_layer(S, D) * args.batch          # per GPU, dense S (padded tokens credited)
     # valid-token accounting (BASELINE.md section 3 / SURVEY.md 8d): only the Nv + len_b real tokens of each sample, averaged over
-    # the rotated batches.  The kernels do compute the padded query rows (their outputs are defined by the reference) and skip
-    # key tiles that hold only padding, so the executed work lies between the two figures.
+    # the rotated batches.  block_mfma_util credits the dense S (BASELINE.md's rule); with the masked tokens dropped (default) the
+    # kernels execute the valid-token figure, with --dense-rows something between the two (all-padding key tiles are skipped).
     valid_S = [[NV + n for n in b[5]] for b in batches]
     train_flops_valid = sum(3 * L * sum(flops_per_sample_layer(sb, D) for sb in vs) for vs in valid_S) / len(valid_S)
     attn_valid_ratio = sum(sum(sb * sb for sb in vs) for vs in valid_S) / (len(valid_S) * args.batch * S * S)
@@ -494,7 +508,8 @@ def main():
         "dtype": "fp32" if args.precision == "fp32" else ("fp8 projections + bf16" if os.environ.get("TF_FP8_PROJ") == "1" else "bf16"),
         "data": "synthetic",
         "config": {"workload": f"fusion-encoder{' + RoI heads and losses (512 RoIs / image)' if args.with_heads else ''} train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
-                               f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding",
+                               f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding"
+                               f"{' (masked tokens dropped from the row-wise kernels)' if PACK_TOKENS else ' (masked tokens carried as dead rows)'}",
                    "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "comm": args.comm if world > 1 else None},
         "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "block_tflops_per_gpu": round(train_flops_step / (ms * 1e-3) / 1e12, 1),

@@ -92,7 +92,9 @@ def test_packed_equals_dense(dev, shape, kind, precision):
     packed = run(enc, x, lang, mask, gv, gl, dev, packed=True)
     assert enc.packed_row_error() == 0
     valid = torch.from_numpy(~mask)
-    tol = 2e-3 if precision == "bf16" else 1e-5                # same arithmetic per row; only tile shapes / atomic orders differ
+    # right padding: the same arithmetic per row, only tile shapes / atomic orders differ.  A mask with holes compacts the keys, so the
+    # attention sums run over differently grouped key tiles (online-softmax order, bf16 rounding of P): bf16-level differences
+    tol = (2e-3 if kind != "holes" else 8e-3) if precision == "bf16" else 1e-5
     assert rel(packed[0], dense[0]) < tol
     assert rel(packed[1].cpu()[valid], dense[1].cpu()[valid]) < tol
     assert float(packed[1].cpu()[~valid].abs().max() if (~valid).any() else 0.0) == 0.0       # masked tokens: zero rows

@@ -54,7 +54,7 @@ def test_every_step_uses_the_updated_weights():
     # RAdam does not move the parameters in its first five (un-rectified) steps unless degenerated_to_sgd (radam_optim.py:64-84); with it
     # the first steps are lr * g -- large here, so that stale weights are unmistakable
     opt_cls = lambda params, lr, weight_decay: FusedRAdam(params, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
-    tr = FusionTrainStep(model, lr=0.5, weight_decay=0.0, grad_clip=None, optimizer_cls=opt_cls)
+    tr = FusionTrainStep(model, lr=10.0, weight_decay=0.0, grad_clip=None, optimizer_cls=opt_cls)
     feats = [torch.randn(4, C, 12, 12, generator=torch.Generator().manual_seed(50 + i)) for i in range(4)]
     first = {n: q.detach().clone() for n, q in model.named_parameters()}
 
@@ -75,8 +75,8 @@ def test_every_step_uses_the_updated_weights():
             assert rel(ho[k], r_ho[k]) < 2e-2, (step, k)
         if step > 0:
             # and the step DID move every weight far enough for a stale shadow to fail the checks above
-            moved = min(rel(sd[n], first[n].cpu()) for n in ("k1.weight", "layer.linear1.weight", "heads.noun_classifier.weight"))
-            assert moved > 3e-2, moved
+            moved = {n: rel(sd[n], first[n].cpu()) for n in ("k1.weight", "layer.linear1.weight", "heads.noun_classifier.weight")}
+            assert min(moved.values()) > 3e-2, moved
             o_tok, _, _ = _oracle_forward({n: v.cpu() for n, v in first.items()}, feats[step], H)
             assert rel(tok, o_tok) > 3e-2                   # ... i.e. the step-0 weights give a visibly different answer
         tr.step([feat], loss_fn)
