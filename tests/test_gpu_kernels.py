@@ -37,7 +37,9 @@ def gelu_grad(x):
 
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 768), (1000, 2304, 768), (77, 8, 64),
                                    (5000, 776, 192), (4100, 2304, 64), (22656, 768, 768),    # these three take the large-tile kernel
-                                   (9000, 2304, 128)])   # 63 x 9 = 567 tiles of 144 x 256: the two-workgroups-per-CU form, ragged last row tile
+                                   (9000, 2304, 128),    # 63 x 9 = 567 tiles of 144 x 256: the two-workgroups-per-CU form, ragged last row tile
+                                   # row counts of packed batches: the large tile's height follows the grid (160 / 192 / 224-row tiles, ragged tails)
+                                   (12010, 768, 192), (14003, 768, 128), (16519, 768, 192)])
 def test_gemm_epilogues(dev, M, N, K):
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
       // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
       constexpr int MM = FP8 ? 2 : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
-      constexpr int GAP = NWR == 2 ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
+      constexpr int GAP = (NWR == 2 && (4 * MF) / PER_WAVE > 7) ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
   #pragma unroll
       for (int q = 0; q < PER_WAVE; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, GAP * MM, 0);
@@ -1031,7 +1031,7 @@ template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, h
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
     hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a, 0, 0, 0);                 \
   } break;
-  if constexpr (!SPLIT) if (a->fp8) {
+  if constexpr (!SPLIT && MF >= 8) if (a->fp8) {          // fp8 operands: 256 / 288-row tiles only
     switch (a->epilogue) {
       TF_GEMM_CASE8(TF_EPI_NONE)
       TF_GEMM_CASE8(TF_EPI_BIAS)
@@ -1095,16 +1095,32 @@ int num_cus() {
   }
   return cus;
 }
-// large tile: rows 256 or 288, one workgroup per CU: minimise rounds x height
-int pick_mf(int M, int N) {
+// large tile: 160 .. 288 rows (MF = 5 .. 9), one workgroup per CU: minimise rounds x (height + the per-tile fixed cost, ~3 row
+// blocks' worth: fill, the C-tile burst).  The row count is whatever the batch's real tokens add up to (packed batches), so
+// the height that makes the tile grid an exact number of rounds changes from step to step; fp8 / fp32-accuracy operands keep 8 / 9.
+int pick_mf(int M, int N, int mf_lo = 5) {
   const int tn = (N + BIG_BN - 1) / BIG_BN, slots = num_cus();
-  int best = 8; long best_cost = -1;
-  for (int mf = 8; mf <= 9; ++mf) {
+  static const int env_lo = getenv("TF_GEMM_MF_MIN") ? atoi(getenv("TF_GEMM_MF_MIN")) : 0;      // experiment switch
+  if (env_lo > mf_lo) mf_lo = env_lo > 9 ? 9 : env_lo;
+  int best = 9; long best_cost = -1;
+  for (int mf = 9; mf >= mf_lo; --mf) {                 // ties go to the taller tile (fewer W re-stagings)
     const long tiles = (long)((M + 32 * mf - 1) / (32 * mf)) * tn;
-    const long cost = ((tiles + slots - 1) / slots) * mf;
+    const long cost = ((tiles + slots - 1) / slots) * (mf + 3);
     if (best_cost < 0 || cost < best_cost) { best = mf; best_cost = cost; }
   }
   return best;
+}
+template <bool SPLIT> int launch_gemm_big_mf(int mf, const TfGemmArgs* a, hipStream_t stream) {
+  if constexpr (SPLIT) return mf == 9 ? launch_gemm_big<9, true>(a, stream) : launch_gemm_big<8, true>(a, stream);
+  else {
+    switch (mf) {
+      case 5: return launch_gemm_big<5>(a, stream);
+      case 6: return launch_gemm_big<6>(a, stream);
+      case 7: return launch_gemm_big<7>(a, stream);
+      case 8: return launch_gemm_big<8>(a, stream);
+      default: return launch_gemm_big<9>(a, stream);
+    }
+  }
 }
 }  // namespace
 
@@ -1124,7 +1140,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   }
   if (a->fp8) {                                   // fp8 operands: large-tile kernel only (any shape; rows are clamped)
     if ((a->lda % 16) || (a->ldw % 16)) return -3;
-    const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    const int mf = pick_mf(a->M, a->N, 8);
     char nm[56];
     snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d, fp8>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
@@ -1136,11 +1152,11 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   // MI355X (large: 13.3 us + 26.4 us per 1000 K; 128-wide at two per CU: ~8 us + 21 us per 1000 K).
   bool use_big = big && a->M >= 1024 && a->N >= 256;
   if (use_big) {
-    const int mfp = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    const int mfp = pick_mf(a->M, a->N, split ? 8 : 5);
     const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
     const int mi = pick_mi(a->M, a->N);
     const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
-    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
+    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * ((mfp + 3) / 12.0);
     const double t_small = (double)((ts + 2 * num_cus() - 1) / (2 * num_cus())) * (8.0 + 0.021 * a->K) * (mi / 4.0);
     static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
     if (model && t_small < t_big) use_big = false;
@@ -1163,12 +1179,12 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     }
   }
   if (use_big) {
-    const int mf = pick_mf(a->M, a->N) == 9 ? 9 : 8;
+    const int mf = pick_mf(a->M, a->N, split ? 8 : 5);
     char nm[56];
     snprintf(nm, sizeof(nm), split ? "gemm_nt_big_kernel<%d, %d, x3>" : "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
-    if (split) return mf == 9 ? launch_gemm_big<9, true>(a, stream) : launch_gemm_big<8, true>(a, stream);
-    return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+    if (split) return launch_gemm_big_mf<true>(mf, a, stream);
+    return launch_gemm_big_mf<false>(mf, a, stream);
   }
   if (split) {                                     // one tile height in this mode (fewer instantiations)
     char nm[56];
