@@ -108,6 +108,10 @@ typedef struct TfAttnArgs {
   // S_b = cu_rows[b+1] - cu_rows[b] <= S keys and queries, all of them attended: key_mask and q must be null); lse / delta / drop_bits
   // keep their dense [B,H,S] row indexing with sample-local row numbers.  S stays the maximum length (grid and bitmask geometry).
   const int* cu_rows;                     // [B+1] int32 device array, or null: every sample has S rows starting at b*S
+  // Backward, optional workspace of tf_attn_ds_bytes(B, H, S) bytes.  With it (head dims <= 192, self attention) S and dP are computed
+  // ONCE: a small kernel forms delta, the dK / dV kernel writes its dS tiles here (bf16, one coalesced 1-KiB chunk per 16 keys x 32
+  // queries) and a thin kernel forms dQ = dS . K from them -- instead of a dQ kernel that recomputes S and dP.  null: the two-kernel form.
+  void* ds_work;
 } TfAttnArgs;
 
 
@@ -263,6 +267,8 @@ size_t tf_attn_dropmask_bytes(int B, int H, int S);
 int tf_attn_dropmask(void* bits, int B, int H, int S, uint32_t key, uint32_t thr, tf_stream_t s);
 /* cross attention (TfAttnArgs.q): nrows = B * H * Sq query rows of S key bits, [nrows, ceil(S/64)] u64 */
 int tf_attn_dropmask_rows(void* bits, long long nrows, int S, uint32_t key, uint32_t thr, tf_stream_t s);
+/* bytes of TfAttnArgs.ds_work for (B, H, S) */
+size_t tf_attn_ds_bytes(int B, int H, int S);
 
 /* ---- library ---- */
 int tf_version(void);

@@ -131,7 +131,10 @@ def _attn_ref(qkv, B, S, H, hd, hdp, key_mask, keep=None, p=0.0):
                                       # the padded 178 of Ego4Dv1, 160, 256 (one wave per SIMD forms), a batch of single-tile samples
                                       (3, 1, 2, 64), (2, 64, 1, 96), (1, 65, 2, 128), (2, 128, 3, 40), (1, 129, 8, 8), (1, 257, 4, 178),
                                       (2, 200, 1, 160), (1, 321, 2, 256), (5, 33, 4, 32)])
-def test_attention_fwd_bwd(dev, B, S, H, hd):
+@pytest.mark.parametrize("ds", [False, True])
+def test_attention_fwd_bwd(dev, B, S, H, hd, ds):
+    """``ds``: with TfAttnArgs.ds_work the backward is delta -> dK / dV (+ dS tiles) -> dQ = dS . K (S and dP computed once; head dims
+    <= 192), without it the dQ kernel recomputes them."""
     from transfusion_amd import _lib as L, ops
     hdp = (hd + 31) // 32 * 32
     g = torch.Generator().manual_seed(S + hd)
@@ -177,6 +180,8 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
         dqkv = torch.zeros(B * S, ldq, dtype=torch.bfloat16, device=dev)
         delta = torch.empty(B * H * S, device=dev)
         a.dout, a.ld_dout, a.dqkv, a.ld_dqkv, a.delta = L.ptr(do), ldo, L.ptr(dqkv), ldq, L.ptr(delta)
+        dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
+        a.ds_work = L.ptr(dsw)                 # NaN-filled: tiles the dK / dV kernel does not write must not reach a stored dQ row
         L.call("tf_attn_bwd", a, ops._stream())
         xr = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd].clone().requires_grad_(True)
         q, k, v = xr[:, :, 0].permute(0, 2, 1, 3), xr[:, :, 1].permute(0, 2, 1, 3), xr[:, :, 2].permute(0, 2, 1, 3)
@@ -196,6 +201,63 @@ def test_attention_fwd_bwd(dev, B, S, H, hd):
             assert (got - want).norm().item() < 1.5e-2 * want.norm().item() + floor, f"d{nm} p={p}"
         if hdp > hd:
             assert g_hip[..., hd:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("ds", [False, True])
+@pytest.mark.parametrize("lens,H,hd", [([150, 1, 64, 129], 2, 64), ([708, 324, 500], 4, 192), ([33, 70], 4, 18), ([0, 200, 17], 1, 128),
+                                       ([130, 260], 1, 224)])
+def test_attention_packed_rows(dev, lens, H, hd, ds):
+    """TfAttnArgs.cu_rows: sample b owns rows cu[b] .. cu[b+1]-1 of the token-major tensors (ragged batch, no key mask); lse / delta /
+    the dropout rows keep their dense [B, H, S] indexing.  Every sample against fp64 attention on its own rows, with dropout."""
+    from transfusion_amd import _lib as L, ops
+    B, S = len(lens), max(lens)
+    hdp = (hd + 31) // 32 * 32
+    M = sum(lens)
+    g = torch.Generator().manual_seed(M + hd)
+    ldq, ldo = (3 * H * hdp + 63) // 64 * 64, (H * hdp + 63) // 64 * 64
+    qkv = torch.zeros(M + 5, ldq)                            # a few spare rows behind the last sample
+    qkv[:M, : 3 * H * hdp].view(M, 3, H, hdp)[..., :hd] = torch.randn(M, 3, H, hd, generator=g)
+    qkv = bf(qkv).to(dev)
+    do = torch.zeros(M + 5, ldo)
+    do[:M, : H * hdp].view(M, H, hdp)[..., :hd] = torch.randn(M, H, hd, generator=g)
+    do = bf(do).to(dev)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(dev)
+    out = torch.zeros(M + 5, ldo, dtype=torch.bfloat16, device=dev)
+    dqkv = torch.zeros(M + 5, ldq, dtype=torch.bfloat16, device=dev)
+    lse, delta = torch.zeros(B * H * S, device=dev), torch.zeros(B * H * S, device=dev)
+    p, seed, site = 0.15, 7, 21
+    drop = ops.drop_params(p, seed, site)
+    bits = ops.attn_dropmask(B, H, S, p, seed, site, dev)
+    dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
+    a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hdp,
+                     scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=L.ptr(bits),
+                     dout=L.ptr(do), ld_dout=ldo, dqkv=L.ptr(dqkv), ld_dqkv=ldq, delta=L.ptr(delta), cu_rows=L.ptr(cu), ds_work=L.ptr(dsw))
+    L.call("tf_attn_fwd", a, ops._stream())
+    L.call("tf_attn_bwd", a, ops._stream())
+    torch.cuda.synchronize()
+    keep = ops.dropout_mask(B * H * S * S, p, seed, site, dev).view(B, H, S, S).double().cpu()
+    p_eff = 1.0 - 1.0 / drop[2]
+    assert float(out[M:].float().abs().max()) == 0 and float(dqkv[M:].float().abs().max()) == 0      # nothing written past the last sample
+    r0 = 0
+    for b, n in enumerate(lens):
+        if n == 0:
+            continue
+        x = qkv[r0:r0 + n, : 3 * H * hdp].double().cpu().view(n, 3, H, hdp)[..., :hd].clone().requires_grad_(True)
+        q, k, v = x[:, 0].permute(1, 0, 2), x[:, 1].permute(1, 0, 2), x[:, 2].permute(1, 0, 2)          # [H, n, hd]
+        sc = q @ k.transpose(-1, -2) / math.sqrt(hd)
+        Pr = torch.softmax(sc, -1) * keep[b, :, :n, :n] / (1 - p_eff)
+        o = (Pr @ v).permute(1, 0, 2)                                                                  # [n, H, hd]
+        o.backward(do[r0:r0 + n, : H * hdp].double().cpu().view(n, H, hdp)[..., :hd])
+        got_o = out[r0:r0 + n, : H * hdp].float().cpu().view(n, H, hdp)[..., :hd]
+        assert rel(got_o, o.detach()) < 8e-3, (b, "fwd")
+        lse_ref = torch.logsumexp(sc, -1).detach() / math.log(2.0)                                      # [H, n]
+        assert (lse.cpu().view(B, H, S)[b, :, :n].double() - lse_ref).abs().max() < 2e-2
+        got = dqkv[r0:r0 + n, : 3 * H * hdp].float().cpu().view(n, 3, H, hdp)[..., :hd].double()
+        for which, nm in enumerate("qkv"):
+            want = x.grad[:, which]
+            floor = (5e-3 if n == 1 else 1e-6) * want.numel() ** 0.5
+            assert (got[:, which] - want).norm().item() < 1.5e-2 * want.norm().item() + floor, (b, nm)
+        r0 += n
 
 
 def test_attention_online_softmax_rescale(dev):

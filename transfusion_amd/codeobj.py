@@ -103,7 +103,8 @@ def spilling(table: Dict[str, Dict[str, int]]) -> Dict[str, Dict[str, int]]:
 if __name__ == "__main__":
     import sys
     from transfusion_amd.build import LIB_PATH
-    t = kernel_table(sys.argv[1] if len(sys.argv) > 1 else LIB_PATH)
+    paths = [x for x in sys.argv[1:] if not x.startswith("-")]
+    t = kernel_table(paths[0] if paths else LIB_PATH)
     bad = spilling(t)
     print(f"{len(t)} kernels, {len(bad)} with spills / scratch")
     for k in sorted(t, key=lambda k: (-t[k]["vgpr_spill_count"], k)):

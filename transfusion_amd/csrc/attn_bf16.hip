@@ -775,7 +775,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 //   S[q][key] = Q.K^T -> P ;  dP = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
 //   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
 // ================================================================================================
-template <int HDP, bool BLK, int QT>     // QT query rows per LDS tile (32 or 64)
+// DS: the dS tile of every (16 keys of this wave) x (32-query sub-tile) is also written to TfAttnArgs.ds_work as one 1-KiB chunk, the lanes'
+// 16-B fragments side by side (a fully coalesced store of registers the kernel holds anyway), for attn_bwd_dq_ds_kernel -- which then
+// forms dQ = dS . K without recomputing S and dP.  Chunk (bh, kb16, qb32) lives at (((bh * nkb + kb16) * nqb + qb32) KiB; inside it the
+// fragment of lane (g, n) -- key n, queries 16 j + 4 g + i in element 4 j + i -- sits at byte 64 n + 16 g with its two 8-B halves swapped
+// when (n >> 2) is odd, which makes the consumer's transposed LDS reads bank-conflict free.
+__host__ __device__ inline int ds_nkb(int S) { return 8 * ((S + 127) / 128); }     // 16-key blocks per (batch, head): whole 128-key workgroups
+__host__ __device__ inline int ds_nqb(int S) { return 4 * ((S + 127) / 128); }     // 32-query blocks per (batch, head): whole 128-query workgroups
+
+template <int HDP, bool BLK, int QT, bool DS = false>     // QT query rows per LDS tile (32 or 64)
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   constexpr int NT = 512;
@@ -818,6 +826,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const float sc = a.scale * LOG2E;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const int kbit = (key0 & 16) + n;                       // this lane's key inside the 32-bit keep / block words
+  // DS: this wave's row of chunks (one per 32-query sub-tile), already offset to the lane's 16-B slot
+  unsigned char* ds_row = nullptr;
+  if constexpr (DS) ds_row = (unsigned char*)a.ds_work + (((size_t)bh * ds_nkb(S) + (key0 >> 4)) * ds_nqb(S)) * 1024 + 64 * n + 16 * g;
 
   const int rbase = n * TSTR + ((g ^ swz16(n)) << 4);                 // row read: + 16j * TSTR + 64 * ks
   const int q4 = n >> 2, p = n & 3, fz = swz16(4 * g);
@@ -929,6 +940,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
         dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], keep_scale, -d4[i]));   // dS
       }
     }
+    if constexpr (DS) {
+      const u32x4 v = __builtin_bit_cast(u32x4, dsf);
+      const bool swp = ((n >> 2) & 1) != 0;
+      const u32x4 w = {swp ? v[2] : v[0], swp ? v[3] : v[1], swp ? v[0] : v[2], swp ? v[1] : v[3]};
+      *(u32x4*)(ds_row + (size_t)(t * (QT / 32) + u) * 1024) = w;
+    }
     // phase C: dV^T += dO^T . Pd and dK^T += Q^T . dS; 2 * DB transposed fragments (2 reads each), AH fragments ahead
     {
       constexpr int NF = 2 * DB, AH = 4;
@@ -971,6 +988,141 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   }
 }
 
+// ================================================================================================
+// delta[b, h, q] = rowsum(dO . O) over the head's columns, one wave per token row (both tensors are read once, 16 B per lane)
+// ================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const TfAttnArgs a) {
+  __shared__ float part[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, nrb = (S + 3) / 4;
+  const int b = blockIdx.x / nrb, q = (blockIdx.x % nrb) * 4 + wave;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  if (q >= sr.len) return;                                 // (no barrier below: waves are independent)
+  const int cph = a.HDP / 8, nch = a.H * cph;             // 16-B chunks per head / per row (<= 256)
+  const u16* orow = (const u16*)a.out + (sr.row0 + q) * a.ld_out;
+  const u16* drow = (const u16*)a.dout + (sr.row0 + q) * a.ld_dout;
+  for (int c = lane; c < nch; c += 64) {
+    float of[8], df[8];
+    unpack8(*(const u32x4*)(orow + c * 8), of);
+    unpack8(*(const u32x4*)(drow + c * 8), df);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(of[e], df[e], s);
+    part[wave][c] = s;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes have landed (wave-private rows of `part`)
+  __builtin_amdgcn_wave_barrier();
+  if (lane < a.H) {
+    float s = 0.f;
+    for (int c = 0; c < cph; ++c) s += part[wave][lane * cph + c];
+    a.delta[((size_t)b * a.H + lane) * S + q] = s;
+  }
+}
+
+// ================================================================================================
+// backward, dQ from the dS tiles the dK / dV kernel wrote (attn_bwd_dkv16_kernel<.., DS = true>):
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q];  dQ = scale * dQ^T^T
+// One third of the matrix work of attn_bwd_dq16_kernel and none of its softmax: S and dP are computed once per layer.  4 waves x 32
+// queries per workgroup, two workgroups per CU; per 64-key tile the K tile is staged once for the workgroup (as in the dq16 kernel)
+// and every wave copies the four 1-KiB chunks of ITS 32 queries into a wave-private LDS region, from which ds_read_b64_tr_b16 hands
+// each lane (query n) the 8 keys of its B-operand fragment -- the transposition the chunk layout was built for.
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  constexpr int NT = 256, DB = HDP / 16, TSTR = G::TSTR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, n = lane & 15;
+  unsigned char* kt = smem;
+  unsigned char* dsw = smem + 64 * TSTR + wave * 4096;
+  const int S = a.S;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int qblk = logical % nqb;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len;
+  if (qblk * 128 >= Sb) return;                          // query blocks past the sample's end (workgroup-uniform)
+  const size_t ld = a.ld_qkv;
+  const u16* kbase = (const u16*)a.qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
+  const int qb32 = 4 * qblk + wave;
+  // the dK / dV kernel walks the queries in tiles of TF_DKV16_QT rows: sub-tiles at or beyond ceil(Sb / QT) * QT were never written --
+  // and hold no query of this sample, so a wave that owns one has nothing to compute (it still takes part in the barriers)
+  const bool active = qb32 * 32 < ((Sb + TF_DKV16_QT - 1) / TF_DKV16_QT) * TF_DKV16_QT;
+  const unsigned char* ds_col = (const unsigned char*)a.ds_work + (((size_t)bh * ds_nkb(S)) * ds_nqb(S) + qb32) * 1024 + 16 * lane;
+  const size_t ds_kstride = (size_t)ds_nqb(S) * 1024;     // from one 16-key block to the next
+
+  f32x4 dq[2][DB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) dq[j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane LDS addresses (as in attn_bwd_dq16_kernel): transposed K^T reads, and the chunk reads
+  const int q4 = n >> 2, p = n & 3, fz = swz16(4 * g);
+  const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);
+  const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
+  const int cbase = 64 * (4 * g + q4) + 16 * p;          // chunk row of key 4g + q4, the 16-B slot of the producer lanes that held queries 4p..4p+3
+
+  TileRegs16<64, HDP, NT> kr;
+  u32x4 cr[4];
+  if (ntiles > 0) {
+    kr.load(kbase, ld, 0, Sb - 1, tid);
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)c * ds_kstride);
+    }
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                                     // every wave is done with the previous K tile
+    kr.store(kt, tid);
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *(u32x4*)(dsw + c * 1024 + 16 * lane) = cr[c];
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      kr.load(kbase, ld, (t + 1) * 64, Sb - 1, tid);
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)(4 * (t + 1) + c) * ds_kstride);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        bf16x8 bfr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned char* ca = dsw + (2 * hh) * 1024 + cbase + 8 * (j ^ (g & 1));
+          bfr[j] = join_tr(lds_read_tr16(ca), lds_read_tr16(ca + 1024));
+        }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const unsigned char* tp = kt + tbase + (32 * hh) * TSTR + 64 * (d >> 1) + ((d & 1) ? xo : xe);
+          const bf16x8 af = join_tr(lds_read_tr16(tp), lds_read_tr16(tp + 16 * TSTR));
+          dq[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[0], dq[0][d], 0, 0, 0);
+          dq[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[1], dq[1][d], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qrow = qblk * 128 + wave * 32 + 16 * j + n;
+    if (qrow < Sb) {
+      u16* orow = (u16*)a.dqkv + (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        u32x2 v;
+        v[0] = pack2bf(dq[j][d][0] * a.scale, dq[j][d][1] * a.scale);
+        v[1] = pack2bf(dq[j][d][2] * a.scale, dq[j][d][3] * a.scale);
+        *(u32x2*)(orow + d * 16 + 4 * g) = v;
+      }
+    }
+  }
+}
+
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 128 * Geo<HDP>::TSTR;
   static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1006,6 +1158,31 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
   bool done_q = part == 2, done_kv = part == 1;
   if constexpr (HAS16) {
     constexpr int QT = TF_DKV16_QT;
+    static const int use_ds = [] { const char* e = getenv("TF_ATTN_DS"); return e ? atoi(e) : 1; }();     // A/B switch
+    if (part == 0 && use_ds && dq16 && dkv16 && !cross && a->ds_work != nullptr) {
+      // S and dP once: delta -> dK / dV (+ dS tiles) -> dQ = dS . K
+      const size_t lds_kv16d = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT), lds_qd = 64 * Geo<HDP>::TSTR + 4 * 4096;
+      static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+      static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+      static const hipError_t o3 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qd);
+      (void)o1; (void)o2; (void)o3;
+      {
+        TfTraceScope tr("attn_delta_kernel", st, 0.0, 4.0 * a->B * a->S * a->H * HDP);
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(a->B * ((a->S + 3) / 4)), dim3(256), 0, st, *a);
+      }
+      {
+        snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d, dS>", HDP);
+        TfTraceScope tr(nm, st, 1.5 * fl);                 // credited: dP, dV, dK (the S recompute is not)
+        if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
+      }
+      {
+        snprintf(nm, sizeof(nm), "attn_bwd_dq_ds_kernel<%d>", HDP);
+        TfTraceScope tr(nm, st, 0.5 * fl);
+        hipLaunchKernelGGL(attn_bwd_dq_ds_kernel<HDP>, grid, dim3(256), lds_qd, st, *a);
+      }
+      return (int)hipGetLastError();
+    }
     const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
     const size_t lds_kv16 = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT);
     static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
@@ -1047,6 +1224,13 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
   }
   return (int)hipGetLastError();
 }
+
+}  // namespace
+extern "C" size_t tf_attn_ds_bytes(int B, int H, int S) {
+  if (B <= 0 || H <= 0 || S <= 0) return 0;
+  return (size_t)B * H * ds_nkb(S) * ds_nqb(S) * 1024 + 4096;
+}
+namespace {
 
 int check(const TfAttnArgs* a) {
   if (a->B <= 0 || a->S <= 0 || a->H <= 0) return 1;

@@ -94,6 +94,7 @@ struct AOff {   // byte offsets inside work
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
   size_t dxa, dxb, dz, dy, dzb, dyb, du, d_o, dqkv, delta;
+  size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work), bf16 mode
   size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
   size_t total;
 };
@@ -124,6 +125,7 @@ AOff make_aoff(const Dims& D) {
   a.dxa = take2(md); a.dxb = take2(md); a.dz = take2(md); a.dy = take2(md); a.dzb = take2(md); a.dyb = take2(md); a.du = take2(mf); a.d_o = take2(md);
   a.dqkv = take2(mq);
   a.delta = take(st);
+  a.dsw = take(D.split ? 256 : tf_attn_ds_bytes(D.B, D.H, D.S));
   a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
   return a;
@@ -723,6 +725,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
+      a.ds_work = D.split ? nullptr : (void*)(c.wk + c.A.dsw);
       // TF_SPLIT_INPROJ (0 off, 1 last layer of the backward only, 2 every layer): the Q third of the in-proj weight gradient needs dQ
       // only, so it can start under the dK / dV kernel instead of after it -- which shortens the un-overlapped tail behind layer 0
       static const int split_inproj = getenv("TF_SPLIT_INPROJ") ? atoi(getenv("TF_SPLIT_INPROJ")) : 0;
