@@ -382,8 +382,8 @@ template <int ROWS, int HDP, int NT> struct TileRegs16 {
       const int id = i * NT + tid;
       if (TOTAL % NT == 0 || id < TOTAL) {
         const int r = id / (HDP / 8), c = id % (HDP / 8);
+        v[i] = *(const u32x4*)((const unsigned char*)base + ((unsigned)min(row0 + r, row_max) * (unsigned)(ld * 2) + (unsigned)(c * 16)));   // (see TileRegs::load)
         if (zero_fill && row0 + r > row_max) v[i] = u32x4{0, 0, 0, 0};
-        else v[i] = *(const u32x4*)(base + (size_t)min(row0 + r, row_max) * ld + c * 8);
       }
     }
   }

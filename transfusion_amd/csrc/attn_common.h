@@ -33,8 +33,13 @@ template <int ROWS, int HDP> struct TileRegs {
       if (TOTAL % 256 == 0 || id < TOTAL) {
         const int r = id / (HDP / 8), c = id % (HDP / 8);
         const int gr = row0 + r;
+        // wave-uniform base + a 32-bit per-lane byte offset (a sample's rows span far less than 4 GiB): one offset register per
+        // piece.  As 64-bit per-lane pointers the loop-invariant parts were hoisted out of the tile loop -- 2 x 6 pointer pairs at head
+        // dim 192 -- and spilled there (11-15 VGPRs in attn_fwd_kernel<192>).
+        // (branch-free: the clamped row is always fetched and a select zeroes it -- an exec-masked branch around every piece kept one
+        // loop-invariant offset register per piece alive and put a scratch reload + vmcnt(0) into the tile loop of the dK / dV kernels)
+        v[i] = *(const u32x4*)((const unsigned char*)base + ((unsigned)min(gr, row_max) * (unsigned)(ld * 2) + (unsigned)(c * 16)));
         if (zero_fill && gr > row_max) v[i] = u32x4{0, 0, 0, 0};
-        else v[i] = *(const u32x4*)(base + (size_t)min(gr, row_max) * ld + c * 8);
       }
     }
   }

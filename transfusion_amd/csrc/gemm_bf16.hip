@@ -871,11 +871,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
   const bool has_bias = g.db != nullptr;
   const int bias_mod = 2 * tiles_k;                            // k-tile blocks x wave columns share one n-range: take turns
   int bias_cnt = 2 * (tile % tiles_k) + wc;
-  bf16x8 sel[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sel[nb][e] = (((lane & 31) >> 3) == nb) ? (__bf16)1.0f : (__bf16)0.0f;
+  // (the selector operands of the bias MFMAs -- ones in rows 8 nb .. 8 nb + 7 -- are rebuilt where they are used, on the few steps
+  // in which this wave has the bias duty: kept resident, their 16 registers pushed the kernel one register past its 256 and into scratch)
+  const int sel_nb = (lane & 31) >> 3;
 
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
   const int h = grp >> 1, cb = grp & 1;
@@ -922,7 +920,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
       bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
       if (my_turn) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel[nb], af[nb], accb, 0, 0, 0);
+        for (int nb = 0; nb < 4; ++nb) {
+          const unsigned w = sel_nb == nb ? 0x3F803F80u : 0u;          // two bf16 ones
+          const u32x4 sv = {w, w, w, w};
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(sv), af[nb], accb, 0, 0, 0);
+        }
       }
     };
     // substep 0 may start when its 12 reads are back (the 12 of substep 1 still in flight)
@@ -1156,7 +1158,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
     const int mi = pick_mi(a->M, a->N);
     const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
-    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * ((mfp + 3) / 12.0);
+    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
     const double t_small = (double)((ts + 2 * num_cus() - 1) / (2 * num_cus())) * (8.0 + 0.021 * a->K) * (mi / 4.0);
     static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
     if (model && t_small < t_big) use_big = false;

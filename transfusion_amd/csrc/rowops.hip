@@ -898,8 +898,7 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->lddx % 8) || (a->lddy % 8)) return -2;
   const int width = max(a->d, max(a->lddx, a->dx_drop != nullptr ? a->lddxd : 0));
   if (width > 64 * MAXC_MAX * 8) return -2;
-  static const int env_w = getenv("TF_LNB_WAVES") ? atoi(getenv("TF_LNB_WAVES")) : 8;     // experiment switch: 16 waves measured slower (39.9 vs 38.3 us)
-  const int nw = (width <= 1024 && env_w == 16) ? 16 : 8;   // 16 waves where the reduction array fits the 64 KiB static LDS
+  constexpr int nw = 8;        // waves per workgroup (16 measured slower: 39.9 vs 38.3 us; its instantiations spilled and are gone)
   static const int env_g = getenv("TF_LNB_GRID") ? atoi(getenv("TF_LNB_GRID")) : 512;     // experiment switch
   const dim3 grid(grid_for(a->rows, nw * 2, env_g));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
   const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
@@ -907,8 +906,8 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   const dim3 block(64 * nw);
 #define TF_LNB(C, W) do { if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \
                           else hipLaunchKernelGGL((ln_bwd_kernel<C, W, false>), grid, block, 0, st, *a); } while (0)
-  if (width <= 512) { if (nw == 16) TF_LNB(1, 16); else TF_LNB(1, 8); }
-  else if (width <= 1024) { if (nw == 16) TF_LNB(2, 16); else TF_LNB(2, 8); }
+  if (width <= 512) TF_LNB(1, 8);
+  else if (width <= 1024) TF_LNB(2, 8);
   else TF_LNB(4, 8);
 #undef TF_LNB
   return (int)hipGetLastError();
