@@ -50,11 +50,13 @@ def make_encoder(device, d=D, h=H, layers=L, p_tok=P_TOKEN, p_patch=P_PATCH):
     return enc.to(device)
 
 
-def make_batch(B, device, rank, d=D, nv=NV, nl=NL, variant=0):
+def make_batch(B, device, rank, d=D, nv=NV, nl=NL, variant=0, padded=True):
     g = torch.Generator().manual_seed(42 + 1000 * rank + 77 * variant)
     x = torch.randn(B, nv, d, generator=g)
     lang = torch.nn.functional.normalize(torch.randn(B, nl, d, generator=g), dim=-1)     # SBERT normalize: True
     lens = torch.randint(nl // 4, nl + 1, (B,), generator=g)
+    if not padded:
+        lens = torch.full((B,), nl)                     # the no-padding variant
     pad = torch.arange(nl).view(1, -1) >= lens.view(-1, 1)                                # True = ignore
     valid = (~pad).unsqueeze(-1).float()                                                  # batch constants of the synthetic loss
     km = torch.tensor(1.0 / (float(valid.sum()) * d))
@@ -402,6 +404,73 @@ def allreduce_busbw(trainer, comm, reps=10):
                 note="all-reduce alone, back to back (not overlapped with the backward)")
 
 
+def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
+            steps=8, warmup=3, grad_clip=1.0):
+    """One more BASELINE configuration in the same process, after the headline: its own encoder, trainer and batches, `warmup` untimed +
+    `steps` timed training steps between barrier + sync pairs (the headline's protocol), max over ranks.  Returns the leg's numbers;
+    everything it allocated is released before the next leg."""
+    import gc
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    global PACK_TOKENS
+    saved = PACK_TOKENS
+    PACK_TOKENS = pack
+    obj = {}
+    try:
+        enc = make_encoder(device, d=d, h=h, layers=layers)
+        enc.precision = precision
+        enc.fp8_projections = bool(fp8)
+        enc.train()
+        obj["trainer"] = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=grad_clip)
+        obj["batches"] = [make_batch(batch, device, rank, d=d, nv=nv, nl=nl, variant=v, padded=padded) for v in range(2)]
+        del enc
+        last = {}
+
+        def step(i):
+            last["loss"] = obj["trainer"].step([obj["batches"][i % 2]], loss_fn)
+
+        for i in range(warmup):
+            step(i)
+        comm.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        comm.sync()
+        dt = comm.max(time.perf_counter() - t0) / steps
+        loss = float(last["loss"].item())
+        if not math.isfinite(loss):
+            raise SystemExit(f"leg {name}: non-finite loss {loss}")
+        S = nv + nl
+        fl = 3 * layers * flops_per_sample_layer(S, d) * batch                     # per GPU, dense S (BASELINE.md section 3)
+        # peak the leg is priced against: dense bf16 MFMA; a third of it in the fp32-accuracy mode (three bf16 passes per product).
+        # The fp8 leg runs its forward projections on fp8 operands and everything else in bf16: priced against the bf16 peak.
+        peak = PEAK_BF16_TFLOPS / 3.0 if precision == "fp32" else PEAK_BF16_TFLOPS
+        out = dict(ms_per_step=round(dt * 1e3, 3), samples_s=round(comm.world * batch / dt, 1), batch_per_gpu=batch, tokens=[nv, nl], d=d, heads=h,
+                   layers=layers, dtype="fp32" if precision == "fp32" else ("fp8 projections + bf16" if fp8 else "bf16"),
+                   block_tflops_per_gpu=round(fl / dt / 1e12, 1), block_mfma_util=round(fl / dt / 1e12 / peak, 4), peak_used=round(peak, 1),
+                   packed_rows=bool(pack), padded=bool(padded), steps=steps, warmup=warmup, final_loss=round(loss, 5))
+        if rank == 0:
+            log(f"  leg {name:10s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  {out['block_tflops_per_gpu']:7.1f} TFLOP/s/GPU "
+                f"({100 * out['block_mfma_util']:.1f} % of {peak:.0f})")
+        return out
+    finally:
+        PACK_TOKENS = saved
+        obj.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def csrc_hash():
+    """Hash of the kernel sources: profiles/traffic.json is stamped with the value it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "transfusion_amd", "csrc")
+    for fn in sorted(os.listdir(cs)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(cs, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,6 +489,7 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -479,13 +549,14 @@ def main():
 
     elapsed, rows = run_schedule(step, comm, rank, args.warmup, args.steps, 0 if args.no_census else args.trace_steps, traced_kernels)
     final_loss = float(last["loss"].item())
-    if world > 1 and os.environ.get("TF_CHECK_SYNC"):
+    if world > 1 and os.environ.get("TF_CHECK_SYNC", "1") != "0":
         # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
         mine = trainer.flat.flat.double().sum().reshape(1)
         lo, hi = mine.clone(), mine.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert lo.item() == hi.item(), (lo.item(), hi.item())
+        rank_sync = {"parameter_checksum": lo.item(), "identical_on_ranks": world}
         if rank == 0:
             log(f"  parameter checksum identical on {world} ranks: {lo.item():.6f}; overlap={'on' if trainer.layerwise is not None else 'off'}")
     if not math.isfinite(final_loss):
@@ -544,22 +615,24 @@ def main():
                 f"{'  [side stream]' if r['side_stream'] else ''}")
         log(f"  sum of kernel durations {total:.0f} us/step (streams overlap) vs measured step {ms * 1e3:.0f} us")
         dom = rows[0]                                            # the kernel symbol with the largest time per step
-        traffic = None
+        traffic, traffic_stale = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, measured offline
         if os.path.exists(tpath):
             table = json.load(open(tpath))
+            traffic_stale = table.get("_csrc_hash") != csrc_hash()  # measured on other kernel sources than the ones running now
             base = dom["kernel"].split("<")[0]                   # rocprofv3 prints template arguments the tracer's short names omit
             hit = table.get(dom["kernel"]) or next((v for k, v in table.items() if isinstance(v, dict) and k.split("<")[0] == base), {})
             traffic = hit.get("hbm_bytes_per_launch")
         if dom["tflops"] is not None:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": round(peak, 1),
-                                  "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
+                                  "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                                   "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                                   "algorithmic_flops_per_launch": dom["flops_per_launch"], "us_per_step": dom["us_per_step"],
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round((dom["gbs"] or 0.0) / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_us": dom["avg_us"],
+                                  "frac": round((dom["gbs"] or 0.0) / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
+                                  "avg_launch_us": dom["avg_us"],
                                   "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                                   "us_per_step": dom["us_per_step"],
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
@@ -570,6 +643,27 @@ def main():
         if args.isolated_census:
             census = kernel_census(args.batch, device)
             result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
+    if world > 1 and os.environ.get("TF_CHECK_SYNC", "1") != "0":
+        result["rank_sync"] = rank_sync
+    # ---- the other BASELINE configurations, in the same run (every rank takes part: each step holds the gradient collectives) ----
+    if not args.no_legs and not args.with_heads and args.precision == "bf16" and args.batch == 32:
+        legs = {}
+        if world == 1:
+            legs["fp32"] = run_leg("fp32", device, rank, comm, precision="fp32", steps=6, warmup=2)                                  # configs[2]
+            legs["stress"] = run_leg("stress", device, rank, comm, batch=8, d=1024, h=4, nv=784, nl=1024, steps=6, warmup=2)      # configs[3], 64 / 8 GPUs
+            legs["fp8"] = run_leg("fp8", device, rank, comm, fp8=True)                                                             # configs[4]
+            legs["b4"] = run_leg("b4", device, rank, comm, batch=4, steps=16, warmup=4)            # the reference's own per-GPU batch (32 / 8)
+            legs["b16"] = run_leg("b16", device, rank, comm, batch=16)                             # configs[1]: Ego4Dv1, batch 16, one GPU
+            legs["dense_rows"] = run_leg("dense_rows", device, rank, comm, pack=False)             # masked tokens carried as dead rows
+            legs["no_padding"] = run_leg("no_padding", device, rank, comm, padded=False)           # every sample 196 + 512 real tokens
+        else:
+            # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32
+            per = max(1, 32 // world)
+            strong = run_leg("strong", device, rank, comm, batch=per, steps=16, warmup=4)
+            result["strong"] = {"global_batch": per * world, "samples_s": strong["samples_s"], "ms_per_step": strong["ms_per_step"],
+                                "batch_per_gpu": per}
+        if legs:
+            result["legs"] = legs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()

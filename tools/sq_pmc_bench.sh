@@ -12,7 +12,7 @@ P2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTI
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $out/p$i -o t -- python /root/repo/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $out/p$i -o t -- python /root/repo/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline --no-legs "$@" > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
   echo "pass $i done"
 done
 python3 - $out <<'PY' > /root/repo/gpurun_out/sq_$tag.txt

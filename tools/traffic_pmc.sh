@@ -5,7 +5,7 @@
 out=/root/repo/gpurun_out/pmc_traffic
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o t -- python /root/repo/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline > $out.$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out.$c.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o t -- python /root/repo/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline --no-legs > $out.$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out.$c.log; exit 1; }
   echo "pass $c done"
 done
 python3 - $out <<'PY'
@@ -26,6 +26,9 @@ for k in acc["FETCH_SIZE"]:
     if n == 0 or cnt["WRITE_SIZE"][k] == 0: continue
     rd = 2.0 * acc["FETCH_SIZE"][k] / n * 1024; wr = acc["WRITE_SIZE"][k] / cnt["WRITE_SIZE"][k] * 1024
     res[k] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr), "launches_sampled": n}
+sys.path.insert(0, "/root/repo")
+import bench
+res["_csrc_hash"] = bench.csrc_hash()      # bench.py prints traffic_stale: true when the kernel sources have changed since
 res["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; bytes = (2*FETCH_SIZE + "
                "WRITE_SIZE)*1024 (gfx950 FETCH_SIZE tallies 64 B per 128-B request: MI355X_MICROARCH.md, HBM); mean over all launches of the symbol; "
                "counter mode serialises the kernels, so side-stream overlap does not mix their traffic")
