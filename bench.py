@@ -490,6 +490,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
+    ap.add_argument("--legs", default="fp32,stress,fp8,b4,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -649,13 +650,19 @@ def main():
     if not args.no_legs and not args.with_heads and args.precision == "bf16" and args.batch == 32:
         legs = {}
         if world == 1:
-            legs["fp32"] = run_leg("fp32", device, rank, comm, precision="fp32", steps=6, warmup=2)                                  # configs[2]
-            legs["stress"] = run_leg("stress", device, rank, comm, batch=8, d=1024, h=4, nv=784, nl=1024, steps=6, warmup=2)      # configs[3], 64 / 8 GPUs
-            legs["fp8"] = run_leg("fp8", device, rank, comm, fp8=True)                                                             # configs[4]
-            legs["b4"] = run_leg("b4", device, rank, comm, batch=4, steps=16, warmup=4)            # the reference's own per-GPU batch (32 / 8)
-            legs["b16"] = run_leg("b16", device, rank, comm, batch=16)                             # configs[1]: Ego4Dv1, batch 16, one GPU
-            legs["dense_rows"] = run_leg("dense_rows", device, rank, comm, pack=False)             # masked tokens carried as dead rows
-            legs["no_padding"] = run_leg("no_padding", device, rank, comm, padded=False)           # every sample 196 + 512 real tokens
+            specs = {
+                "fp32": dict(precision="fp32", steps=6, warmup=2),                                    # configs[2]: run.precision 32
+                "stress": dict(batch=8, d=1024, h=4, nv=784, nl=1024, steps=6, warmup=2),             # configs[3]: 64 samples / 8 GPUs
+                "fp8": dict(fp8=True),                                                                # configs[4]
+                "b4": dict(batch=4, steps=16, warmup=4),                                              # the reference's own per-GPU batch (32 / 8)
+                "b16": dict(batch=16),                                                                # configs[1]: Ego4Dv1, batch 16, one GPU
+                "dense_rows": dict(pack=False),                                                       # masked tokens carried as dead rows
+                "no_padding": dict(padded=False),                                                     # 196 + 512 real tokens each
+            }
+            for name in [n.strip() for n in args.legs.split(",") if n.strip()]:
+                if name not in specs:
+                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)})")
+                legs[name if name not in legs else f"{name}#{len(legs)}"] = run_leg(name, device, rank, comm, **specs[name])
         else:
             # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32
             per = max(1, 32 // world)

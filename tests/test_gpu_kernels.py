@@ -511,3 +511,29 @@ def test_gemm_fp8_operands(dev, M, N, K):
     ref = x.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
     assert rel(out, ref_q) < 6e-3
     assert rel(out, ref) < 6e-2
+
+
+def test_sumsq_is_a_pure_function_of_its_input(dev):
+    """tf_sumsq (global-norm clipping): the block partials are summed in index order by the last block to arrive -- no float atomics --
+    so repeated runs give the same BITS (data-parallel ranks holding the same reduced gradient then compute the same clip coefficient
+    and stay bit-identical), launches accumulate into `out`, and the value is the fp64 sum to fp32 accuracy."""
+    from transfusion_amd import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 1000, 18_912_000 + 3):
+        x = (torch.randn(n + 4, generator=g) * 3).to(dev)[4:] if n > 1000 else (torch.randn(n, generator=g) * 3).to(dev)
+        if x.data_ptr() % 16:
+            x = x.clone()
+        outs = []
+        for rep in range(6):
+            out = torch.zeros(1, device=dev)
+            L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(out), ops._stream()), "tf_sumsq")
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, outs[0]) for o in outs), [float(o) for o in outs]
+        ref = x.double().pow(2).sum().item()
+        assert abs(outs[0].item() - ref) <= 2e-6 * ref + 1e-30
+        acc = torch.zeros(1, device=dev)
+        for _ in range(3):
+            L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(acc), ops._stream()), "tf_sumsq")
+        assert abs(acc.item() - 3 * ref) <= 1e-5 * ref + 1e-30

@@ -5,6 +5,7 @@
 // wave-shuffle reduction with no LDS.
 #include "tf_common.h"
 #include "tf_kernels.h"
+#include <atomic>
 
 namespace {
 
@@ -532,7 +533,15 @@ __global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a) {
     }
   }
 }
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
+// sum(x^2), accumulated into out[0], with a result that is a pure function of (x, n): the block partials go to a scratch row and the
+// block that arrives LAST adds them in index order -- no float atomics, so two runs (and two data-parallel ranks holding the same
+// reduced gradient) get the same bits, the same clip coefficient and therefore identical parameters.  Scratch rows are handed out
+// round-robin by the launcher (16 rows: one optimiser step holds one).
+constexpr int SUMSQ_MAX_BLOCKS = 512, SUMSQ_SLOTS = 16;
+__device__ float g_sumsq_part[SUMSQ_SLOTS][SUMSQ_MAX_BLOCKS];
+__device__ unsigned g_sumsq_ticket[SUMSQ_SLOTS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out, int slot) {
   float s = 0.f;
   const long long n4 = n >> 2;                               // 16-B lanes over the aligned body, scalar tail
   const f32x4* x4 = (const f32x4*)x;
@@ -553,12 +562,31 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   }
   s += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
-  // one atomic per BLOCK: adds to a single address serialise at ~90 per microsecond chip-wide
   __shared__ float part[4];
+  __shared__ int is_last;
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&g_sumsq_part[slot][blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the release's write-back must be complete before the ticket: MI355X_MICROARCH.md)
+    const unsigned t = __hip_atomic_fetch_add(&g_sumsq_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // last arriver: every partial is visible behind an agent-scope acquire (this CU's L1 may hold an earlier launch's row)
+  if (threadIdx.x < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) t += __hip_atomic_load(&g_sumsq_part[slot][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+      out[0] += t;                                           // single writer; launches that share `out` are stream-ordered
+      __hip_atomic_store(&g_sumsq_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // K1 gather: cols[(b*Hp+hp)*Wp+wp][(c*ph+i)*pw+j] = feat[b][c][hp*ph+i][wp*pw+j]
@@ -1033,7 +1061,9 @@ extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStrea
   if (n <= 0) return 0;
   if (((size_t)x & 15) != 0) return -2;
   TfTraceScope tr("sumsq_kernel", st);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 32, 512)), dim3(256), 0, st, x, n, out);
+  static std::atomic<unsigned> next_slot{0};
+  const int slot = (int)(next_slot.fetch_add(1u) % SUMSQ_SLOTS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS)), dim3(256), 0, st, x, n, out, slot);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
