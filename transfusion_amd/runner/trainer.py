@@ -166,6 +166,203 @@ class LayerwiseReducer:
         self.handles = []
 
 
+class OrderedRangeReducer:
+    """Gradient all-reduce overlapped with the backward for ANY module tree -- the fusion wrapper's four encoders with their patch
+    embedding (K1) and back-projection (K9) GEMMs, an encoder with RoI heads, ... -- where ``LayerwiseReducer`` knows one bare encoder.
+
+    The flat gradient buffer is cut into contiguous UNITS: one per encoder layer of every module that offers a ``layer_grad_hook``
+    (final norm with its top layer, kind embeddings with layer 0), and one per remaining sub-module (``patches_to_token.2``,
+    ``tokens_to_features.0``, ``heads.box_regressor`` ...), whose parameters receive their gradients through autograd: a
+    post-accumulate hook per parameter counts the unit down.  A unit that is complete is all-reduced asynchronously behind a
+    communication stream that waits for the streams its gradients were produced on.
+
+    Every rank must issue the same collectives in the same order, whatever order its own backward happens to finish things in, so
+    units are FIRED IN A FIXED ORDER: the order in which they completed during the first optimiser step (which itself reduces the
+    whole buffer after its backward, un-overlapped), checked to be identical on all ranks; later steps fire unit k as soon as it and
+    all units before it are complete.  Units that never complete (a branch without gradient this step) are flushed by ``finish()``.
+    What the reference gets from torch DDP's bucket order (runner/run_experiment.py:444-446, 452)."""
+
+    joins_overlap = True
+
+    def __init__(self, flat: FlatParams, module: nn.Module, group=None, bucket_comm=None):
+        self.flat, self.group, self.bucket_comm = flat, group, bucket_comm
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bytes_per_step = flat.grad.numel() * 4
+        total = flat.grad.numel()
+        slice_of = {n: (off, num) for n, _, off, num in flat.slices}
+        params = {n: p for n, p, _, _ in flat.slices}
+        claimed = {}
+        self.units = []                      # {"key": str, "lo": int, "hi": int}
+        self._enc_units = {}                 # id(encoder module) -> {layer: unit index}
+        for prefix, m in module.named_modules():
+            if not hasattr(m, "layer_grad_hook"):
+                continue
+            pre = prefix + "." if prefix else ""
+            ends = {}
+            for n in slice_of:
+                if not n.startswith(pre):
+                    continue
+                toks = n[len(pre):].split(".")
+                layer = int(toks[toks.index("layers") + 1]) if "layers" in toks else None
+                key = layer if layer is not None else ("tail" if "final_norm" in n else "head")
+                off, num = slice_of[n]
+                lo, hi = ends.get(key, (off, off + num))
+                ends[key] = (min(lo, off), max(hi, off + num))
+                claimed[n] = True
+            layers = sorted(k for k in ends if isinstance(k, int))
+            if not layers:
+                continue
+            table = {}
+            for layer in layers:
+                lo, hi = ends[layer]
+                if layer == layers[-1] and "tail" in ends:
+                    lo, hi = min(lo, ends["tail"][0]), max(hi, ends["tail"][1])
+                if layer == layers[0] and "head" in ends:
+                    lo, hi = min(lo, ends["head"][0]), max(hi, ends["head"][1])
+                table[layer] = len(self.units)
+                self.units.append({"key": f"{pre}layer{layer}", "lo": lo, "hi": hi})
+            self._enc_units[id(m)] = table
+            m.layer_grad_hook = self._make_encoder_hook(id(m))
+        # everything else: one unit per owning sub-module (the parameter name without its last component)
+        self._pending_init, self._param_unit = {}, {}
+        by_owner = {}
+        for n, _, off, num in flat.slices:
+            if n in claimed:
+                continue
+            by_owner.setdefault(n.rsplit(".", 1)[0] if "." in n else n, []).append(n)
+        for owner, names in by_owner.items():
+            lo = min(slice_of[n][0] for n in names)
+            hi = max(sum(slice_of[n]) for n in names)
+            u = len(self.units)
+            self.units.append({"key": owner, "lo": lo, "hi": hi})
+            self._pending_init[u] = len(names)
+            for n in names:
+                self._param_unit[n] = u
+                params[n].register_post_accumulate_grad_hook(self._make_param_hook(u))
+        # the units must tile the flat buffer: alignment padding belongs to the unit in front of it
+        order = sorted(range(len(self.units)), key=lambda u: self.units[u]["lo"])
+        for a, b in zip(order, order[1:] + [None]):
+            nxt = total if b is None else self.units[b]["lo"]
+            if self.units[a]["hi"] > nxt:
+                raise ValueError(f"gradient units overlap: {self.units[a]} / {self.units[b]}")
+            self.units[a]["hi"] = nxt
+        if self.units[order[0]]["lo"] != 0:
+            raise ValueError("gradient units do not start at 0")
+        self.order = None                    # firing order, learnt in the first optimiser step
+        self.agreed = None                   # set after the first step: did every rank complete its units in the same order
+        self.active = True
+        self.collectives = 0
+        self.handles, self.comm = [], None
+        self._begin()
+
+    @property
+    def ranges(self):
+        """unit index -> (lo, hi) of the flat gradient buffer (the slices the collectives cover)"""
+        return {u: (unit["lo"], unit["hi"]) for u, unit in enumerate(self.units)}
+
+    # ---- per optimiser step ----
+    def _begin(self):
+        self._ready = [False] * len(self.units)
+        self._fired = [False] * len(self.units)
+        self._pending = dict(self._pending_init)
+        self._seen = []                      # completion order of this step (first step: becomes self.order)
+        self._next = 0
+
+    def _make_encoder_hook(self, enc_id):
+        def hook(mod, layer):
+            self._complete(self._enc_units[enc_id][layer])
+        hook.__self__ = self                 # (the encoder's backward asks its hook's owner whether it joins the side stream)
+        return hook
+
+    def _make_param_hook(self, u):
+        def hook(param):
+            if not self.active:
+                return
+            self._pending[u] -= 1
+            if self._pending[u] == 0:
+                self._complete(u)
+        return hook
+
+    def _complete(self, u):
+        if self.world == 1 or not self.active or self._ready[u]:
+            return
+        self._ready[u] = True
+        self._seen.append(u)
+        g = self.flat.grad
+        if g.is_cuda:                        # where this unit's gradients were produced: the current stream and its wgrad side stream
+            from transfusion_amd import ops
+            main = torch.cuda.current_stream(g.device)
+            side = ops.side_stream(g.device)
+            self.units[u]["events"] = [main.record_event()] + ([side.record_event()] if side is not None else [])
+        if self.order is None:
+            return                           # first step: learn the order, reduce everything in finish()
+        while self._next < len(self.order) and self._ready[self.order[self._next]]:
+            self._fire(self.order[self._next])
+            self._next += 1
+
+    def _fire(self, u):
+        unit = self.units[u]
+        g = self.flat.grad[unit["lo"]:unit["hi"]]
+        self._fired[u] = True
+        self.collectives += 1
+        if not g.is_cuda:
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=g.device)
+        for ev in unit.pop("events", []):
+            self.comm.wait_event(ev)
+        if self.bucket_comm is not None:
+            self.bucket_comm.all_reduce_(g, stream=self.comm)
+            return
+        with torch.cuda.stream(self.comm):
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        g = self.flat.grad
+        if g.is_cuda:
+            from transfusion_amd import ops
+            ops.join_overlap(g.device)
+        if self.world > 1:
+            if self.order is None:
+                # first step: everything at once, then agree on the order (identical on every rank, or no overlap at all)
+                if g.is_cuda:                # ... behind every stream a unit's gradients came from (level streams and their side streams)
+                    cur = torch.cuda.current_stream(g.device)
+                    for unit in self.units:
+                        for ev in unit.pop("events", []):
+                            cur.wait_event(ev)
+                self.collectives += 1
+                if self.bucket_comm is not None:
+                    self.bucket_comm.all_reduce_(g)
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                mine = self._seen + [u for u in range(len(self.units)) if u not in self._seen]
+                orders = [None] * self.world
+                dist.all_gather_object(orders, mine, group=self.group)
+                self.order = mine if all(o == orders[0] for o in orders) else []
+                self.agreed = bool(self.order)   # False: the ranks disagree -- keep reducing after the backward (one collective), never overlap
+            else:
+                if g.is_cuda:                # units flushed here were produced on streams the current one has already joined
+                    ev = torch.cuda.current_stream(g.device).record_event()
+                if not self.order:           # no agreed order: one collective over the whole buffer
+                    self.collectives += 1
+                    if self.bucket_comm is not None:
+                        self.bucket_comm.all_reduce_(g)
+                    else:
+                        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    for u in self.order[self._next:]:
+                        if g.is_cuda:
+                            self.units[u].setdefault("events", []).append(ev)
+                        self._fire(u)
+                for h in self.handles:
+                    h.wait()
+                if self.comm is not None:
+                    torch.cuda.current_stream(g.device).wait_stream(self.comm)
+        self.handles = []
+        self._begin()
+
+
 class FusionTrainStep:
     """One optimiser step over ``accumulate`` micro-batches for a module that writes into ``p.grad`` directly."""
 
@@ -196,6 +393,9 @@ class FusionTrainStep:
         if overlap and (self.world > 1 or force) and len(encoders) == 1 and encoders[0] is module:
             self.layerwise = LayerwiseReducer(self.flat, bucket_comm=self.bucket_comm)
             module.layer_grad_hook = self.layerwise.hook
+        elif overlap and (self.world > 1 or force):
+            # any other module tree (the 4-level wrapper, encoder + heads, ...): units fired in a learnt, rank-agreed order
+            self.layerwise = OrderedRangeReducer(self.flat, module, bucket_comm=self.bucket_comm)
         self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
         self.accumulate = accumulate
