@@ -39,7 +39,9 @@ def gelu_grad(x):
                                    (5000, 776, 192), (4100, 2304, 64), (22656, 768, 768),    # these three take the large-tile kernel
                                    (9000, 2304, 128),    # 63 x 9 = 567 tiles of 144 x 256: the two-workgroups-per-CU form, ragged last row tile
                                    # row counts of packed batches: the large tile's height follows the grid (160 / 192 / 224-row tiles, ragged tails)
-                                   (12010, 768, 192), (14003, 768, 128), (16519, 768, 192)])
+                                   (12010, 768, 192), (14003, 768, 128), (16519, 768, 192),
+                                   # small row counts (the reference's per-GPU batch of 4): 64- and 96-row tiles of the 128-wide kernel
+                                   (2070, 768, 128), (2833, 1536, 64), (3011, 768, 192)])
 def test_gemm_epilogues(dev, M, N, K):
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)

@@ -1000,15 +1000,22 @@ template <int MI, int BK, bool SPLIT = false> int launch_gemm_mi(const TfGemmArg
   return (int)hipGetLastError();
 }
 int num_cus();
-// tile-height choice: minimise rounds(over 2 workgroups x #CUs) x height; ties go to the smaller tile
+// tile-height choice: minimise rounds(over 2 workgroups x #CUs) x (height + per-tile fixed cost, ~2 row blocks' worth); ties go to
+// the taller tile.  64- and 96-row tiles (MI = 2, 3) exist for SMALL row counts -- the reference's own per-GPU batch of 4 - 5 samples is
+// ~2,000 - 3,500 token rows, where a 128-row tiling of an N = 768 GEMM is ~100 - 170 tiles for 512 slots.
 int pick_mi(int M, int N) {
   const int slots = 2 * num_cus();
   const int tn = (N + BN - 1) / BN;
-  int best = 4; long best_cost = -1;
-  for (int mi = 4; mi <= 6; ++mi) {
+  static const int env_lo = getenv("TF_GEMM_MI_MIN") ? atoi(getenv("TF_GEMM_MI_MIN")) : 2;       // experiment switch
+  // half-filled chips: the time is one tile's, so the shortest tile that still leaves every CU at most one workgroup wins
+  int best = 6; double best_cost = -1.0;
+  for (int mi = 6; mi >= (env_lo < 2 ? 2 : env_lo); --mi) {
     const long tiles = (long)((M + 32 * mi - 1) / (32 * mi)) * tn;
-    const long cost = ((tiles + slots - 1) / slots) * mi;
-    if (best_cost < 0 || cost < best_cost) { best = mi; best_cost = cost; }
+    const long rounds = (tiles + slots - 1) / slots;
+    // two workgroups share a CU: a round in which at most half the slots are taken runs each workgroup alone on its CU (~1.6x as fast)
+    const double share = (tiles - (rounds - 1) * slots) * 2 <= slots ? 0.62 : 1.0;
+    const double cost = ((rounds - 1) + share) * (mi + 2);
+    if (best_cost < 0 || cost < best_cost - 1e-9) { best = mi; best_cost = cost; }
   }
   return best;
 }
@@ -1156,10 +1163,12 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (use_big) {
     const int mfp = pick_mf(a->M, a->N, split ? 8 : 5);
     const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
-    const int mi = pick_mi(a->M, a->N);
+    const int mi = split ? 4 : pick_mi(a->M, a->N);            // (the fp32-accuracy mode has one tile height of this kernel)
     const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
     const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
-    const double t_small = (double)((ts + 2 * num_cus() - 1) / (2 * num_cus())) * (8.0 + 0.021 * a->K) * (mi / 4.0);
+    const long rs = (ts + 2 * num_cus() - 1) / (2 * num_cus());
+    const double sh = (ts - (rs - 1) * 2 * num_cus()) * 2 <= 2 * num_cus() ? 0.62 : 1.0;         // (see pick_mi)
+    const double t_small = ((double)(rs - 1) + sh) * (8.0 + 0.021 * a->K) * ((mi + 2) / 6.0);
     static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
     if (model && t_small < t_big) use_big = false;
   }
@@ -1198,6 +1207,8 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64>", a->epilogue, pick_mi(a->M, a->N));
   TfTraceScope tr(nm, stream, fl);
   switch (pick_mi(a->M, a->N)) {
+    case 2: return launch_gemm_mi<2, 64>(a, stream);
+    case 3: return launch_gemm_mi<3, 64>(a, stream);
     case 5: return launch_gemm_mi<5, 64>(a, stream);
     case 6: return launch_gemm_mi<6, 64>(a, stream);
     default: return launch_gemm_mi<4, 64>(a, stream);
