@@ -154,7 +154,7 @@ def test_packed_dropout_replay_against_oracle(dev):
     from oracle import fusion_oracle as O
     from transfusion_amd import ops
     from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import SITE_PATCH, site_of
-    cfg = dict(B=3, Nv=24, Nl=40, d=64, h=4, L=2, mask_lens=[25, 40, 3], seed=78)
+    cfg = dict(B=4, Nv=24, Nl=40, d=64, h=4, L=2, mask_lens=[25, 40, 3, 25], seed=78)
     p_tok, p_patch = 0.15, 0.1
     enc, params = build(cfg, dev, p_tok, p_patch)
     enc.train()
@@ -169,9 +169,12 @@ def test_packed_dropout_replay_against_oracle(dev):
     S = Nv + Nl
     Mp = B * Nv + nvalid
     dp, ffp = 128, 128
-    # packed row -> (b, s): the visual rows, then the first len_b language tokens of each sample
-    rows = [(b, s) for b in range(B) for s in list(range(Nv)) + [Nv + j for j in range(cfg["mask_lens"][b])]]
+    # packed row -> (b, s).  The samples are laid out LONGEST FIRST (ties in sample order; csrc/rowops.hip row_map_kernel): per sample the
+    # visual rows, then its first len_b language tokens.  The attention bitmask is indexed by that POSITION, not by the sample.
+    order = sorted(range(B), key=lambda b: (-cfg["mask_lens"][b], b))
+    rows = [(b, s) for b in order for s in list(range(Nv)) + [Nv + j for j in range(cfg["mask_lens"][b])]]
     assert len(rows) == Mp
+    pos_of = torch.tensor([order.index(b) for b in range(B)])
     bi = torch.tensor([r[0] for r in rows]); si = torch.tensor([r[1] for r in rows])
 
     def scatter(flat, width, cols):
@@ -183,7 +186,7 @@ def test_packed_dropout_replay_against_oracle(dev):
     masks = {"patch": scatter(mk(Mp * dp, p_patch, SITE_PATCH), dp, d)[:, :Nv]}
     for l in range(L):
         pre = f"t_encoder.layers.{l}."
-        masks[pre + "attn"] = mk(B * H * S * S, p_tok, site_of(l, 1)).view(B, H, S, S).float()
+        masks[pre + "attn"] = mk(B * H * S * S, p_tok, site_of(l, 1)).view(B, H, S, S).float()[pos_of]
         masks[pre + "dropout1"] = scatter(mk(Mp * dp, p_tok, site_of(l, 2)), dp, d)
         masks[pre + "dropout"] = scatter(mk(Mp * ffp, p_tok, site_of(l, 3)), ffp, 2 * d)
         masks[pre + "dropout2"] = scatter(mk(Mp * dp, p_tok, site_of(l, 4)), dp, d)

@@ -412,15 +412,19 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
 }
 
 // Packed batches: which token rows take part.  lm [B, Nl] (1 = masked language token) ->
-//   cu[b]            first packed row of sample b (cu[B] = total): the Nv visual rows, then the un-masked language tokens in order
+//   cu[p]            first packed row of the sample in POSITION p (cu[B] = total): samples are laid out LONGEST FIRST, so that the
+//                    attention kernels -- whose workgroups walk the positions in order -- start with the long samples and end on the
+//                    short ones (longest-processing-time-first: a ragged batch otherwise ends on a few long stragglers)
+//   start_of[b]      first packed row of sample b: its Nv visual rows, then its un-masked language tokens in order
 //   dense_of[m]      b * S + s of packed row m
 //   packed_of_lang[b * Nl + j]   packed row of language token j of sample b, or -1 when it is masked
-// One workgroup (B is a few dozen samples of a few hundred tokens): a wave per sample counts, thread 0 scans the counts, a wave
-// per sample fills.  err[0] is set to the mask's total when it differs from the host's `expected` (tf_encoder_packed_error).
+// One workgroup (B is a few dozen samples of a few hundred tokens): a wave per sample counts, every thread ranks one sample, thread 0
+// scans the positions, a wave per sample fills.  err[0] is set to the mask's total when it differs from the host's `expected`.
 __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
-                                                       int* __restrict__ dense_of, int* __restrict__ packed_of_lang, int expected,
-                                                       int* __restrict__ err) {
-  extern __shared__ int cnt[];                                    // [B + 1]
+                                                       int* __restrict__ start_of, int* __restrict__ dense_of, int* __restrict__ packed_of_lang,
+                                                       int expected, int* __restrict__ err) {
+  extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position)
+  int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int S = Nv + Nl;
   for (int b = wave; b < B; b += nw) {
@@ -433,15 +437,24 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
     if (lane == 0) cnt[b] = Nv + c;
   }
   __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {             // position of sample b in the longest-first order (stable)
+    const int mine = cnt[b];
+    int r = 0;
+    for (int o = 0; o < B; ++o) r += (cnt[o] > mine || (cnt[o] == mine && o < b)) ? 1 : 0;
+    pos_of[b] = r;
+    start[r + 1] = mine;                                          // (counts by position; scanned below)
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int b = 0; b < B; ++b) { const int c = cnt[b]; cnt[b] = run; cu[b] = run; run += c; }
-    cnt[B] = run; cu[B] = run;
+    for (int p = 0; p < B; ++p) { const int c = start[p + 1]; start[p] = run; cu[p] = run; run += c; }
+    start[B] = run; cu[B] = run;
     if (run != expected) err[0] = run;
   }
   __syncthreads();
   for (int b = wave; b < B; b += nw) {
-    const int base = cnt[b];
+    const int base = start[pos_of[b]];
+    if (lane == 0) start_of[b] = base;
     for (int i = lane; i < Nv; i += 64) dense_of[base + i] = b * S + i;
     int run = base + Nv;
     for (int j0 = 0; j0 < Nl; j0 += 64) {
@@ -987,12 +1000,13 @@ extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   hipLaunchKernelGGL(copy_rows_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
-extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* dense_of, int* packed_of_lang, int expected,
-                                 int* err, hipStream_t st) {
-  if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
-  if ((size_t)(B + 1) * sizeof(int) > 60000) return -2;          // the per-sample counts live in LDS
+extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang,
+                                 int expected, int* err, hipStream_t st) {
+  if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || start_of == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
+  const size_t lds = (size_t)(3 * B + 1) * sizeof(int);
+  if (lds > 60000) return -2;          // the per-sample tables live in LDS
   TfTraceScope tr("row_map_kernel", st);
-  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), (size_t)(B + 1) * sizeof(int), st, lm, B, Nv, Nl, cu, dense_of, packed_of_lang, expected, err);
+  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {

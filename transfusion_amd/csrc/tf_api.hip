@@ -89,7 +89,8 @@ WOff make_woff(const Dims& D) {
 }
 struct AOff {   // byte offsets inside work
   size_t keymask, zeros, x0, x_stride;            // X[l] = x0 + l * x_stride, l = 0..L
-  size_t perr, cu, dense_of, pol;                 // packed batches: mismatch word, cu[B+1], dense_of[Md], packed_of_lang[B*Nl] (int32)
+  size_t perr, cu, starts, dense_of, pol;         // packed batches: mismatch word, cu[B+1] (by position), start_of[B] (by sample), dense_of[Md],
+                                                  // packed_of_lang[B*Nl] (int32)
   size_t layer0, layer_stride;                    // per-layer block
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
@@ -107,7 +108,7 @@ AOff make_aoff(const Dims& D) {
   // (everything up to x0 is sized by the DENSE shape: these offsets do not move with the packed row count)
   a.zeros = take(256);
   a.perr = take(256);
-  a.cu = take((size_t)(D.B + 1) * 4); a.dense_of = take((size_t)D.Md * 4); a.pol = take((size_t)D.B * (D.Nl > 0 ? D.Nl : 1) * 4);
+  a.cu = take((size_t)(D.B + 1) * 4); a.starts = take((size_t)D.B * 4); a.dense_of = take((size_t)D.Md * 4); a.pol = take((size_t)D.B * (D.Nl > 0 ? D.Nl : 1) * 4);
   a.keymask = take((size_t)D.Md);
   a.x0 = o; a.x_stride = plane(md) * (size_t)(1 + D.split); o += a.x_stride * (D.L + 1);
   a.layer0 = o;
@@ -147,7 +148,8 @@ struct Ctx {
   Buf wgt(const unsigned char* p, int rows, int ld) const { return Buf{p, lo(p, plane((size_t)rows * ld * 2)), ld}; }
   void* X(int l) const { return wk + A.x0 + (size_t)l * A.x_stride; }
   bool packed() const { return e->packed_rows > 0; }
-  const int* cu() const { return packed() ? (const int*)(wk + A.cu) : nullptr; }                // first packed row of every sample
+  const int* cu() const { return packed() ? (const int*)(wk + A.cu) : nullptr; }                // attention: rows of the sample in position p (longest first)
+  const int* starts() const { return packed() ? (const int*)(wk + A.starts) : nullptr; }        // first packed row of sample b
   const int* dense_of() const { return packed() ? (const int*)(wk + A.dense_of) : nullptr; }    // packed row -> b * S + s
   const int* pol() const { return packed() ? (const int*)(wk + A.pol) : nullptr; }              // language token (b, j) -> packed row or -1
   unsigned char* LB(int l) const { return wk + A.layer0 + (size_t)l * A.layer_stride; }
@@ -498,7 +500,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
-    TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
+    TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
                              e->packed_rows, (int*)(c.wk + c.A.perr), c.st), "row_map");
     km = nullptr;
   } else {
@@ -593,11 +595,11 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       TfLnArgs n{};
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
       n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
-      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f; n.x_group_row0 = c.cu();
+      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f; n.x_group_row0 = c.starts();
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
     } else {
       TfCopyRowsArgs r{};
-      r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S; r.src_group_row0 = c.cu();
+      r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S; r.src_group_row0 = c.starts();
       r.dst = e->vis_out; r.dst_is_f32 = e->vis_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nv; r.dst_gstride = D.Nv; r.rows = D.B * D.Nv; r.cols = D.d;
       TF_TRY(tf_launch_copy_rows(&r, c.st), "vis_copy");
     }
@@ -642,7 +644,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Buf xl = c.act_d(c.X(D.L));
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
       n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
-      n.x_group_row0 = c.cu();
+      n.x_group_row0 = c.starts();
       n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = (void*)dxa.p; n.dx_lo = (void*)dxa.lo; n.lddx = D.dp;
       n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
@@ -650,7 +652,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TfCopyRowsArgs r{};
       r.src = e->d_vis_out; r.src_is_f32 = e->d_vis_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nv; r.src_gstride = D.Nv;
       r.dst = (void*)dxa.p; r.dst_lo = (void*)dxa.lo; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
-      r.dst_group_row0 = c.cu();
+      r.dst_group_row0 = c.starts();
       TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
     }
   }
