@@ -219,6 +219,24 @@ typedef struct TfLmPoolArgs {
   float* scratch;                    // backward work [2, B, d] fp32, when ln_w != null
 } TfLmPoolArgs;
 
+// tensor-in narration pooling layer, everything behind its out_mlp GEMM in one kernel each way (SlowFastPooling.forward,
+// modeling/narration_embeds/datasets/slowfast_features_dsets.py:229-235; the same tail as SBertLayer's, narr_pooling_layers.py:193-199):
+//   u = tanh(x) (iff use_tanh) with the rows t >= lens[b] zeroed (ragged batches: right padding),
+//   n[b, c] = max(||u[b, :, c]||_2, 1e-12), z = u / n when T > 1 (F.normalize(p=2, dim=1): over the TOKEN axis), else z = u,
+//   y = dropout(z) (keep(i) of the element index i = (b * T + t) * d + c, as everywhere in this library).
+// backward: gz = dropout'(gy); gu = (gz - z * sum_t(gz * z)) / n (T > 1); gx = gu * (1 - u^2) (tanh) on the kept rows, 0 on the padded ones.
+typedef struct TfPoolNormArgs {
+  const void* x; int x_is_f32; int ldx;  // [B, T, ldx] bf16 or fp32 (the out_mlp GEMM's output, or the raw embeddings)
+  const int* lens;                       // [B] int32 valid tokens per sample, or null: all T
+  int B, T, d;
+  int use_tanh;
+  unsigned drop_thr, drop_key; float drop_scale;
+  float* y;                              // forward out [B, T, d] fp32
+  float* z; float* n;                    // saved for backward: z [B, T, d] fp32 (may alias y when drop_thr == 0), n [B, d] fp32
+  const float* gy;                       // backward in  [B, T, d] fp32
+  void* gx; int gx_is_f32; int ldgx;     // backward out [B, T, ldgx] (pad columns zeroed when bf16)
+} TfPoolNormArgs;
+
 // RoI heads' losses.  The four Linears (faster_rcnn_wrapper.py:93-100: box_regressor, noun_classifier,
 // verb_classifier; roi_wrappers.py:306: ttc_pred_layer) are tf_gemm_fwd calls: `box` = box_regression [R, 4*Cn] and `cls` =
 // noun | verb | ttc pre-activation concatenated [R, Cn + Cv + 1 (+ pad)], both bf16 (+ lo plane in the fp32-accuracy mode).
@@ -311,6 +329,8 @@ int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s);
 /* dy == null: y[r] = softplus(x[r, col]) (F.softplus defaults, roi_wrappers.py:229); dy != null: dx[r, col] += dy[r] * sigmoid(x[r, col]).
  * x / dx: bf16 [R, ld] (+ lo planes or null) */
 int tf_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, const float* dy, void* dx, void* dx_lo, int R, tf_stream_t s);
+int tf_pool_norm_fwd(const TfPoolNormArgs* a, tf_stream_t s);
+int tf_pool_norm_bwd(const TfPoolNormArgs* a, tf_stream_t s);
 int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s);
 int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s);
 /* y = dropout(x) over a dense bf16 array of n (multiple of 8) elements; the same call is its backward (utils.py:115) */

@@ -405,3 +405,23 @@ def asymmetric_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, lang: torch
         v_k = torch.cat((x, lang), dim=1)
         x = qkv_encoder_layer(sd, f"cross_vis_layers.{i}.", x, v_k, num_heads, None, activation)
     return (x[:, 0] if back_to_img_fn == "token" else x[:, :n]), lang                    # :112-115
+
+
+# ----------------------------------------------------------------------------
+# tensor-in narration pooling layer
+# ----------------------------------------------------------------------------
+def slowfast_pooling(sd: Dict[str, torch.Tensor], tensors, out_tanh: bool, keep: Optional[torch.Tensor] = None, p_out: float = 0.0):
+    """SlowFastPooling.forward, modeling/narration_embeds/datasets/slowfast_features_dsets.py:223-240: stack the B [T, size] tensors (:224),
+    out_mlp Linear when present (:226-227; narr_pooling_layers.py:93-97 is the same projection for the SBERT layer), tanh (:229-230),
+    L2 normalisation over the TOKEN axis when T > 1 (:232-233: F.normalize(p=2, dim=1), eps 1e-12), out_dropout (:235, through an explicit
+    keep mask here), and an all-ones HuggingFace-style attention mask (:238).  -> (tokens [B, T, d], att_mask [B, T])."""
+    x = torch.stack(list(tensors), dim=0)
+    if "out_mlp.weight" in sd:
+        x = x @ sd["out_mlp.weight"].t() + sd["out_mlp.bias"]
+    if out_tanh:
+        x = torch.tanh(x)
+    if x.shape[1] > 1:
+        x = x / x.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)
+    if keep is not None:
+        x = x * keep / (1.0 - p_out)
+    return x, torch.ones(x.shape[:2])

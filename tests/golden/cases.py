@@ -276,3 +276,24 @@ def make_asym_case(cfg):
     x = rs.randn(cfg["B"], cfg["Nv"], d).astype(np.float32)
     lang = rs.randn(cfg["B"], cfg["Nl"], d).astype(np.float32)
     return params, x, lang, rs.randn(cfg["B"], cfg["Nv"], d).astype(np.float32), rs.randn(cfg["B"], cfg["Nl"], d).astype(np.float32)
+
+
+# tensor-in narration pooling layer (SlowFastPooling, modeling/narration_embeds/datasets/slowfast_features_dsets.py:207-240)
+POOL_CASES = {
+    "pool_mlp_tanh": dict(B=3, T=6, size=40, out_mlp=64, out_tanh=True, seed=701),        # Linear + tanh + L2 normalisation over the tokens
+    "pool_mlp": dict(B=2, T=5, size=72, out_mlp=32, out_tanh=False, seed=702),            # Linear + normalisation
+    "pool_plain": dict(B=2, T=4, size=24, out_mlp=0, out_tanh=True, seed=703),            # no projection
+    "pool_single": dict(B=3, T=1, size=16, out_mlp=24, out_tanh=False, seed=704),         # T = 1: the normalisation is skipped (:232)
+}
+
+
+def make_pool_case(cfg):
+    """-> (params {out_mlp.weight, out_mlp.bias} or {}, list of B [T, size] tensors, cotangent [B, T, d_out])"""
+    rs = np.random.RandomState(cfg["seed"])
+    params = {}
+    if cfg["out_mlp"]:
+        params = {"out_mlp.weight": (rs.randn(cfg["out_mlp"], cfg["size"]) / np.sqrt(cfg["size"])).astype(np.float32),
+                  "out_mlp.bias": (0.1 * rs.randn(cfg["out_mlp"])).astype(np.float32)}
+    xs = [rs.randn(cfg["T"], cfg["size"]).astype(np.float32) for _ in range(cfg["B"])]
+    cot = rs.randn(cfg["B"], cfg["T"], cfg["out_mlp"] or cfg["size"]).astype(np.float32)
+    return params, xs, cot

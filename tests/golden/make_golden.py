@@ -24,9 +24,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ASYM_CASES, ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, QKV_CASES, RADAM_CASES,  # noqa: E402
+from cases import (ASYM_CASES, ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, POOL_CASES, QKV_CASES, RADAM_CASES,  # noqa: E402
                    make_asym_case, make_encoder_inputs, make_encoder_params, make_heads_case, make_level_extras, make_lm_case,
-                   make_qkv_case, make_radam_case)
+                   make_pool_case, make_qkv_case, make_radam_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -381,6 +381,37 @@ def run_asym_case(name, cfg, ref_utils):
     print(name, "ok", res["vis"].shape, res["lang"].shape)
 
 
+def run_pool_case(name, cfg):
+    """The reference's tensor-in narration pooling layer, ``SlowFastPooling`` (slowfast_features_dsets.py:207-240), on seeded inputs.  Its
+    module imports, at the top, ``data_preprocessing.datasets.readers.SFastFeaturesReader`` (dataset reader: cv2 / pandas file readers,
+    not used by the pooling layer); as for ``is_torch_18v`` and ``losses.py`` above that ONE name is supplied through ``sys.modules`` and
+    the reference file itself is imported unmodified."""
+    for modname, attrs in (("data_preprocessing", {}), ("data_preprocessing.datasets", {}),
+                           ("data_preprocessing.datasets.readers", {"SFastFeaturesReader": object})):
+        if modname not in sys.modules:
+            m = types.ModuleType(modname)
+            m.__path__ = []
+            sys.modules[modname] = m
+        for k, v in attrs.items():
+            if not hasattr(sys.modules[modname], k):
+                setattr(sys.modules[modname], k, v)
+    from modeling.narration_embeds.datasets.slowfast_features_dsets import SlowFastPooling
+    params, xs, cot = make_pool_case(cfg)
+    layer = SlowFastPooling({"strategy": "current", "out_mlp": cfg["out_mlp"], "size": cfg["size"], "out_dropout": 0.0, "out_tanh": cfg["out_tanh"]})
+    assert sorted(layer.state_dict().keys()) == sorted(params.keys())
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    layer.train()
+    tx = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    tokens, none, att = layer(tx, pad_mask=True)
+    assert none is None
+    (tokens * torch.from_numpy(cot)).sum().backward()
+    out = {"tokens": tokens.detach().numpy(), "att_mask": att.numpy(), "grad_x": np.stack([t.grad.numpy() for t in tx])}
+    for k, p in layer.named_parameters():
+        out["gradp/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: tokens {tuple(tokens.shape)} |tokens| {tokens.abs().mean():.4f}")
+
+
 def main():
     """python tests/golden/make_golden.py [case-name ...]   (no names: every fixture)"""
     only = set(sys.argv[1:])
@@ -409,6 +440,9 @@ def main():
     for name, cfg in ASYM_CASES.items():
         if want(name):
             run_asym_case(name, cfg, ref_utils)
+    for name, cfg in POOL_CASES.items():
+        if want(name):
+            run_pool_case(name, cfg)
     if want("sin1d_768"):
         # sin1d table spot values (utils.py:267-273) at the real width
         pe = ref_utils.get_sin1d_embed(8192, 768)

@@ -204,6 +204,71 @@ def test_slowfast_pooling_contract():
     assert rel(y[0], ref) < 1e-2
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", ["pool_mlp_tanh", "pool_mlp", "pool_plain", "pool_single"])
+def test_slowfast_pooling_against_reference_fixture(golden_dir, name, precision):
+    """The tensor-in pooling layer (out_mlp on the MFMA GEMM; tanh, token-axis L2 normalisation and dropout in tf_pool_norm_fwd / bwd)
+    against fixtures produced by the reference's own SlowFastPooling class: tokens, mask, input gradients, out_mlp gradients.
+    bf16 GEMM: 1e-2 / 3e-2; fp32-accuracy mode: 1e-3; without out_mlp the path is fp32 arithmetic: 1e-5."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from cases import POOL_CASES, make_pool_case
+    from transfusion_amd.modeling.narration_embeds.narr_pooling_layers import get_narr_pooling_layer
+    dev = torch.device("cuda:0")
+    cfg = POOL_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params, xs, cot = make_pool_case(cfg)
+    layer = get_narr_pooling_layer("slowfast")({"strategy": "current", "out_mlp": cfg["out_mlp"], "size": cfg["size"], "out_dropout": 0.0,
+                                                "out_tanh": cfg["out_tanh"]}, "tokens")
+    assert sorted(layer.state_dict().keys()) == sorted(params.keys())          # the reference's checkpoint keys
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    layer = layer.to(dev).train()
+    layer.precision = precision
+    tx = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
+    tokens, none, att = layer(tx, pad_mask=True)
+    assert none is None and torch.equal(att.cpu(), torch.from_numpy(g["att_mask"])) and att.tf_valid_tokens == cfg["B"] * cfg["T"]
+    ftol, gtol = (1e-5, 1e-5) if not cfg["out_mlp"] else ((1e-2, 3e-2) if precision == "bf16" else (1e-3, 1e-3))
+    assert tokens.dtype == torch.float32 and rel(tokens, g["tokens"]) < ftol
+    (tokens * torch.from_numpy(cot).to(dev)).sum().backward()
+    assert rel(torch.stack([t.grad for t in tx]), g["grad_x"]) < gtol
+    for k, prm in layer.named_parameters():
+        assert rel(prm.grad, g["gradp/" + k]) < gtol, k
+
+
+def test_slowfast_pooling_ragged_and_dropout():
+    """The ragged extension (right-padded samples: padded rows zero, the token-axis norm taken over the real tokens only) and the fused
+    out_dropout (the keep mask is the library's index hash: replayed through ops.dropout_mask)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    B, T, d = 3, 7, 40
+    x = torch.randn(B, T, d, generator=g)
+    lens = [7, 3, 1]
+    xd = x.to(dev).requires_grad_(True)
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    y = ops.pool_norm(xd, lt, use_tanh=True, p_drop=0.0)
+    xr = x.clone().requires_grad_(True)
+    m = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()[..., None]
+    u = torch.tanh(xr) * m
+    ref = u / u.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)
+    assert rel(y, ref.detach()) < 1e-5 and float(y[1, 3:].abs().max()) == 0 and float(y[2, 1:].abs().max()) == 0
+    cot = torch.randn(B, T, d, generator=g)
+    (y * cot.to(dev)).sum().backward()
+    (ref * cot).sum().backward()
+    assert rel(xd.grad, xr.grad) < 1e-5 and float(xd.grad[1, 3:].abs().max()) == 0
+    # dropout: same values where kept (scaled), zero elsewhere, at the library's own keep probability
+    p = 0.25
+    torch.manual_seed(1)
+    yd = ops.pool_norm(xd.detach(), lt, use_tanh=True, p_drop=p)
+    kept = yd != 0
+    scale = ops.drop_params(p, 1, 9)[2]
+    assert torch.allclose(yd[kept], (y.detach() * scale)[kept], rtol=1e-6, atol=1e-7)
+    frac = kept.float().sum() / (y != 0).float().sum()
+    assert abs(float(frac) - (1 - p)) < 0.06
+
+
 @pytest.mark.parametrize("mode", ["use_lm_f", "fused", "multi"])
 def test_wrapper_language_head(golden_dir, mode):
     """criterion.lm > 0 (cross_f_box_wrapper.py:77-81, :199-200, :223-228): which tokens feed the head in each mode, the

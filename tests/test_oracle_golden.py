@@ -245,3 +245,23 @@ def test_asymmetric_forward_oracle_matches_reference(golden_dir):
     for k in params:
         gr = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         _close(gr, g["gradp/" + k], tol=1e-4, what=k)
+
+
+@pytest.mark.parametrize("name", ["pool_mlp_tanh", "pool_mlp", "pool_plain", "pool_single"])
+def test_slowfast_pooling_restatement_equals_reference(golden_dir, name):
+    """oracle.slowfast_pooling against fixtures produced by the reference's own SlowFastPooling class
+    (modeling/narration_embeds/datasets/slowfast_features_dsets.py:207-240, imported by make_golden.py::run_pool_case): tokens, the all-ones
+    attention mask, and the gradients of the inputs and of out_mlp."""
+    from cases import POOL_CASES, make_pool_case
+    cfg = POOL_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params, xs, cot = make_pool_case(cfg)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in params.items()}
+    tx = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    tokens, att = O.slowfast_pooling(sd, tx, cfg["out_tanh"])
+    assert tokens.shape == g["tokens"].shape and torch.equal(att, torch.from_numpy(g["att_mask"]))
+    assert (tokens.detach() - torch.from_numpy(g["tokens"])).abs().max() < 2e-6
+    (tokens * torch.from_numpy(cot)).sum().backward()
+    assert (torch.stack([t.grad for t in tx]) - torch.from_numpy(g["grad_x"])).abs().max() < 2e-5
+    for k in params:
+        assert (sd[k].grad - torch.from_numpy(g["gradp/" + k])).abs().max() < 2e-5, k

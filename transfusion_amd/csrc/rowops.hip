@@ -907,6 +907,72 @@ __global__ __launch_bounds__(64) void lm_pool_bwd_kernel(const TfLmPoolArgs a) {
 }
 
 // d(gamma)[c] = sum_b scratch[0][b][c], d(beta)[c] = sum_b scratch[1][b][c] in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+// narration pooling tail (TfPoolNormArgs): one thread per feature column of one sample, the token axis walked in registers / L2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pn_load(const void* x, int is_f32, size_t i) { return is_f32 ? ((const float*)x)[i] : bf2f(((const u16*)x)[i]); }
+
+__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs a) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.d) return;
+  const int len = a.lens != nullptr ? min(max(a.lens[b], 0), a.T) : a.T;
+  float ss = 0.f;
+  for (int t = 0; t < len; ++t) {
+    float u = pn_load(a.x, a.x_is_f32, ((size_t)b * a.T + t) * a.ldx + c);
+    if (a.use_tanh) u = tanhf(u);
+    ss = fmaf(u, u, ss);
+  }
+  const float nrm = a.T > 1 ? fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+  a.n[(size_t)b * a.d + c] = nrm;
+  const float inv = 1.f / nrm;
+  for (int t = 0; t < a.T; ++t) {
+    const size_t o = ((size_t)b * a.T + t) * a.d + c;
+    float zv = 0.f;
+    if (t < len) {
+      float u = pn_load(a.x, a.x_is_f32, ((size_t)b * a.T + t) * a.ldx + c);
+      if (a.use_tanh) u = tanhf(u);
+      zv = u * inv;
+    }
+    a.z[o] = zv;
+    if (a.drop_thr) a.y[o] = tf_keep((unsigned)o, a.drop_key, a.drop_thr) ? zv * a.drop_scale : 0.f;
+    else if (a.y != a.z) a.y[o] = zv;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const TfPoolNormArgs a) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ldgx) return;
+  const bool bf = !a.gx_is_f32;
+  if (c >= a.d) {                                          // pad columns of a bf16 gradient
+    if (bf) for (int t = 0; t < a.T; ++t) ((u16*)a.gx)[((size_t)b * a.T + t) * a.ldgx + c] = 0;
+    return;
+  }
+  const int len = a.lens != nullptr ? min(max(a.lens[b], 0), a.T) : a.T;
+  const float nrm = a.n[(size_t)b * a.d + c];
+  float dot = 0.f;
+  if (a.T > 1)
+    for (int t = 0; t < len; ++t) {
+      const size_t o = ((size_t)b * a.T + t) * a.d + c;
+      float g = a.gy[o];
+      if (a.drop_thr) g = tf_keep((unsigned)o, a.drop_key, a.drop_thr) ? g * a.drop_scale : 0.f;
+      dot = fmaf(g, a.z[o], dot);
+    }
+  for (int t = 0; t < a.T; ++t) {
+    const size_t o = ((size_t)b * a.T + t) * a.d + c;
+    float gx = 0.f;
+    if (t < len) {
+      float g = a.gy[o];
+      if (a.drop_thr) g = tf_keep((unsigned)o, a.drop_key, a.drop_thr) ? g * a.drop_scale : 0.f;
+      const float zv = a.z[o];
+      float gu = a.T > 1 ? (g - zv * dot) / nrm : g;
+      if (a.use_tanh) { const float u = zv * nrm; gu *= 1.f - u * u; }
+      gx = gu;
+    }
+    const size_t go = ((size_t)b * a.T + t) * a.ldgx + c;
+    if (bf) ((u16*)a.gx)[go] = f2bf(gx); else ((float*)a.gx)[go] = gx;
+  }
+}
+
 __global__ void lm_pool_affine_kernel(const float* __restrict__ scratch, float* __restrict__ dw, float* __restrict__ db, int B, int d) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
@@ -1105,6 +1171,21 @@ extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_
   return (int)hipGetLastError();
 }
 
+extern "C" int tf_launch_pool_norm_fwd(const TfPoolNormArgs* a, hipStream_t st) {
+  if (a->B <= 0 || a->T <= 0 || a->d <= 0) return 0;
+  if (a->x == nullptr || a->y == nullptr || a->z == nullptr || a->n == nullptr || a->ldx < a->d) return -2;
+  if ((long long)a->B * a->T * a->d >= (1ll << 32)) return -5;                 // 32-bit dropout index space
+  TfTraceScope tr("pool_norm_fwd_kernel", st);
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3((a->d + 255) / 256, a->B), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+extern "C" int tf_launch_pool_norm_bwd(const TfPoolNormArgs* a, hipStream_t st) {
+  if (a->B <= 0 || a->T <= 0 || a->d <= 0) return 0;
+  if (a->gy == nullptr || a->gx == nullptr || a->z == nullptr || a->n == nullptr || a->ldgx < a->d) return -2;
+  TfTraceScope tr("pool_norm_bwd_kernel", st);
+  hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3((a->ldgx + 255) / 256, a->B), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
 static int lm_pool_check(const TfLmPoolArgs* a) {
   if (a->B <= 0) return 0;
   if (a->L <= 0 || a->d <= 0 || (a->d % 8) || a->d > 64 * MAXC_MAX * 8 || (a->type != 0 && a->type != 1)) return -2;

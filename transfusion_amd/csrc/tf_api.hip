@@ -386,6 +386,8 @@ int tf_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, 
   TF_TRY(tf_launch_softplus_col(x, x_lo, ld, col, y, dy, dx, dx_lo, R, (hipStream_t)s), "tf_softplus_col");
   return 0;
 }
+int tf_pool_norm_fwd(const TfPoolNormArgs* a, tf_stream_t s) { TF_WRAP("tf_pool_norm_fwd", tf_launch_pool_norm_fwd(a, (hipStream_t)s)); }
+int tf_pool_norm_bwd(const TfPoolNormArgs* a, tf_stream_t s) { TF_WRAP("tf_pool_norm_bwd", tf_launch_pool_norm_bwd(a, (hipStream_t)s)); }
 int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_fwd(a, (hipStream_t)s), "tf_lm_pool_fwd"); return 0; }
 int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_bwd(a, (hipStream_t)s), "tf_lm_pool_bwd"); return 0; }
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq(x, n, out, (hipStream_t)s), "tf_sumsq"); return 0; }

@@ -38,6 +38,8 @@ int tf_launch_radam(const TfRadamArgs* a, hipStream_t stream);
 int tf_launch_heads_loss_fwd(const TfHeadsLossArgs* a, hipStream_t stream);
 int tf_launch_heads_loss_bwd(const TfHeadsLossArgs* a, hipStream_t stream);
 int tf_launch_softplus_col(const void* x, const void* x_lo, int ld, int col, float* y, const float* dy, void* dx, void* dx_lo, int R, hipStream_t stream);
+int tf_launch_pool_norm_fwd(const TfPoolNormArgs* a, hipStream_t stream);
+int tf_launch_pool_norm_bwd(const TfPoolNormArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_fwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_bwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);

@@ -50,16 +50,12 @@ class SlowFastPooling(nn.Module):
             lens_t = lens_t.pin_memory().to(tensor.device, non_blocking=True)
         att_mask = (torch.arange(T, device=tensor.device, dtype=torch.int32).unsqueeze(0) < lens_t.unsqueeze(1)).to(torch.float32)
         if self.out_mlp:
-            tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias, precision=self.precision).float()
-        if self.use_out_tanh:
-            tensor = torch.tanh(tensor)
-        if min(lens) != T:
-            # ragged extension: padded rows became tanh(bias) above; zero them so that the L2 norm over the token axis (and
-            # hence every real token's value) does not depend on how much padding the batch happens to carry
-            tensor = tensor * att_mask.unsqueeze(-1)
-        if tensor.shape[1] > 1:
-            tensor = F.normalize(tensor, p=2, dim=1)
-        tensor = self.out_dropout(tensor)
+            tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias, precision=self.precision)
+        # tanh, zeroing of the padded rows (ragged extension: they would be tanh(bias) and weigh on the token-axis norm of every real
+        # token), F.normalize(p=2, dim=1) and out_dropout in ONE kernel each way (tf_pool_norm_fwd / bwd); device tensors only, like
+        # every other op of this package
+        p_out = float(self.out_dropout.p) if self.training else 0.0
+        tensor = ops.pool_norm(tensor, lens_t if min(lens) != T else None, self.use_out_tanh, p_out)
         # the number of real tokens in the batch, known here on the host: with it the fusion encoders drop the padded tokens from their
         # row-wise kernels (CrossTransformerModuleBox.forward(..., lang_valid_rows=...)) instead of carrying them as dead rows
         att_mask.tf_valid_tokens = int(sum(lens))

@@ -532,6 +532,47 @@ def lm_pool(x, att_mask, pool_type: str, ln_w=None, ln_b=None, eps: float = 1e-5
 
 
 # ------------------------------------------------------------------------------------------------------
+# narration pooling tail: tanh, token-axis L2 normalisation, out_dropout in one kernel each way (slowfast_features_dsets.py:229-235)
+# ------------------------------------------------------------------------------------------------------
+class _PoolNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens, use_tanh, p_drop, seed):
+        _require_cuda(x)
+        if x.dim() != 3 or x.dtype not in (torch.float32, torch.bfloat16) or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+            x = x.contiguous()
+        B, T, d = x.shape
+        drop = drop_params(p_drop, seed, 9)
+        z = torch.empty(B, T, d, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(z) if drop[0] else z
+        n = torch.empty(B, d, dtype=torch.float32, device=x.device)
+        a = L.TfPoolNormArgs(x=L.ptr(x), x_is_f32=_is_f32(x), ldx=x.stride(1), lens=L.ptr(lens), B=B, T=T, d=d, use_tanh=1 if use_tanh else 0,
+                             drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], y=L.ptr(y), z=L.ptr(z), n=L.ptr(n))
+        L.call("tf_pool_norm_fwd", a, _stream())
+        ctx.save_for_backward(z, n, lens)
+        ctx.meta = (B, T, d, use_tanh, drop, x.dtype, x.stride(1))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, n, lens = ctx.saved_tensors
+        B, T, d, use_tanh, drop, xdtype, ldx = ctx.meta
+        gy = gy.float().contiguous()
+        ldg = ldx if xdtype == torch.bfloat16 else d
+        gx = torch.empty(B, T, ldg, dtype=xdtype, device=gy.device)
+        a = L.TfPoolNormArgs(lens=L.ptr(lens), B=B, T=T, d=d, use_tanh=1 if use_tanh else 0, drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
+                             z=L.ptr(z), n=L.ptr(n), gy=L.ptr(gy), gx=L.ptr(gx), gx_is_f32=_is_f32(gx), ldgx=ldg)
+        L.call("tf_pool_norm_bwd", a, _stream())
+        return (gx[..., :d] if ldg != d else gx), None, None, None, None
+
+
+def pool_norm(x, lens=None, use_tanh: bool = False, p_drop: float = 0.0):
+    """[B, T, d] (bf16 / fp32) -> fp32 [B, T, d]: tanh (optional), rows t >= lens[b] zeroed (``lens``: int32 device tensor or None),
+    L2 normalisation over the token axis when T > 1, dropout -- SlowFastPooling.forward's tail behind its out_mlp GEMM."""
+    seed = next_seed() if p_drop > 0 else 0
+    return _PoolNormFn.apply(x, lens, bool(use_tanh), float(p_drop), seed)
+
+
+# ------------------------------------------------------------------------------------------------------
 # RoI heads: softplus TTC output and the four losses (csrc/heads.hip)
 # ------------------------------------------------------------------------------------------------------
 class _SoftplusColFn(torch.autograd.Function):
