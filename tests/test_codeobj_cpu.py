@@ -16,9 +16,11 @@ import pytest
 from transfusion_amd import build as tb
 from transfusion_amd import codeobj
 
-# kernel (demangled, without parameter list) -> VGPRs spilled today.  hd 224 / 256 only: the one-wave-per-SIMD kernels of the wide heads
-# (d = 896: the reference's Ego4Dv2 width; d = 1024: BASELINE configs[3]) keep dK^T + dV^T + K + V fragments resident and overflow
-# even the 512-register file; DESIGN.md "Register audit" has the plan (dK / dV as two passes, as the fp32-accuracy kernels do).
+# kernel (demangled, without parameter list) -> VGPRs spilled today.  hd 224 / 256 only, and only FALLBACK forms: the one-wave-per-SIMD
+# 32-row dK / dV kernel keeps dK^T + dV^T + K + V fragments resident and overflows even the 512-register file; the encoder runtime
+# no longer runs it (with its dS workspace the wide heads take the spill-free two-pass 16-row kernels) -- it serves stand-alone
+# tf_attn_bwd calls without a workspace and cross attention.  The fp32-accuracy dQ kernel at 224 (d = 896 in run.precision 32) is the one
+# training-path entry left (31 VGPRs, prologue fragments; DESIGN.md "Register audit").
 ALLOWED_SPILLS = {
     "attn_bwd_dkv_kernel<224, true>": 48,
     "attn_bwd_dkv_kernel<256, false>": 46,
@@ -73,12 +75,18 @@ def test_allow_list_is_current(table):
 
 
 def test_dead_wide_head_instantiations_stay_out(table):
-    """The 16-row (two waves per SIMD) attention backward kernels are never dispatched for head dims above 192 (attn_bf16.hip
-    launch_bwd): they must not be instantiated either (they were -- 70 to 177 spilled VGPRs of dead code in the library)."""
+    """Head dims above 192: the one-pass 16-row kernels (dQ with S / dP recompute; dK + dV together) do not fit 256 registers and are
+    never dispatched there (attn_bf16.hip launch_bwd) -- they must not be instantiated either (they were: 70 to 177 spilled VGPRs of dead
+    code).  What IS live at 224 / 256 is the two-pass form (dV pass, dK + dS pass) and the thin dQ kernel, spill-free."""
     for k in table:
         hd = _head_dim(k)
         if hd is not None and hd > 192:
-            assert not k.startswith(("attn_bwd_dq16_kernel", "attn_bwd_dkv16_kernel", "attn_bwd_dq_ds_kernel")), k
+            assert not k.startswith("attn_bwd_dq16_kernel"), k
+            if k.startswith("attn_bwd_dkv16_kernel"):
+                assert k.rstrip(">").endswith((", 0", ", 1")), k                  # WHICH = 0 (dV) or 1 (dK + dS), never the one-pass form
+    for hd in (224, 256):
+        for k in (f"attn_bwd_dkv16_kernel<{hd}, false, 64, false, 0>", f"attn_bwd_dkv16_kernel<{hd}, false, 64, true, 1>", f"attn_bwd_dq_ds_kernel<{hd}>"):
+            assert k in table and table[k]["vgpr_spill_count"] == 0 and table[k]["private_segment_fixed_size"] == 0, k
 
 
 def test_occupancy_assumptions(table):

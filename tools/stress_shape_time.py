@@ -23,7 +23,7 @@ pad = (torch.arange(NL).view(1, -1) >= lens.view(-1, 1)).to(dev)
 valid = (~pad).unsqueeze(-1).float()
 
 def loss_fn(m, batch):
-    v, l_, _, _ = m(x, lang, pad)
+    v, l_, _, _ = m(x, lang, pad, lang_valid_rows=int(lens.sum()) if os.environ.get("DENSE") != "1" else None)
     return v.float().square().mean() + (l_.float().square() * valid).sum() / (valid.sum() * D)
 
 for _ in range(3):

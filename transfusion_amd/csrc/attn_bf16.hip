@@ -783,9 +783,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
 __host__ __device__ inline int ds_nkb(int S) { return 8 * ((S + 127) / 128); }     // 16-key blocks per (batch, head): whole 128-key workgroups
 __host__ __device__ inline int ds_nqb(int S) { return 4 * ((S + 127) / 128); }     // 32-query blocks per (batch, head): whole 128-query workgroups
 
-template <int HDP, bool BLK, int QT, bool DS = false>     // QT query rows per LDS tile (32 or 64)
+// WHICH: 2 = dK and dV in one pass (head dims <= 192).  At head dims 224 / 256 the two accumulator sets (2 x HDP / 4 registers) plus
+// the K and V fragments overflow 256 registers, so the work is two passes of the same kernel, each inside the budget at two waves per
+// SIMD: WHICH = 0 forms S -> P -> dV (K fragments and dV^T resident), WHICH = 1 forms S, dP -> dS -> dK (K, V fragments and dK^T
+// resident) and emits the dS tiles.  One more S recompute, no spills (the one-pass 32-row kernel spilled 46 - 89 registers there).
+template <int HDP, bool BLK, int QT, bool DS = false, int WHICH = 2>     // QT query rows per LDS tile (32 or 64)
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
+  constexpr bool DO_V = WHICH != 1, DO_K = WHICH != 0;
+  static_assert(!DS || DO_K, "the dS tiles come from the pass that forms dS");
   constexpr int NT = 512;
   constexpr int KS = HDP / 32, DB = HDP / 16, TSTR = G::TSTR;
   constexpr int PAIR = 2 * QT * TSTR;                     // Q tile (QT rows) + dO tile (QT rows)
@@ -814,15 +820,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
   const int kr_ = min(key, Sb - 1);
   bool key_ok = key < Sb;
   if (key_ok && a.key_mask != nullptr) key_ok = a.key_mask[(size_t)b * S + key] == 0;
-  bf16x8 kf[KS], vf[KS];           // B operands: key n, hd elements 32ks + 8g .. +7
+  bf16x8 kf[KS], vf[DO_K ? KS : 1];           // B operands: key n, hd elements 32ks + 8g .. +7 (V only where dP is formed)
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     kf[ks] = as_bf16x8(*(const u32x4*)(kbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
-    vf[ks] = as_bf16x8(*(const u32x4*)(vbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
+    if constexpr (DO_K) vf[ks] = as_bf16x8(*(const u32x4*)(vbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
   }
-  f32x4 dk[DB], dv[DB];
+  f32x4 dk[DO_K ? DB : 1], dv[DO_V ? DB : 1];
 #pragma unroll
-  for (int d = 0; d < DB; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int d = 0; d < DB; ++d) {
+    if constexpr (DO_K) dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (DO_V) dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float sc = a.scale * LOG2E;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const int kbit = (key0 & 16) + n;                       // this lane's key inside the 32-bit keep / block words
@@ -889,24 +898,28 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     // phase A: S and dP, the row fragments of Q / dO run ahead of the MFMAs
     __builtin_amdgcn_sched_barrier(0);
     {
-      bf16x8 qfr[2 * KS], dfr[2 * KS];
+      bf16x8 qfr[2 * KS], dfr[DO_K ? 2 * KS : 1];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qfr[j * KS + ks] = *(const bf16x8*)(qt + rbase + 16 * j * TSTR + 64 * ks);
+      if constexpr (DO_K) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dfr[j * KS + ks] = *(const bf16x8*)(dot + rbase + 16 * j * TSTR + 64 * ks);
+          for (int ks = 0; ks < KS; ++ks) dfr[j * KS + ks] = *(const bf16x8*)(dot + rbase + 16 * j * TSTR + 64 * ks);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[j * KS + ks], kf[ks], st[j], 0, 0, 0);
+      if constexpr (DO_K) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[j * KS + ks], vf[ks], dp[j], 0, 0, 0);
-      constexpr int NR = 4 * KS, AHEAD = NR < 6 ? NR : 6;
+          for (int ks = 0; ks < KS; ++ks) dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[j * KS + ks], vf[ks], dp[j], 0, 0, 0);
+      }
+      constexpr int NR = (DO_K ? 4 : 2) * KS, AHEAD = NR < 6 ? NR : 6;
       __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
       for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -936,8 +949,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
         const bool att = BLK ? (key_ok && !((b4[i] >> kbit) & 1u)) : key_ok;
         const float pr = att ? fast_exp2(fmaf(st[j][i], sc, -l4[i])) : 0.f;
         const float keep_scale = ((w4[i] >> kbit) & 1u) ? dscale : 0.f;
-        pf[4 * j + i] = (__bf16)(pr * keep_scale);                             // Pd
-        dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], keep_scale, -d4[i]));   // dS
+        if constexpr (DO_V) pf[4 * j + i] = (__bf16)(pr * keep_scale);                             // Pd
+        if constexpr (DO_K) dsf[4 * j + i] = (__bf16)(pr * fmaf(dp[j][i], keep_scale, -d4[i]));   // dS
       }
     }
     if constexpr (DS) {
@@ -948,20 +961,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
     }
     // phase C: dV^T += dO^T . Pd and dK^T += Q^T . dS; 2 * DB transposed fragments (2 reads each), AH fragments ahead
     {
-      constexpr int NF = 2 * DB, AH = 4;
+      constexpr int NF = (WHICH == 2 ? 2 : 1) * DB, AH = 4;
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 tf[NF];
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const int d = i >> 1;
-        const unsigned char* tp = ((i & 1) ? qt : dot) + tbase + 64 * (d >> 1) + ((d & 1) ? xo : xe);
+        const int d = WHICH == 2 ? i >> 1 : i;
+        const bool from_q = WHICH == 2 ? (i & 1) != 0 : DO_K;       // dK^T += Q^T . dS reads the Q tile, dV^T += dO^T . Pd the dO tile
+        const unsigned char* tp = (from_q ? qt : dot) + tbase + 64 * (d >> 1) + ((d & 1) ? xo : xe);
         tf[i] = join_tr(lds_read_tr16(tp), lds_read_tr16(tp + 16 * TSTR));
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const int d = i >> 1;
-        if (i & 1) dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], dsf, dk[d], 0, 0, 0);
-        else dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], pf, dv[d], 0, 0, 0);
+        const int d = WHICH == 2 ? i >> 1 : i;
+        const bool from_q = WHICH == 2 ? (i & 1) != 0 : DO_K;
+        if constexpr (DO_K) { if (from_q) dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], dsf, dk[d], 0, 0, 0); }
+        if constexpr (DO_V) { if (!from_q) dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[i], pf, dv[d], 0, 0, 0); }
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);
 #pragma unroll
@@ -978,12 +993,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
       u32x2 v;
-      v[0] = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
-      v[1] = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
-      *(u32x2*)(krow + d * 16 + 4 * g) = v;
-      v[0] = pack2bf(dv[d][0], dv[d][1]);
-      v[1] = pack2bf(dv[d][2], dv[d][3]);
-      *(u32x2*)(vrow + d * 16 + 4 * g) = v;
+      if constexpr (DO_K) {
+        v[0] = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
+        v[1] = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
+        *(u32x2*)(krow + d * 16 + 4 * g) = v;
+      }
+      if constexpr (DO_V) {
+        v[0] = pack2bf(dv[d][0], dv[d][1]);
+        v[1] = pack2bf(dv[d][2], dv[d][3]);
+        *(u32x2*)(vrow + d * 16 + 4 * g) = v;
+      }
     }
   }
 }
@@ -1150,31 +1169,51 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
   // credited work: backward = 2x forward = four S x S x hd products; the recomputed St / dPt are not credited
   const double fl = 4.0 * a->B * a->H * (double)Sq * a->S * HDP;
   char nm[56];
-  // The 16-row (two waves per SIMD) kernels exist for head dims <= 192 only: at 224 / 256 their resident fragments do not fit 256
-  // registers (70-177 spilled VGPRs), so those widths are not even instantiated and take the 32-row kernels (one wave per SIMD).
+  // The one-pass 16-row (two waves per SIMD) dQ / dK+dV kernels exist for head dims <= 192 only: at 224 / 256 their resident fragments
+  // do not fit 256 registers.  With a dS workspace those widths still run at two waves per SIMD -- dV and dK as two passes of the
+  // 16-row kernel (WHICH = 0 / 1) and the thin dQ kernel; without one they take the 32-row kernels (one wave per SIMD).
   constexpr bool HAS16 = HDP <= 192;
   static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
   static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
   bool done_q = part == 2, done_kv = part == 1;
-  if constexpr (HAS16) {
+  {
     constexpr int QT = TF_DKV16_QT;
     static const int use_ds = [] { const char* e = getenv("TF_ATTN_DS"); return e ? atoi(e) : 1; }();     // A/B switch
     if (part == 0 && use_ds && dq16 && dkv16 && !cross && a->ds_work != nullptr) {
       // S and dP once: delta -> dK / dV (+ dS tiles) -> dQ = dS . K
       const size_t lds_kv16d = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT), lds_qd = 64 * Geo<HDP>::TSTR + 4 * 4096;
-      static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
-      static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
       static const hipError_t o3 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_qd);
-      (void)o1; (void)o2; (void)o3;
+      (void)o3;
       {
         TfTraceScope tr("attn_delta_kernel", st, 0.0, 4.0 * a->B * a->S * a->H * HDP);
         hipLaunchKernelGGL(attn_delta_kernel, dim3(a->B * ((a->S + 3) / 4)), dim3(256), 0, st, *a);
       }
-      {
+      if constexpr (HAS16) {
+        static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        (void)o1; (void)o2;
         snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d, dS>", HDP);
         TfTraceScope tr(nm, st, 1.5 * fl);                 // credited: dP, dV, dK (the S recompute is not)
         if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
         else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
+      } else {
+        static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        static const hipError_t o4 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        static const hipError_t o5 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
+        (void)o1; (void)o2; (void)o4; (void)o5;
+        {
+          snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d, dV>", HDP);
+          TfTraceScope tr(nm, st, 0.5 * fl);               // credited: dV
+          if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT, false, 0>), grid, dim3(512), lds_kv16d, st, *a);
+          else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT, false, 0>), grid, dim3(512), lds_kv16d, st, *a);
+        }
+        {
+          snprintf(nm, sizeof(nm), "attn_bwd_dkv16_kernel<%d, dK, dS>", HDP);
+          TfTraceScope tr(nm, st, 1.0 * fl);               // credited: dP, dK
+          if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT, true, 1>), grid, dim3(512), lds_kv16d, st, *a);
+          else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT, true, 1>), grid, dim3(512), lds_kv16d, st, *a);
+        }
       }
       {
         snprintf(nm, sizeof(nm), "attn_bwd_dq_ds_kernel<%d>", HDP);
@@ -1183,6 +1222,9 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
       }
       return (int)hipGetLastError();
     }
+  }
+  if constexpr (HAS16) {
+    constexpr int QT = TF_DKV16_QT;
     const size_t lds_q16 = 256 * Geo<HDP>::TSTR;        // two K/V tile pairs
     const size_t lds_kv16 = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT);
     static const hipError_t once_q16 = hipFuncSetAttribute((const void*)attn_bwd_dq16_kernel<HDP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q16);
