@@ -45,7 +45,7 @@ def _head_dim(name):
 def test_library_holds_the_expected_kernels(table):
     assert len(table) > 150
     for must in ("gemm_nt_big_kernel<1, 9, false, false, 2>", "wgrad_tn2_kernel<false, 3>", "attn_fwd_kernel<192, false>",
-                 "attn_bwd_dkv16_kernel<192, false, 64, true>", "attn_bwd_dq_ds_kernel<192>", "attn_delta_kernel", "row_map_kernel",
+                 "attn_bwd_dkv16_kernel<192, false, 64, true, 2>", "attn_bwd_dq_ds_kernel<192>", "attn_delta_kernel", "row_map_kernel",
                  "ln_bwd_kernel<2, 8, false>", "radam_kernel"):
         assert must in table, must
     # every kernel was compiled for wave64 workgroups of at most 1024 threads and declares its registers
@@ -94,7 +94,7 @@ def test_occupancy_assumptions(table):
     alloc = lambda k: (table[k]["vgpr_count"] + table[k]["agpr_count"] + 7) // 8 * 8
     assert alloc("attn_fwd_kernel<192, false>") <= 256               # two 4-wave workgroups per CU
     assert alloc("attn_bwd_dq_ds_kernel<192>") <= 256
-    assert alloc("attn_bwd_dkv16_kernel<192, false, 64, true>") <= 256    # 8 waves = two per SIMD
+    assert alloc("attn_bwd_dkv16_kernel<192, false, 64, true, 2>") <= 256    # 8 waves = two per SIMD
     assert alloc("wgrad_tn2_kernel<false, 3>") <= 256                # leaves half of every SIMD's file to the backward chain
     assert alloc("ln_bwd_kernel<2, 8, false>") <= 128                # four waves per SIMD at d <= 1024
     assert alloc("gemm_nt_big_kernel<1, 9, false, false, 1>") <= 256 # the two-workgroups-per-CU form

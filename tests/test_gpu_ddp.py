@@ -121,14 +121,17 @@ def test_bench_two_ranks_on_one_gpu_does_not_hang(tmp_path):
     import json
     env = dict(os.environ, TF_FORCE_DEVICE="0", TF_DIST_BACKEND="gloo", TF_CHECK_SYNC="1", TF_BENCH_WATCHDOG_S="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--trace-steps", "2"]
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--trace-steps", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["allreduce"]["collectives_per_step"] == 4 and res["allreduce"]["bytes"] > 7e7
     assert "parameter checksum identical on 2 ranks" in r.stderr
+    assert res["rank_sync"]["identical_on_ranks"] == 2                      # the self-check runs by default at N > 1
+    # strong scaling next to the weak number: the reference divides the GLOBAL batch of 32 by the device count (run_experiment.py:373)
+    assert res["strong"]["global_batch"] == 32 and res["strong"]["batch_per_gpu"] == 16 and res["strong"]["samples_s"] > 0
 
 
 _TREE_WORKER = r'''
