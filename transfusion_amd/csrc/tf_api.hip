@@ -293,10 +293,10 @@ int tf_overlap_create(TfOverlap* o) {
   if (o == nullptr) return fail(-1, "tf_overlap_create");
   memset(o, 0, sizeof(*o));
   hipStream_t st = nullptr;
-  // TF_SIDE_PRIORITY: -1 = the device's highest stream priority, 1 = its lowest (default), 0 = the default priority.  The weight
-  // gradients have slack (they are needed only by the optimiser), the chain does not: with the packed batches of round 3 the lowest
-  // priority measured 4.235 / 4.237 ms per step against 4.255 / 4.269 at the default priority, same box.
-  static const int prio_sel = getenv("TF_SIDE_PRIORITY") ? atoi(getenv("TF_SIDE_PRIORITY")) : 1;
+  // TF_SIDE_PRIORITY (experiment): -1 = the device's highest stream priority, 1 = its lowest, unset / 0 = default.  The lowest priority
+  // is worth -0.6 % on the single-encoder benchmark (4.235 vs 4.26 ms, same box) and is a disaster for the wrapper, whose four level
+  // streams then starve their four side streams (B = 4: 11.5 vs 6.35 ms per step): the default priority stays.
+  static const int prio_sel = getenv("TF_SIDE_PRIORITY") ? atoi(getenv("TF_SIDE_PRIORITY")) : 0;
   if (prio_sel != 0) {
     int least = 0, greatest = 0;
     TF_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest), "tf_overlap_create(priority range)");
