@@ -308,6 +308,9 @@ const char* tf_last_error(void);
  * tf_heads_loss_*    runner/metrics_losses/losses.py:98-135 (box_loss), runner/nao/ego_nao_trainer.py:307-359 (noun / verb CE, TTC)
  * tf_softplus_col    modeling/obj_detection/roi_wrappers.py:228-229 (ttcs = softplus(ttc_pred_layer(box_features)))
  */
+/* planning hint, process-wide: n independent launch sequences (the wrapper's feature levels on their own streams) share the chip, so a
+ * GEMM plans its tile grid for 1 / n of the CUs.  1 (default): a launch has the chip to itself.  Affects speed only, never results. */
+void tf_set_gemm_concurrency(int n);
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);

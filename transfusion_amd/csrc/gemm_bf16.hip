@@ -14,6 +14,7 @@
 // residual) works on 16-B row chunks and HBM sees full 256-B row segments.
 #include <cstdlib>
 #include <type_traits>
+#include <atomic>
 #include "tf_common.h"
 #include <cstdio>
 #include "tf_kernels.h"
@@ -1003,8 +1004,9 @@ int num_cus();
 // tile-height choice: minimise rounds(over 2 workgroups x #CUs) x (height + per-tile fixed cost, ~2 row blocks' worth); ties go to
 // the taller tile.  64- and 96-row tiles (MI = 2, 3) exist for SMALL row counts -- the reference's own per-GPU batch of 4 - 5 samples is
 // ~2,000 - 3,500 token rows, where a 128-row tiling of an N = 768 GEMM is ~100 - 170 tiles for 512 slots.
+int plan_cus();
 int pick_mi(int M, int N) {
-  const int slots = 2 * num_cus();
+  const int slots = 2 * plan_cus();
   const int tn = (N + BN - 1) / BN;
   static const int env_lo = getenv("TF_GEMM_MI_MIN") ? atoi(getenv("TF_GEMM_MI_MIN")) : 2;       // experiment switch
   // half-filled chips: the time is one tile's, so the shortest tile that still leaves every CU at most one workgroup wins
@@ -1094,6 +1096,11 @@ int launch_gemm_duo(const TfGemmArgs* a, hipStream_t stream, int stagger_ticks) 
 #undef TF_GEMM_CASE
   return (int)hipGetLastError();
 }
+// How many independent launch sequences share the chip right now (the wrapper's feature levels run on their own streams): the tile
+// choice then plans for its SHARE of the CUs -- with four levels side by side the chip is full anyway, and the short tiles that fill an
+// empty chip at small row counts only cost efficiency (wrapper at B = 4: 6.68 ms with 128-row tiles against 7.11 with 64-row ones).
+std::atomic<int> g_gemm_concurrency{1};
+int plan_cus() { const int c = g_gemm_concurrency.load(std::memory_order_relaxed); const int n = num_cus() / (c < 1 ? 1 : c); return n < 8 ? 8 : n; }
 int num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -1108,7 +1115,7 @@ int num_cus() {
 // blocks' worth: fill, the C-tile burst).  The row count is whatever the batch's real tokens add up to (packed batches), so
 // the height that makes the tile grid an exact number of rounds changes from step to step; fp8 / fp32-accuracy operands keep 8 / 9.
 int pick_mf(int M, int N, int mf_lo = 5) {
-  const int tn = (N + BIG_BN - 1) / BIG_BN, slots = num_cus();
+  const int tn = (N + BIG_BN - 1) / BIG_BN, slots = plan_cus();
   static const int env_lo = getenv("TF_GEMM_MF_MIN") ? atoi(getenv("TF_GEMM_MF_MIN")) : 0;      // experiment switch
   if (env_lo > mf_lo) mf_lo = env_lo > 9 ? 9 : env_lo;
   int best = 9; long best_cost = -1;
@@ -1132,6 +1139,8 @@ template <bool SPLIT> int launch_gemm_big_mf(int mf, const TfGemmArgs* a, hipStr
   }
 }
 }  // namespace
+
+extern "C" void tf_set_gemm_concurrency(int n) { g_gemm_concurrency.store(n < 1 ? 1 : n, std::memory_order_relaxed); }
 
 extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0) return 0;
@@ -1165,9 +1174,10 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
     const int mi = split ? 4 : pick_mi(a->M, a->N);            // (the fp32-accuracy mode has one tile height of this kernel)
     const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
-    const double t_big = (double)((tb + num_cus() - 1) / num_cus()) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
-    const long rs = (ts + 2 * num_cus() - 1) / (2 * num_cus());
-    const double sh = (ts - (rs - 1) * 2 * num_cus()) * 2 <= 2 * num_cus() ? 0.62 : 1.0;         // (see pick_mi)
+    const int pc = plan_cus();
+    const double t_big = (double)((tb + pc - 1) / pc) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
+    const long rs = (ts + 2 * pc - 1) / (2 * pc);
+    const double sh = (ts - (rs - 1) * 2 * pc) * 2 <= 2 * pc ? 0.62 : 1.0;         // (see pick_mi)
     const double t_small = ((double)(rs - 1) + sh) * (8.0 + 0.021 * a->K) * ((mi + 2) / 6.0);
     static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
     if (model && t_small < t_big) use_big = false;

@@ -182,6 +182,10 @@ class CrossFusionBoxWrapper(nn.Module):
         main = torch.cuda.current_stream(language_f.device) if language_f.is_cuda else None
         parallel = (main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
                     and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
+        if main is not None:
+            # the GEMMs plan their tile grids for their share of the chip while the levels run side by side (backward included:
+            # autograd replays the levels on the same streams)
+            ops.set_gemm_concurrency(len(self.fpn_features_idx) if parallel else 1)
         if parallel and (self._level_streams is None or self._level_streams[0].device != language_f.device):
             self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
         for i, key in enumerate(self.fpn_features_idx):

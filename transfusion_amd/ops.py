@@ -160,6 +160,11 @@ def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
     return q, sc
 
 
+def set_gemm_concurrency(n: int):
+    """Planning hint for the GEMM tile choice: ``n`` launch sequences share the chip (tf_set_gemm_concurrency)."""
+    L.load().tf_set_gemm_concurrency(int(n))
+
+
 _overlap_cache = {}      # (device index, stream handle) -> TfOverlap: every stream that runs encoders has its own side stream + events
 
 
