@@ -73,11 +73,41 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sqb - 1)) * SW : nullptr;
   const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sqb - 1) * SW : nullptr;
 
+  const FragAddr<HDP> fk(lds_addr_of(kt), lane), fv(lds_addr_of(vt), lane);
   const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
+#ifndef TF_FWD_NO_DMA
+  const TileDma<HDP, 4> dma(__builtin_amdgcn_readfirstlane(wave), lane, ld);
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc(kbase, ld, Sb, HDP), vrs = make_rsrc(vbase, ld, Sb, HDP);
+  const unsigned tile_bytes = 64u * (unsigned)(ld * 2);
+  unsigned long long dm_n = ~0ull, blk_n = 0ull;
+  unsigned kmb_n = 0;
+  auto fetch_words = [&](int tn) {          // raw loads only; they are consumed one tile later
+    if (a.drop_thr) dm_n = drow[tn];
+    if (BLK) blk_n = brow[tn];
+    if (a.key_mask != nullptr) kmb_n = a.key_mask[(size_t)b * S + min(tn * 64 + lane, Sb - 1)];
+  };
+  if (ntiles > 0) { fetch_words(0); dma.issue(krs, 0u, kt); }
+#endif
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * 64;
-    // No register prefetch: the kernel stays under 256 VGPRs so that TWO workgroups share a CU (2 waves per SIMD)
-    // and one's K/V staging overlaps the other's MFMA / softmax work.
+    // K / V staging is LDS-DMA (no staging registers: the kernel stays under 256 VGPRs, two workgroups per CU): V(t) travels
+    // under S(t) + softmax, K(t+1) under PV(t); each buffer is rewritten only after the barrier that every wave reaches once it
+    // has stopped reading it.  TF_FWD_NO_DMA keeps the register-staged form (global -> registers -> LDS between two barriers).
+#if defined(TF_ABL_FWD) && (TF_ABL_FWD & 1)
+    if (t == 0) {
+      TileRegs<64, HDP> kr;
+      kr.load(kbase, ld, kv0, Sb - 1, false, tid);
+      __syncthreads();
+      kr.store(kt, tid);
+      kr.load(vbase, ld, kv0, Sb - 1, false, tid);
+      kr.store(vt, tid);
+      __syncthreads();
+    }
+    else { __syncthreads(); __syncthreads(); }
+#elif !defined(TF_FWD_NO_DMA)
+    dma_wait_barrier();                    // K(t) landed (it travelled under PV(t-1)) and visible; every wave has finished PV(t-1)
+    dma.issue(vrs, t * tile_bytes, vt);    // V(t) travels under S(t) and the softmax
+#else
     {
       TileRegs<64, HDP> kr;
       kr.load(kbase, ld, kv0, Sb - 1, false, tid);
@@ -87,25 +117,52 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
       kr.store(vt, tid);
     }
     __syncthreads();
+#endif
+#if !defined(TF_FWD_NO_DMA) && !(defined(TF_ABL_FWD) && (TF_ABL_FWD & 1))
+    // (the per-tile words were fetched one tile ahead, BEFORE the K transfer was issued: a load issued after a DMA can only be
+    // waited for together with it)
+    const unsigned long long dm = dm_n >> (4 * h), blk = blk_n;
+    const unsigned long long vall = __ballot(kv0 + lane < Sb && kmb_n == 0);
+#else
     const unsigned long long dm = a.drop_thr ? (drow[t] >> (4 * h)) : ~0ull;
     // keys this lane's query may attend: not padded / out of range (wave-uniform ballot) and, with a block mask, not
     // blocked for this query (per lane).  Without a block mask nothing per-lane is computed outside the rare masked tile.
     const unsigned long long vall = key_bits(a.key_mask, b, Sb, kv0, lane);
     const unsigned long long blk = BLK ? brow[t] : 0ull;
+#endif
     const bool masked_tile = vall != ~0ull || (BLK && __any(blk != 0ull));
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
 
-    // ---- St[key][q] = K . Q^T ----
+    // ---- St[key][q] = K . Q^T ----  (two accumulator chains interleaved, fragment reads PF ahead: attn_common.h)
     f32x16 st[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < G::KSTEPS; ++ks)
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HDP>(kt, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
+    {
+#ifdef TF_FWD_PRIO
+      __builtin_amdgcn_s_setprio(TF_FWD_PRIO);
+#endif
+      constexpr int NF = 2 * G::KSTEPS, PF = 3;
+      u32x4 fr[NF];
+      static_for<PF>([&](auto I) { fr[I] = fk.template row<(I & 1) * 32, (I >> 1)>(); });
+      static_for<NF>([&](auto I) {
+        constexpr int i = I, nx = i + PF;
+#if defined(TF_ABL_FWD) && (TF_ABL_FWD & 16)
+        if constexpr (i >= PF) fr[i] = fr[i - PF];
+#else
+        if constexpr (nx < NF) fr[nx] = fk.template row<(nx & 1) * 32, (nx >> 1)>();
+        lgkm_wait<(NF - 1 - i < PF ? NF - 1 - i : PF)>(fr[i]);
+#endif
+        st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fr[i]), qf[i >> 1], st[i & 1], 0, 0, 0);
+      });
     }
+    unsigned pk[2][8];
     // ---- online softmax (log2 domain; raw scores stay unscaled, the scale rides in the FMA) ----
+#ifdef TF_FWD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if !(defined(TF_ABL_FWD) && (TF_ABL_FWD & 4))
     if (masked_tile) {                     // wave-uniform: only tiles that contain padded / out-of-range / blocked keys pay for the select
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -130,26 +187,58 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
     }
-    float psum = 0.f;
+    // probabilities two at a time: packed fp32 FMA / add, the keep bit as a sign-extended one-bit field ANDed into the value
+    // (v_bfe_i32 + v_and instead of and / compare / select), one v_cvt_pk per pair.  pk[kb][i] = elements 2i, 2i+1 of sub-tile kb.
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 ps2 = {0.f, 0.f};
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+    static_for<16>([&](auto I) {
+      constexpr int kb = I / 8, r = 2 * (I % 8), b0 = (r & 3) + 8 * (r >> 2);
+      const int dword = (int)(unsigned)(dm >> (32 * kb));
+      const f32x2 e2 = f32x2{st[kb][r], st[kb][r + 1]} * sc2 + nm2;
+      const float p0 = fast_exp2(e2[0]), p1 = fast_exp2(e2[1]);
+      ps2 += f32x2{p0, p1};
+      pk[kb][r >> 1] = cvt_pk_bf16(and_bit<b0>(p0, dword), and_bit<b0 + 1>(p1, dword));
+    });
+    l_run += ps2[0] + ps2[1];
+#else
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(st[kb][r], sc, -m_run));
-        psum += p;
-        st[kb][r] = ((dm >> (kb * 32 + (r & 3) + 8 * (r >> 2))) & 1ull) ? p : 0.f;
+      for (int r = 0; r < 16; r += 2) pk[kb][r >> 1] = cvt_pk_bf16(st[kb][r], st[kb][r + 1]);
+#endif
+#ifndef TF_FWD_NO_DMA
+    dma_wait_barrier();                    // V(t) landed and visible; every wave has finished S(t)
+    if (t + 1 < ntiles) { fetch_words(t + 1); dma.issue(krs, (t + 1) * tile_bytes, kt); }     // K(t+1) travels under PV(t)
+#endif
+    // ---- O^T[d][q] += V^T . Pt ----  (transposed V fragments PF ahead of their MFMA)
+    {
+      constexpr int NF = 4 * G::DBLK, PF = 2;
+      u64 fa[NF], fb[NF];
+      bf16x8 pf[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kb = g >> 1, s4 = 4 * (g & 1);
+        pf[g] = as_bf16x8(u32x4{pk[kb][s4], pk[kb][s4 + 1], pk[kb][s4 + 2], pk[kb][s4 + 3]});
       }
-    l_run += psum;
-    // ---- O^T[d][q] += V^T . Pt ----
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = acc_frag(st[kb], s);
-#pragma unroll
-        for (int d = 0; d < G::DBLK; ++d)
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HDP>(vt, kb * 32 + 16 * s, d * 32, lane), pf, o[d], 0, 0, 0);
-      }
+#ifdef TF_FWD_PRIO
+      __builtin_amdgcn_s_setprio(TF_FWD_PRIO);
+#endif
+      static_for<PF>([&](auto I) { fv.template tr<(I / G::DBLK) * 16, (I % G::DBLK) * 32>(fa[I], fb[I]); });
+      static_for<NF>([&](auto I) {
+        constexpr int i = I, nx = i + PF;
+#if defined(TF_ABL_FWD) && (TF_ABL_FWD & 8)
+        if constexpr (i >= PF) { fa[i] = fa[i - PF]; fb[i] = fb[i - PF]; }
+#else
+        if constexpr (nx < NF) fv.template tr<(nx / G::DBLK) * 16, (nx % G::DBLK) * 32>(fa[nx], fb[nx]);
+        lgkm_wait<2 * (NF - 1 - i < PF ? NF - 1 - i : PF)>(fa[i], fb[i]);
+#endif
+        o[i % G::DBLK] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_tr64(fa[i], fb[i]), pf[i / G::DBLK], o[i % G::DBLK], 0, 0, 0);
+      });
+#ifdef TF_FWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
   }
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

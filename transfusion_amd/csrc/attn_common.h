@@ -2,6 +2,7 @@
 // dual-use LDS tile geometry, operand fragment reads, key-validity scans, the (batch, head) -> XCD mapping.
 #pragma once
 #include "tf_common.h"
+#include <utility>
 
 namespace {
 
@@ -55,6 +56,39 @@ template <int ROWS, int HDP> struct TileRegs {
   }
 };
 
+// LDS-DMA staging of a 64-row dual-use tile by NW waves (global_load_lds_dwordx4: a wave-instruction fills 1 KiB of CONSECUTIVE
+// LDS, 16 B per lane).  The tile image is lane-linear, so the layout lives on the SOURCE side: the lane whose slot is chunk position
+// cp of tile row r fetches global chunk cp ^ ((r >> 2) & 3) of that row; lanes whose slot is row padding re-fetch chunk 0 (never read).
+// No staging registers: per lane NI loop-invariant 32-bit source offsets; a tile advances the wave-uniform base.
+template <int HDP, int NW> struct TileDma {
+  static constexpr int T = Geo<HDP>::TSTR, NI = 64 * T / 1024 / NW;
+  static_assert(64 * T % (1024 * NW) == 0, "tile bytes divide into whole wave-instructions");
+  unsigned off[NI];                   // byte offset of this lane's source chunk inside a 64-row block, instruction i
+  int wave, lane;
+  __device__ __forceinline__ TileDma(int wave_, int lane_, size_t ld) : wave(wave_), lane(lane_) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) off[i] = slot_row(i) * (unsigned)(ld * 2) + slot_col(i);
+  }
+  __device__ __forceinline__ unsigned slot_row(int i) const { return (unsigned)(((wave * NI + i) * 1024 + lane * 16) / T); }
+  __device__ __forceinline__ unsigned slot_col(int i) const {
+    const int pos = (wave * NI + i) * 1024 + lane * 16, r = pos / T, cp = (pos % T) >> 4;
+    return cp < HDP / 8 ? ((cp ^ ((r >> 2) & 3)) << 4) : 0;
+  }
+  // 64 rows starting soff bytes into the buffer (a sample's rows of one head: make_rsrc); bytes past the buffer's end arrive as zeros,
+  // so a ragged last tile needs no clamping and its surplus V rows are finite
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned soff_, unsigned char* tile) const {
+    const int soff = __builtin_amdgcn_readfirstlane((int)soff_);      // (the tile counter descends from a wave reduction)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TF_LDS_PTR(tile + (wave * NI + i) * 1024), 16, (int)off[i], soff, 0, 0);
+  }
+};
+// buffer over rows 0 .. rows-1 of one head's HDP columns in a [*, ld] bf16 matrix (base = row 0, the head's first column)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const u16* base, size_t ld, int rows, int hdp) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((size_t)(rows - 1) * ld * 2 + hdp * 2), 0x00020000);
+}
+__device__ __forceinline__ void dma_wait_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // A-operand row fragment (32 rows x 16 k) of a dual-use tile: row = row0 + (lane&31), chunk 2*ks + (lane>>5)
 template <int HDP> __device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int row0, int ks, int lane) {
   const int r = row0 + (lane & 31);
@@ -71,6 +105,49 @@ template <int HDP> __device__ __forceinline__ bf16x8 tr_frag(const unsigned char
   const s16x4 b = lds_read_tr16(tile + tile_off(r1, ch, Geo<HDP>::TSTR) + o8);
   return join_tr(a, b);
 }
+// ---- software-pipelined operand reads (inline asm) ----------------------------------------------------------------
+// hipcc schedules "ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma" with ONE fragment buffer when the reads are intrinsics
+// (every MFMA then waits a full LDS round trip: the forward kernel's matrix pipe was busy a third of the time).  Issued
+// from inline asm the reads run PF fragments ahead of the MFMA that consumes them; the wait asm names the fragment it
+// releases, so its consumer cannot be scheduled above it.  LDS returns in order, so lgkmcnt(n) with n = reads issued
+// after the wanted one is exact, and any other outstanding LDS / scalar op only makes it conservative.
+template <int N, class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <int OFF> __device__ __forceinline__ u32x4 rd128_asm(unsigned addr) {
+  u32x4 d;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+  return d;
+}
+template <int N> __device__ __forceinline__ void lgkm_wait(u32x4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait(u64& a, u64& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+// Per-lane LDS byte addresses of the two fragment kinds of a dual-use tile (tile_off with the per-k-step / per-column parts as
+// immediates): row fragments need two addresses (even / odd k-step), transposed fragments two (rows r0 and r0 + 8).
+template <int HDP> struct FragAddr {
+  unsigned row_e, row_o, tr_a, tr_b;
+  __device__ __forceinline__ FragAddr(unsigned tile_lds, int lane) {
+    constexpr int T = Geo<HDP>::TSTR;
+    const int r = lane & 31, x = (r >> 2) & 3, hh = lane >> 5;
+    row_e = tile_lds + r * T + ((hh ^ x) << 4);
+    row_o = tile_lds + r * T + (((2 + hh) ^ x) << 4);
+    const int li = lane & 15, q4 = li >> 2, p = li & 3, cb = (lane >> 4) & 1, low2 = 2 * cb + (p >> 1);
+    tr_a = tile_lds + (4 * hh + q4) * T + ((low2 ^ hh) << 4) + (p & 1) * 8;
+    tr_b = tile_lds + (4 * hh + q4 + 8) * T + ((low2 ^ (hh + 2)) << 4) + (p & 1) * 8;
+  }
+  // row_frag(tile, ROW0, KS): ROW0 a multiple of 32
+  template <int ROW0, int KS> __device__ __forceinline__ u32x4 row() const {
+    return rd128_asm<ROW0 * Geo<HDP>::TSTR + 64 * (KS >> 1)>((KS & 1) ? row_o : row_e);
+  }
+  // tr_frag(tile, KROW0, COL0): KROW0 a multiple of 16, COL0 a multiple of 32
+  template <int KROW0, int COL0> __device__ __forceinline__ void tr(u64& a, u64& b) const {
+    a = tr_read_asm<KROW0 * Geo<HDP>::TSTR + 2 * COL0>(tr_a);
+    b = tr_read_asm<KROW0 * Geo<HDP>::TSTR + 2 * COL0>(tr_b);
+  }
+};
+
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16 B-operand fragment of k-step s
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
   bf16x8 f;

@@ -33,6 +33,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(u16 b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
+// two floats -> packed bf16 pair in ONE v_cvt_pk_bf16_f32 (element-wise conversions of a vector compile to one instruction per
+// element plus a v_perm per pair)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// x where bit BIT of word is set, else +0: the bit as a sign-extended field ANDed into the value (two VALU ops; written as C the
+// compiler turns it back into and / compare / select, three ops and a VCC hazard)
+template <int BIT> __device__ __forceinline__ float and_bit(float x, int word) {
+  int m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+}
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
 // 8 bf16 packed in a u32x4 -> 8 floats
