@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 3
+#define TF_ABI_VERSION 4
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -197,6 +197,9 @@ typedef struct TfRadamArgs {
   float n_sma; float step_size; int rectified;   // host-computed schedule terms
   float grad_scale;                               // multiplies g first (loss-scale / 1/world)
   const float* sumsq; float clip;                 // optional device scalar sum(g^2): global-norm clip without a host sync
+  // optional (a step captured in a HIP graph, see tf_clock_ptr): the step number is step0 + *step_clock and beta2_t, bias1, n_sma,
+  // step_size, rectified are formed on the device from it (degenerated_to_sgd: radam_optim.py:31,80-84)
+  const uint32_t* step_clock; long long step0; int degenerated_to_sgd;
 } TfRadamArgs;
 
 // language auxiliary head, pooling stage (modeling/cross_fusion/ego_fusion/lm_layers.py:59-72, PoolPredictor.forward):
@@ -326,6 +329,15 @@ int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s);                  /* d(f
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s);
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s);
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s);
+/* The step clock (no reference counterpart; what replaces torch's advancing Philox offset when a whole training step is captured in a
+ * HIP graph).  Every kernel that draws a dropout mask folds mix(*clock) into the key it was launched with; the word is 0 until the
+ * caller advances it and mix(0) = 0, so callers that never touch it see the keys they pass.  A captured step puts tf_clock_advance
+ * first: each replay then draws fresh masks (forward and backward of one replay agree), and tf_radam_step with step_clock = the same
+ * word counts its steps.  tf_clock_ptr: the device word (allocated on first use, one per process); tf_clock_advance: *clock += by on
+ * the stream; tf_clock_set: *clock = value (tests). */
+const uint32_t* tf_clock_ptr(void);
+int tf_clock_advance(uint32_t by, tf_stream_t s);
+int tf_clock_set(uint32_t value, tf_stream_t s);
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
 int tf_heads_loss_fwd(const TfHeadsLossArgs* a, tf_stream_t s);
 int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s);

@@ -41,7 +41,8 @@ def gelu_grad(x):
                                    # row counts of packed batches: the large tile's height follows the grid (160 / 192 / 224-row tiles, ragged tails)
                                    (12010, 768, 192), (14003, 768, 128), (16519, 768, 192),
                                    # small row counts (the reference's per-GPU batch of 4): 64- and 96-row tiles of the 128-wide kernel
-                                   (2070, 768, 128), (2833, 1536, 64), (3011, 768, 192)])
+                                   (2070, 768, 128), (2833, 1536, 64), (3011, 768, 192),
+                                   (2083, 768, 1536), (2083, 1536, 768), (1200, 2304, 768), (700, 768, 2304)])    # one workgroup per CU or fewer: the ring form of the 128-wide kernel
 def test_gemm_epilogues(dev, M, N, K):
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)

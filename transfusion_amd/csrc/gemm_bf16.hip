@@ -231,8 +231,15 @@ template <int BK> __device__ __forceinline__ int swz(int r) { return BK == 64 ? 
 
 // SPLIT (fp32-accuracy mode), this 128x128 kernel: the K loop runs three times over the operands' planes -- (A_hi, W_hi), (A_lo, W_hi), (A_hi, W_lo) -- into
 // the same fp32 accumulators; the epilogue works on fp32 values and writes hi + lo planes.
-template <int EPI, int MI, int BK, bool SPLIT = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
+// NSLOT > 2 ("ring"): for grids of at most about one workgroup per CU (small row counts: the reference's per-GPU batch of 4 - 5
+// samples, the wrapper's upper levels).  There no second workgroup hides the DMA latency and the double-buffered loop runs at one
+// L2 round trip per K-tile (M = 2083, N = 768, K = 1536: 34 us for 5 GFLOP); a 4-slot ring with counted waits keeps three K-tiles
+// of transfers in flight, as in the large-tile kernel.
+template <int EPI, int MI, int BK, bool SPLIT = false, int NSLOT = 2>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g_in) {
+  TfGemmArgs g = g_in;
+  g.drop_key = tf_salted(g.drop_key);                            // the step clock (tf_common.h)
+  static_assert(NSLOT == 2 || (!SPLIT && BK == 64), "the ring form exists for bf16 operands, BK = 64");
   constexpr int BM = 32 * MI;
   constexpr int ROWB = BK * 2;                                   // bytes per tile row (128 or 64)
   constexpr int RPI = 1024 / ROWB;                               // rows per 1-KiB DMA instruction (8 or 16)
@@ -290,9 +297,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = SPLIT ? 3 * nk0 : nk0;
+  const int frow = lane & 15, fch = lane >> 4;
+  if constexpr (NSLOT > 2) {
+    constexpr int DIST = NSLOT - 1, PER_WAVE = MI + 4;             // DMA instructions per wave and K-tile: 4 MI (A) + 16 (W) over 4 waves
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) stage(d, min(d, nk - 1));       // (past the end the last tile is re-fetched: one counted wait fits all phases)
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * PER_WAVE) : "memory");
+      const unsigned char* abase = smem + cur * BUF_BYTES;
+      const unsigned char* bbase = abase + A_BYTES;
+      bf16x8 wf[2][4], xf[2][MI];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rn = wc * 64 + i * 16 + frow;
+          wf[ks][i] = *(const bf16x8*)(bbase + rn * ROWB + (((ks * 4 + fch) ^ swz<BK>(rn)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int rm = wr * (BM / 2) + i * 16 + frow;
+          xf[ks][i] = *(const bf16x8*)(abase + rm * ROWB + (((ks * 4 + fch) ^ swz<BK>(rm)) << 4));
+        }
+      }
+      // (after the reads in program order: hipcc cannot tell the DMA's LDS destination from the slot being read)
+      // slot of tile kt + DIST == slot of tile kt - 1: every wave finished reading it before this barrier
+      stage(cur == 0 ? NSLOT - 1 : cur - 1, min(kt + DIST, nk - 1));
+      cur = cur == NSLOT - 1 ? 0 : cur + 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the C tile reuses LDS
+  } else {
   stage(0, 0);
   __syncthreads();
-  const int frow = lane & 15, fch = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -318,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g) {
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
     }
     __syncthreads();
+  }
   }
 
   if constexpr (SPLIT) {
@@ -383,7 +428,9 @@ __device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmc
 // can start `stagger_ticks` (100 MHz) late, to put one workgroup's store burst under the other's K loop -- measured neutral to
 // negative at 5 / 15 / 30 us, alone and in the step, so the default is 0.
 template <int EPI, int MF, bool FP8 = false, bool SPLIT = false, int NWR = 2>
-__global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmArgs g, int stagger_lo, int stagger_hi, int stagger_ticks) {
+__global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmArgs g_in, int stagger_lo, int stagger_hi, int stagger_ticks) {
+  TfGemmArgs g = g_in;
+  g.drop_key = tf_salted(g.drop_key);                            // the step clock (tf_common.h)
   static_assert(!(FP8 && SPLIT), "fp8 operands have no lo plane");
   static_assert(NWR == 2 || !(FP8 || SPLIT), "the two-per-CU form exists for bf16 operands only");
   constexpr int ES = FP8 ? 1 : 2;                                  // bytes per operand element
@@ -974,17 +1021,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
 // launchers (host)
 // ------------------------------------------------------------------------------------------------
 namespace {
-template <int MI, int BK, bool SPLIT = false> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
+template <int MI, int BK, bool SPLIT = false, int NSLOT = 2> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
   constexpr int BM = 32 * MI;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  size_t lds = 2 * (size_t)(BM + 128) * BK * 2;                    // BK 64: 64 / 72 / 80 KiB
+  size_t lds = NSLOT * (size_t)(BM + 128) * BK * 2;                // BK 64, two slots: 64 / 72 / 80 KiB
   if (lds < (size_t)BM * CT_STRIDE) lds = (size_t)BM * CT_STRIDE;  // never below the C tile of BM x 272 B
   dim3 grid(tiles), block(256);
 #define TF_GEMM_CASE(E)                                                                                           \
   case E: {                                                                                                       \
     static bool attr_set = false;                                                                                 \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, MI, BK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
-    hipLaunchKernelGGL((gemm_nt_kernel<E, MI, BK, SPLIT>), grid, block, lds, stream, *a);                         \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, MI, BK, SPLIT, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+    hipLaunchKernelGGL((gemm_nt_kernel<E, MI, BK, SPLIT, NSLOT>), grid, block, lds, stream, *a);                  \
   } break;
   switch (a->epilogue) {
     TF_GEMM_CASE(TF_EPI_NONE)
@@ -1140,6 +1187,7 @@ template <bool SPLIT> int launch_gemm_big_mf(int mf, const TfGemmArgs* a, hipStr
 }
 }  // namespace
 
+TF_TU_SET_CLOCK(tf_tu_set_clock_gemm)
 extern "C" void tf_set_gemm_concurrency(int n) { g_gemm_concurrency.store(n < 1 ? 1 : n, std::memory_order_relaxed); }
 
 extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
@@ -1213,10 +1261,37 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     TfTraceScope tr(nm, stream, fl);
     return launch_gemm_mi<4, 64, true>(a, stream);
   }
+  const int mi_sel = pick_mi(a->M, a->N);
+  // at most about one workgroup per CU: the 4-slot ring form (see the kernel's header).  TF_GEMM_RING = percent of the CU count up
+  // to which a grid takes it (0 = never).
+  static const int ring_pct = getenv("TF_GEMM_RING") ? atoi(getenv("TF_GEMM_RING")) : 100;
+  if (ring_pct > 0 && mi_sel <= 5) {
+    const long tiles = (long)((a->M + 32 * mi_sel - 1) / (32 * mi_sel)) * ((a->N + BN - 1) / BN);
+    if (tiles * 100 <= (long)ring_pct * num_cus()) {
+      char nm[56];
+      snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64, ring>", a->epilogue, mi_sel);
+      TfTraceScope tr(nm, stream, fl);
+      static const int ring_slots = getenv("TF_GEMM_RING_SLOTS") ? atoi(getenv("TF_GEMM_RING_SLOTS")) : 4;
+      if (ring_slots == 3) {
+        switch (mi_sel) {
+          case 2: return launch_gemm_mi<2, 64, false, 3>(a, stream);
+          case 3: return launch_gemm_mi<3, 64, false, 3>(a, stream);
+          case 4: return launch_gemm_mi<4, 64, false, 3>(a, stream);
+          default: return launch_gemm_mi<5, 64, false, 3>(a, stream);
+        }
+      }
+      switch (mi_sel) {
+        case 2: return launch_gemm_mi<2, 64, false, 4>(a, stream);
+        case 3: return launch_gemm_mi<3, 64, false, 4>(a, stream);
+        case 4: return launch_gemm_mi<4, 64, false, 4>(a, stream);
+        default: return launch_gemm_mi<5, 64, false, 4>(a, stream);
+      }
+    }
+  }
   char nm[56];
-  snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64>", a->epilogue, pick_mi(a->M, a->N));
+  snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64>", a->epilogue, mi_sel);
   TfTraceScope tr(nm, stream, fl);
-  switch (pick_mi(a->M, a->N)) {
+  switch (mi_sel) {
     case 2: return launch_gemm_mi<2, 64>(a, stream);
     case 3: return launch_gemm_mi<3, 64>(a, stream);
     case 5: return launch_gemm_mi<5, 64>(a, stream);

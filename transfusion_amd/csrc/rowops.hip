@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 // row, so its HBM rate is set by rows in flight (4-wave blocks at the 512-block cap ran 2 waves per SIMD: 3.2 TB/s)
 template <int MAXC, int LNB_WAVES, bool SPLIT>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a) {
+  const unsigned drop_key = tf_salted(a.drop_key);       // the step clock (tf_common.h); (a copy of the whole struct cost 10 registers)
   __shared__ float red[LNB_WAVES][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[MAXC][8], db[MAXC][8];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
         st8s<SPLIT>(a.dx, a.dx_lo, (size_t)xr * a.lddx + c, o);
         if (a.dx_drop != nullptr) {
           if (a.drop_thr) {
-            const unsigned km = tf_keep8((unsigned)xr * (unsigned)a.drop_ld + (unsigned)c, a.drop_key, a.drop_thr);
+            const unsigned km = tf_keep8((unsigned)xr * (unsigned)a.drop_ld + (unsigned)c, drop_key, a.drop_thr);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = ((km >> e) & 1u) ? o[e] * a.drop_scale : 0.f;
           }
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 // ------------------------------------------------------------------------------------------------
 // Token assemble (K2): out[b, s] = s < Nv ? dropout(vis[b,s] + pe[s] + kind_v) : lang[b,s-Nv] + kind_l
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs a) {
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs a_in) {
+  TfAssembleArgs a = a_in;
+  a.drop_key = tf_salted(a.drop_key);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.Nv + a.Nl;
   const int row = blockIdx.x * 4 + wave;
@@ -237,7 +240,9 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
 }
 
 template <int MAXC>
-__global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs a) {
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs a_in) {
+  TfAssembleArgs a = a_in;
+  a.drop_key = tf_salted(a.drop_key);
   __shared__ float red[4][64 * MAXC * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.Nv + a.Nl;
@@ -470,8 +475,9 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
 }
 
 // y = keep(i) ? x * scale : 0 over a dense bf16 array (16 B per lane); its own backward
-__global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restrict__ x, u16* __restrict__ y, long long n8, unsigned key,
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restrict__ x, u16* __restrict__ y, long long n8, unsigned key_in,
                                                             unsigned thr, float scale) {
+  const unsigned key = tf_salted(key_in);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float f[8];
     unpack8(*(const u32x4*)(x + i * 8), f);
@@ -484,8 +490,9 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restric
 
 // Attention-probability dropout as a bitmask: bits[row][w] bit k = keep(element row*S + 32*w + k), row = (b*H+h)*S + q.
 // Generated once per layer and forward; read by attn_fwd / attn_bwd_dq / attn_bwd_dkv (2 VALU ops per element there).
-__global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict__ bits, long long nrows, int S, int SW32, unsigned key,
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict__ bits, long long nrows, int S, int SW32, unsigned key_in,
                                                             unsigned thr16) {
+  const unsigned key = tf_salted(key_in);
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= nrows * SW32) return;
   // (the grid is checked against 2^32 elements by the launcher, so the row / word split fits 32-bit arithmetic)
@@ -508,7 +515,8 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict
   bits[t] = m;
 }
 
-__global__ void dropout_mask_kernel(uint8_t* out, long long n, unsigned key, unsigned thr) {
+__global__ void dropout_mask_kernel(uint8_t* out, long long n, unsigned key_in, unsigned thr) {
+  const unsigned key = tf_salted(key_in);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = tf_keep((unsigned)i, key, thr) ? 1 : 0;
 }
@@ -521,7 +529,27 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ s, float* __restric
 
 // RAdam (runner/metrics_losses/radam_optim.py:55-100): moments always updated; parameter update only
 // when the variance is rectifiable (N_sma >= 5) or in the SGD-degenerated mode.
-__global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a) {
+// step_clock != null (a step captured in a HIP graph): the step number is step0 + *step_clock and the schedule terms the host
+// normally computes (radam_optim.py:64-84; optim.radam_schedule) are formed here, in double, by every thread alike.
+__global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a_in) {
+  TfRadamArgs a = a_in;
+  if (a.step_clock != nullptr) {
+    const double t = (double)(a.step0 + (long long)*a.step_clock);
+    const double b2t = pow((double)a.beta2, t), b1t = pow((double)a.beta1, t);
+    const double nmax = 2.0 / (1.0 - (double)a.beta2) - 1.0;
+    const double nsma = nmax - 2.0 * t * b2t / (1.0 - b2t);
+    a.beta2_t = (float)b2t; a.bias1 = (float)(1.0 - b1t); a.n_sma = (float)nsma;
+    if (nsma >= 5.0) {
+      a.step_size = (float)(sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma * nmax / (nmax - 2.0)) / (1.0 - b1t));
+      a.rectified = 1;
+    } else if (a.degenerated_to_sgd) {
+      a.step_size = (float)(1.0 / (1.0 - b1t));
+      a.rectified = 2;
+    } else {
+      a.step_size = -1.f;
+      a.rectified = 0;
+    }
+  }
   float gs = a.grad_scale;
   if (a.sumsq != nullptr && a.clip > 0.f) {          // torch.nn.utils.clip_grad_norm_: coef = clip / (norm + 1e-6), clamped to 1
     const float norm = sqrtf(*a.sumsq) * a.grad_scale;
@@ -912,7 +940,9 @@ __global__ __launch_bounds__(64) void lm_pool_bwd_kernel(const TfLmPoolArgs a) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pn_load(const void* x, int is_f32, size_t i) { return is_f32 ? ((const float*)x)[i] : bf2f(((const u16*)x)[i]); }
 
-__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs a) {
+__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs a_in) {
+  TfPoolNormArgs a = a_in;
+  a.drop_key = tf_salted(a.drop_key);
   const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (c >= a.d) return;
   const int len = a.lens != nullptr ? min(max(a.lens[b], 0), a.T) : a.T;
@@ -939,7 +969,9 @@ __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs
   }
 }
 
-__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const TfPoolNormArgs a) {
+__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const TfPoolNormArgs a_in) {
+  TfPoolNormArgs a = a_in;
+  a.drop_key = tf_salted(a.drop_key);
   const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (c >= a.ldgx) return;
   const bool bf = !a.gx_is_f32;
@@ -1007,7 +1039,8 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (width > 64 * MAXC_MAX * 8) return -2;
   constexpr int nw = 8;        // waves per workgroup (16 measured slower: 39.9 vs 38.3 us; its instantiations spilled and are gone)
   static const int env_g = getenv("TF_LNB_GRID") ? atoi(getenv("TF_LNB_GRID")) : 512;     // experiment switch
-  const dim3 grid(grid_for(a->rows, nw * 2, env_g));   // every block ends with 2*d atomics onto the SAME addresses: keep blocks few
+  const dim3 grid(grid_for(a->rows, nw, env_g));       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
+                                                       // small row counts get one row per wave (2,083 rows: 261 blocks instead of 131, 17 -> 13 us)
   const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
@@ -1033,7 +1066,7 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   if (rows <= 0) return 0;
   if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
-  const dim3 grid(grid_for(rows, 4 * 8, 512));
+  const dim3 grid(grid_for(rows, 4, 512));             // (small row counts: one row per wave)
   TfTraceScope tr("assemble_bwd_kernel", st, 0.0, 0.0);
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
@@ -1131,6 +1164,12 @@ extern "C" int tf_launch_quant_rows_fp8(const void* src, int ld_src, void* dst, 
   else hipLaunchKernelGGL(quant_rows_fp8_kernel<4>, grid, dim3(256), 0, st, (const u16*)src, ld_src, (unsigned char*)dst, ld_dst, scale, rows, cols);
   return (int)hipGetLastError();
 }
+__global__ void clock_advance_kernel(unsigned* c, unsigned by) { *c += by; }
+extern "C" int tf_launch_clock_advance(unsigned* c, unsigned by, hipStream_t st) {
+  hipLaunchKernelGGL(clock_advance_kernel, dim3(1), dim3(1), 0, st, c, by);
+  return (int)hipGetLastError();
+}
+TF_TU_SET_CLOCK(tf_tu_set_clock_rowops)
 extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
   if (a->n <= 0) return 0;
   TfTraceScope tr("radam_kernel", st);

@@ -379,6 +379,38 @@ int tf_regroup_fwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_r
 int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bwd", tf_launch_im2col(a, (hipStream_t)s)); }
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
+// ---- the step clock -------------------------------------------------------------------------------------------------------
+namespace {
+unsigned* g_clock_word = nullptr;
+std::mutex g_clock_mu;
+}
+const uint32_t* tf_clock_ptr(void) {
+  std::lock_guard<std::mutex> lk(g_clock_mu);
+  if (g_clock_word == nullptr) {
+    unsigned* w = nullptr;
+    if (hipMalloc((void**)&w, 256) != hipSuccess) { (void)fail(-9, "tf_clock_ptr (hipMalloc)"); return nullptr; }
+    if (hipMemset(w, 0, 256) != hipSuccess || tf_tu_set_clock_gemm(w) != 0 || tf_tu_set_clock_rowops(w) != 0) {
+      (void)hipFree(w);
+      (void)fail(-9, "tf_clock_ptr (publishing the clock word)");
+      return nullptr;
+    }
+    g_clock_word = w;
+  }
+  return g_clock_word;
+}
+int tf_clock_advance(uint32_t by, tf_stream_t s) {
+  unsigned* w = (unsigned*)tf_clock_ptr();
+  if (w == nullptr) return -9;
+  TF_TRY(tf_launch_clock_advance(w, by, (hipStream_t)s), "tf_clock_advance");
+  return 0;
+}
+int tf_clock_set(uint32_t value, tf_stream_t s) {
+  unsigned* w = (unsigned*)tf_clock_ptr();
+  if (w == nullptr) return -9;
+  TF_TRY((int)hipMemsetAsync(w, 0, sizeof(unsigned), (hipStream_t)s), "tf_clock_set");
+  if (value != 0) TF_TRY(tf_launch_clock_advance(w, value, (hipStream_t)s), "tf_clock_set");
+  return 0;
+}
 int tf_radam_step(const TfRadamArgs* a, tf_stream_t s) { TF_WRAP("tf_radam_step", tf_launch_radam(a, (hipStream_t)s)); }
 int tf_heads_loss_fwd(const TfHeadsLossArgs* a, tf_stream_t s) { TF_WRAP("tf_heads_loss_fwd", tf_launch_heads_loss_fwd(a, (hipStream_t)s)); }
 int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s) { TF_WRAP("tf_heads_loss_bwd", tf_launch_heads_loss_bwd(a, (hipStream_t)s)); }

@@ -108,6 +108,18 @@ __device__ __forceinline__ unsigned tf_hash32(unsigned x, unsigned key) {
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
   return h;
 }
+// The step clock (tf_clock_ptr / tf_clock_advance): a device word every dropout-drawing kernel folds into its key at entry.  It stays
+// 0 unless the caller advances it, and mix(0) = 0, so eager callers -- who hand over a fresh key per call -- see no change; a step
+// captured in a HIP graph bakes its keys into the graph, advances the clock as its first node, and so draws new masks on every
+// replay.  One copy of the pointer per translation unit (no relocatable device code): tf_tu_set_clock, called once by tf_clock_ptr.
+static __device__ const unsigned* g_tf_clock = nullptr;
+__device__ __forceinline__ unsigned tf_salted(unsigned key) {
+  const unsigned* c = g_tf_clock;
+  unsigned h = c != nullptr ? *c : 0u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(key ^ h));     // wave-uniform by construction: keep it in a scalar register
+}
+#define TF_TU_SET_CLOCK(name) extern "C" int name(const unsigned* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tf_clock), &p, sizeof(p)); }
 __device__ __forceinline__ bool tf_keep(unsigned idx, unsigned key, unsigned thr16) {
   const unsigned h = tf_hash32(idx >> 1, key);
   return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;

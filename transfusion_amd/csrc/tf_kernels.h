@@ -43,6 +43,9 @@ int tf_launch_pool_norm_bwd(const TfPoolNormArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_fwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_bwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);
+int tf_launch_clock_advance(unsigned* clock, unsigned by, hipStream_t stream);
+int tf_tu_set_clock_gemm(const unsigned* clock);                       // per translation unit: where its kernels find the step clock
+int tf_tu_set_clock_rowops(const unsigned* clock);
 int tf_launch_im2col(const TfPatchArgs* a, hipStream_t stream);       // feat -> cols
 int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t stream);  // cols -> feat (fold; border zero)
 

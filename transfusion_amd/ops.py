@@ -160,6 +160,33 @@ def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
     return q, sc
 
 
+# ---- the step clock (tf_clock_ptr): what makes a step captured in a HIP graph draw fresh dropout masks on every replay ----
+_clock_host = [0]          # host mirror of the device word (graph replays advance the device side; GraphedTrainStep keeps this in step)
+
+
+def clock_ptr() -> int:
+    p = L.load().tf_clock_ptr()
+    if not p:
+        L.check(-9, "tf_clock_ptr")
+    return int(p)
+
+
+def clock_advance(by: int = 1):
+    """*clock += by on the current stream (the first node of a captured training step)."""
+    L.check(L.load().tf_clock_advance(int(by), _stream()), "tf_clock_advance")
+    _clock_host[0] += int(by)
+
+
+def clock_set(value: int):
+    L.check(L.load().tf_clock_set(int(value), _stream()), "tf_clock_set")
+    _clock_host[0] = int(value)
+
+
+def clock_value() -> int:
+    """The clock as the host last left it (plus the replays GraphedTrainStep has counted)."""
+    return _clock_host[0]
+
+
 def set_gemm_concurrency(n: int):
     """Planning hint for the GEMM tile choice: ``n`` launch sequences share the chip (tf_set_gemm_concurrency)."""
     L.load().tf_set_gemm_concurrency(int(n))

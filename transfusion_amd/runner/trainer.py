@@ -409,8 +409,8 @@ class FusionTrainStep:
     def zero_grad(self):
         self.flat.grad.zero_()
 
-    def step(self, micro_batches: List, loss_fn):
-        """``loss_fn(module, batch) -> scalar``; returns the last loss (detached)."""
+    def step(self, micro_batches: List, loss_fn, on_clock: bool = False):
+        """``loss_fn(module, batch) -> scalar``; returns the last loss (detached).  ``on_clock``: see FusedRAdam.step."""
         self.zero_grad()
         self.flat.check_bound()
         loss = None
@@ -429,9 +429,9 @@ class FusionTrainStep:
         if self.grad_clip:
             self._norm.zero_()
             self.opt.grad_sumsq(self._norm)                        # stays on the device: no host sync in the step
-            self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip)
+            self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip, **({"on_clock": True} if on_clock else {}))
         else:
-            self.opt.step(grad_scale=scale)
+            self.opt.step(grad_scale=scale, **({"on_clock": True} if on_clock else {}))
         self.mark_parameters_updated()
         return loss.detach()
 
@@ -445,3 +445,78 @@ class FusionTrainStep:
         for m in self.module.modules():
             if hasattr(m, "mark_weights_updated"):
                 m.mark_weights_updated()
+
+
+class GraphedTrainStep:
+    """A whole training step of a ``FusionTrainStep`` -- forward, backward, clip, fused RAdam -- captured ONCE in a HIP graph and
+    replayed: one host call per step instead of several hundred kernel launches, event records and autograd nodes.  For the
+    reference's own per-GPU batch (4 - 5 samples) the step of the four-level wrapper is bound by exactly that host work.
+
+    What makes a replay a NEW step rather than a copy of the captured one:
+      * the library's step clock (``ops.clock_*``, tf_clock_ptr): the captured sequence starts by advancing it, every dropout site
+        folds it into its key, so every replay draws fresh masks (forward and backward of one replay agree);
+      * the optimiser reads its step number from the same clock and forms RAdam's schedule terms on the device;
+      * the batch lives in static tensors: ``load(batch)`` copies the next batch in, ``replay()`` runs the step.
+    Restrictions: one GPU (no collectives inside the graph), one micro-batch per step, dense rows (packed batches size their grids
+    from the batch's token count, which a graph cannot change), tensors of fixed shape.  The eager path stays the reference semantics;
+    tests/test_gpu_graph.py checks that replays and eager steps on the same clock give the same parameters."""
+
+    def __init__(self, trainer: FusionTrainStep, batch, loss_fn, warmup: int = 3):
+        from transfusion_amd import ops
+        if trainer.world != 1:
+            raise ValueError("GraphedTrainStep: one GPU only (the gradient exchange is not captured)")
+        if trainer.accumulate != 1:
+            raise ValueError("GraphedTrainStep: one micro-batch per optimiser step")
+        import inspect
+        if "on_clock" not in inspect.signature(trainer.opt.step).parameters:
+            raise ValueError("GraphedTrainStep needs an optimiser whose step number can live on the device (FusedRAdam)")
+        self.trainer, self.batch, self.loss_fn, self._ops = trainer, batch, loss_fn, ops
+        for m in trainer.module.modules():
+            if hasattr(m, "pack_tokens"):
+                m.pack_tokens = False
+        ops.clock_ptr()                                  # allocate + publish the clock before anything is captured
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):             # lazily created state (function attributes, side streams, shadows) settles here
+            for _ in range(max(1, warmup)):
+                ops.clock_advance()
+                trainer.step([batch], loss_fn, on_clock=True)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            ops.clock_advance()
+            self.loss = trainer.step([batch], loss_fn, on_clock=True)
+        # capturing RECORDED one step, it did not run it: take its host-side bookkeeping back (replay() redoes it per replay)
+        ops._clock_host[0] -= 1
+        for st in trainer.opt.state.values():
+            if "step" in st:
+                st["step"] -= 1
+        self.replays = 0
+
+    def load(self, batch):
+        """Copies ``batch`` (same tree of tensors, same shapes) into the static tensors the graph reads."""
+        def copy(dst, src):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+            elif isinstance(dst, dict):
+                for k in dst:
+                    copy(dst[k], src[k])
+            elif isinstance(dst, (list, tuple)):
+                for d, s_ in zip(dst, src):
+                    copy(d, s_)
+        copy(self.batch, batch)
+
+    def replay(self):
+        """One optimiser step.  Returns the (static) loss tensor of that step."""
+        self.graph.replay()
+        self.replays += 1
+        self._ops._clock_host[0] += 1                    # the graph advanced the device word
+        for st in self.trainer.opt.state.values():
+            if "step" in st:
+                st["step"] += 1
+        return self.loss
+
+    def finish(self):
+        """Call before going back to eager calls on the module: the parameter versions the shadow caches key on."""
+        self.trainer.mark_parameters_updated()
