@@ -51,6 +51,14 @@ if os.environ.get("TRAINER") == "1":
     def step():
         return trainer.step([None], _loss)
 
+    if os.environ.get("GRAPH") == "1":
+        # the same step captured once in a HIP graph and replayed (dense rows; fresh dropout masks per replay through the step clock)
+        from transfusion_amd.runner.trainer import GraphedTrainStep
+        for f in feats:
+            f.grad = None
+        gs = GraphedTrainStep(trainer, None, _loss, warmup=3)
+        step = gs.replay
+
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -63,6 +71,8 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print(f"host enqueue {t_host:.2f} ms/step")
 print(f"wrapper fwd+bwd, B={B}, 4 levels x 4 layers: {ms:.2f} ms/step ({B / ms * 1e3:.1f} samples/s), loss {float(loss):.4f}")
+if os.environ.get("GRAPH") == "1":
+    sys.exit(0)                                     # (the launch tracer sees launches, a replay makes none)
 lib = Lb.load()
 Lb.check(lib.tf_trace_start(), "trace")
 for _ in range(2):

@@ -187,7 +187,10 @@ class CrossFusionBoxWrapper(nn.Module):
             # autograd replays the levels on the same streams)
             ops.set_gemm_concurrency(len(self.fpn_features_idx) if parallel else 1)
         if parallel and (self._level_streams is None or self._level_streams[0].device != language_f.device):
-            self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
+            # TF_LEVEL_STREAMS = n > 1: n streams shared round-robin by the levels (default: one per level)
+            n_st = int(os.environ.get("TF_LEVEL_STREAMS", "1"))
+            pool = [torch.cuda.Stream(device=language_f.device) for _ in range(n_st if n_st > 1 else len(self.fpn_features_idx))]
+            self._level_streams = [pool[i % len(pool)] for i in range(len(self.fpn_features_idx))]
         for i, key in enumerate(self.fpn_features_idx):
             key = str(key)
             feat = features_dict["features"][key]
@@ -223,7 +226,7 @@ class CrossFusionBoxWrapper(nn.Module):
                     raise NotImplementedError()
             features_dict["features"][key] = out_i
         if parallel:
-            for st in self._level_streams:
+            for st in dict.fromkeys(self._level_streams):
                 main.wait_stream(st)
 
         features_dict = self.rcnn_model.apply_fpn(features_dict)

@@ -45,9 +45,16 @@ class SlowFastPooling(nn.Module):
         # HF style: 1 = keep, 0 = cancelled; built on the host in one piece (no per-sample device writes)
         # (on a GPU the lengths travel through pinned memory without blocking: a pageable copy would stall the host until the
         # stream has drained, once per step)
-        lens_t = torch.tensor(lens, dtype=torch.int32)
-        if tensor.is_cuda:
-            lens_t = lens_t.pin_memory().to(tensor.device, non_blocking=True)
+        cached = getattr(self, "_lens_cache", None)
+        if cached is not None and cached[0] == lens and cached[1].device == tensor.device:
+            # same lengths as the previous call: the device copy is still right.  (Also what lets a step with fixed-shape inputs be
+            # captured in a HIP graph -- a host-to-device copy of per-call host data cannot be.)
+            lens_t = cached[1]
+        else:
+            lens_t = torch.tensor(lens, dtype=torch.int32)
+            if tensor.is_cuda:
+                lens_t = lens_t.pin_memory().to(tensor.device, non_blocking=True)
+            self._lens_cache = (list(lens), lens_t)
         att_mask = (torch.arange(T, device=tensor.device, dtype=torch.int32).unsqueeze(0) < lens_t.unsqueeze(1)).to(torch.float32)
         if self.out_mlp:
             tensor = ops.linear(tensor, self.out_mlp.weight, self.out_mlp.bias, precision=self.precision)
