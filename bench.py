@@ -472,6 +472,90 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         torch.cuda.empty_cache()
 
 
+class _PassThroughDetector(torch.nn.Module):
+    """rcnn_model stand-in for the wrapper leg: the feature maps pass straight through (the detector is out of scope)."""
+
+    def __init__(self, shapes, channels):
+        super().__init__()
+        self.shapes, self.channels = shapes, channels
+        self.noun_classes, self.verb_classes = 88, 75
+
+    def get_dsampled_shapes(self):
+        return self.shapes
+
+    def get_features_out_channels(self):
+        return self.channels
+
+    def forward_features(self, images, targets=None):
+        return {"features": {str(i): f for i, f in enumerate(images)}}
+
+    def apply_fpn(self, fd):
+        return fd
+
+    def apply_rpn_roi_on_features(self, fd):
+        return fd
+
+    def call_model_epoch_triggers(self, epoch):
+        pass
+
+
+def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4):
+    """The reference's REAL module around the hot path, at its own per-GPU batch: CrossFusionBoxWrapper over four FPN levels (level maps
+    14p x 14p, p = 4, 4, 2, 1; C = 256 .. 2048; patch-embedding GEMM, 4-layer encoder on [196 + 512] tokens, back-projection + fold per
+    level) with a pass-through detector, full training step (FusionTrainStep: flat buffers, clip, fused RAdam).  Host-bound at this size
+    (several hundred launches per step): `host_enqueue_ms` is the time the host needs to issue one step."""
+    import gc
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    obj = {}
+    try:
+        ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]
+        shapes = [(14 * p, 14 * p) for p in ps]
+        fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+        fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})
+        fusion["args"].update({"input_f_size": D})
+        run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 16,
+                   "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": D,
+                                                             "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+        torch.manual_seed(42)
+        model = get_fusion_model(_PassThroughDetector(shapes, chans), {}, run_cfg, None).to(device).train()
+        g = torch.Generator().manual_seed(4242 + 1000 * rank)
+        feats = [torch.randn(batch, c, h, w, generator=g).to(device).requires_grad_(True) for c, (h, w) in zip(chans, shapes)]
+        lens = torch.randint(NL // 4, NL + 1, (batch,), generator=g).tolist()
+        lang = [torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1).to(device) for n in lens]
+        obj["trainer"] = FusionTrainStep(model, lr=1e-4, weight_decay=2e-4, grad_clip=1.0)
+        del model
+
+        def wloss(m, _):
+            out = m({"image": feats, "language_f": lang})
+            return sum(f.float().square().mean() for f in out["features"].values())
+
+        last = {}
+        for _ in range(warmup):
+            last["loss"] = obj["trainer"].step([None], wloss)
+        comm.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last["loss"] = obj["trainer"].step([None], wloss)
+        t_host = (time.perf_counter() - t0) / steps
+        comm.sync()
+        dt = comm.max(time.perf_counter() - t0) / steps
+        loss = float(last["loss"].item())
+        if not math.isfinite(loss):
+            raise SystemExit(f"leg wrapper_b{batch}: non-finite loss {loss}")
+        out = dict(ms_per_step=round(dt * 1e3, 3), samples_s=round(comm.world * batch / dt, 1), host_enqueue_ms=round(t_host * 1e3, 3),
+                   batch_per_gpu=batch, levels=4, layers_per_level=L, tokens=[NV, NL], d=D, dtype="bf16", steps=steps, warmup=warmup,
+                   final_loss=round(loss, 5), module="CrossFusionBoxWrapper (4 FPN levels) + pass-through detector, full training step")
+        if rank == 0:
+            log(f"  leg wrapper_b{batch:<3d} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  (host enqueue {out['host_enqueue_ms']:.2f} ms/step)")
+        return out
+    finally:
+        obj.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def csrc_hash():
     """Hash of the kernel sources: profiles/traffic.json is stamped with the value it was measured on."""
     import hashlib
@@ -503,7 +587,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,fp8,b4,b4_dense,b4_graph,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,fp8,b4,b4_dense,b4_graph,wrapper_b4,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -675,8 +759,11 @@ def main():
                 "no_padding": dict(padded=False),                                                     # 196 + 512 real tokens each
             }
             for name in [n.strip() for n in args.legs.split(",") if n.strip()]:
+                if name == "wrapper_b4":
+                    legs[name] = run_wrapper_leg(device, rank, comm, batch=4)
+                    continue
                 if name not in specs:
-                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)})")
+                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4)")
                 legs[name if name not in legs else f"{name}#{len(legs)}"] = run_leg(name, device, rank, comm, **specs[name])
         else:
             # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32
