@@ -493,7 +493,8 @@ def test_attention_block_mask(dev, B, S, H, hd, p):
         assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm}"
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2500, 768, 768), (4096, 1536, 768), (700, 768, 1536)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2500, 768, 768), (4096, 1536, 768), (700, 768, 1536),
+                                   (900, 520, 192), (520, 264, 64), (1100, 776, 832)])     # odd counts of 64-value K-steps: the 128-deep MFMA's missing half is zeros
 def test_gemm_fp8_operands(dev, M, N, K):
     """BASELINE configs[4]: fp8 (OCP e4m3) MFMA with fp32 accumulation for the projections.  Exactness: against the fp64
     product of the DEQUANTISED operands (only the bf16 rounding of the result remains); accuracy: against the product of the

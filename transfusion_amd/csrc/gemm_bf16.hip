@@ -416,9 +416,9 @@ __device__ __forceinline__ void wait_vm_barrier8() { asm volatile("s_waitcnt vmc
 __device__ __forceinline__ void wait_vm_barrier4() { asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void wait_vm_barrier0() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// FP8: operands are OCP e4m3 bytes.  The byte geometry is unchanged (64-B tile rows = 64 values, one K-step = 64 values): a
-// 16-B fragment feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes; both operands use the same k <-> byte map,
-// so every k is multiplied exactly once), and the per-row / per-output-channel scales are applied with the bias.
+// FP8: operands are OCP e4m3 bytes.  The byte geometry is unchanged (64-B tile rows = 64 values, one K-step = 64 values); the K loop
+// pairs two K-steps per v_mfma_scale_f32_16x16x128_f8f6f4 (see the loop), and the per-row / per-output-channel scales are applied with
+// the bias.
 // NWR = 1 ("duo"): half the rows -- (16*MF) x 256, 256 threads = 4 waves of the same 144 x 64 wave tile, 3-slot ring (76.8 KB), TWO
 // workgroups per CU.  Costs 47 % more DMA bytes per MFMA (the W tile is staged once per 144 rows instead of once per 288) and is no
 // faster with the chip to itself (N = 1536, K = 768: 70 vs 66 us), but inside the step the launches of two or more rounds gain 2-4 %
@@ -544,6 +544,46 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
         product(wl, xh);
       }
     }
+  } else if constexpr (FP8) {
+    // fp8 operands at the DOUBLE rate: v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE configs[4]).  One instruction contracts 128 values:
+    // a lane's 32 operand bytes are its 16-B chunk of K-step 2j followed by the same chunk of K-step 2j+1 -- both operands use the same
+    // byte <-> k map, so every k meets its partner exactly once.  The four ring slots work as two PAIRS: pair j is consumed while the
+    // transfers of pair j+1 land in the other two slots (issued after this pair's fragment reads in program order, behind the barrier
+    // that proves the other pair was fully read).  The block scales of the instruction are 2^0 (E8M0 127): the per-row / per-channel
+    // scales of TfGemmArgs are applied with the bias, as before.  An odd K-step count: the missing half contributes zeros.
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    const int npair = (nk + 1) >> 1;
+    stage(0, 0);
+    stage(1, min(1, nk - 1));
+    for (int j = 0; j < npair; ++j) {
+      const int s0 = (2 * j) & 3, s1 = s0 + 1;
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      const bool full = 2 * j + 1 < nk;                              // wave-uniform
+      i32x8 wf[4], xf[MF];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const i32x4 lo = *(const i32x4*)(smem + s0 * SLOT + woff0 + q * 1024);
+        i32x4 hi = *(const i32x4*)(smem + s1 * SLOT + woff0 + q * 1024);
+        if (!full) hi = i32x4{0, 0, 0, 0};
+        wf[q] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int q = 0; q < MF; ++q) {
+        const i32x4 lo = *(const i32x4*)(smem + s0 * SLOT + xoff0 + q * 1024);
+        i32x4 hi = *(const i32x4*)(smem + s1 * SLOT + xoff0 + q * 1024);
+        if (!full) hi = i32x4{0, 0, 0, 0};
+        xf[q] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      if (j + 1 < npair) {                                           // (wave-uniform) the next pair into the other two slots
+        stage((2 * j + 2) & 3, min(2 * j + 2, nk - 1));
+        stage((2 * j + 3) & 3, min(2 * j + 3, nk - 1));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
   } else {
   // prologue: steps 0, 1, 2 in flight (past the end the last step is re-fetched: the loop body is branch-free, and
     // every phase always has exactly two younger steps' transfers in flight, so one counted wait fits all phases)
@@ -568,18 +608,11 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
       for (int mi = 0; mi < MF; ++mi)
   #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          if constexpr (FP8) {
-            typedef long long2_t __attribute__((ext_vector_type(2)));
-            const long2_t w2 = __builtin_bit_cast(long2_t, wf[ni]), x2 = __builtin_bit_cast(long2_t, xf[mi]);
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[0], x2[0], acc[ni][mi], 0, 0, 0);
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w2[1], x2[1], acc[ni][mi], 0, 0, 0);
-          } else {
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-          }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
       // schedule: fragment reads first, then the step's DMA instructions spread one per 7 MFMAs, so that a wave's DMA
       // issue (tens of cycles each) overlaps its own and its SIMD partner's matrix work instead of preceding it
-      constexpr int MM = FP8 ? 2 : 1;
+      constexpr int MM = 1;
       __builtin_amdgcn_sched_group_barrier(0x100, 4 + MF, 0);
       constexpr int GAP = (NWR == 2 && (4 * MF) / PER_WAVE > 7) ? 7 : (4 * MF) / PER_WAVE;      // MFMAs between two DMA instructions
   #pragma unroll
@@ -1089,7 +1122,7 @@ template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, h
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<E, MF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
     hipLaunchKernelGGL((gemm_nt_big_kernel<E, MF, true>), grid, block, lds, stream, *a, 0, 0, 0);                 \
   } break;
-  if constexpr (!SPLIT && MF >= 8) if (a->fp8) {          // fp8 operands: 256 / 288-row tiles only
+  if constexpr (!SPLIT && MF == 8) if (a->fp8) {          // fp8 operands: the 256-row tile (the 32-byte fragments of the 128-deep MFMA leave no room for a ninth row block)
     switch (a->epilogue) {
       TF_GEMM_CASE8(TF_EPI_NONE)
       TF_GEMM_CASE8(TF_EPI_BIAS)
@@ -1206,11 +1239,10 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   }
   if (a->fp8) {                                   // fp8 operands: large-tile kernel only (any shape; rows are clamped)
     if ((a->lda % 16) || (a->ldw % 16)) return -3;
-    const int mf = pick_mf(a->M, a->N, 8);
     char nm[56];
-    snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, %d, fp8>", a->epilogue, mf);
+    snprintf(nm, sizeof(nm), "gemm_nt_big_kernel<%d, 8, fp8>", a->epilogue);
     TfTraceScope tr(nm, stream, fl);
-    return mf == 9 ? launch_gemm_big<9>(a, stream) : launch_gemm_big<8>(a, stream);
+    return launch_gemm_big<8>(a, stream);
   }
   // Which kernel: the large tile (288/256 x 256, one workgroup per CU) is ~1.8x as efficient per CU as the 128-wide one (two
   // per CU) once the chip is full, but at small M its grid is a fraction of a round -- M = 5664, N = 768 is 69 tiles for 256
