@@ -531,6 +531,31 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_fwd");
   const Dims& D = c.D;
   if (e->vis == nullptr || e->lang == nullptr || e->vis_out == nullptr) return fail(-1, "tf_encoder_fwd(null io)");
+  // ---- side stream: everything of this forward that does not depend on activations (see TfOverlap) -- forked FIRST, so that layer 0's
+  // weight re-pack runs under the row map and the token assemble instead of ahead of the first GEMM ----
+  hipStream_t side = nullptr; hipEvent_t* ev = nullptr;
+  if (e->overlap != nullptr && e->overlap->stream != nullptr) { side = (hipStream_t)e->overlap->stream; ev = (hipEvent_t*)e->overlap->ev; }
+  // one event per layer on the side stream, recorded after that layer's re-pack AND dropout mask (FIFO: it covers both);
+  // layers >= 3 share an event: a wait on it then covers every later record too (correct, less overlap); ev[1]: layer 0's re-pack alone
+  auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
+  bool side_work[TF_MAX_LAYERS] = {};
+  if (side != nullptr && e->overlap->pending != 0u) TF_TRY(tf_overlap_join(e->overlap, s), "fwd join");   // events are about to be reused
+  if (side != nullptr) {
+    TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
+    TF_TRY((int)hipStreamWaitEvent(side, ev[0], 0), "fwd fork");
+    if (e->repack) {
+      TF_TRY(pack_layer(c, 0, side), "pack layer 0");
+      TF_TRY((int)hipEventRecord(ev[1], side), "pack 0 event");
+    }
+    for (int l = 0; l < c.D.L; ++l) {
+      const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
+      if (e->repack && l >= 1) { TF_TRY(pack_layer(c, l, side), "pack layer"); side_work[l] = true; }
+      if (dr.thr) { TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, c.D.B, c.D.H, c.D.S, dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
+      if (side_work[l]) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
+    }
+  } else if (e->repack) {
+    for (int l = 0; l < c.D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
+  }
   uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
@@ -551,27 +576,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
   }
-  // ---- side stream: everything of this forward that does not depend on activations (see TfOverlap) ----
-  hipStream_t side = nullptr; hipEvent_t* ev = nullptr;
-  if (e->overlap != nullptr && e->overlap->stream != nullptr) { side = (hipStream_t)e->overlap->stream; ev = (hipEvent_t*)e->overlap->ev; }
-  // one event per layer on the side stream, recorded after that layer's re-pack AND dropout mask (FIFO: it covers both);
-  // layers >= 3 share an event: a wait on it then covers every later record too (correct, less overlap)
-  auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
-  bool side_work[TF_MAX_LAYERS] = {};
-  if (side != nullptr && e->overlap->pending != 0u) TF_TRY(tf_overlap_join(e->overlap, s), "fwd join");   // events are about to be reused
-  if (e->repack) TF_TRY(pack_layer(c, 0, c.st), "pack layer 0");
-  if (side != nullptr) {
-    TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
-    TF_TRY((int)hipStreamWaitEvent(side, ev[0], 0), "fwd fork");
-    for (int l = 0; l < D.L; ++l) {
-      const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
-      if (e->repack && l >= 1) { TF_TRY(pack_layer(c, l, side), "pack layer"); side_work[l] = true; }
-      if (dr.thr) { TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
-      if (side_work[l]) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
-    }
-  } else if (e->repack) {
-    for (int l = 1; l < D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
-  }
+  if (side != nullptr && e->repack) TF_TRY((int)hipStreamWaitEvent(c.st, ev[1], 0), "pack 0 wait");     // before the first GEMM
   const float scale = 1.0f / sqrtf((float)D.hd);
   for (int l = 0; l < D.L; ++l) {
     // layer 0 needs only its mask (before the attention); later layers wait once, at the top, for pack + mask
