@@ -60,6 +60,10 @@ typedef struct TfGemmArgs {
   // A_hi.W_hi + A_lo.W_hi + A_hi.W_lo.  A_lo != null selects it; then W_lo and C_lo are required, and R_lo / C2_lo
   // wherever R / C2 are.  Planes share the leading dimension of their hi plane.  Not combinable with fp8.
   const void* A_lo; const void* W_lo; void* C_lo; const void* R_lo; void* C2_lo;
+  // grouped launch (no reference counterpart: the wrapper's FPN levels, cross_f_box_wrapper.py:177-212, run identical encoders with
+  // different weights): groups > 1 splits the M rows into `groups` equal ranges; range g multiplies by the weight / bias / scale_w
+  // tensors that start g * w_gstride BYTES after W / bias / scale_w (W_lo likewise).  A, C, R, C2, scale_a are indexed by global row.
+  int groups; long long w_gstride;
 } TfGemmArgs;
 
 /* row-wise fp8 (e4m3) quantisation: dst[r][c] = fp8(src[r][c] / scale[r]), scale[r] = max|src[r][:]| / 448 (1 for an all-zero row);
@@ -77,6 +81,9 @@ typedef struct TfWgradArgs {
   int cg, cgp, k_src;         // same for columns
   int m_chunk;                // rows of M per block (0 = auto)
   const void* dY_lo; const void* X_lo;   // fp32-accuracy mode (see TfGemmArgs): lo planes, dW += dY_hi^T X_hi + dY_lo^T X_hi + dY_hi^T X_lo
+  // grouped launch (see TfGemmArgs.groups): `groups` equal row ranges of dY / X, range g accumulates into the dW / db that start
+  // g * dw_gstride BYTES after dW / db; m_chunk counts rows inside a group
+  int groups; long long dw_gstride;
 } TfWgradArgs;
 
 

@@ -541,3 +541,68 @@ def test_sumsq_is_a_pure_function_of_its_input(dev):
         for _ in range(3):
             L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(acc), ops._stream()), "tf_sumsq")
         assert abs(acc.item() - 3 * ref) <= 1e-5 * ref + 1e-30
+
+
+@pytest.mark.parametrize("G,Mg,N,K", [(4, 2083, 768, 768), (4, 2083, 2304, 768), (4, 2832, 768, 1536), (3, 300, 264, 128), (4, 5000, 1536, 768),
+                                      (2, 8300, 768, 768)])     # 128-wide (ring and two-slot), large-tile and two-per-CU forms
+def test_gemm_grouped_rows(dev, G, Mg, N, K):
+    """TfGemmArgs.groups: G equal row ranges, each against its own weight / bias (w_gstride apart) -- the wrapper's FPN levels as one
+    launch.  Must equal G separate launches bit for bit (same tiles, same arithmetic), ragged last row tile of every group included."""
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(G * Mg + N)
+    x = bf(torch.randn(G * Mg, K, generator=g)).to(dev)
+    r = bf(torch.randn(G * Mg, N, generator=g)).to(dev)
+    # one buffer holds [W_g | bias_g] blocks at a constant byte stride, as the encoder runtime's per-level shadow blocks do
+    blk = (N * K * 2 + N * 4 + 255) // 256 * 256
+    store = torch.zeros(G * blk, dtype=torch.uint8, device=dev)
+    Ws, bs = [], []
+    for k in range(G):
+        w = store[k * blk: k * blk + N * K * 2].view(torch.bfloat16).view(N, K)
+        b = store[k * blk + N * K * 2: k * blk + N * K * 2 + N * 4].view(torch.float32)
+        w.copy_(bf(torch.randn(N, K, generator=g) * 0.05))
+        b.copy_(torch.randn(N, generator=g))
+        Ws.append(w)
+        bs.append(b)
+    drop = ops.drop_params(0.15, 5, 2)
+    for epi, kw in ((L.TF_EPI_BIAS, {}), (L.TF_EPI_BIAS_DROP_RES, {"R": r, "drop": drop}), (L.TF_EPI_ADD, {"R": r})):
+        out_g = torch.zeros(G * Mg, N, dtype=torch.bfloat16, device=dev)
+        has_b = epi != L.TF_EPI_ADD
+        ops.gemm(x, Ws[0], out_g, N, K, epi, bias=bs[0] if has_b else None, groups=G, w_gstride=blk, **kw)
+        out_s = torch.zeros_like(out_g)
+        full = torch.zeros_like(out_g)
+        for k in range(G):
+            kw_k = dict(kw)
+            if "R" in kw_k:
+                kw_k["R"] = r                                   # full-height views: rows (and dropout indices) stay global
+            # a single-group launch over ALL rows with group k's weights; its rows of range k are what the grouped launch must produce
+            ops.gemm(x, Ws[k], full, N, K, epi, bias=bs[k] if has_b else None, **kw_k)
+            out_s[k * Mg:(k + 1) * Mg] = full[k * Mg:(k + 1) * Mg]
+        ref = torch.cat([x[k * Mg:(k + 1) * Mg].double().cpu() @ Ws[k].double().cpu().t() + (bs[k].double().cpu() if epi == L.TF_EPI_BIAS else 0)
+                         for k in range(G)]) if epi == L.TF_EPI_BIAS else None
+        assert (out_g.float() - out_s.float()).abs().max().item() <= 2e-2 * out_s.float().abs().max().item(), epi       # (tile shapes may differ: bf16 ulp)
+        if ref is not None:
+            assert rel(out_g, ref) < 6e-3
+
+
+@pytest.mark.parametrize("G,Mg,N,K,chunk", [(4, 2083, 768, 768, 0), (4, 2832, 2304, 768, 704), (3, 300, 264, 136, 0), (2, 8300, 768, 1536, 2080)])
+def test_wgrad_grouped_rows(dev, G, Mg, N, K, chunk):
+    """TfWgradArgs.groups: range g of the rows accumulates dY_g^T X_g into ITS dW / db (dw_gstride apart); both kernels (caller-sized
+    256x128 and self-sized 128x128), ragged group heights."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(G * Mg + K)
+    dy = bf(torch.randn(G * Mg, N, generator=g) * 0.1).to(dev)
+    x = bf(torch.randn(G * Mg, K, generator=g)).to(dev)
+    blk = N * K + N + 13                                     # floats per group: [dW | db | slack], an odd stride on purpose
+    blk = (blk + 3) // 4 * 4
+    store = torch.zeros(G * blk, dtype=torch.float32, device=dev)
+    dW0 = store[: N * K].view(N, K)
+    db0 = store[N * K: N * K + N]
+    ops.wgrad(dy, N, x, K, dW0, db0, m_chunk=chunk, groups=G, dw_gstride=blk * 4)
+    torch.cuda.synchronize()
+    for k in range(G):
+        dW = store[k * blk: k * blk + N * K].view(N, K).double().cpu()
+        db = store[k * blk + N * K: k * blk + N * K + N].double().cpu()
+        yk, xk = dy[k * Mg:(k + 1) * Mg].double().cpu(), x[k * Mg:(k + 1) * Mg].double().cpu()
+        assert rel(dW, yk.t() @ xk) < 2e-5, k
+        assert rel(db, yk.sum(0)) < 2e-5, k
+    assert float(store.view(G, blk)[:, N * K + N:].abs().max()) == 0.0       # nothing written between the groups' tensors

@@ -23,6 +23,26 @@ namespace {
 
 constexpr int BN = 128;
 int num_cus();
+// row tiles of a launch: TfGemmArgs.groups independent row ranges of M / groups rows each (tiles never straddle two groups)
+inline long row_tiles(int M, int G, int BM) { const int g = G > 1 ? G : 1; return (long)g * ((M / g + BM - 1) / BM); }
+inline long row_tiles(const TfGemmArgs* a, int BM) { return row_tiles(a->M, a->groups, BM); }
+// Device side of the grouping: logical tile -> (group, tile inside the group); the local copy of the arguments is narrowed to the
+// group -- rows [m_lo, M) of the global row space, the group's weight / bias / scale tensors -- so that every later bound and clamp of
+// the kernel (which all read g.M) holds unchanged.  Returns the tile index inside the group.
+__device__ __forceinline__ int enter_group(TfGemmArgs& g, int logical, int BM, int tiles_n, int& m_lo) {
+  m_lo = 0;
+  if (g.groups <= 1) return logical;
+  const int Mg = g.M / g.groups, tiles_g = ((Mg + BM - 1) / BM) * tiles_n;
+  const int grp = logical / tiles_g;
+  const long long off = (long long)grp * g.w_gstride;
+  m_lo = grp * Mg;
+  g.M = m_lo + Mg;
+  g.W = (const unsigned char*)g.W + off;
+  if (g.W_lo != nullptr) g.W_lo = (const unsigned char*)g.W_lo + off;
+  if (g.bias != nullptr) g.bias = (const float*)((const unsigned char*)g.bias + off);
+  if (g.scale_w != nullptr) g.scale_w = (const float*)((const unsigned char*)g.scale_w + off);
+  return logical - grp * tiles_g;
+}
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per 128-row x 64-deep operand tile (wgrad; the W operand at BK = 64)
 constexpr int CT_STRIDE = 272;                    // C-tile row stride in LDS (256 B + 16 B pad)
 
@@ -250,8 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TfGemmArgs g_in) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (g.N + BN - 1) / BN;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  int m_lo;
+  const int logical = enter_group(g, xcd_remap(blockIdx.x, gridDim.x), BM, tiles_n, m_lo);
+  const int m0 = m_lo + (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
   const int nk0 = g.K / BK;
 
   auto stage = [&](int buf, int kstep) {
@@ -451,8 +472,9 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
     }
   }
   const int tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BIG_BN;
+  int m_lo;
+  const int logical = enter_group(g, xcd_remap(blockIdx.x, gridDim.x), BM, tiles_n, m_lo);
+  const int m0 = m_lo + (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BIG_BN;
   const unsigned char* __restrict__ A = (const unsigned char*)g.A;
   const unsigned char* __restrict__ W = (const unsigned char*)g.W;
 
@@ -694,8 +716,23 @@ __global__ __launch_bounds__(256 * NWR, 2) void gemm_nt_big_kernel(const TfGemmA
 // ------------------------------------------------------------------------------------------------
 // SPLIT (fp32-accuracy mode): three passes over the block's rows -- (dY_hi, X_hi), (dY_lo, X_hi), (dY_hi, X_lo) -- into the same
 // accumulators; the bias grad (column sums of dY) takes passes 0 and 1.
+// grouped weight gradient (TfWgradArgs.groups, blockIdx.y = group): the local copy of the arguments is moved to the group's row range
+// of dY / X (M / groups rows) and to its own dW / db, groups * dw_gstride bytes apart
+__device__ __forceinline__ void enter_wgrad_group(TfWgradArgs& g) {
+  if (g.groups <= 1) return;
+  const int grp = blockIdx.y, Mg = g.M / g.groups;
+  g.dY = (const unsigned char*)g.dY + (size_t)grp * Mg * g.ldy * 2;
+  g.X = (const unsigned char*)g.X + (size_t)grp * Mg * g.ldx * 2;
+  if (g.dY_lo != nullptr) g.dY_lo = (const unsigned char*)g.dY_lo + (size_t)grp * Mg * g.ldy * 2;
+  if (g.X_lo != nullptr) g.X_lo = (const unsigned char*)g.X_lo + (size_t)grp * Mg * g.ldx * 2;
+  g.dW = (float*)((unsigned char*)g.dW + (long long)grp * g.dw_gstride);
+  if (g.db != nullptr) g.db = (float*)((unsigned char*)g.db + (long long)grp * g.dw_gstride);
+  g.M = Mg;
+}
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g_in) {
+  TfWgradArgs g = g_in;
+  enter_wgrad_group(g);
   // K (= rows of M) advances in 32-row steps through a 4-slot LDS ring (16 KiB per slot: dY [32][128] | X [32][128]);
   // the DMA of step i+3 is issued in phase i, so a transfer has three phases to land (with one-step prefetch the loop
   // ran at DMA latency: ~2500 cycles per 64 rows against ~500 cycles of MFMA).  Counted vmcnt + raw s_barrier.
@@ -854,7 +891,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const TfWgradArgs g) {
 // ------------------------------------------------------------------------------------------------
 // NS = ring slots (3; 2 = 48 KiB: the workgroup then fits on a CU next to an attention-backward workgroup of the chain -- experiment)
 template <bool SPLIT, int NS = 3>        // see wgrad_tn_kernel
-__global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) {
+__global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g_in) {
+  TfWgradArgs g = g_in;
+  enter_wgrad_group(g);
   constexpr int STEP = 32, YB = STEP * 512, XB = STEP * 256, SLOT = YB + XB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1056,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn2_kernel(const TfWgradArgs g) 
 namespace {
 template <int MI, int BK, bool SPLIT = false, int NSLOT = 2> int launch_gemm_mi(const TfGemmArgs* a, hipStream_t stream) {
   constexpr int BM = 32 * MI;
-  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  const int tiles = (int)row_tiles(a, BM) * ((a->N + BN - 1) / BN);
   size_t lds = NSLOT * (size_t)(BM + 128) * BK * 2;                // BK 64, two slots: 64 / 72 / 80 KiB
   if (lds < (size_t)BM * CT_STRIDE) lds = (size_t)BM * CT_STRIDE;  // never below the C tile of BM x 272 B
   dim3 grid(tiles), block(256);
@@ -1085,14 +1124,14 @@ int num_cus();
 // the taller tile.  64- and 96-row tiles (MI = 2, 3) exist for SMALL row counts -- the reference's own per-GPU batch of 4 - 5 samples is
 // ~2,000 - 3,500 token rows, where a 128-row tiling of an N = 768 GEMM is ~100 - 170 tiles for 512 slots.
 int plan_cus();
-int pick_mi(int M, int N) {
+int pick_mi(int M, int N, int G = 1) {
   const int slots = 2 * plan_cus();
   const int tn = (N + BN - 1) / BN;
   static const int env_lo = getenv("TF_GEMM_MI_MIN") ? atoi(getenv("TF_GEMM_MI_MIN")) : 2;       // experiment switch
   // half-filled chips: the time is one tile's, so the shortest tile that still leaves every CU at most one workgroup wins
   int best = 6; double best_cost = -1.0;
   for (int mi = 6; mi >= (env_lo < 2 ? 2 : env_lo); --mi) {
-    const long tiles = (long)((M + 32 * mi - 1) / (32 * mi)) * tn;
+    const long tiles = row_tiles(M, G, 32 * mi) * tn;
     const long rounds = (tiles + slots - 1) / slots;
     // two workgroups share a CU: a round in which at most half the slots are taken runs each workgroup alone on its CU (~1.6x as fast)
     const double share = (tiles - (rounds - 1) * slots) * 2 <= slots ? 0.62 : 1.0;
@@ -1106,7 +1145,7 @@ int pick_mi(int M, int N) {
 namespace {
 template <int MF, bool SPLIT = false> int launch_gemm_big(const TfGemmArgs* a, hipStream_t stream) {
   constexpr int BM = 32 * MF;
-  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BIG_BN - 1) / BIG_BN);
+  const int tiles = (int)row_tiles(a, BM) * ((a->N + BIG_BN - 1) / BIG_BN);
   size_t lds = 4 * (size_t)(BM + BIG_BN) * BIG_ROWB;               // 4-slot ring
   if (lds < (size_t)BM * BIG_CT_STRIDE) lds = (size_t)BM * BIG_CT_STRIDE;
   dim3 grid(tiles), block(512);
@@ -1151,7 +1190,7 @@ int num_cus();
 // two-per-CU form (NWR = 1): 144 x 256 tiles (MF = 9), 3-slot ring; the second-slot workgroups of the first round start late
 int launch_gemm_duo(const TfGemmArgs* a, hipStream_t stream, int stagger_ticks) {
   constexpr int MF = 9, BM = 16 * MF;
-  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BIG_BN - 1) / BIG_BN);
+  const int tiles = (int)row_tiles(a, BM) * ((a->N + BIG_BN - 1) / BIG_BN);
   size_t lds = 3 * (size_t)(BM + BIG_BN) * BIG_ROWB;               // 76.8 KB: two workgroups per CU
   static_assert((size_t)BM * BIG_CT_STRIDE <= 3 * (size_t)(BM + BIG_BN) * BIG_ROWB, "the C tile must fit the ring");
   dim3 grid(tiles), block(256);
@@ -1194,13 +1233,13 @@ int num_cus() {
 // large tile: 160 .. 288 rows (MF = 5 .. 9), one workgroup per CU: minimise rounds x (height + the per-tile fixed cost, ~3 row
 // blocks' worth: fill, the C-tile burst).  The row count is whatever the batch's real tokens add up to (packed batches), so
 // the height that makes the tile grid an exact number of rounds changes from step to step; fp8 / fp32-accuracy operands keep 8 / 9.
-int pick_mf(int M, int N, int mf_lo = 5) {
+int pick_mf(int M, int N, int mf_lo = 5, int G = 1) {
   const int tn = (N + BIG_BN - 1) / BIG_BN, slots = plan_cus();
   static const int env_lo = getenv("TF_GEMM_MF_MIN") ? atoi(getenv("TF_GEMM_MF_MIN")) : 0;      // experiment switch
   if (env_lo > mf_lo) mf_lo = env_lo > 9 ? 9 : env_lo;
   int best = 9; long best_cost = -1;
   for (int mf = 9; mf >= mf_lo; --mf) {                 // ties go to the taller tile (fewer W re-stagings)
-    const long tiles = (long)((M + 32 * mf - 1) / (32 * mf)) * tn;
+    const long tiles = row_tiles(M, G, 32 * mf) * tn;
     const long cost = ((tiles + slots - 1) / slots) * (mf + 3);
     if (best_cost < 0 || cost < best_cost) { best = mf; best_cost = cost; }
   }
@@ -1225,6 +1264,7 @@ extern "C" void tf_set_gemm_concurrency(int n) { g_gemm_concurrency.store(n < 1 
 
 extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0) return 0;
+  if (a->groups > 1 && (a->M % a->groups) != 0) return -7;          // equal row ranges
   if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
   static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
@@ -1250,10 +1290,10 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   // MI355X (large: 13.3 us + 26.4 us per 1000 K; 128-wide at two per CU: ~8 us + 21 us per 1000 K).
   bool use_big = big && a->M >= 1024 && a->N >= 256;
   if (use_big) {
-    const int mfp = pick_mf(a->M, a->N, split ? 8 : 5);
-    const long tb = (long)((a->M + 32 * mfp - 1) / (32 * mfp)) * ((a->N + BIG_BN - 1) / BIG_BN);
-    const int mi = split ? 4 : pick_mi(a->M, a->N);            // (the fp32-accuracy mode has one tile height of this kernel)
-    const long ts = (long)((a->M + 32 * mi - 1) / (32 * mi)) * ((a->N + BN - 1) / BN);
+    const int mfp = pick_mf(a->M, a->N, split ? 8 : 5, a->groups);
+    const long tb = row_tiles(a, 32 * mfp) * ((a->N + BIG_BN - 1) / BIG_BN);
+    const int mi = split ? 4 : pick_mi(a->M, a->N, a->groups);            // (the fp32-accuracy mode has one tile height of this kernel)
+    const long ts = row_tiles(a, 32 * mi) * ((a->N + BN - 1) / BN);
     const int pc = plan_cus();
     const double t_big = (double)((tb + pc - 1) / pc) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
     const long rs = (ts + 2 * pc - 1) / (2 * pc);
@@ -1268,7 +1308,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   static const int duo_min = getenv("TF_GEMM_DUO_MIN") ? atoi(getenv("TF_GEMM_DUO_MIN")) : 0;
   static const double duo_us = getenv("TF_GEMM_DUO_US") ? atof(getenv("TF_GEMM_DUO_US")) : -1.0;
   if (use_big && duo && !split) {
-    const long td = (long)((a->M + 143) / 144) * ((a->N + BIG_BN - 1) / BIG_BN);
+    const long td = row_tiles(a, 144) * ((a->N + BIG_BN - 1) / BIG_BN);
     static const int duo_1r = getenv("TF_GEMM_DUO_1R") ? atoi(getenv("TF_GEMM_DUO_1R")) : 0;   // experiment: epilogue bitmask -> also single-round launches
     const long need = duo_min > 0 ? duo_min : (((duo_1r >> a->epilogue) & 1) ? num_cus() + 1 : 2L * num_cus() + 1);
     if (td >= need) {
@@ -1280,7 +1320,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     }
   }
   if (use_big) {
-    const int mf = pick_mf(a->M, a->N, split ? 8 : 5);
+    const int mf = pick_mf(a->M, a->N, split ? 8 : 5, a->groups);
     char nm[56];
     snprintf(nm, sizeof(nm), split ? "gemm_nt_big_kernel<%d, %d, x3>" : "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
@@ -1293,12 +1333,12 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     TfTraceScope tr(nm, stream, fl);
     return launch_gemm_mi<4, 64, true>(a, stream);
   }
-  const int mi_sel = pick_mi(a->M, a->N);
+  const int mi_sel = pick_mi(a->M, a->N, a->groups);
   // at most about one workgroup per CU: the 4-slot ring form (see the kernel's header).  TF_GEMM_RING = percent of the CU count up
   // to which a grid takes it (0 = never).
   static const int ring_pct = getenv("TF_GEMM_RING") ? atoi(getenv("TF_GEMM_RING")) : 100;
   if (ring_pct > 0 && mi_sel <= 5) {
-    const long tiles = (long)((a->M + 32 * mi_sel - 1) / (32 * mi_sel)) * ((a->N + BN - 1) / BN);
+    const long tiles = row_tiles(a, 32 * mi_sel) * ((a->N + BN - 1) / BN);
     if (tiles * 100 <= (long)ring_pct * num_cus()) {
       char nm[56];
       snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64, ring>", a->epilogue, mi_sel);
@@ -1350,6 +1390,10 @@ extern "C" int tf_wgrad_tiles(int N, int K, int caller_sized) {
 extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   TfWgradArgs a = *a_in;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
+  const int ngroups = a.groups > 1 ? a.groups : 1;
+  if (a.M % ngroups) return -7;
+  const int M_all = a.M;
+  a.M = M_all / ngroups;                      // the sizing below is per group; the kernels get the full extent back
   if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8) || a.zeros == nullptr) return -2;
   if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
   const int v2 = wgrad_version(a.m_chunk > 0) == 2;
@@ -1370,11 +1414,13 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   if (splits < 1) splits = 1;
   if (a.m_chunk <= 0) a.m_chunk = ((steps + splits - 1) / splits) * 32;
   splits = (a.M + a.m_chunk - 1) / a.m_chunk;
-  dim3 grid(tiles * splits), block(256);
+  dim3 grid(tiles * splits, ngroups), block(256);
+  const double flops = 2.0 * M_all * a.N * a.K;
+  a.M = M_all;
   const bool split = a.dY_lo != nullptr;
   if (split && a.X_lo == nullptr) return -6;
   TfTraceScope tr(v2 ? (split ? "wgrad_tn2_kernel<x3>" : "wgrad_tn2_kernel") : (split ? "wgrad_tn_kernel<x3>" : "wgrad_tn_kernel"), stream,
-                  2.0 * a.M * a.N * a.K);
+                  flops);
   if (v2) {
     constexpr int LDS2 = 3 * (32 * 512 + 32 * 256);
     static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);

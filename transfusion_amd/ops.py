@@ -134,7 +134,7 @@ def split_planes(x: torch.Tensor):
 
 
 def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 0, 1.0), scale_a=None, scale_w=None, act=0,
-         A_lo=None, W_lo=None, C_lo=None, R_lo=None, C2_lo=None):
+         A_lo=None, W_lo=None, C_lo=None, R_lo=None, C2_lo=None, groups=1, w_gstride=0):
     """C = epilogue(A @ W^T).  A / W are bf16, or -- when ``scale_a`` / ``scale_w`` are given -- uint8 tensors of OCP e4m3
     values from ``quant_rows_fp8`` (fp8 MFMA, fp32 accumulate, result scaled per row and per output channel), or -- with the
     ``*_lo`` planes -- hi + lo bf16 pairs (fp32-accuracy mode: three MFMA passes, fp32 epilogue, hi + lo outputs)."""
@@ -145,7 +145,8 @@ def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 
                      epilogue=L.TF_EPI_NONE if epilogue is None else epilogue,
                      drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
                      fp8=1 if fp8 else 0, scale_a=L.ptr(scale_a), scale_w=L.ptr(scale_w), act=act,
-                     A_lo=L.ptr(A_lo), W_lo=L.ptr(W_lo), C_lo=L.ptr(C_lo), R_lo=L.ptr(R_lo), C2_lo=L.ptr(C2_lo))
+                     A_lo=L.ptr(A_lo), W_lo=L.ptr(W_lo), C_lo=L.ptr(C_lo), R_lo=L.ptr(R_lo), C2_lo=L.ptr(C2_lo),
+                     groups=int(groups), w_gstride=int(w_gstride))
     L.call("tf_gemm_fwd", g, _stream())
 
 
@@ -258,12 +259,13 @@ def _zeros256(device):
     return z
 
 
-def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0, dY_lo=None, X_lo=None):
+def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0, dY_lo=None, X_lo=None, groups=1,
+          dw_gstride=0):
     w = L.TfWgradArgs(dY=L.ptr(dY), ldy=dY.stride(0), X=L.ptr(X), ldx=X.stride(0), dW=L.ptr(dW), lddw=dW.stride(0), db=L.ptr(db),
                       dY_lo=L.ptr(dY_lo), X_lo=L.ptr(X_lo),
                       zeros=L.ptr(_zeros256(dY.device)), M=dY.shape[0], N=N, K=K, rg=rg, rgp=rgp,
                       n_src=dW.shape[0] if n_src is None else n_src, cg=cg, cgp=cgp,
-                      k_src=dW.shape[1] if k_src is None else k_src, m_chunk=m_chunk)
+                      k_src=dW.shape[1] if k_src is None else k_src, m_chunk=m_chunk, groups=int(groups), dw_gstride=int(dw_gstride))
     L.call("tf_gemm_wgrad", w, _stream())
 
 
