@@ -144,6 +144,9 @@ typedef struct TfLnArgs {
   const void* x_lo; void* y_lo; const void* dy_lo; void* dx_lo; void* dx_drop_lo; const void* dres_lo;
   // packed batches: group g of the x side (x, dx, dx_drop, dres) starts at row x_group_row0[g] instead of g * x_group_stride
   const int* x_group_row0;       // [ceil(rows / rows_per_group)] int32 device array or null
+  // parameter groups (see TfGemmArgs.groups): pgroups equal ranges of the `rows`, range g normalised with the gamma / beta that start
+  // g * p_gstride BYTES after gamma / beta (dgamma / dbeta likewise)
+  int pgroups; long long p_gstride;
 } TfLnArgs;
 
 typedef struct TfAssembleArgs {
@@ -164,6 +167,9 @@ typedef struct TfAssembleArgs {
   // packed batches (padded language tokens dropped): out / dout hold `rows` token rows and row_map[m] = b * (Nv + Nl) + s names the
   // (sample, position) row m was gathered from; dlang rows of dropped tokens are NOT written (the caller zero-fills dlang).
   const int* row_map; int rows;                  // null / 0: dense, row m = b * S + s
+  // parameter groups (see TfGemmArgs.groups): sample b belongs to group b / (B / pgroups); group g adds the kind embeddings that start
+  // g * p_gstride BYTES after kind_v / kind_l (dkind_v / dkind_l likewise); with a row_map the rows must be group-major
+  int pgroups; long long p_gstride;
 } TfAssembleArgs;
 
 // rowsum(dO . O) per (b, head, s)
@@ -444,6 +450,16 @@ typedef struct TfEncoderDesc {
                                  * All row-wise work (GEMMs, LayerNorm, attention queries, weight gradients) shrinks to the real tokens.
                                  * 0: dense (bit-for-bit the reference's semantics, padded rows included).  A count that disagrees with
                                  * the mask is reported through tf_encoder_packed_error. */
+  int groups;                   /* > 1: the batch holds the samples of `groups` INDEPENDENT encoders of identical shape, B / groups samples
+                                 * each (group g = samples [g B / groups, (g+1) B / groups)) -- the wrapper's FPN levels
+                                 * (cross_f_box_wrapper.py:177-212), which run the same [Nv + Nl]-token encoder with four weight sets, as ONE
+                                 * launch sequence: a quarter of the launches, grids four times the size.  Every parameter and gradient
+                                 * pointer of this struct (p[], g[], kind_*, fn_*, g_*) names group 0's tensor; group g's tensor starts
+                                 * g * param_gstride BYTES further (true for every tensor alike: the parameters of the encoders sit at one
+                                 * common stride, as in FusionTrainStep's flat buffer).  wpack holds `groups` shadow blocks back to back
+                                 * (tf_encoder_plan_ex sizes it).  pe / pe_lang are shared by the groups; attn_block_bits must be null;
+                                 * with packed_rows every group must drop the same tokens (same lang_pad_mask rows).  0 / 1: one encoder. */
+  long long param_gstride;
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);   /* precision 0 */

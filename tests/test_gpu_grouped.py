@@ -1,0 +1,114 @@
+"""TfEncoderDesc.groups: G encoders of identical shape and different weights (the wrapper's FPN levels) as ONE runtime call -- every
+row range against its own parameters in the GEMM, weight-gradient, LayerNorm and assemble kernels.  The yardstick is the same G
+encoders called one after the other (the path every other test pins to the reference): outputs, input gradients and every parameter
+gradient must agree."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _encoders(dev, G, d, H, layers, p_tok, p_patch):
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
+    from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
+    mods = []
+    for k in range(G):
+        torch.manual_seed(100 + k)                                 # different weights per level
+        pe = PositionalEmbeddingLayer("sin1d", 256, d)
+        m = CrossTransformerModuleBox(no_patches=256, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=layers, patch_dropout=p_patch,
+                                      num_heads=H, fforward_multiplier=2, token_dropout=p_tok, back_to_img_fn="regroup", activ_f="gelu",
+                                      final_norm="ln", input_f_size=d)
+        # LayerNorm weights / kind embeddings away from their defaults, so that a group reading ANOTHER group's vector shows
+        with torch.no_grad():
+            for q in m.parameters():
+                if q.dim() == 1:
+                    q.add_(0.3 * torch.randn_like(q))
+        mods.append(m)
+    return torch.nn.ModuleList(mods).to(dev).train()
+
+
+@pytest.mark.parametrize("G,B,Nv,Nl,d,H,layers,packed,precision", [
+    (4, 2, 36, 40, 64, 2, 2, False, "bf16"),
+    (4, 2, 36, 40, 64, 2, 2, True, "bf16"),
+    (3, 3, 49, 24, 192, 4, 1, True, "bf16"),
+    (2, 4, 196, 128, 768, 4, 2, True, "bf16"),       # the wrapper's level shape (d = 768, 196 visual tokens), large-tile kernels
+    (2, 2, 36, 40, 64, 2, 2, True, "fp32"),
+])
+def test_grouped_call_equals_separate_calls(G, B, Nv, Nl, d, H, layers, packed, precision):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    dev = torch.device("cuda:0")
+    mods = _encoders(dev, G, d, H, layers, 0.0, 0.0)              # dropout off: element indices (hence masks) differ between the two paths
+    for m in mods:
+        m.precision = precision
+    tr = FusionTrainStep(mods, lr=0.0, weight_decay=0.0, grad_clip=None)     # flat parameter / gradient buffers: one common stride
+    g = torch.Generator().manual_seed(G * 1000 + Nv)
+    xs = [torch.randn(B, Nv, d, generator=g).to(dev).requires_grad_(True) for _ in range(G)]
+    lang = torch.randn(B, Nl, d, generator=g).to(dev).requires_grad_(True)
+    lens = torch.randint(Nl // 3, Nl + 1, (B,), generator=g)
+    lens[0] = Nl
+    pad = (torch.arange(Nl).view(1, -1) >= lens.view(-1, 1)).to(dev)
+    n_valid = int(lens.sum())
+    gv = [torch.randn(B, Nv, d, generator=g).to(dev) for _ in range(G)]
+    gl = [(torch.randn(B, Nl, d, generator=g) * (~pad.cpu()).unsqueeze(-1)).to(dev) for _ in range(G)]
+    assert mods[0].group_stride(list(mods)) is not None
+
+    # ---- separate calls ----
+    tr.zero_grad()
+    outs, louts = [], []
+    for k, m in enumerate(mods):
+        v, lo, _, _ = m(xs[k], lang, pad, lang_valid_rows=n_valid if packed else None)
+        outs.append(v)
+        louts.append(lo)
+    torch.autograd.backward(outs + louts, gv + gl)
+    torch.cuda.synchronize()
+    ref_grad = tr.flat.grad.detach().clone()
+    ref_dx = [x.grad.detach().clone() for x in xs]
+    ref_dlang = lang.grad.detach().clone()
+    for x in xs:
+        x.grad = None
+    lang.grad = None
+
+    # ---- one grouped call ----
+    tr.zero_grad()
+    X = torch.cat(xs, dim=0)
+    Lg, Pg = lang.repeat(G, 1, 1), pad.repeat(G, 1)
+    V, LO, _, _ = mods[0].forward_grouped(list(mods), X, Lg, Pg, lang_valid_rows=G * n_valid if packed else None)
+    torch.autograd.backward([V, LO], [torch.cat(gv, dim=0), torch.cat(gl, dim=0)])
+    torch.cuda.synchronize()
+    if packed:
+        assert mods[0].packed_row_error() == 0
+    tol = 1e-4 if precision == "fp32" else 6e-3                    # tile shapes differ between the two paths: bf16 rounding, nothing more
+    for k in range(G):
+        assert rel(V[k * B:(k + 1) * B], outs[k]) < tol, ("vis", k)
+        keep = (~pad).unsqueeze(-1)
+        assert rel(LO[k * B:(k + 1) * B] * keep, louts[k] * keep) < tol, ("lang", k)
+        assert rel(xs[k].grad, ref_dx[k]) < 3 * tol, ("dx", k)
+    assert rel(lang.grad, ref_dlang) < 3 * tol
+    # every parameter gradient, encoder by encoder
+    for name, p, off, n in tr.flat.slices:
+        a, b = tr.flat.grad[off:off + n], ref_grad[off:off + n]
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, name
+        else:
+            assert rel(a, b) < 4 * tol, (name, rel(a, b))
+
+
+def test_group_stride_refuses_what_cannot_be_grouped():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda:0")
+    mods = _encoders(dev, 2, 64, 2, 1, 0.0, 0.0)
+    assert mods[0].group_stride(list(mods)) is None               # separate allocations, gradients through autograd: no common stride
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    FusionTrainStep(mods, lr=0.0, weight_decay=0.0, grad_clip=None)
+    assert mods[0].group_stride(list(mods)) is not None
+    mods[1].token_dropout = 0.3
+    mods[0]._group_check = None
+    assert mods[0].group_stride(list(mods)) is None               # different configuration

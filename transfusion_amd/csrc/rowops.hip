@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   if (row >= a.rows) return;
   const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
   const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
+  // parameter groups (TfLnArgs.pgroups): equal row ranges, each with its own gamma / beta, p_gstride bytes apart
+  const long long poff = a.pgroups > 1 ? (long long)(row / (a.rows / a.pgroups)) * a.p_gstride : 0;
+  const float* gamma = (const float*)((const unsigned char*)a.gamma + poff);
+  const float* beta = (const float*)((const unsigned char*)a.beta + poff);
   float v[MAXC][8];
   float s = 0.f;
 #pragma unroll
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
     const int c = (lane + 64 * i) * 8;
     if (c < a.d) {
       float g[8], b[8], o[8];
-      load8_f32(a.gamma + c, g);
-      load8_f32(a.beta + c, b);
+      load8_f32(gamma + c, g);
+      load8_f32(beta + c, b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       if (a.y_is_f32) store8_f32((float*)a.y + (size_t)yr * a.ldy + c, o);
@@ -121,7 +125,11 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
 
-  for (int row = blockIdx.x * LNB_WAVES + wave; row < a.rows; row += gridDim.x * LNB_WAVES) {
+  // parameter groups (blockIdx.y): a block's column partials belong to ONE group's dgamma / dbeta
+  const int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g;
+  const long long poff = (long long)blockIdx.y * a.p_gstride;
+  const float* gamma_g = (const float*)((const unsigned char*)a.gamma + poff);
+  for (int row = row_lo + blockIdx.x * LNB_WAVES + wave; row < row_lo + rows_g; row += gridDim.x * LNB_WAVES) {
     const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
     const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
     const float mean = a.mean[row], rstd = a.rstd[row];
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 #pragma unroll
           for (int e = 0; e < 8; ++e) dy[e] += r[e];
         }
-        load8_f32(a.gamma + c, gm);
+        load8_f32(gamma_g + c, gm);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[i][e] = (xv[e] - mean) * rstd;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[wave][(lane + 64 * i) * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
     __syncthreads();
-    float* dst = pass == 0 ? a.dgamma : a.dbeta;
+    float* dst = (float*)((unsigned char*)(pass == 0 ? a.dgamma : a.dbeta) + poff);
     for (int c = threadIdx.x; c < a.d; c += 64 * LNB_WAVES) {
       float t = 0.f;
 #pragma unroll
@@ -207,6 +215,10 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   if (row >= (a.row_map != nullptr ? a.rows : a.B * S)) return;
   const int dense = a.row_map != nullptr ? a.row_map[row] : row;       // packed batches: the (sample, position) this row is gathered from
   const int b = dense / S, s = dense - b * S;
+  // parameter groups (TfAssembleArgs.pgroups): sample b belongs to group b / (B / pgroups); its kind embeddings sit p_gstride bytes apart
+  const long long poff = a.pgroups > 1 ? (long long)(b / (a.B / a.pgroups)) * a.p_gstride : 0;
+  const float* kind_v = (const float*)((const unsigned char*)a.kind_v + poff);
+  const float* kind_l = (const float*)((const unsigned char*)a.kind_l + poff);
   u16* out = (u16*)a.out + (size_t)row * a.ld_out;
   for (int c = lane * 8; c < a.ld_out; c += 512) {
     if (c >= a.d) {
@@ -219,13 +231,13 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
       float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       load8_any(a.vis, (size_t)(b * a.Nv + s) * a.ld_vis + c, a.vis_is_f32, v);
       if (a.pe != nullptr) load8_f32(a.pe + (size_t)s * a.d + c, pe);
-      load8_f32(a.kind_v + c, k);
+      load8_f32(kind_v + c, k);
       const unsigned km = a.drop_thr ? tf_keep8((unsigned)row * (unsigned)a.ld_out + (unsigned)c, a.drop_key, a.drop_thr) : 0xffu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((km >> e) & 1u) ? (v[e] + pe[e] + k[e]) * a.drop_scale : 0.f;
     } else {
       load8_any(a.lang, (size_t)(b * a.Nl + s - a.Nv) * a.ld_lang + c, a.lang_is_f32, v);
-      load8_f32(a.kind_l + c, k);
+      load8_f32(kind_l + c, k);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += k[e];
       if (a.pe_lang != nullptr) {                                  // lang_pos_embedding: added after the kind embedding (:76-78)
@@ -251,8 +263,10 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
   for (int i = 0; i < MAXC; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kv[i][e] = 0.f; kl[i][e] = 0.f; }
-  const int nrows = a.row_map != nullptr ? a.rows : a.B * S;
-  for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+  const int nrows_all = a.row_map != nullptr ? a.rows : a.B * S;
+  const int nrows_g = a.pgroups > 1 ? nrows_all / a.pgroups : nrows_all, row_lo = (int)blockIdx.y * nrows_g;
+  const long long poff = (long long)blockIdx.y * a.p_gstride;
+  for (int row = row_lo + blockIdx.x * 4 + wave; row < row_lo + nrows_g; row += gridDim.x * 4) {
     const int dense = a.row_map != nullptr ? a.row_map[row] : row;
     const int b = dense / S, s = dense - b * S;
 #pragma unroll
@@ -285,8 +299,10 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
       for (int e = 0; e < 8; ++e) red[wave][(lane + 64 * i) * 8 + e] = pass == 0 ? kv[i][e] : kl[i][e];
     __syncthreads();
     float* dst = pass == 0 ? a.dkind_v : a.dkind_l;
-    if (dst != nullptr)
+    if (dst != nullptr) {
+      dst = (float*)((unsigned char*)dst + poff);
       for (int c = threadIdx.x; c < a.d; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
     __syncthreads();
   }
 }
@@ -427,7 +443,7 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
 // scans the positions, a wave per sample fills.  err[0] is set to the mask's total when it differs from the host's `expected`.
 __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
                                                        int* __restrict__ start_of, int* __restrict__ dense_of, int* __restrict__ packed_of_lang,
-                                                       int expected, int* __restrict__ err) {
+                                                       int expected, int* __restrict__ err, int groups) {
   extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position)
   int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -443,9 +459,11 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {             // position of sample b in the longest-first order (stable)
-    const int mine = cnt[b];
-    int r = 0;
-    for (int o = 0; o < B; ++o) r += (cnt[o] > mine || (cnt[o] == mine && o < b)) ? 1 : 0;
+    // (grouped launches: the samples of a group stay together -- group-major order, longest first INSIDE each group -- so that a
+    // group's rows are one contiguous range, which is what the grouped GEMM / LayerNorm / weight-gradient launches index by)
+    const int mine = cnt[b], Bg = B / groups, g0 = (b / Bg) * Bg;
+    int r = g0;
+    for (int o = g0; o < g0 + Bg; ++o) r += (cnt[o] > mine || (cnt[o] == mine && o < b)) ? 1 : 0;
     pos_of[b] = r;
     start[r + 1] = mine;                                          // (counts by position; scanned below)
   }
@@ -1039,7 +1057,9 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   if (width > 64 * MAXC_MAX * 8) return -2;
   constexpr int nw = 8;        // waves per workgroup (16 measured slower: 39.9 vs 38.3 us; its instantiations spilled and are gone)
   static const int env_g = getenv("TF_LNB_GRID") ? atoi(getenv("TF_LNB_GRID")) : 512;     // experiment switch
-  const dim3 grid(grid_for(a->rows, nw, env_g));       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
+  const int pg = a->pgroups > 1 ? a->pgroups : 1;
+  if (a->rows % pg) return -2;
+  const dim3 grid(grid_for(a->rows / pg, nw, max(1, env_g / pg)), pg);       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
                                                        // small row counts get one row per wave (2,083 rows: 261 blocks instead of 131, 17 -> 13 us)
   const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
@@ -1066,7 +1086,9 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   if (rows <= 0) return 0;
   if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
-  const dim3 grid(grid_for(rows, 4, 512));             // (small row counts: one row per wave)
+  const int pg = a->pgroups > 1 ? a->pgroups : 1;
+  if (rows % pg || a->B % pg) return -2;
+  const dim3 grid(grid_for(rows / pg, 4, max(1, 512 / pg)), pg);             // (small row counts: one row per wave)
   TfTraceScope tr("assemble_bwd_kernel", st, 0.0, 0.0);
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
@@ -1100,12 +1122,13 @@ extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang,
-                                 int expected, int* err, hipStream_t st) {
+                                 int expected, int* err, int groups, hipStream_t st) {
+  if (groups < 1 || B % groups) return -2;
   if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || start_of == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
   const size_t lds = (size_t)(3 * B + 1) * sizeof(int);
   if (lds > 60000) return -2;          // the per-sample tables live in LDS
   TfTraceScope tr("row_map_kernel", st);
-  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err);
+  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err, groups);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {

@@ -44,9 +44,12 @@ struct Dims {
   int S, M, hd, hdp, dp, ffp, nqkv, ldq;
   int Md;           // B * S: token rows of the dense layout.  M = rows that take part: Md, or TfEncoderDesc.packed_rows (packed batches)
   int split;        // fp32-accuracy mode: every bf16 tensor of the workspace and of the weight shadows is a hi + lo plane pair
+  int G;            // TfEncoderDesc.groups: G encoders' samples (B / G each) in one batch, each with its own parameters
 };
-bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0, int packed_rows = 0) {
+bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0, int packed_rows = 0, int groups = 1) {
   o->split = split ? 1 : 0;
+  o->G = groups > 1 ? groups : 1;
+  if (B % o->G != 0 || packed_rows % o->G != 0) return false;       // equal groups (packed: every group drops the same tokens)
   if (B <= 0 || Nv < 0 || Nl < 0 || Nv + Nl <= 0 || d <= 0 || H <= 0 || L <= 0 || L > TF_MAX_LAYERS || ff <= 0) return false;
   if (d % H != 0 || d % 8 != 0) return false;
   o->B = B; o->Nv = Nv; o->Nl = Nl; o->d = d; o->H = H; o->L = L; o->ff = ff;
@@ -154,10 +157,13 @@ struct Ctx {
   const int* pol() const { return packed() ? (const int*)(wk + A.pol) : nullptr; }              // language token (b, j) -> packed row or -1
   unsigned char* LB(int l) const { return wk + A.layer0 + (size_t)l * A.layer_stride; }
   unsigned char* WB(int l) const { return wp + (size_t)l * W.stride; }
+  long long wg() const { return (long long)(W.stride * (size_t)D.L); }        // bytes between the shadow blocks of two groups
+  long long pg() const { return D.G > 1 ? e->param_gstride : 0; }             // bytes between the parameters (and gradients) of two groups
 };
 bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
   if (e == nullptr || e->wpack == nullptr || e->work == nullptr) return false;
-  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision, e->packed_rows)) return false;
+  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision, e->packed_rows, e->groups)) return false;
+  if (c->D.G > 1 && (e->param_gstride <= 0 || (e->param_gstride & 15) != 0 || e->attn_block_bits != nullptr)) return false;
   if (e->precision != 0 && e->precision != 1) return false;
   if (e->precision && e->fp8_proj) return false;      // fp8 operands have no lo plane
   if (e->act != 0 && e->act != 1) return false;
@@ -183,6 +189,7 @@ int gemm(const Ctx& c, Buf A, Buf W, Buf C, const float* bias, Buf R, Buf C2, in
   g.C2 = (void*)C2.p; g.ldc2 = C2.ld;
   g.A_lo = A.lo; g.W_lo = W.lo; g.C_lo = (void*)C.lo; g.R_lo = R.lo; g.C2_lo = (void*)C2.lo;
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
+  g.groups = c.D.G; g.w_gstride = c.wg();            // (every W / bias of the runtime lives in a layer's shadow block)
   return tf_launch_gemm_nt(&g, c.st);
 }
 // forward projection with fp8 operands: quantise the bf16 activation per token, then the fp8 large-tile GEMM
@@ -195,6 +202,7 @@ int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const 
   g.A = a8; g.lda = K; g.W = W8; g.ldw = K; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr; g.C2 = C2; g.ldc2 = ldc2;
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
   g.fp8 = 1; g.scale_a = sa; g.scale_w = sw;
+  g.groups = c.D.G; g.w_gstride = c.wg();
   return tf_launch_gemm_nt(&g, c.st);
 }
 // Side stream of one tf_encoder_bwd call.  An event record or wait on the chain is a barrier packet and costs ~5 us of
@@ -232,13 +240,14 @@ int wgrad(const Ctx& c, Side& sd, Buf dY, int N, Buf X, int K, float* dW, int ld
   static const int exp_skip = getenv("TF_EXP_SKIP_WGRAD") ? atoi(getenv("TF_EXP_SKIP_WGRAD")) : 0;   // timing experiment only: WRONG gradients
   if (exp_skip) return 0;
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
+  w.groups = c.D.G; w.dw_gstride = c.pg();
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
   static const int tail_alone = getenv("TF_WGRAD_TAIL_ALONE") ? atoi(getenv("TF_WGRAD_TAIL_ALONE")) : 1;   // experiment switch
   if (alone && tail_alone) return tf_launch_wgrad_tn(&w, sd.st);   // the last wgrad of the backward has the chip to itself: stand-alone sizing
   {
     // Overlapped with the chain the wgrad no longer has to fill the chip by itself: fewer, longer blocks mean fewer fp32
     // atomic flushes (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
-    const int tiles = tf_wgrad_tiles(N, K, 1), steps = (c.D.M + 31) / 32;
+    const int tiles = tf_wgrad_tiles(N, K, 1) * c.D.G, steps = (c.D.M / c.D.G + 31) / 32;      // (grouped: blocks of all groups, steps inside one)
     // ... and proportionally fewer when M is small, so that a block still has a few dozen 32-row steps to amortise its prologue
     // and flush (M = 2832: 64 blocks 2078 samples/s vs 1823 at 256; M = 5664: 128 blocks 3419 vs 3175; M = 22656: 256)
     static const int env_target = getenv("TF_WGRAD_OVL_TARGET") ? atoi(getenv("TF_WGRAD_OVL_TARGET")) : 0;     // experiment switch
@@ -465,10 +474,19 @@ void tf_trace_mark_side(hipStream_t side) {
   g_trace_sides.push_back(side);
 }
 namespace {
+int pack_layer_group(const Ctx& c, int l, int grp, hipStream_t st);
 int pack_layer(const Ctx& c, int l, hipStream_t st) {
+  for (int grp = 0; grp < c.D.G; ++grp) { const int rc = pack_layer_group(c, l, grp, st); if (rc != 0) return rc; }
+  return 0;
+}
+int pack_layer_group(const Ctx& c, int l, int grp, hipStream_t st) {
   const Dims& D = c.D;
-  unsigned char* w = c.WB(l);
-  const TfLayerParams& p = c.e->p[l];
+  unsigned char* w = c.WB(l) + (size_t)grp * c.wg();
+  TfLayerParams p = c.e->p[l];
+  if (grp > 0) {                                                   // group grp's parameters: the same tensors, param_gstride bytes further
+    float** f = (float**)&p;
+    for (size_t i = 0; i < sizeof(TfLayerParams) / sizeof(float*); ++i) f[i] = (float*)((unsigned char*)f[i] + (size_t)grp * c.pg());
+  }
   for (int residual = 0; residual <= D.split; ++residual) {      // split mode: a second launch writes the lo planes, bf16(w - bf16(w))
     TfPackArgs batch[8];
     int nb = 0;
@@ -505,6 +523,7 @@ int pack_layer(const Ctx& c, int l, hipStream_t st) {
 void ln_rows(const Ctx& c, TfLnArgs& n, Buf x, const float* gamma, float* mean, float* rstd) {
   n.x = x.p; n.x_lo = x.lo; n.ldx = x.ld; n.gamma = gamma; n.mean = mean; n.rstd = rstd;
   n.rows = c.D.M; n.d = c.D.d; n.rows_per_group = c.D.M; n.x_group_stride = c.D.M; n.y_group_stride = c.D.M; n.eps = 1e-5f;
+  n.pgroups = c.D.G; n.p_gstride = c.pg();
 }
 }  // namespace
 extern "C" {
@@ -512,10 +531,10 @@ extern "C" {
 int tf_encoder_plan_ex(const TfEncoderDesc* e, TfEncoderPlan* out) {
   Dims D;
   if (e == nullptr || out == nullptr || (e->precision != 0 && e->precision != 1) ||
-      !make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &D, e->precision)) return fail(-1, "tf_encoder_plan_ex");
+      !make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &D, e->precision, 0, e->groups)) return fail(-1, "tf_encoder_plan_ex");
   const WOff W = make_woff(D); const AOff A = make_aoff(D);
   out->hd = D.hd; out->hdp = D.hdp; out->dp = D.dp; out->ffp = D.ffp; out->ldq = D.ldq; out->S = D.S; out->M = D.M;
-  out->wpack_bytes = W.stride * (size_t)D.L; out->work_bytes = A.total;
+  out->wpack_bytes = W.stride * (size_t)D.L * (size_t)D.G; out->work_bytes = A.total;       // one shadow block per group, back to back
   return 0;
 }
 
@@ -560,7 +579,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
     TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
-                             e->packed_rows, (int*)(c.wk + c.A.perr), c.st), "row_map");
+                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, c.st), "row_map");
     km = nullptr;
   } else {
     TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
@@ -572,6 +591,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.pe = e->pe; a.pe_lang = e->pe_lang; a.kind_v = e->kind_v; a.kind_l = e->kind_l; a.out = (void*)x0.p; a.out_lo = (void*)x0.lo; a.ld_out = D.dp;
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
     a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
+    a.pgroups = D.G; a.p_gstride = c.pg();
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
@@ -635,6 +655,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
       n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
       n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f; n.x_group_row0 = c.starts();
+      n.pgroups = D.G; n.p_gstride = c.pg();
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
     } else {
       TfCopyRowsArgs r{};
@@ -686,6 +707,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       n.x_group_row0 = c.starts();
       n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = (void*)dxa.p; n.dx_lo = (void*)dxa.lo; n.lddx = D.dp;
       n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
+      n.pgroups = D.G; n.p_gstride = c.pg();
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
     } else {
       TfCopyRowsArgs r{};
@@ -802,6 +824,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d; a.dout = dxa.p; a.dout_lo = dxa.lo; a.ld_dout = D.dp;
     a.dvis = e->d_vis; a.dvis_is_f32 = e->d_vis_is_f32; a.ld_dvis = D.d; a.dlang = e->d_lang; a.dlang_is_f32 = e->d_lang_is_f32; a.ld_dlang = D.d;
     a.dkind_v = e->g_kind_v; a.dkind_l = e->g_kind_l;
+    a.pgroups = D.G; a.p_gstride = c.pg();
     a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
     if (c.packed() && e->d_lang != nullptr)          // rows of masked language tokens are not visited: their gradient is zero
       TF_TRY((int)hipMemsetAsync(e->d_lang, 0, (size_t)D.B * D.Nl * D.d * (e->d_lang_is_f32 ? 4 : 2), c.st), "d_lang zero fill");

@@ -25,7 +25,7 @@ int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t stream);
 // packed batches: cu [B+1] (by position, longest sample first), start_of [B] (by sample), dense_of [B*S], packed_of_lang [B*Nl] from the
 // language padding mask; err[0] = the mask's row total when != expected
 int tf_launch_row_map(const uint8_t* lang_pad_mask, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang, int expected,
-                      int* err, hipStream_t stream);
+                      int* err, int groups, hipStream_t stream);
 int tf_launch_key_mask(const uint8_t* lang_pad_mask, uint8_t* key_mask, int B, int Nv, int Nl, hipStream_t stream);
 int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t stream);
 int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t stream);

@@ -225,6 +225,8 @@ class CrossTransformerModuleBox(nn.Module):
         self.pack_tokens = os.environ.get("TF_PACK_TOKENS", "1") != "0"
         self._packed_rows = 0
         self._params_cache = None
+        self._group_mods = None               # set for the duration of a forward_grouped call: [self, the other encoders of the group]
+        self._group_stride = None
         self._wpack = None
         self._wpack_versions = None
         self._work_pool = {}
@@ -248,7 +250,8 @@ class CrossTransformerModuleBox(nn.Module):
         return ps
 
     def _wpack_dirty(self) -> bool:
-        vers = tuple((p.data_ptr(), p._version) for p in self._param_list()) + (bool(self.fp8_projections), self.precision)
+        mods = self._group_mods or (self,)
+        vers = tuple((p.data_ptr(), p._version) for m in mods for p in m._param_list()) + (bool(self.fp8_projections), self.precision, len(mods))
         if vers != self._wpack_versions:
             self._wpack_versions = vers
             return True
@@ -302,6 +305,8 @@ class CrossTransformerModuleBox(nn.Module):
         e.precision = 1 if self.precision == "fp32" else 0
         e.act = 1 if self.activ_f == "relu" else 0
         e.packed_rows = 0                   # the plan is the dense one (an upper bound for every packed layout of this shape)
+        if self._group_mods:
+            e.groups, e.param_gstride = len(self._group_mods), int(self._group_stride)
         plan = L.TfEncoderPlan()
         L.check(lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(plan)), "tf_encoder_plan_ex")
         if self._wpack is None or self._wpack.numel() != plan.wpack_bytes or self._wpack.device != x.device:
@@ -375,6 +380,8 @@ class CrossTransformerModuleBox(nn.Module):
         with ``accumulate_into_grad``, straight at the preallocated ``p.grad`` tensors."""
         params = self._param_list()
         direct = self.accumulate_into_grad
+        if desc.groups > 1 and not direct:
+            raise L.TfError("a grouped encoder call accumulates straight into .grad (accumulate_into_grad, FusionTrainStep)")
         grads = []
         if direct:
             for p in params:
@@ -450,6 +457,62 @@ class CrossTransformerModuleBox(nn.Module):
         need_grad = torch.is_grad_enabled() and (x.requires_grad or language_tokens.requires_grad or any(p.requires_grad for p in params))
         vis_tokens, lang_tokens = _EncoderFn.apply(self, need_grad, x, language_tokens, language_tokens_att_maks, *params)
         return vis_tokens, lang_tokens, None, None
+
+    # ---- the wrapper's FPN levels as ONE launch sequence (TfEncoderDesc.groups) ----------------------------------
+    _GROUP_CFG = ("num_layers", "num_heads", "token_dim", "dim_feedforward", "token_dropout", "patch_dropout", "activ_f", "final_norm",
+                  "precision", "fp8_projections", "training", "accumulate_into_grad", "pack_tokens")
+
+    def group_stride(self, mods):
+        """Byte stride between the parameters of consecutive encoders of ``mods`` (``mods[0] is self``) if they can run as one grouped
+        call, else None: identical configuration, gradients accumulated in place, no per-layer gradient hook, fixed positional tables
+        with equal contents, and every parameter AND every gradient tensor of encoder g exactly g * stride bytes after encoder 0's --
+        what FusionTrainStep's flat buffers give.  Cached on the tensors' addresses."""
+        if len(mods) < 2 or mods[0] is not self:
+            return None
+        key = tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr()) for m in mods for p in m._param_list())
+        cached = getattr(self, "_group_check", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        stride = None
+        ok = all(isinstance(m, CrossTransformerModuleBox) and m.layer_grad_hook is None and m.accumulate_into_grad for m in mods)
+        ok = ok and all(getattr(m, a) == getattr(self, a) for m in mods for a in self._GROUP_CFG)
+        if ok:
+            p0 = self._param_list()
+            ok = all(p.grad is not None and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() for p in p0)
+        if ok:
+            base = mods[1]._param_list()[0].data_ptr() - p0[0].data_ptr()
+            ok = base > 0 and base % 16 == 0
+            for gi, m in enumerate(mods):
+                pm = m._param_list()
+                ok = ok and len(pm) == len(p0) and all(
+                    q.shape == p.shape and q.grad is not None and q.data_ptr() - p.data_ptr() == gi * base
+                    and q.grad.data_ptr() - p.grad.data_ptr() == gi * base for p, q in zip(p0, pm))
+            if ok:
+                stride = base
+        if stride is not None:
+            pe0 = self.pos_embedding_layer.pos_embedding
+            ok = not isinstance(pe0, nn.Parameter) and not self.lang_pos_embedding
+            ok = ok and all(not m.lang_pos_embedding and not isinstance(m.pos_embedding_layer.pos_embedding, nn.Parameter)
+                            and m.pos_embedding_layer.pos_embedding.shape == pe0.shape
+                            and (m.pos_embedding_layer.pos_embedding is pe0 or torch.equal(m.pos_embedding_layer.pos_embedding, pe0)) for m in mods[1:])
+            if not ok:
+                stride = None
+        self._group_check = (key, stride)
+        return stride
+
+    def forward_grouped(self, mods, x, language_tokens, language_tokens_att_maks, lang_valid_rows=None):
+        """``x`` [G * B, Nv, d]: the visual tokens of the G encoders ``mods`` (``mods[0] is self``), group-major; ``language_tokens`` /
+        mask [G * B, Nl, ...] likewise (the wrapper repeats the shared narration tokens).  One runtime call for all G encoders, each
+        row range against its own parameters (TfEncoderDesc.groups).  ``lang_valid_rows`` counts the un-masked tokens of ALL groups.
+        Returns what ``forward`` returns, for the stacked batch.  Check ``group_stride(mods)`` first."""
+        stride = self.group_stride(mods)
+        if stride is None:
+            raise L.TfError("these encoders cannot run as one grouped call (CrossTransformerModuleBox.group_stride)")
+        self._group_mods, self._group_stride = list(mods), stride
+        try:
+            return self.forward(x, language_tokens, language_tokens_att_maks, None, lang_valid_rows)
+        finally:
+            self._group_mods = None
 
     def _pack_block_bits(self, vis_tokens_mask, Nv, Nl, device):
         """vis_tokens_mask [Nv,Nv] (nonzero = blocked, reference utils.py:14-30) -> the [S, ceil(S/64)] u64 block-bit matrix of
