@@ -961,19 +961,29 @@ __device__ __forceinline__ float pn_load(const void* x, int is_f32, size_t i) { 
 __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs a_in) {
   TfPoolNormArgs a = a_in;
   a.drop_key = tf_salted(a.drop_key);
-  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.d) return;
+  // a block = 32 columns x 8 token lanes (a [B, d] grid of single columns was 12 workgroups walking 512 tokens one after the other at
+  // the wrapper's shape: 194 us at the head of every step); the token-axis sum goes through LDS
+  __shared__ float part[8][32];
+  const int b = blockIdx.y, cl = threadIdx.x & 31, tl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool col_ok = c < a.d;
   const int len = a.lens != nullptr ? min(max(a.lens[b], 0), a.T) : a.T;
   float ss = 0.f;
-  for (int t = 0; t < len; ++t) {
-    float u = pn_load(a.x, a.x_is_f32, ((size_t)b * a.T + t) * a.ldx + c);
-    if (a.use_tanh) u = tanhf(u);
-    ss = fmaf(u, u, ss);
-  }
+  if (col_ok)
+    for (int t = tl; t < len; t += 8) {
+      float u = pn_load(a.x, a.x_is_f32, ((size_t)b * a.T + t) * a.ldx + c);
+      if (a.use_tanh) u = tanhf(u);
+      ss = fmaf(u, u, ss);
+    }
+  part[tl][cl] = ss;
+  __syncthreads();
+  if (!col_ok) return;
+  ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ss += part[k][cl];                  // (the same order in every token lane: one value per column)
   const float nrm = a.T > 1 ? fmaxf(sqrtf(ss), 1e-12f) : 1.f;
-  a.n[(size_t)b * a.d + c] = nrm;
+  if (tl == 0) a.n[(size_t)b * a.d + c] = nrm;
   const float inv = 1.f / nrm;
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = tl; t < a.T; t += 8) {
     const size_t o = ((size_t)b * a.T + t) * a.d + c;
     float zv = 0.f;
     if (t < len) {
@@ -990,24 +1000,29 @@ __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const TfPoolNormArgs
 __global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const TfPoolNormArgs a_in) {
   TfPoolNormArgs a = a_in;
   a.drop_key = tf_salted(a.drop_key);
-  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.ldgx) return;
+  __shared__ float part[8][32];
+  const int b = blockIdx.y, cl = threadIdx.x & 31, tl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   const bool bf = !a.gx_is_f32;
-  if (c >= a.d) {                                          // pad columns of a bf16 gradient
-    if (bf) for (int t = 0; t < a.T; ++t) ((u16*)a.gx)[((size_t)b * a.T + t) * a.ldgx + c] = 0;
-    return;
-  }
+  const bool col_ok = c < a.d;
+  if (!col_ok && c < a.ldgx && bf)                           // pad columns of a bf16 gradient
+    for (int t = tl; t < a.T; t += 8) ((u16*)a.gx)[((size_t)b * a.T + t) * a.ldgx + c] = 0;
   const int len = a.lens != nullptr ? min(max(a.lens[b], 0), a.T) : a.T;
-  const float nrm = a.n[(size_t)b * a.d + c];
+  const float nrm = col_ok ? a.n[(size_t)b * a.d + c] : 1.f;
   float dot = 0.f;
-  if (a.T > 1)
-    for (int t = 0; t < len; ++t) {
+  if (a.T > 1 && col_ok)
+    for (int t = tl; t < len; t += 8) {
       const size_t o = ((size_t)b * a.T + t) * a.d + c;
       float g = a.gy[o];
       if (a.drop_thr) g = tf_keep((unsigned)o, a.drop_key, a.drop_thr) ? g * a.drop_scale : 0.f;
       dot = fmaf(g, a.z[o], dot);
     }
-  for (int t = 0; t < a.T; ++t) {
+  part[tl][cl] = dot;
+  __syncthreads();
+  if (!col_ok) return;
+  dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dot += part[k][cl];
+  for (int t = tl; t < a.T; t += 8) {
     const size_t o = ((size_t)b * a.T + t) * a.d + c;
     float gx = 0.f;
     if (t < len) {
@@ -1238,14 +1253,14 @@ extern "C" int tf_launch_pool_norm_fwd(const TfPoolNormArgs* a, hipStream_t st) 
   if (a->x == nullptr || a->y == nullptr || a->z == nullptr || a->n == nullptr || a->ldx < a->d) return -2;
   if ((long long)a->B * a->T * a->d >= (1ll << 32)) return -5;                 // 32-bit dropout index space
   TfTraceScope tr("pool_norm_fwd_kernel", st);
-  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3((a->d + 255) / 256, a->B), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3((a->d + 31) / 32, a->B), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_pool_norm_bwd(const TfPoolNormArgs* a, hipStream_t st) {
   if (a->B <= 0 || a->T <= 0 || a->d <= 0) return 0;
   if (a->gy == nullptr || a->gx == nullptr || a->z == nullptr || a->n == nullptr || a->ldgx < a->d) return -2;
   TfTraceScope tr("pool_norm_bwd_kernel", st);
-  hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3((a->ldgx + 255) / 256, a->B), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3((a->ldgx + 31) / 32, a->B), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
 static int lm_pool_check(const TfLmPoolArgs* a) {

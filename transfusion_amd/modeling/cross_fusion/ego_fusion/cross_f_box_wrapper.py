@@ -180,7 +180,19 @@ class CrossFusionBoxWrapper(nn.Module):
         # one level's kernels cover a fraction of the 256 CUs (grids of 50-150 workgroups); four levels side by side fill the chip.
         # Autograd replays every node's backward on the stream its forward ran on, so the backward is level-parallel too.
         main = torch.cuda.current_stream(language_f.device) if language_f.is_cuda else None
-        parallel = (main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
+        # Better than side by side: the levels as ONE grouped encoder call (TfEncoderDesc.groups) when their encoders allow it --
+        # identical shape, parameters at one common stride (FusionTrainStep's flat buffers), same token count on every level: a
+        # quarter of the launches (the step is host-bound at the reference's batch sizes) on grids four times the size.
+        grouped = None
+        if main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1 and os.environ.get("TF_GROUP_LEVELS", "1") != "0":
+            grouped = self._grouped_levels(features_dict, language_f, pad_mask, n_valid)
+        if grouped is not None:
+            for i, key in enumerate(self.fpn_features_idx):
+                features_dict["features"][str(key)] = grouped[0][i]
+                if self.multi_lm:
+                    mscale_l_features.append(grouped[1][i])
+            fused_l_features = grouped[1][-1]
+        parallel = (grouped is None and main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
                     and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
         if main is not None:
             # the GEMMs plan their tile grids for their share of the chip while the levels run side by side (backward included:
@@ -191,7 +203,7 @@ class CrossFusionBoxWrapper(nn.Module):
             n_st = int(os.environ.get("TF_LEVEL_STREAMS", "1"))
             pool = [torch.cuda.Stream(device=language_f.device) for _ in range(n_st if n_st > 1 else len(self.fpn_features_idx))]
             self._level_streams = [pool[i % len(pool)] for i in range(len(self.fpn_features_idx))]
-        for i, key in enumerate(self.fpn_features_idx):
+        for i, key in enumerate(() if grouped is not None else self.fpn_features_idx):
             key = str(key)
             feat = features_dict["features"][key]
             self.tokens_to_features[i].init_h = feat.shape[2]
@@ -241,6 +253,36 @@ class CrossFusionBoxWrapper(nn.Module):
                 att_mask.type(torch.bool),
             )
         return rcnn_outs
+
+    def _grouped_levels(self, features_dict, language_f, pad_mask, n_valid):
+        """All levels through ONE grouped encoder call, or None when they cannot be grouped (then the level loop runs).  -> (fused
+        feature maps per level, fused language tokens per level)."""
+        encs = list(self.cross_fusion_encoders)
+        lead = encs[0]
+        if not hasattr(lead, "group_stride") or self.vis_mask_type != "global":          # (a local visual mask: per-level block bits)
+            return None
+        keys = [str(k) for k in self.fpn_features_idx]
+        feats = [features_dict["features"][k] for k in keys]
+        G, B = len(encs), language_f.shape[0]
+        n_tok = set()
+        for i, feat in enumerate(feats):
+            n_tok.add((feat.shape[2] // self.patches_to_token[i].patch_h) * (feat.shape[3] // self.patches_to_token[i].patch_w))
+        if len(n_tok) != 1 or any(f.shape[0] != B for f in feats) or lead.group_stride(encs) is None:
+            return None
+        toks = []
+        for i, feat in enumerate(feats):
+            self.tokens_to_features[i].init_h, self.tokens_to_features[i].init_w = feat.shape[2], feat.shape[3]
+            toks.append(self.patches_to_token[i](feat))
+        if len({t.dtype for t in toks}) != 1:
+            return None
+        x = torch.cat(toks, dim=0)                                 # [G * B, Nv, d], group-major
+        lang_g, pad_g = language_f.repeat(G, 1, 1), pad_mask.repeat(G, 1)
+        kw = {}
+        if n_valid is not None and getattr(lead, "pack_tokens", False):
+            kw["lang_valid_rows"] = G * n_valid
+        fused, fused_l, _, _ = lead.forward_grouped(encs, x, lang_g, pad_g, **kw)
+        outs = [self.tokens_to_features[i](fused[i * B:(i + 1) * B]) for i in range(G)]
+        return outs, list(fused_l.chunk(G, dim=0))
 
     def _pack_kw(self, i, n_valid):
         """``lang_valid_rows`` for encoders that can drop masked tokens (the joint-attention encoder; the asymmetric variant attends over
