@@ -269,10 +269,30 @@ class CrossFusionBoxWrapper(nn.Module):
             n_tok.add((feat.shape[2] // self.patches_to_token[i].patch_h) * (feat.shape[3] // self.patches_to_token[i].patch_w))
         if len(n_tok) != 1 or any(f.shape[0] != B for f in feats) or lead.group_stride(encs) is None:
             return None
-        toks = []
+        # the per-level pieces either side of the grouped call (patch embedding, back-projection + fold: different shapes per level) run
+        # side by side on the level streams, forward and -- autograd replays a node on its forward stream -- backward
+        main = torch.cuda.current_stream(language_f.device)
+        use_streams = os.environ.get("TF_LEVEL_STREAMS", "1") != "0"
+        if use_streams and (self._level_streams is None or self._level_streams[0].device != language_f.device):
+            self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
+
+        def per_level(fn, args):
+            if not use_streams:
+                return [fn(i, a) for i, a in enumerate(args)]
+            res = []
+            for i, a in enumerate(args):
+                st = self._level_streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    r = fn(i, a)
+                r.record_stream(main)
+                res.append(r)
+            for st in self._level_streams[:len(args)]:
+                main.wait_stream(st)
+            return res
         for i, feat in enumerate(feats):
             self.tokens_to_features[i].init_h, self.tokens_to_features[i].init_w = feat.shape[2], feat.shape[3]
-            toks.append(self.patches_to_token[i](feat))
+        toks = per_level(lambda i, feat: self.patches_to_token[i](feat), feats)
         if len({t.dtype for t in toks}) != 1:
             return None
         x = torch.cat(toks, dim=0)                                 # [G * B, Nv, d], group-major
@@ -281,7 +301,7 @@ class CrossFusionBoxWrapper(nn.Module):
         if n_valid is not None and getattr(lead, "pack_tokens", False):
             kw["lang_valid_rows"] = G * n_valid
         fused, fused_l, _, _ = lead.forward_grouped(encs, x, lang_g, pad_g, **kw)
-        outs = [self.tokens_to_features[i](fused[i * B:(i + 1) * B]) for i in range(G)]
+        outs = per_level(lambda i, f: self.tokens_to_features[i](f), [fused[i * B:(i + 1) * B] for i in range(G)])
         return outs, list(fused_l.chunk(G, dim=0))
 
     def _pack_kw(self, i, n_valid):

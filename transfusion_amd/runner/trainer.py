@@ -400,6 +400,9 @@ class FusionTrainStep:
         self.grad_clip = grad_clip
         self.accumulate = accumulate
         self._norm = torch.zeros(1, dtype=torch.float32, device=self.flat.flat.device)
+        # (walked once: the module tree is fixed, and this runs every step of a host-bound loop)
+        self._all_params = [p for _, p, _, _ in self.flat.slices]
+        self._shadow_owners = [m for m in module.modules() if hasattr(m, "mark_weights_updated")]
 
     def flat_param(self):
         p = self.flat.flat
@@ -441,10 +444,9 @@ class FusionTrainStep:
         ``(p.data_ptr(), p._version)`` (ops._weight_shadows, QKVEncoder._shadows, CrossTransformerModuleBox._wpack_dirty).  Without
         this bump PatchToToken / RegroupPatchesLayerBox / the heads / the asymmetric layers would keep multiplying by their step-0
         weights."""
-        torch._C._increment_version([p for _, p, _, _ in self.flat.slices])
-        for m in self.module.modules():
-            if hasattr(m, "mark_weights_updated"):
-                m.mark_weights_updated()
+        torch._C._increment_version(self._all_params)
+        for m in self._shadow_owners:
+            m.mark_weights_updated()
 
 
 class GraphedTrainStep:
