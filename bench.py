@@ -83,6 +83,7 @@ class _MaskedSquareLoss(torch.autograd.Function):
         return vis * (g * (2.0 * ctx.kv)), m * (g * (2.0 * km)), None, None      # valid is 0/1: d/dlo = 2 km lo valid^2 = 2 km m
 
 
+ZERO_IN_OPT = os.environ.get("TF_ZERO_IN_OPT", "0") == "1"      # A/B switch: the gradient zero fill rides in the optimiser pass (measured neutral)
 PACK_TOKENS = True      # --dense-rows turns it off: the masked language tokens then travel through every kernel as dead rows
 
 
@@ -420,7 +421,7 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         enc.precision = precision
         enc.fp8_projections = bool(fp8)
         enc.train()
-        obj["trainer"] = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=grad_clip)
+        obj["trainer"] = FusionTrainStep(enc, lr=1e-4, weight_decay=2e-4, grad_clip=grad_clip, zero_grads_in_optimizer=ZERO_IN_OPT)
         obj["batches"] = [make_batch(batch, device, rank, d=d, nv=nv, nl=nl, variant=v, padded=padded) for v in range(2)]
         del enc
         last = {}
@@ -524,7 +525,7 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4):
         feats = [torch.randn(batch, c, h, w, generator=g).to(device).requires_grad_(True) for c, (h, w) in zip(chans, shapes)]
         lens = torch.randint(NL // 4, NL + 1, (batch,), generator=g).tolist()
         lang = [torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1).to(device) for n in lens]
-        obj["trainer"] = FusionTrainStep(model, lr=1e-4, weight_decay=2e-4, grad_clip=1.0)
+        obj["trainer"] = FusionTrainStep(model, lr=1e-4, weight_decay=2e-4, grad_clip=1.0, zero_grads_in_optimizer=ZERO_IN_OPT)
         del model
 
         def wloss(m, _):
@@ -633,7 +634,8 @@ def main():
         heads.precision = args.precision
         crit = NaoHeadLosses(torch.ones(88), torch.ones(75)).to(device)
         module, step_loss = _EncoderWithHeads(enc, heads, crit).train(), loss_fn_heads
-    trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap, comm=args.comm)
+    trainer = FusionTrainStep(module, lr=1e-4, weight_decay=2e-4, grad_clip=args.grad_clip, overlap=not args.no_overlap, comm=args.comm,
+                              zero_grads_in_optimizer=ZERO_IN_OPT)
     # distinct batches (tensors, padding lengths) rotated through the steps: a real loader hands the encoder a new mask tensor
     # every step, so the padding-mask conversion cache never hits
     batches = [make_batch(args.batch, device, rank, variant=v) for v in range(max(1, args.batches))]

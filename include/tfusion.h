@@ -213,6 +213,7 @@ typedef struct TfRadamArgs {
   // optional (a step captured in a HIP graph, see tf_clock_ptr): the step number is step0 + *step_clock and beta2_t, bias1, n_sma,
   // step_size, rectified are formed on the device from it (degenerated_to_sgd: radam_optim.py:31,80-84)
   const uint32_t* step_clock; long long step0; int degenerated_to_sgd;
+  int zero_grad;                                  // != 0: g[i] = 0 after it has been read (the next step's zero fill, fused: g is writable then)
 } TfRadamArgs;
 
 // language auxiliary head, pooling stage (modeling/cross_fusion/ego_fusion/lm_layers.py:59-72, PoolPredictor.forward):

@@ -161,3 +161,24 @@ def test_replays_draw_new_masks(monkeypatch):
     ops.clock_set(0)
     assert len({round(v, 7) for v in ls}) == 4, ls                # four replays of one batch at fixed weights: four different losses
     assert max(ls) - min(ls) < 0.2 * max(ls)
+
+
+def test_optimizer_can_zero_the_gradients_it_reads():
+    """FusionTrainStep(zero_grads_in_optimizer=True): the fused optimiser zeroes each gradient as it reads it and the step skips its
+    own zero fill from the second step on -- same parameters as the plain form, gradient buffer all zeros between steps."""
+    dev = _dev()
+    from transfusion_amd.optim import FusedRAdam
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    opt_cls = lambda params, lr, weight_decay: FusedRAdam(params, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+    finals = []
+    for fused in (False, True):
+        enc = _encoder(dev)
+        enc.token_dropout = enc.patch_dropout = 0.0
+        tr = FusionTrainStep(enc, lr=0.05, weight_decay=1e-3, grad_clip=1.0, optimizer_cls=opt_cls, zero_grads_in_optimizer=fused)
+        for k in range(4):
+            tr.step([_batch(dev, k)], _loss)
+            if fused:
+                assert float(tr.flat.grad.abs().max()) == 0.0
+        torch.cuda.synchronize()
+        finals.append(tr.flat.flat.detach().cpu().clone())
+    assert (finals[0] - finals[1]).abs().max().item() < 2e-5

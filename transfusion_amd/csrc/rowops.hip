@@ -576,6 +576,7 @@ __global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a_in) {
   }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
     const float g = a.g[i] * gs;
+    if (a.zero_grad) const_cast<float*>(a.g)[i] = 0.f;
     float v = a.v[i] * a.beta2 + (1.f - a.beta2) * g * g;
     float m = a.m[i] * a.beta1 + (1.f - a.beta1) * g;
     a.v[i] = v; a.m[i] = m;

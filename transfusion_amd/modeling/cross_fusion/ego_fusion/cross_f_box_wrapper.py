@@ -53,6 +53,7 @@ class PatchToToken(nn.Module):
         self.weight = nn.Parameter(holder.weight.detach().clone())      # same init family as the reference
         self.patch_h, self.patch_w = patch_h, patch_w
         self.precision = "bf16"          # "fp32": run.precision 32 (set_precision)
+        self.accumulate_linear_grad = False       # FusionTrainStep (one GPU): the weight gradient goes straight into .grad (ops.linear)
 
     def forward(self, feat):
         """[B,C,H,W] -> tokens [B, H'*W', d] (already token-major: the reference's patchify_image(.,1,1) is fused)."""
@@ -65,7 +66,7 @@ class PatchToToken(nn.Module):
             rows = feat[:, :, : Hp * ph, : Wp * pw].float().reshape(B, Cc, Hp, ph, Wp, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * Hp * Wp, K)
             return ops.linear(rows, self.weight, None, precision="fp32").view(B, Hp * Wp, -1)
         rows = ops.patchify(feat, self.patch_h, self.patch_w, ld=(K + 63) // 64 * 64)
-        tok = ops.linear(rows[:, :K] if rows.shape[1] != K else rows, self.weight, None)
+        tok = ops.linear(rows[:, :K] if rows.shape[1] != K else rows, self.weight, None, accumulate=self.accumulate_linear_grad)
         return tok.view(B, (H // self.patch_h) * (W // self.patch_w), -1)
 
 

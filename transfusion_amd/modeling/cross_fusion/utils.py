@@ -105,6 +105,7 @@ class RegroupPatchesLayerBox(nn.Module):
         self.linear = nn.Linear(token_dim, patch_h * patch_w * out_channels)   # parameter holder; forward never called
         self.final_norm = final_norm
         self.precision = "bf16"          # "fp32": run.precision 32 (CrossFusionBoxWrapper.set_precision)
+        self.accumulate_linear_grad = False       # see PatchToToken
 
     def forward(self, x, cls_f=None):
         p_drop = self.backproj_dropout if self.training else 0.0
@@ -118,5 +119,5 @@ class RegroupPatchesLayerBox(nn.Module):
                 raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {self.init_h}x{self.init_w} map with {ph}x{pw} patches")
             img = y.view(B, Hp, Wp, self.out_channels, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(B, self.out_channels, Hp * ph, Wp * pw)
             return torch.nn.functional.pad(img, (0, self.init_w - Wp * pw, 0, self.init_h - Hp * ph))
-        y = ops.linear(x, self.linear.weight, self.linear.bias, p_drop_in=p_drop)
+        y = ops.linear(x, self.linear.weight, self.linear.bias, p_drop_in=p_drop, accumulate=self.accumulate_linear_grad)
         return ops.regroup(y, self.init_h, self.init_w, self.patch_h, self.patch_w, out_dtype=torch.float32)

@@ -449,8 +449,9 @@ class _LinearX3Fn(torch.autograd.Function):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, weight, bias, p_drop_in, seed, wsh, wsh_t):
+    def forward(ctx, x2d, weight, bias, p_drop_in, seed, wsh, wsh_t, into=None):
         _require_cuda(x2d, weight)
+        ctx.into = into     # (weight.grad, bias.grad or None): the weight gradient is accumulated THERE by the kernel (see linear)
         M, K = x2d.shape
         N = weight.shape[0]
         N8 = _up(N, 8)      # class-count heads (87 nouns, 74 verbs): zero weight rows up to the 16-B store width
@@ -485,16 +486,23 @@ class _LinearFn(torch.autograd.Function):
             if drop[0]:
                 L.check(L.load().tf_dropout_apply(L.ptr(dx), L.ptr(dx), dx.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
             dx = from_padded(dx, K, xdtype)
+        if ctx.into is not None:
+            gw, gb = ctx.into
+            wgrad(gyb, N8, xb, Kp, gw.view(N, -1), gb)
+            return dx, None, None, None, None, None, None, None
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
         wgrad(gyb, N8, xb, Kp, dW.view(N, -1), db)      # rows >= N are masked by n_src = N
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16", weight_sources=None):
+def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16", weight_sources=None, accumulate: bool = False):
     """y = dropout(x) @ W^T + b on the MFMA GEMM; x [..., K] -> bf16 [..., N] (``precision="fp32"``: the fp32-accuracy mode, fp32 out).
     ``weight`` may have any trailing shape (the k = s = p Conv2d weight [d, C, p, p] of K1): it is used as [N, prod(rest)].
-    ``weight_sources``: the Parameters a derived ``weight`` (a concatenation) was built from -- see ``_weight_shadows``."""
+    ``weight_sources``: the Parameters a derived ``weight`` (a concatenation) was built from -- see ``_weight_shadows``.
+    ``accumulate`` (bf16 path, ``weight`` / ``bias`` leaf Parameters with preallocated contiguous fp32 ``.grad``): the backward adds the
+    weight / bias gradient straight into ``.grad`` -- what the encoders do under FusionTrainStep -- instead of handing autograd a fresh
+    zero-filled tensor per call to add (one fill, one add and two autograd nodes per weight and step less)."""
     lead = x.shape[:-1]
     K = x.shape[-1]
     N = weight.shape[0]
@@ -510,7 +518,14 @@ def linear(x, weight, bias=None, p_drop_in: float = 0.0, precision: str = "bf16"
         y = _LinearX3Fn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t, wsh_lo, wsh_t_lo)
     else:
         wsh, wsh_t = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), sources=weight_sources)
-        y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t)
+        into = None
+        if accumulate and weight_sources is None and torch.is_grad_enabled() and weight.requires_grad:
+            gw, gb = weight.grad, None if bias is None else bias.grad
+            ok = gw is not None and gw.dtype == torch.float32 and gw.is_contiguous() and gw.shape == weight.shape
+            ok = ok and (bias is None or (bias.requires_grad and gb is not None and gb.dtype == torch.float32 and gb.is_contiguous()))
+            if ok:
+                into = (gw, gb)
+        y = _LinearFn.apply(x.reshape(-1, K), w2, bias, float(p_drop_in), seed, wsh, wsh_t, into)
     return y.reshape(*lead, N)
 
 

@@ -59,11 +59,13 @@ class FusedRAdam(torch.optim.Optimizer):
                     L.check(lib.tf_sumsq(L.ptr(p.grad), p.grad.numel(), L.ptr(out), ops._stream()), "tf_sumsq")
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0, sumsq: torch.Tensor = None, clip: float = 0.0, on_clock: bool = False):
+    def step(self, closure=None, grad_scale: float = 1.0, sumsq: torch.Tensor = None, clip: float = 0.0, on_clock: bool = False,
+             zero_grad: bool = False):
         """``sumsq`` (1-element device tensor holding sum(g^2) over ALL gradients) + ``clip`` > 0 apply torch's
         clip_grad_norm_ coefficient on the device, with no host synchronisation.  ``on_clock``: the step number is read from the
         library's step clock on the device (``ops.clock_*``) and the schedule terms are formed there -- what a step captured in a
-        HIP graph needs, since its host-computed terms would be frozen into the graph (GraphedTrainStep)."""
+        HIP graph needs, since its host-computed terms would be frozen into the graph (GraphedTrainStep).  ``zero_grad``: every gradient
+        is zeroed by the kernel once it has been read (the next step's zero fill, fused into this pass)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -89,7 +91,7 @@ class FusedRAdam(torch.optim.Optimizer):
                                   lr=g["lr"], beta1=beta1, beta2=beta2, eps=g["eps"], weight_decay=g["weight_decay"],
                                   beta2_t=beta2 ** step, bias1=1 - beta1 ** step, n_sma=n_sma,
                                   step_size=step_size, rectified=mode, grad_scale=grad_scale, sumsq=L.ptr(sumsq),
-                                  clip=float(clip))
+                                  clip=float(clip), zero_grad=1 if zero_grad else 0)
                 if on_clock:      # step = step0 + *clock: right now, and after every advance of the clock (one per replay)
                     a.step_clock, a.step0, a.degenerated_to_sgd = ops.clock_ptr(), step - ops.clock_value(), int(self.degenerated_to_sgd)
                 L.call("tf_radam_step", a, st)

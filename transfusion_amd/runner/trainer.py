@@ -367,7 +367,8 @@ class FusionTrainStep:
     """One optimiser step over ``accumulate`` micro-batches for a module that writes into ``p.grad`` directly."""
 
     def __init__(self, module: nn.Module, lr=1e-4, weight_decay=2e-4, grad_clip: Optional[float] = 1.0, accumulate: int = 1,
-                 bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True, comm: Optional[str] = None):
+                 bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True, comm: Optional[str] = None,
+                 zero_grads_in_optimizer: bool = False):
         """``comm``: "torch" (default; torch.distributed's process group) or "rccl" (the C ABI's own communicator,
         tf_allreduce_bucket; also selected by TF_COMM=rccl) -- both are RCCL on a GPU."""
         from transfusion_amd.optim import FusedRAdam
@@ -399,8 +400,18 @@ class FusionTrainStep:
         self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
         self.grad_clip = grad_clip
         self.accumulate = accumulate
+        # True: the fused optimiser zeroes each gradient as it reads it, and step() skips its own zero fill from the second step on
+        # (the flat gradient buffer is then all zeros BETWEEN steps -- a caller who reads gradients after step() keeps this False)
+        import inspect
+        self.zero_in_opt = bool(zero_grads_in_optimizer) and "zero_grad" in inspect.signature(self.opt.step).parameters
+        self._grads_clean = False
         self._norm = torch.zeros(1, dtype=torch.float32, device=self.flat.flat.device)
         # (walked once: the module tree is fixed, and this runs every step of a host-bound loop)
+        # one GPU: the linear-type modules (K1 / K9) add their weight gradients straight into the flat gradient buffer too (with a
+        # reducer their post-accumulate hooks are what reports a range complete, so there autograd keeps accumulating)
+        for m in module.modules():
+            if hasattr(m, "accumulate_linear_grad"):
+                m.accumulate_linear_grad = self.world == 1
         self._all_params = [p for _, p, _, _ in self.flat.slices]
         self._shadow_owners = [m for m in module.modules() if hasattr(m, "mark_weights_updated")]
 
@@ -414,7 +425,8 @@ class FusionTrainStep:
 
     def step(self, micro_batches: List, loss_fn, on_clock: bool = False):
         """``loss_fn(module, batch) -> scalar``; returns the last loss (detached).  ``on_clock``: see FusedRAdam.step."""
-        self.zero_grad()
+        if not (self.zero_in_opt and self._grads_clean):
+            self.zero_grad()
         self.flat.check_bound()
         loss = None
         for i, mb in enumerate(micro_batches):
@@ -429,12 +441,18 @@ class FusionTrainStep:
         else:
             self.reducer.all_reduce()
         scale = 1.0 / self.world
+        extra = {}
+        if on_clock:
+            extra["on_clock"] = True
+        if self.zero_in_opt:
+            extra["zero_grad"] = True
         if self.grad_clip:
             self._norm.zero_()
             self.opt.grad_sumsq(self._norm)                        # stays on the device: no host sync in the step
-            self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip, **({"on_clock": True} if on_clock else {}))
+            self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip, **extra)
         else:
-            self.opt.step(grad_scale=scale, **({"on_clock": True} if on_clock else {}))
+            self.opt.step(grad_scale=scale, **extra)
+        self._grads_clean = self.zero_in_opt
         self.mark_parameters_updated()
         return loss.detach()
 
