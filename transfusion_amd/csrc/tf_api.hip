@@ -238,7 +238,11 @@ int wgrad(const Ctx& c, Side& sd, Buf dY, int N, Buf X, int K, float* dW, int ld
   w.dY = dY.p; w.ldy = dY.ld; w.X = X.p; w.ldx = X.ld; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
   w.dY_lo = dY.lo; w.X_lo = X.lo;
   static const int exp_skip = getenv("TF_EXP_SKIP_WGRAD") ? atoi(getenv("TF_EXP_SKIP_WGRAD")) : 0;   // timing experiment only: WRONG gradients
-  if (exp_skip) return 0;
+  if (exp_skip) {
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "[tfusion] TF_EXP_SKIP_WGRAD=1: weight gradients are NOT computed (timing experiment; training is wrong)\n"); }
+    return 0;
+  }
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   w.groups = c.D.G; w.dw_gstride = c.pg();
   if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
