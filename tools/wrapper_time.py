@@ -37,6 +37,21 @@ def step():
     loss.backward()
     return loss
 
+if os.environ.get("FLAT") == "1":
+    # forward + backward only, but with the parameters re-homed into flat buffers (what lets the levels run as one grouped encoder
+    # call) and gradients accumulated in place: FusionTrainStep's layout without its optimiser
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    _tr = FusionTrainStep(model, lr=0.0, weight_decay=0.0, grad_clip=None)
+
+    def step():
+        _tr.zero_grad()
+        for f in feats:
+            f.grad = None
+        out = model({"image": feats, "language_f": lang})
+        loss = sum(f.float().square().mean() for f in out["features"].values())
+        loss.backward()
+        return loss
+
 if os.environ.get("TRAINER") == "1":
     # the library's own training step around the whole wrapper: flat parameter / gradient buffers, the encoders accumulate straight
     # into .grad (no AccumulateGrad node per parameter), bucketed reduce (no-op on one GPU), clip + fused RAdam -- MORE work per step
