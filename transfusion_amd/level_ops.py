@@ -1,0 +1,232 @@
+"""The per-level pieces either side of the wrapper's grouped encoder call -- K1 (patch embedding: im2col + GEMM) and K9 (back-projection:
+dropout + GEMM + fold) of ALL feature levels -- each as ONE autograd node that issues its levels' kernels side by side on the level
+streams (reference cross_f_box_wrapper.py:177-212 with :266-274 and utils.py:84-119).
+
+Why: at the reference's per-GPU batch the wrapper's step is bound by the host, and these pieces were most of what was left of its host
+time after the encoders became one call -- four autograd nodes, ~10 torch ops and ~8 stream / event calls per level and direction.
+Here a level costs its two or three kernel launches.  Numerically these are the same kernels with the same arguments as
+``ops.patchify`` / ``ops.linear`` / ``ops.regroup`` (bf16 path); ``tests/test_gpu_grouped.py`` compares the wrapper with and without.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _on(streams, main, i):
+    """Context for level i: its stream (ordered behind everything on ``main`` so far), or main itself."""
+    if streams is None:
+        return torch.cuda.stream(main)
+    st = streams[i]
+    st.wait_stream(main)
+    return torch.cuda.stream(st)
+
+
+def _join(streams, main, n):
+    if streams is not None:
+        for st in streams[:n]:
+            main.wait_stream(st)
+
+
+def k1_supported(mods, feats, d):
+    """K and d multiples of 64 (no padded copies), bf16 arithmetic, 4-D feature maps that tile into patches."""
+    if d % 64:
+        return False
+    for m, f in zip(mods, feats):
+        if getattr(m, "precision", "bf16") != "bf16" or f.dim() != 4 or not f.is_cuda:
+            return False
+        if (f.shape[1] * m.patch_h * m.patch_w) % 64 or m.weight.shape[0] != d:
+            return False
+    return True
+
+
+def k9_supported(mods, d):
+    if d % 64:
+        return False
+    for m in mods:
+        n = m.linear.weight.shape[0]
+        if getattr(m, "precision", "bf16") != "bf16" or n % 64 or m.linear.weight.shape[1] != d or m.linear.bias is None:
+            return False
+    return True
+
+
+class _LevelsK1Fn(torch.autograd.Function):
+    """feats[g] [B, C_g, H_g, W_g] -> tokens [G * B, Nv, d] bf16, group-major (what the grouped encoder call takes): per level an im2col
+    gather and a GEMM that writes straight into its slice of the stacked output."""
+
+    @staticmethod
+    def forward(ctx, cfg, *tensors):
+        mods, streams, accumulate = cfg
+        G = len(mods)
+        feats, weights = tensors[:G], tensors[G:]
+        main = torch.cuda.current_stream(feats[0].device)
+        B = feats[0].shape[0]
+        d = weights[0].shape[0]
+        Nv = (feats[0].shape[2] // mods[0].patch_h) * (feats[0].shape[3] // mods[0].patch_w)
+        out = torch.empty(G * B * Nv, d, dtype=torch.bfloat16, device=feats[0].device)
+        saved, meta = [], []
+        for g, (m, f, w) in enumerate(zip(mods, feats, weights)):
+            Bc, Cc, H, W = f.shape
+            K = Cc * m.patch_h * m.patch_w
+            wsh, wsh_t = ops._weight_shadows(w, d, K, d)
+            with _on(streams, main, g):
+                f = f.contiguous()
+                rows = torch.empty(Bc * Nv, K, dtype=torch.bfloat16, device=f.device)
+                L.call("tf_patchify_fwd", ops._patch_args(f, rows, Bc, Cc, H, W, m.patch_h, m.patch_w), ops._stream())
+                ops.gemm(rows, wsh, out[g * B * Nv:(g + 1) * B * Nv], d, K, L.TF_EPI_NONE)
+            saved += [rows, wsh_t]
+            meta.append((tuple(f.shape), f.dtype, m.patch_h, m.patch_w, K))
+        _join(streams, main, G)
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (mods, streams, accumulate, meta, B, Nv, d)
+        ctx.into = [(w.grad if (accumulate and w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == torch.float32) else None)
+                    for w in weights]
+        return out.view(G * B, Nv, d)
+
+    @staticmethod
+    def backward(ctx, gy):
+        mods, streams, accumulate, meta, B, Nv, d = ctx.cfg
+        G = len(mods)
+        saved = ctx.saved_tensors
+        gy = gy.reshape(G * B * Nv, d)
+        if gy.dtype != torch.bfloat16 or not gy.is_contiguous():
+            gy = gy.contiguous().to(torch.bfloat16)
+        main = torch.cuda.current_stream(gy.device)
+        dfeats, dws = [], []
+        for g, m in enumerate(mods):
+            rows, wsh_t = saved[2 * g], saved[2 * g + 1]
+            shape, dtype, ph, pw, K = meta[g]
+            gyg = gy[g * B * Nv:(g + 1) * B * Nv]
+            with _on(streams, main, g):
+                gw = ctx.into[g]
+                if gw is None:
+                    gw = torch.zeros(d, K, dtype=torch.float32, device=gy.device)
+                    if streams is not None:
+                        gw.record_stream(main)
+                    dws.append(gw.view(m.weight.shape))
+                else:
+                    dws.append(None)
+                ops.wgrad(gyg, d, rows, K, gw.view(d, K), None)
+                if ctx.needs_input_grad[1 + g]:
+                    dx = torch.empty(B * Nv, K, dtype=torch.bfloat16, device=gy.device)
+                    ops.gemm(gyg, wsh_t, dx, K, d, L.TF_EPI_NONE)
+                    df = torch.empty(shape, dtype=dtype, device=gy.device)
+                    L.call("tf_patchify_bwd", ops._patch_args(df, dx, shape[0], shape[1], shape[2], shape[3], ph, pw), ops._stream(), ops._is_f32(df))
+                    if streams is not None:
+                        df.record_stream(main)
+                    dfeats.append(df)
+                else:
+                    dfeats.append(None)
+        _join(streams, main, G)
+        return (None,) + tuple(dfeats) + tuple(dws)
+
+
+class _LevelsK9Fn(torch.autograd.Function):
+    """fused tokens [G * B, Nv, d] -> per level the feature map [B, C_g, H_g, W_g] fp32: (input dropout) -> GEMM + bias -> fold."""
+
+    @staticmethod
+    def forward(ctx, cfg, fused, *params):
+        mods, streams, accumulate, training = cfg
+        G = len(mods)
+        weights, biases = params[:G], params[G:]
+        dev = fused.device
+        main = torch.cuda.current_stream(dev)
+        B = fused.shape[0] // G
+        Nv, d = fused.shape[1], fused.shape[2]
+        x = fused.reshape(G * B * Nv, d)
+        if x.dtype != torch.bfloat16 or not x.is_contiguous():
+            x = x.contiguous().to(torch.bfloat16)
+        outs, saved, meta = [], [], []
+        for g, (m, w, b) in enumerate(zip(mods, weights, biases)):
+            N = w.shape[0]
+            Cc = N // (m.patch_h * m.patch_w)
+            H, W = m.init_h, m.init_w
+            if (H // m.patch_h) * (W // m.patch_w) != Nv:
+                raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {H}x{W} map with {m.patch_h}x{m.patch_w} patches")
+            wsh, wsh_t = ops._weight_shadows(w, N, d, N)
+            p = float(m.backproj_dropout) if training else 0.0
+            drop = ops.drop_params(p, ops.next_seed() if p > 0 else 0, 7)
+            xg = x[g * B * Nv:(g + 1) * B * Nv]
+            with _on(streams, main, g):
+                if drop[0]:
+                    xd = torch.empty_like(xg)
+                    L.check(L.load().tf_dropout_apply(L.ptr(xg), L.ptr(xd), xg.numel(), drop[1], drop[0], drop[2], ops._stream()), "tf_dropout_apply")
+                else:
+                    xd = xg
+                y = torch.empty(B * Nv, N, dtype=torch.bfloat16, device=dev)
+                ops.gemm(xd, wsh, y, N, d, L.TF_EPI_BIAS, bias=b)
+                o = torch.empty(B, Cc, H, W, dtype=torch.float32, device=dev)
+                L.call("tf_regroup_fwd", ops._patch_args(o, y, B, Cc, H, W, m.patch_h, m.patch_w), ops._stream(), 1)
+                if streams is not None:
+                    o.record_stream(main)
+                    xd.record_stream(main)
+            outs.append(o)
+            saved += [xd, wsh_t]
+            meta.append((N, Cc, H, W, m.patch_h, m.patch_w, drop))
+        _join(streams, main, G)
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (mods, streams, meta, B, Nv, d, fused.dtype)
+        ok = lambda t: t is not None and t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32
+        ctx.into = [((w.grad, b.grad) if (accumulate and ok(w) and ok(b)) else None) for w, b in zip(weights, biases)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        mods, streams, meta, B, Nv, d, xdtype = ctx.cfg
+        G = len(mods)
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        main = torch.cuda.current_stream(dev)
+        dx = torch.empty(G * B * Nv, d, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
+        dws, dbs = [], []
+        for g, m in enumerate(mods):
+            xd, wsh_t = saved[2 * g], saved[2 * g + 1]
+            N, Cc, H, W, ph, pw, drop = meta[g]
+            go = gouts[g]
+            with _on(streams, main, g):
+                if go is None:
+                    go = torch.zeros(B, Cc, H, W, dtype=torch.float32, device=dev)
+                go = go.contiguous()
+                drows = torch.empty(B * Nv, N, dtype=torch.bfloat16, device=dev)
+                L.call("tf_regroup_bwd", ops._patch_args(go, drows, B, Cc, H, W, ph, pw), ops._stream())
+                into = ctx.into[g]
+                if into is None:
+                    gw = torch.zeros(N, d, dtype=torch.float32, device=dev)
+                    gb = torch.zeros(N, dtype=torch.float32, device=dev)
+                    if streams is not None:
+                        gw.record_stream(main)
+                        gb.record_stream(main)
+                    dws.append(gw)
+                    dbs.append(gb)
+                else:
+                    gw, gb = into
+                    dws.append(None)
+                    dbs.append(None)
+                ops.wgrad(drows, N, xd, d, gw.view(N, d), gb)
+                if dx is not None:
+                    dxg = dx[g * B * Nv:(g + 1) * B * Nv]
+                    ops.gemm(drows, wsh_t, dxg, d, N, L.TF_EPI_NONE)
+                    if drop[0]:
+                        L.check(L.load().tf_dropout_apply(L.ptr(dxg), L.ptr(dxg), dxg.numel(), drop[1], drop[0], drop[2], ops._stream()), "tf_dropout_apply")
+        _join(streams, main, G)
+        gx = None
+        if dx is not None:
+            gx = dx.view(G * B, Nv, d)
+            if xdtype != torch.bfloat16:
+                gx = gx.to(xdtype)
+        return (None, gx) + tuple(dws) + tuple(dbs)
+
+
+def levels_patch_embed(mods, feats, streams=None):
+    """``mods``: the PatchToToken modules of the levels.  -> [G * B, Nv, d] bf16."""
+    acc = all(getattr(m, "accumulate_linear_grad", False) for m in mods) and torch.is_grad_enabled()
+    return _LevelsK1Fn.apply((list(mods), streams, acc), *feats, *[m.weight for m in mods])
+
+
+def levels_back_project(mods, fused, streams=None):
+    """``mods``: the RegroupPatchesLayerBox modules (``init_h`` / ``init_w`` set).  -> list of [B, C_g, H_g, W_g] fp32."""
+    acc = all(getattr(m, "accumulate_linear_grad", False) for m in mods) and torch.is_grad_enabled()
+    training = bool(mods[0].training)
+    return list(_LevelsK9Fn.apply((list(mods), streams, acc, training), fused, *[m.linear.weight for m in mods], *[m.linear.bias for m in mods]))

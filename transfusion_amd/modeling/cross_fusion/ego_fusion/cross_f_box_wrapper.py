@@ -293,16 +293,27 @@ class CrossFusionBoxWrapper(nn.Module):
             return res
         for i, feat in enumerate(feats):
             self.tokens_to_features[i].init_h, self.tokens_to_features[i].init_w = feat.shape[2], feat.shape[3]
-        toks = per_level(lambda i, feat: self.patches_to_token[i](feat), feats)
-        if len({t.dtype for t in toks}) != 1:
-            return None
-        x = torch.cat(toks, dim=0)                                 # [G * B, Nv, d], group-major
+        # ... each side as ONE autograd node when the shapes allow it (level_ops: the host issues a level's two or three kernels instead of
+        # four autograd nodes and a dozen torch / stream calls per level and direction); TF_LEVEL_OPS=0 keeps the per-level modules
+        from transfusion_amd import level_ops
+        fused_ops = os.environ.get("TF_LEVEL_OPS", "1") != "0"
+        sts = self._level_streams if use_streams else None
+        if fused_ops and level_ops.k1_supported(self.patches_to_token, feats, self.token_dim):
+            x = level_ops.levels_patch_embed(self.patches_to_token, feats, sts)
+        else:
+            toks = per_level(lambda i, feat: self.patches_to_token[i](feat), feats)
+            if len({t.dtype for t in toks}) != 1:
+                return None
+            x = torch.cat(toks, dim=0)                             # [G * B, Nv, d], group-major
         lang_g, pad_g = language_f.repeat(G, 1, 1), pad_mask.repeat(G, 1)
         kw = {}
         if n_valid is not None and getattr(lead, "pack_tokens", False):
             kw["lang_valid_rows"] = G * n_valid
         fused, fused_l, _, _ = lead.forward_grouped(encs, x, lang_g, pad_g, **kw)
-        outs = per_level(lambda i, f: self.tokens_to_features[i](f), [fused[i * B:(i + 1) * B] for i in range(G)])
+        if fused_ops and level_ops.k9_supported(self.tokens_to_features, self.token_dim):
+            outs = level_ops.levels_back_project(self.tokens_to_features, fused, sts)
+        else:
+            outs = per_level(lambda i, f: self.tokens_to_features[i](f), [fused[i * B:(i + 1) * B] for i in range(G)])
         return outs, list(fused_l.chunk(G, dim=0))
 
     def _pack_kw(self, i, n_valid):
