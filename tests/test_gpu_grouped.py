@@ -167,3 +167,66 @@ def test_wrapper_levels_grouped_equal_level_loop(monkeypatch):
         a, b = res["1"][2][off:off + n], res["0"][2][off:off + n]
         if float(b.abs().max()) > 0:
             assert rel(a, b) < 2.5e-2, (name, rel(a, b))
+
+
+def test_level_nodes_with_dropout_against_torch(monkeypatch):
+    """level_ops (K1 / K9 of all levels as one autograd node each) with the back-projection dropout ON: forward and every gradient
+    against fp64 torch on the bf16-rounded operands, the dropout mask replayed from the library (tf_dropout_mask: same key, same
+    element index = position inside the level's [B * Nv, d] input)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd import level_ops, ops
+    from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_wrapper import PatchToToken
+    from transfusion_amd.modeling.cross_fusion.utils import RegroupPatchesLayerBox
+    dev = torch.device("cuda:0")
+    SEED = 0x5151
+    monkeypatch.setattr(ops, "next_seed", lambda: SEED)
+    B, d, p = 2, 128, 0.25
+    ps, chans = [4, 2, 1], [8, 32, 64]
+    shapes = [(6 * q, 6 * q) for q in ps]                        # 36 tokens per level
+    Nv = 36
+    torch.manual_seed(5)
+    k1 = [PatchToToken(c, d, q, q).to(dev) for c, q in zip(chans, ps)]
+    k9 = [RegroupPatchesLayerBox(d, h, w, q, q, c, backproj_dropout=p).to(dev).train() for c, q, (h, w) in zip(chans, ps, shapes)]
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn(B, c, h, w, generator=g).to(dev).requires_grad_(True) for c, (h, w) in zip(chans, shapes)]
+    streams = [torch.cuda.Stream() for _ in ps]
+    bfr = lambda t: t.detach().to(torch.bfloat16).double().cpu()
+
+    # ---- K1 ----
+    x = level_ops.levels_patch_embed(k1, feats, streams)          # [G * B, Nv, d]
+    gx = torch.randn(x.shape, generator=g).to(dev).to(torch.bfloat16)
+    x.backward(gx)
+    torch.cuda.synchronize()
+    for i, (m, f) in enumerate(zip(k1, feats)):
+        q = ps[i]
+        rows = torch.nn.functional.unfold(bfr(f), kernel_size=q, stride=q).transpose(1, 2).reshape(B * Nv, -1)      # [B * Nv, C * q * q]
+        w = bfr(m.weight).reshape(d, -1)
+        assert rel(x[i * B:(i + 1) * B].reshape(B * Nv, d), rows @ w.t()) < 6e-3, i
+        gy = gx[i * B:(i + 1) * B].reshape(B * Nv, d).double().cpu()
+        assert rel(m.weight.grad.reshape(d, -1), gy.t() @ rows) < 2e-5 + 6e-3, i
+        dcols = (gy @ w).reshape(B, Nv, -1).transpose(1, 2)
+        dref = torch.nn.functional.fold(dcols, output_size=shapes[i], kernel_size=q, stride=q)
+        assert rel(f.grad, dref) < 8e-3, i
+
+    # ---- K9 with dropout ----
+    fused = torch.randn(len(ps) * B, Nv, d, generator=g).to(dev).to(torch.bfloat16).requires_grad_(True)
+    outs = level_ops.levels_back_project(k9, fused, streams)
+    gouts = [torch.randn(o.shape, generator=g).to(dev) for o in outs]
+    torch.autograd.backward(outs, gouts)
+    torch.cuda.synchronize()
+    thr, key, scale = ops.drop_params(p, SEED, 7)
+    for i, m in enumerate(k9):
+        q, (h, w_) = ps[i], shapes[i]
+        keep = ops.dropout_mask(B * Nv * d, p, SEED, 7, dev).view(B * Nv, d).double().cpu() * scale
+        xi = fused[i * B:(i + 1) * B].detach().reshape(B * Nv, d).double().cpu()
+        xd = (xi * keep).to(torch.bfloat16).double()              # the kernel rounds the dropped-out input to bf16
+        W, bias = bfr(m.linear.weight), m.linear.bias.detach().double().cpu()
+        y = (xd @ W.t() + bias).to(torch.bfloat16).double()       # [B * Nv, C * q * q] (stored as bf16 before the fold)
+        ref = torch.nn.functional.fold(y.reshape(B, Nv, -1).transpose(1, 2), output_size=(h, w_), kernel_size=q, stride=q)
+        assert rel(outs[i], ref) < 6e-3, i
+        gy = torch.nn.functional.unfold(gouts[i].double().cpu(), kernel_size=q, stride=q).transpose(1, 2).reshape(B * Nv, -1)
+        gy = gy.to(torch.bfloat16).double()
+        assert rel(m.linear.weight.grad, gy.t() @ xd) < 8e-3, i
+        assert rel(m.linear.bias.grad, gy.sum(0)) < 8e-3, i
+        assert rel(fused.grad[i * B:(i + 1) * B].reshape(B * Nv, d), (gy @ W) * keep) < 1e-2, i
