@@ -149,7 +149,7 @@ if not single:
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 d, h, L = 64, 4, 2
-levels = [dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3)]
+levels = {levels}
 fusion = load_fusion_config(os.path.join({root!r}, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
 fusion.update({{"fpn_features": [0, 1], "replace_fpn_features": True, "patch_h": [l["p"] for l in levels], "patch_w": [l["p"] for l in levels],
                "backproj_dropout": 0.0}})
@@ -184,14 +184,63 @@ if not single:
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert lo.item() == hi.item(), (lo.item(), hi.item())
+grouped = int(getattr(model.cross_fusion_encoders[0], "_last_desc").groups)
 if rank == 0:
-    extra = {{}} if single else dict(agreed=tr.layerwise.agreed, collectives=tr.layerwise.collectives, nunits=len(tr.layerwise.units),
-                                     keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order)
+    extra = dict(grouped=grouped) if single else dict(grouped=grouped, agreed=tr.layerwise.agreed, collectives=tr.layerwise.collectives, nunits=len(tr.layerwise.units),
+                                          keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order)
     torch.save(dict(hist=hist, **extra), {out!r})
 if not single:
     dist.barrier()
     dist.destroy_process_group()
 '''
+
+
+_LEVELS_RAGGED = "[dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3)]"          # 30 and 9 visual tokens: the level loop
+_LEVELS_EQUAL = "[dict(C=16, H=12, W=12, p=2), dict(C=8, H=18, W=18, p=3)]"          # 36 and 36: ONE grouped encoder call
+
+
+def _run_tree(tmp_path, levels, tag):
+    out2, out1 = str(tmp_path / f"{tag}2.pt"), str(tmp_path / f"{tag}1.pt")
+    s2, s1 = tmp_path / f"{tag}_w2.py", tmp_path / f"{tag}_w1.py"
+    s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2, levels=levels))
+    s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1, levels=levels))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(s2)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank run hung (a rank issued a different collective sequence?)")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", TF_TREE_SINGLE="1")
+    r = subprocess.run([sys.executable, str(s1)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return torch.load(out2), torch.load(out1)
+
+
+def test_two_ranks_grouped_levels_under_the_ordered_reducer(tmp_path):
+    """Levels with equal token counts run as ONE grouped encoder call (TfEncoderDesc.groups) -- also under a data-parallel reducer: the
+    grouped backward then goes layer by layer and reports each layer of EVERY member encoder to its hook.  Same checks as the level-loop
+    test below: rank-agreed order, one collective per unit from step 2 on, gradients equal to one process that sees all samples."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    two, one = _run_tree(tmp_path, _LEVELS_EQUAL, "grp")
+    assert two["grouped"] == 2 and one["grouped"] == 2, (two["grouped"], one["grouped"])
+    assert two["agreed"] is True
+    assert two["nunits"] == 8 and two["collectives"] == 1 + 2 * 8, (two["nunits"], two["collectives"], two["keys"])
+    for st2, st1 in zip(two["hist"], one["hist"]):
+        err = ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item()
+        assert err < 5e-3, err
+    m2 = two["hist"][0]["param"] - two["hist"][0]["before"]
+    m1 = one["hist"][0]["param"] - one["hist"][0]["before"]
+    assert float(m1.abs().max()) > 0 and ((m2 - m1).norm() / m1.norm()).item() < 2e-2
 
 
 def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path):
@@ -203,8 +252,8 @@ def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path):
         pytest.skip("needs an MI355X")
     out2, out1 = str(tmp_path / "tree2.pt"), str(tmp_path / "tree1.pt")
     s2, s1 = tmp_path / "w2.py", tmp_path / "w1.py"
-    s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2))
-    s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1))
+    s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2, levels=_LEVELS_RAGGED))
+    s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1, levels=_LEVELS_RAGGED))
     port = _free_port()
     procs = []
     for rank in range(2):

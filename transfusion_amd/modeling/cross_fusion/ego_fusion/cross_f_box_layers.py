@@ -101,6 +101,7 @@ class _EncoderFn(torch.autograd.Function):
         L.call("tf_encoder_fwd", desc, st)
         desc.repack = 0
         ctx.mod, ctx.desc, ctx.keep, ctx.gen = mod, desc, keep, keep["gen"]
+        ctx.group_mods = list(mod._group_mods) if mod._group_mods else None
         mod._last_desc = desc               # debug / test hooks (packed_row_error, peek)
         # per-call tensors the descriptor points at live on ctx (the workspace item may be recycled by a later forward)
         ctx.held = (keep["inputs"], keep.get("mask"), keep.get("block_bits"))
@@ -141,10 +142,12 @@ class _EncoderFn(torch.autograd.Function):
             # side stream's own events, and whoever consumes the gradients calls ops.join_overlap() first.
             st = ops._stream()
             desc.defer_join = 1
+            members = ctx.group_mods or (mod,)
             for layer in range(desc.L - 1, -1, -1):
                 desc.bwd_hi, desc.bwd_nlayers = layer, 1
                 L.call("tf_encoder_bwd", desc, st)
-                hook(mod, layer)
+                for m in members:                      # a grouped call finishes this layer of EVERY member at once
+                    m.layer_grad_hook(m, layer)
             desc.bwd_nlayers, desc.defer_join = 0, 0
             if not getattr(getattr(hook, "__self__", None), "joins_overlap", False):
                 ops.join_overlap(dev)
@@ -464,7 +467,7 @@ class CrossTransformerModuleBox(nn.Module):
 
     def group_stride(self, mods):
         """Byte stride between the parameters of consecutive encoders of ``mods`` (``mods[0] is self``) if they can run as one grouped
-        call, else None: identical configuration, gradients accumulated in place, no per-layer gradient hook, fixed positional tables
+        call, else None: identical configuration, gradients accumulated in place, per-layer gradient hooks on all members or on none, fixed positional tables
         with equal contents, and every parameter AND every gradient tensor of encoder g exactly g * stride bytes after encoder 0's --
         what FusionTrainStep's flat buffers give.  Cached on the tensors' addresses."""
         if len(mods) < 2 or mods[0] is not self:
@@ -474,7 +477,10 @@ class CrossTransformerModuleBox(nn.Module):
         if cached is not None and cached[0] == key:
             return cached[1]
         stride = None
-        ok = all(isinstance(m, CrossTransformerModuleBox) and m.layer_grad_hook is None and m.accumulate_into_grad for m in mods)
+        # (per-layer gradient hooks -- a data-parallel reducer -- are fine when EVERY member has one: the grouped backward then runs layer
+        # by layer and calls each member's hook for that layer)
+        ok = all(isinstance(m, CrossTransformerModuleBox) and m.accumulate_into_grad for m in mods)
+        ok = ok and len({m.layer_grad_hook is None for m in mods}) == 1
         ok = ok and all(getattr(m, a) == getattr(self, a) for m in mods for a in self._GROUP_CFG)
         if ok:
             p0 = self._param_list()
