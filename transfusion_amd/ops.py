@@ -81,13 +81,17 @@ def from_padded(x2d: torch.Tensor, cols: int, dtype) -> torch.Tensor:
     return out
 
 
-def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG):
+def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG, into=None):
     """fp32 [N,K] parameter -> bf16 shadow [rows_p, ld] and transpose [cols_p, ld_t]; rows / columns may be regrouped (source index
-    (p // gp) * g + p % gp, valid iff p % gp < g): heads of width hd padded to hdp."""
+    (p // gp) * g + p % gp, valid iff p % gp < g): heads of width hd padded to hdp.  ``into``: (dst, dst_t) of an earlier call with
+    the same geometry, re-packed in place (their pad columns are still the zeros they were created with)."""
     N, K = w.shape
     w = w.detach().contiguous().float()
-    dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
-    dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
+    if into is not None and into[0].shape == (rows_p, ld) and (not want_t or (into[1] is not None and into[1].shape == (cols_p, ld_t))):
+        dst, dst_t = into[0], into[1] if want_t else None
+    else:
+        dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
+        dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
     a = L.TfPackArgs(src=L.ptr(w), rows=N, cols=K, dst=L.ptr(dst), ld_dst=ld, dst_t=L.ptr(dst_t), ld_dst_t=ld_t,
                      rows_p=rows_p, cols_p=cols_p, rg=rg, rgp=rgp, cg=cg, cgp=cgp, dst_is_f32=0)
     L.call("tf_pack_weight", a, _stream())
@@ -367,7 +371,12 @@ def _weight_shadows(weight, N8, Kp, Np, planes=False, sources=None):
     hit = _shadow_cache.get(slot) if cacheable else None
     if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == key:
         return hit[2]
-    wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np)
+    # same owners, new version (the optimiser stepped): re-pack into the entry's tensors instead of zero-filling two fresh ones per
+    # weight and step.  (As with the encoders' shadow blocks, a forward whose backward is still pending must not be followed by an
+    # optimiser step and another forward of the same weight before that backward runs.)
+    reuse = hit[2][:2] if (hit is not None and not planes and all(r() is o for r, o in zip(hit[0], owners))
+                          and hit[2][0].device == w2.device) else None
+    wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np, into=reuse)
     out = (wsh, wsh_t)
     if planes:
         wf = w2.detach().float()
