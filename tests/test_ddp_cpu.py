@@ -355,3 +355,24 @@ def test_gloo_world2_ordered_range_reducer_on_a_module_tree(tmp_path, accumulate
             torch.testing.assert_close(st["grad"][off:off + k], named[nme].grad.reshape(-1) / accumulate, rtol=1e-4, atol=1e-5)
             want = named[nme].data.reshape(-1) - 0.05 * named[nme].grad.reshape(-1) / accumulate / world
             torch.testing.assert_close(st["param"][off:off + k], want, rtol=1e-4, atol=1e-5)
+
+
+def test_lr_scale_builds_contiguous_ranges_with_their_own_rate():
+    """FusionTrainStep(lr_scale=...): the reference's parameter groups (lr / div_rate, lr / ttc_rate) as ranges of the flat buffer."""
+    import torch
+    from transfusion_amd.runner.trainer import FusionTrainStep
+
+    class Opt(torch.optim.Optimizer):                              # records what it was given; never steps (no GPU here)
+        def __init__(self, params, lr, weight_decay):
+            super().__init__(params, dict(lr=lr, weight_decay=weight_decay))
+
+    m = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Linear(6, 3), torch.nn.Linear(3, 2))
+    tr = FusionTrainStep(m, lr=1e-3, weight_decay=0.0, grad_clip=None, optimizer_cls=Opt,
+                         lr_scale=lambda name: 0.1 if name.startswith("1.") else 1.0)
+    starts = [off for _, _, off, _ in tr.flat.slices] + [tr.flat.flat.numel()]           # slices start 256-B aligned
+    assert [(lo, hi) for lo, hi, _ in tr.lr_ranges] == [(starts[0], starts[2]), (starts[2], starts[4]), (starts[4], starts[6])]
+    assert [round(g["lr"], 8) for g in tr.opt.param_groups] == [1e-3, 1e-4, 1e-3]
+    for g, (lo, hi, _) in zip(tr.opt.param_groups, tr.lr_ranges):
+        p = g["params"][0]
+        assert p.data_ptr() == tr.flat.flat.data_ptr() + 4 * lo and p.numel() == hi - lo
+        assert p.grad.data_ptr() == tr.flat.grad.data_ptr() + 4 * lo

@@ -182,3 +182,30 @@ def test_optimizer_can_zero_the_gradients_it_reads():
         torch.cuda.synchronize()
         finals.append(tr.flat.flat.detach().cpu().clone())
     assert (finals[0] - finals[1]).abs().max().item() < 2e-5
+
+
+def test_lr_scale_ranges_equal_parameter_groups():
+    """FusionTrainStep(lr_scale=...) -- ranges of the flat buffer with their own learning rate -- against FusedRAdam over the separate
+    parameters with the same groups (the reference's lr / div_rate, lr / ttc_rate layout, ego_nao_trainer.py:440-497)."""
+    dev = _dev()
+    from transfusion_amd.optim import FusedRAdam
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    torch.manual_seed(3)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(16, 24), torch.nn.Tanh(), torch.nn.Linear(24, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4)).to(dev)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    scale = lambda name: 0.25 if name.startswith("2.") else 1.0
+    sgd = lambda ps, lr, weight_decay: FusedRAdam(ps, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+    tr = FusionTrainStep(a, lr=0.05, weight_decay=1e-3, grad_clip=None, optimizer_cls=sgd, lr_scale=scale)
+    assert len(tr.opt.param_groups) == 3
+    ref = FusedRAdam([{"params": [p], "lr": 0.05 * scale(n)} for n, p in b.named_parameters()], lr=0.05, weight_decay=1e-3, degenerated_to_sgd=True)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        x = torch.randn(32, 16, generator=g).to(dev)
+        tr.step([x], lambda m, xb: m(xb).pow(2).mean())
+        ref.zero_grad()
+        b(x).pow(2).mean().backward()
+        ref.step()
+    torch.cuda.synchronize()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert (p - q).abs().max().item() < 1e-6, n

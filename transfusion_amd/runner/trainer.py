@@ -368,9 +368,12 @@ class FusionTrainStep:
 
     def __init__(self, module: nn.Module, lr=1e-4, weight_decay=2e-4, grad_clip: Optional[float] = 1.0, accumulate: int = 1,
                  bucket_mb: float = 64.0, optimizer_cls=None, overlap: bool = True, comm: Optional[str] = None,
-                 zero_grads_in_optimizer: bool = False):
+                 zero_grads_in_optimizer: bool = False, lr_scale=None):
         """``comm``: "torch" (default; torch.distributed's process group) or "rccl" (the C ABI's own communicator,
-        tf_allreduce_bucket; also selected by TF_COMM=rccl) -- both are RCCL on a GPU."""
+        tf_allreduce_bucket; also selected by TF_COMM=rccl) -- both are RCCL on a GPU.
+        ``lr_scale``: ``callable(parameter_name) -> float`` -- the reference's parameter groups (ego_nao_trainer.py:440-497: ``lr / div_rate``
+        for the backbone and the language model, ``lr / ttc_rate`` for the TTC head): consecutive parameters of equal scale become one
+        range of the flat buffer = one optimiser group with ``lr * scale`` (one fused launch per range; clipping stays global)."""
         from transfusion_amd.optim import FusedRAdam
         comm = comm or os.environ.get("TF_COMM", "torch")
         if comm not in ("torch", "rccl"):
@@ -397,7 +400,26 @@ class FusionTrainStep:
         elif overlap and (self.world > 1 or force):
             # any other module tree (the 4-level wrapper, encoder + heads, ...): units fired in a learnt, rank-agreed order
             self.layerwise = OrderedRangeReducer(self.flat, module, bucket_comm=self.bucket_comm)
-        self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
+        if lr_scale is None:
+            self.opt = (optimizer_cls or FusedRAdam)([self.flat_param()], lr=lr, weight_decay=weight_decay)
+        else:
+            ranges = []                                            # [lo, hi, scale] over the flat buffer, in layout order
+            for n, _, off, num in self.flat.slices:
+                sc = float(lr_scale(n))
+                end = off + (num + 63) // 64 * 64                  # (slices start 256-B aligned; the pad floats are zeros with zero gradients)
+                if ranges and ranges[-1][2] == sc and ranges[-1][1] == off:
+                    ranges[-1][1] = end
+                else:
+                    ranges.append([off, end, sc])
+            groups = []
+            self._range_params = []
+            for lo, hi, sc in ranges:
+                p = self.flat.flat[lo:hi]                          # a view: shares storage (and the optimiser's raw-pointer updates)
+                p.grad = self.flat.grad[lo:hi]
+                self._range_params.append(p)
+                groups.append({"params": [p], "lr": lr * sc})
+            self.opt = (optimizer_cls or FusedRAdam)(groups, lr=lr, weight_decay=weight_decay)
+            self.lr_ranges = [tuple(r) for r in ranges]
         self.grad_clip = grad_clip
         self.accumulate = accumulate
         # True: the fused optimiser zeroes each gradient as it reads it, and step() skips its own zero fill from the second step on
