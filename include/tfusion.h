@@ -85,6 +85,12 @@ typedef struct TfWgradArgs {
   // g * dw_gstride BYTES after dW / db; m_chunk counts rows inside a group
   int groups; long long dw_gstride;
 } TfWgradArgs;
+/* Several weight gradients as ONE launch (tf_gemm_wgrad_multi): a layer's four linears (torch18_adapters.py:683-685,608,111: in-proj,
+ * out-proj, linear1, linear2) are ready together at the end of the layer's backward and fill the chip together at two row chunks per
+ * output tile, where each alone needs 5 - 14 (every chunk adds one fp32 |dW| of atomic traffic).  Problems may differ in every extent
+ * (M included: the wrapper's FPN levels); `groups` of a problem expands into that many problems; zeros and m_chunk are ignored.
+ * At most TF_WGRAD_MULTI_MAX problems after the expansion; one arithmetic mode (lo planes on all or on none). */
+#define TF_WGRAD_MULTI_MAX 16
 
 
 typedef struct TfAttnArgs {
@@ -330,6 +336,9 @@ const char* tf_last_error(void);
 void tf_set_gemm_concurrency(int n);
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
+/* probs[0 .. count): see TF_WGRAD_MULTI_MAX.  blocks: workgroups the caller wants in flight (sizes the row chunks); 0 = a launch that
+ * has the chip to itself (two per CU) */
+int tf_gemm_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, tf_stream_t s);
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);
 int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* dQ (which also fills `delta`), then dK, dV */
 int tf_layernorm_fwd(const TfLnArgs* a, tf_stream_t s);
@@ -390,7 +399,8 @@ typedef struct TfEncoderPlan {
 typedef struct TfOverlap {
   void* stream;                 /* hipStream_t, non-blocking */
   void* ev[8];                  /* hipEvent_t: [0..3] fork (chain -> side), [4..7] done (side -> chain); see tf_api.hip */
-  unsigned pending, reserved;   /* owned by the library: wgrad groups of a tf_encoder_bwd(defer_join) call not yet joined */
+  unsigned pending, reserved;   /* owned by the library: done events (by layer parity) of tf_encoder_bwd(defer_join) calls not yet joined,
+                                 * and the parity of the most recent one */
 } TfOverlap;
 int tf_overlap_create(TfOverlap* o);
 int tf_overlap_destroy(TfOverlap* o);

@@ -9,7 +9,7 @@ python -m transfusion_amd.build >/dev/null
 obj=$out/${src%.hip}.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result "$@" -c transfusion_amd/csrc/$src -o $obj
 objs=""
-for f in gemm_bf16 attn_bf16 attn_x3 rowops heads comm tf_api; do
+for f in gemm_bf16 wgrad_multi attn_bf16 attn_x3 rowops heads comm tf_api; do
   if [ "$f.hip" == "$src" ]; then objs="$objs $obj"; else objs="$objs transfusion_amd/csrc/_obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libtfusion_hip.so $objs -ldl

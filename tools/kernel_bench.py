@@ -56,6 +56,36 @@ if which in ("wgrad", "all"):
     timeit("wgrad_qkv", lambda: ops.wgrad(dYq, 3 * D, X, D, dW, db), 2.0 * M * 3 * D * D)
     timeit("wgrad_ffn", lambda: ops.wgrad(dYf, ff, X, D, dW[:ff], db[:ff]), 2.0 * M * ff * D)
     timeit("wgrad_d_d", lambda: ops.wgrad(X, D, X, D, dW[:D], db[:D]), 2.0 * M * D * D)
+if which in ("wgradm",):
+    # a layer's four weight gradients: four launches of the per-problem kernel (stand-alone and overlapped sizing) against ONE merged
+    # launch at several workgroup counts; packed row count of the benchmark
+    Mp = int(os.environ.get("KB_ROWS", "16672"))
+    x, o, x1, hh = rnd(Mp, D), rnd(Mp, D), rnd(Mp, D), rnd(Mp, ff)
+    dqkv, dy1, dy2, du = rnd(Mp, 3 * D), rnd(Mp, D), rnd(Mp, D), rnd(Mp, ff)
+    pairs = [(dqkv, x), (dy1, o), (du, x1), (dy2, hh)]
+    dWs = [torch.zeros(a.shape[1], b.shape[1], device=dev) for a, b in pairs]
+    dbs = [torch.zeros(a.shape[1], device=dev) for a, _ in pairs]
+    fl = sum(2.0 * Mp * a.shape[1] * b.shape[1] for a, b in pairs)
+
+    def four(chunk):
+        for (a, b), w, v in zip(pairs, dWs, dbs):
+            ops.wgrad(a, a.shape[1], b, b.shape[1], w, v, m_chunk=chunk(a.shape[1], b.shape[1]))
+    timeit("4 launches, self-sized", lambda: four(lambda n, k: 0), fl)
+
+    def ovl_chunk(n, k):          # the encoder runtime's overlapped sizing (tf_api.hip: wgrad())
+        tiles = ((n + 255) // 256) * ((k + 127) // 128)
+        steps = (Mp + 31) // 32
+        splits = max(1, min(steps, (256 + tiles // 2) // tiles))
+        return ((steps + splits - 1) // splits) * 32
+    timeit("4 launches, overlap-sized", lambda: four(ovl_chunk), fl)
+    probs = [ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v) for (a, b), w, v in zip(pairs, dWs, dbs)]
+    for blocks in [int(t) for t in os.environ.get("KB_BLOCKS", "144,256,288,432,512,576").split(",")]:
+        timeit(f"merged, blocks={blocks}", lambda: ops.wgrad_multi(probs, blocks), fl)
+    half = [probs[:2], probs[2:]]
+    fl2 = [sum(2.0 * Mp * a.shape[1] * b.shape[1] for a, b in pairs[:2]), sum(2.0 * Mp * a.shape[1] * b.shape[1] for a, b in pairs[2:])]
+    for blocks in (144, 288, 432):
+        timeit(f"merged {{in,out}} blocks={blocks}", lambda: ops.wgrad_multi(half[0], blocks), fl2[0])
+        timeit(f"merged {{w1,w2}} blocks={blocks}", lambda: ops.wgrad_multi(half[1], blocks), fl2[1])
 if which in ("gemm", "all"):
     X, Xf = rnd(M, D), rnd(M, ff)
     Wq, Wo, W1, W2 = rnd(3 * D, D) * 0.03, rnd(D, D) * 0.03, rnd(ff, D) * 0.03, rnd(D, ff) * 0.03

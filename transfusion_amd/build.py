@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtfusion_hip.so")
-SOURCES = ["gemm_bf16.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "heads.hip", "comm.hip", "tf_api.hip"]
+SOURCES = ["gemm_bf16.hip", "wgrad_multi.hip", "attn_bf16.hip", "attn_x3.hip", "rowops.hip", "heads.hip", "comm.hip", "tf_api.hip"]
 HEADERS = ["tf_common.h", "tf_kernels.h", "attn_common.h", os.path.join("..", "..", "include", "tfusion.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -30,9 +30,18 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(HERE, "csrc", "_obj")
+EXP_DIR = os.path.join(os.path.dirname(HERE), "build", "variants", "exp")
+
+
+def build_lib(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    """experiments=True: a SECOND library with -DTF_EXPERIMENTS (the TF_* environment switches of the kernels' launch planners and
+    the ablation blocks are compiled in) under build/variants/exp/, selected with TFUSION_LIB for A/B runs.  The shipped library reads
+    no experiment switch."""
+    lib_dir = EXP_DIR if experiments else LIB_DIR
+    lib_path = os.path.join(lib_dir, "libtfusion_hip.so")
+    flags = FLAGS + (["-DTF_EXPERIMENTS"] if experiments else [])
+    os.makedirs(lib_dir, exist_ok=True)
+    obj_dir = os.path.join(EXP_DIR, "_obj") if experiments else os.path.join(HERE, "csrc", "_obj")
     os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     hipcc = _hipcc()
@@ -45,7 +54,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -57,15 +66,15 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[transfusion_amd.build] compiled {os.path.basename(done)}", file=sys.stderr)
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
+    if force or jobs or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[transfusion_amd.build] linked {LIB_PATH}", file=sys.stderr)
-    return LIB_PATH
+            print(f"[transfusion_amd.build] linked {lib_path}", file=sys.stderr)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    print(build_lib(force="--force" in sys.argv, experiments="--exp" in sys.argv))

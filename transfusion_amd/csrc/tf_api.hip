@@ -98,6 +98,7 @@ struct AOff {   // byte offsets inside work
   size_t qkv, o, lse, z1, mean1, rstd1, x1, u, h, z2, mean2, rstd2, dbits;   // offsets inside a layer block
   size_t meanf, rstdf;
   size_t dxa, dxb, dz, dy, dzb, dyb, du, d_o, dqkv, delta;
+  size_t dz1, dy1, dzb1, dyb1, du1, dqkv1;        // the same six for odd layers
   size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work), bf16 mode
   size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
   size_t total;
@@ -129,6 +130,10 @@ AOff make_aoff(const Dims& D) {
   a.dxa = take2(md); a.dxb = take2(md); a.dz = take2(md); a.dy = take2(md); a.dzb = take2(md); a.dyb = take2(md); a.du = take2(mf); a.d_o = take2(md);
   a.dqkv = take2(mq);
   a.delta = take(st);
+  // What a layer's weight gradients read -- dz / dy, dzb / dyb, du, dqkv -- exists twice (set 0: even layers, set 1: odd layers): the
+  // gradients of layer l are launched together at the end of the layer's backward and run beside the chain of layer l - 1, which
+  // fills the other set.
+  a.dz1 = take2(md); a.dy1 = take2(md); a.dzb1 = take2(md); a.dyb1 = take2(md); a.du1 = take2(mf); a.dqkv1 = take2(mq);
   a.dsw = take(D.split ? 256 : tf_attn_ds_bytes(D.B, D.H, D.S));
   a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
@@ -205,64 +210,98 @@ int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const 
   g.groups = c.D.G; g.w_gstride = c.wg();
   return tf_launch_gemm_nt(&g, c.st);
 }
-// Side stream of one tf_encoder_bwd call.  An event record or wait on the chain is a barrier packet and costs ~5 us of
-// dispatch overlap (measured: 32 extra records per step = +170 us), so forks and guards are kept few -- but not at the
-// price of starting a wgrad late: forking {out_proj, in_proj} together after the attention backward measured SLOWER
-// (5264 vs 5337 samples/s), because it lengthens the un-overlapped tail after the last layer.  Per layer:
-//   fork A = {linear2, linear1} after the FFN-down dgrad     (reads dy/dz, h, du, x1)
-//   fork O = {out_proj}         after the LN1 backward       (reads dyb/dzb, o)
-//   fork I = {in_proj}          after the attention backward (reads dqkv, x)
-//   guard A at the top of the next layer, guard I (FIFO: covers O) before its LN1 backward.
-enum { EV_FORK_A = 0, EV_FORK_O = 1, EV_FORK_I = 2, EV_FORK_Q = 3, EV_DONE_A = 4, EV_DONE_I = 5 };
+// Side stream of one tf_encoder_bwd call: the weight gradients.  A layer's four weight-gradient products read tensors the chain has
+// produced by the end of the layer's backward (dy / dz and h, du and x1, dyb / dzb and o, dqkv and x); they are launched TOGETHER
+// (tf_launch_wgrad_multi: 144 output tiles at d = 768 fill the chip at three row chunks, where each product alone needed 5 - 14 and
+// merged them with that many times |dW| of fp32 atomics) on the side stream and run beside the chain of the layer below, which
+// writes the OTHER set of dy / dz / du / dyb / dzb / dqkv (AOff: set = layer parity).  An event record or wait on the chain is a
+// barrier packet (~5 us of dispatch overlap), so a layer has one fork, one done event (side stream, by parity) and one guard: layer l
+// waits for the gradients of layer l + 2 before it overwrites their operands.  The LAST layer of a backward has no chain left to hide
+// behind: its products start as early as their operands exist (wgrad_plan).
+enum { EV_FORK0 = 0, EV_FORK1 = 1, EV_FORK2 = 2, EV_DONE0 = 4 };           // fork events by position, done events EV_DONE0 + parity
+enum { W_W2 = 1, W_W1 = 2, W_WO = 4, W_WI = 8 };
 struct Side {
-  hipStream_t st = nullptr; hipEvent_t* ev = nullptr; bool pending[2] = {false, false};
+  hipStream_t st = nullptr; hipEvent_t* ev = nullptr;
+  bool pending[2] = {false, false};       // a done event of this parity is recorded and the chain has not waited for it
+  int last = 0;                           // parity of the most recently recorded done event (FIFO: it covers the other one)
 };
+// which products start at which point of a layer's backward chain: [0] after the FFN-down dgrad, [1] after the LN1 backward,
+// [2] after the attention backward
+struct WPlan { int at[3]; };
+int ncus() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
+int env_int(const char* name, int dflt) {
+#ifdef TF_EXPERIMENTS
+  const char* v = getenv(name);
+  return v != nullptr ? (int)strtol(v, nullptr, 0) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+WPlan wgrad_plan(bool last_layer) {
+  // hex digits, lowest first: the products started at positions 0, 1, 2.  A product can start only where its operands exist (W2 | W1
+  // from position 0, WO from position 1, WI at position 2); whatever the digits leave out starts at position 2.
+  static const int body = env_int("TF_WGM_BODY", 0x000), tail = env_int("TF_WGM_TAIL", 0x843);
+  const int v = last_layer ? tail : body;
+  WPlan p{{v & (W_W2 | W_W1), (v >> 4) & (W_W2 | W_W1 | W_WO), 0}};
+  p.at[1] &= ~p.at[0];
+  p.at[2] = (W_W2 | W_W1 | W_WO | W_WI) & ~(p.at[0] | p.at[1]);
+  return p;
+}
 int side_fork(const Ctx& c, Side& sd, int fork_ev) {            // what the chain has produced so far is visible to the side stream
   if (sd.st == nullptr) return 0;
   int rc = (int)hipEventRecord(sd.ev[fork_ev], c.st);
   if (rc == 0) rc = (int)hipStreamWaitEvent(sd.st, sd.ev[fork_ev], 0);
   return rc;
 }
-int side_done(Side& sd, int grp) {
+int side_done(Side& sd, int parity) {
   if (sd.st == nullptr) return 0;
-  sd.pending[grp] = true;
-  return (int)hipEventRecord(sd.ev[EV_DONE_A + grp], sd.st);
+  sd.pending[parity] = true; sd.last = parity;
+  return (int)hipEventRecord(sd.ev[EV_DONE0 + parity], sd.st);
 }
-int guard(const Ctx& c, Side& sd, int grp) {                    // the chain is about to overwrite what group `grp` reads
-  if (sd.st != nullptr && sd.pending[grp]) { sd.pending[grp] = false; return (int)hipStreamWaitEvent(c.st, sd.ev[EV_DONE_A + grp], 0); }
+int guard(const Ctx& c, Side& sd, int parity) {                 // the chain is about to overwrite what the gradients of this parity read
+  if (sd.st != nullptr && sd.pending[parity]) { sd.pending[parity] = false; return (int)hipStreamWaitEvent(c.st, sd.ev[EV_DONE0 + parity], 0); }
   return 0;
 }
-int wgrad(const Ctx& c, Side& sd, Buf dY, int N, Buf X, int K, float* dW, int lddw, float* db,
-          int rg, int rgp, int n_src, int cg, int cgp, int k_src, bool alone = false) {
+TfWgradArgs wjob(const Ctx& c, Buf dY, int N, Buf X, int K, float* dW, int lddw, float* db, int rg, int rgp, int n_src, int cg, int cgp, int k_src) {
   TfWgradArgs w{};
   w.dY = dY.p; w.ldy = dY.ld; w.X = X.p; w.ldx = X.ld; w.dW = dW; w.lddw = lddw; w.db = db; w.zeros = c.wk + c.A.zeros;
   w.dY_lo = dY.lo; w.X_lo = X.lo;
-  static const int exp_skip = getenv("TF_EXP_SKIP_WGRAD") ? atoi(getenv("TF_EXP_SKIP_WGRAD")) : 0;   // timing experiment only: WRONG gradients
-  if (exp_skip) {
-    static bool warned = false;
-    if (!warned) { warned = true; fprintf(stderr, "[tfusion] TF_EXP_SKIP_WGRAD=1: weight gradients are NOT computed (timing experiment; training is wrong)\n"); }
-    return 0;
-  }
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   w.groups = c.D.G; w.dw_gstride = c.pg();
-  if (sd.st == nullptr) return tf_launch_wgrad_tn(&w, c.st);
-  static const int tail_alone = getenv("TF_WGRAD_TAIL_ALONE") ? atoi(getenv("TF_WGRAD_TAIL_ALONE")) : 1;   // experiment switch
-  if (alone && tail_alone) return tf_launch_wgrad_tn(&w, sd.st);   // the last wgrad of the backward has the chip to itself: stand-alone sizing
-  {
-    // Overlapped with the chain the wgrad no longer has to fill the chip by itself: fewer, longer blocks mean fewer fp32
-    // atomic flushes (256x128 tiles: 252-256 blocks best, 5253 vs 5194 at 288 and 5104 at 144; 128x128 tiles: 288)
-    const int tiles = tf_wgrad_tiles(N, K, 1) * c.D.G, steps = (c.D.M / c.D.G + 31) / 32;      // (grouped: blocks of all groups, steps inside one)
-    // ... and proportionally fewer when M is small, so that a block still has a few dozen 32-row steps to amortise its prologue
-    // and flush (M = 2832: 64 blocks 2078 samples/s vs 1823 at 256; M = 5664: 128 blocks 3419 vs 3175; M = 22656: 256)
-    static const int env_target = getenv("TF_WGRAD_OVL_TARGET") ? atoi(getenv("TF_WGRAD_OVL_TARGET")) : 0;     // experiment switch
-    int ovl_target = env_target > 0 ? env_target : c.D.M / 44;
-    if (env_target <= 0) ovl_target = ovl_target < 32 ? 32 : (ovl_target > 256 ? 256 : ovl_target);
-    int splits = (ovl_target + tiles / 2) / tiles;
-    if (splits < 1) splits = 1;
-    if (splits > steps) splits = steps;
-    w.m_chunk = ((steps + splits - 1) / splits) * 32;
+  return w;
+}
+// the products `mask` selects out of jobs[0..3] (W_W2, W_W1, W_WO, W_WI) as one launch on the side stream (or on the chain without one)
+int wgrad_launch(const Ctx& c, Side& sd, const TfWgradArgs* jobs, int mask, bool alone) {
+  TfWgradArgs sel[4]; int n = 0;
+  for (int i = 0; i < 4; ++i) if ((mask >> i) & 1) sel[n++] = jobs[i];
+  if (n == 0) return 0;
+  hipStream_t st = sd.st != nullptr ? sd.st : c.st;
+  int blocks = 0;                                              // nothing beside it: two workgroups per CU
+  if (sd.st != nullptr && !alone) {
+    // Beside the chain: ~1.7 workgroups per CU (three row chunks for a d = 768 layer's 144 tiles: 172 us alone against 210 at two and 207
+    // at four), and fewer when M is small, so that a workgroup keeps a few dozen 32-row steps to amortise its prologue and flush
+    static const int per_cu_x10 = env_int("TF_WGM_BLOCKS_X10", 17), min_steps = env_int("TF_WGM_MIN_STEPS", 40);
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += ((sel[i].N + 255) / 256) * ((sel[i].K + 127) / 128) * c.D.G;
+    const int steps = (c.D.M / c.D.G + 31) / 32;
+    int chunks = (ncus() * per_cu_x10 / 10 + tiles / 2) / tiles;
+    if (chunks > steps / min_steps) chunks = steps / min_steps;
+    if (chunks < 1) chunks = 1;
+    blocks = chunks * tiles;
   }
-  return tf_launch_wgrad_tn(&w, sd.st);
+  if (n * c.D.G > TF_WGRAD_MULTI_MAX) {                        // more groups than one launch takes: one launch per product
+    for (int i = 0; i < n; ++i) { const int rc = tf_launch_wgrad_multi(&sel[i], 1, blocks > 0 ? blocks / n : 0, st); if (rc != 0) return rc; }
+    return 0;
+  }
+  return tf_launch_wgrad_multi(sel, n, blocks, st);
 }
 
 }  // namespace
@@ -329,8 +368,8 @@ int tf_overlap_create(TfOverlap* o) {
 int tf_overlap_join(TfOverlap* o, tf_stream_t s) {
   if (o == nullptr) return fail(-1, "tf_overlap_join");
   if (o->stream == nullptr || o->pending == 0u) return 0;
-  // FIFO side stream: the in_proj group's event is recorded after the linear2/linear1 group's of the same layer
-  TF_TRY((int)hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)o->ev[(o->pending & 2u) ? EV_DONE_I : EV_DONE_A], 0), "tf_overlap_join");
+  // FIFO side stream: the most recently recorded done event (its parity is kept in `reserved`) covers every earlier one
+  TF_TRY((int)hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)o->ev[EV_DONE0 + (int)(o->reserved & 1u)], 0), "tf_overlap_join");
   o->pending = 0u;
   return 0;
 }
@@ -376,6 +415,11 @@ int tf_quant_rows_fp8(const void* src, int ld_src, void* dst, int ld_dst, float*
 }
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_fwd", tf_launch_gemm_nt(a, (hipStream_t)s)); }
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s) { TF_WRAP("tf_gemm_wgrad", tf_launch_wgrad_tn(a, (hipStream_t)s)); }
+int tf_gemm_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, tf_stream_t s) {
+  if (probs == nullptr || count <= 0) return fail(-1, "tf_gemm_wgrad_multi");
+  TF_TRY(tf_launch_wgrad_multi(probs, count, blocks, (hipStream_t)s), "tf_gemm_wgrad_multi");
+  return 0;
+}
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s) { TF_WRAP("tf_attn_fwd", tf_launch_attn_fwd(a, (hipStream_t)s)); }
 int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s) {
   if (a == nullptr) return fail(-1, "tf_attn_bwd");
@@ -687,9 +731,11 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (!make_ctx(e, (hipStream_t)s, &c)) return fail(-1, "tf_encoder_bwd");
   const Dims& D = c.D;
   if (e->d_vis_out == nullptr && e->d_lang_out == nullptr) return fail(-1, "tf_encoder_bwd(no cotangent)");
-  const Buf dxa = c.act_d(c.wk + c.A.dxa), dxb = c.act_d(c.wk + c.A.dxb), dz = c.act_d(c.wk + c.A.dz), dy = c.act_d(c.wk + c.A.dy);
-  const Buf dzb = c.act_d(c.wk + c.A.dzb), dyb = c.act_d(c.wk + c.A.dyb), du = c.act_f(c.wk + c.A.du), d_o = c.act_d(c.wk + c.A.d_o);
-  const Buf dqkv = c.act_q(c.wk + c.A.dqkv);
+  const Buf dxa = c.act_d(c.wk + c.A.dxa), dxb = c.act_d(c.wk + c.A.dxb), d_o = c.act_d(c.wk + c.A.d_o);
+  // the tensors a layer's weight gradients read, by layer parity (see Side)
+  const Buf dz_[2] = {c.act_d(c.wk + c.A.dz), c.act_d(c.wk + c.A.dz1)}, dy_[2] = {c.act_d(c.wk + c.A.dy), c.act_d(c.wk + c.A.dy1)};
+  const Buf dzb_[2] = {c.act_d(c.wk + c.A.dzb), c.act_d(c.wk + c.A.dzb1)}, dyb_[2] = {c.act_d(c.wk + c.A.dyb), c.act_d(c.wk + c.A.dyb1)};
+  const Buf du_[2] = {c.act_f(c.wk + c.A.du), c.act_f(c.wk + c.A.du1)}, dqkv_[2] = {c.act_q(c.wk + c.A.dqkv), c.act_q(c.wk + c.A.dqkv1)};
   float* delta = (float*)(c.wk + c.A.delta);
   const uint8_t* km = c.packed() ? nullptr : (const uint8_t*)(c.wk + c.A.keymask);
   const int l_hi = e->bwd_nlayers > 0 ? e->bwd_hi : D.L - 1;
@@ -700,6 +746,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (e->overlap != nullptr && e->overlap->stream != nullptr) {
     sd.st = (hipStream_t)e->overlap->stream; sd.ev = (hipEvent_t*)e->overlap->ev;
     sd.pending[0] = (e->overlap->pending & 1u) != 0; sd.pending[1] = (e->overlap->pending & 2u) != 0;   // left by a defer_join call
+    sd.last = (int)(e->overlap->reserved & 1u);
   }
   // ---- gradient w.r.t. the last layer's output X[L] -> dxa ----
   if (head && D.Nv > 0) {
@@ -739,9 +786,13 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     const TfLayerParams& p = e->p[l]; const TfLayerParams& g = e->g[l];
     const Buf x = c.act_d(c.X(l)), qkv = c.act_q(b + c.A.qkv), o = c.act_d(b + c.A.o), z1 = c.act_d(b + c.A.z1), x1 = c.act_d(b + c.A.x1);
     const Buf u = c.act_f(b + c.A.u), hh = c.act_f(b + c.A.h), z2 = c.act_d(b + c.A.z2);
+    const int par = l & 1;
+    const Buf dz = dz_[par], dy = dy_[par], dzb = dzb_[par], dyb = dyb_[par], du = du_[par], dqkv = dqkv_[par];
+    const WPlan plan = wgrad_plan(tail && l == l_lo && sd.st != nullptr);
+    TfWgradArgs jobs[4] = {};
     // ---- LN2 backward: dxa -> dz (= d z2), dy (= dropout2-masked) ----
     const Drop d2 = drop_for(e, e->p_token, site_of(l, SITE_DROP2));
-    TF_TRY(guard(c, sd, 0), "guard A");                      // previous layer's linear2 / linear1 wgrads read dy / dz / du
+    TF_TRY(guard(c, sd, par), "guard");                      // the weight gradients of layer l + 2 read this set
     {
       TfLnArgs n{};
       ln_rows(c, n, z2, p.n2_w, (float*)(b + c.A.mean2), (float*)(b + c.A.rstd2));
@@ -753,21 +804,15 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     const Buf dy2 = d2.thr ? dy : dz;
     TF_TRY(gemm(c, dy2, c.wgt(w + c.W.w2T, D.ffp, D.dp), du, nullptr, u, NOBUF, D.ffp, D.dp, TF_EPI_MUL, none),
            "dgrad ffn_down");                                 // dU = dH . G (G stored by the forward FFN-up epilogue)
-    // where the side stream picks up its work (experiment switches; defaults = measured best)
-    static const int fork_a_pos = getenv("TF_FORK_A_POS") ? atoi(getenv("TF_FORK_A_POS")) : 0;   // 0 after dgrad ffn_down, 1 after LN1 bwd, 2 after dgrad out_proj
-    static const int fork_o_pos = getenv("TF_FORK_O_POS") ? atoi(getenv("TF_FORK_O_POS")) : 0;   // 0 before dgrad out_proj, 1 after it
-    auto fork_a = [&]() -> int {
-      int rc = side_fork(c, sd, EV_FORK_A);
-      if (rc == 0) rc = wgrad(c, sd, dy2, D.dp, hh, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff);
-      if (rc == 0) rc = wgrad(c, sd, du, D.ffp, x1, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d);
-      if (rc == 0) rc = side_done(sd, 0);
-      return rc;
-    };
-    if (fork_a_pos == 0) TF_TRY(fork_a(), "wgrad w2 / w1");
+    jobs[0] = wjob(c, dy2, D.dp, hh, D.ffp, g.w2, D.ff, g.b2, BIG, BIG, D.d, BIG, BIG, D.ff);
+    jobs[1] = wjob(c, du, D.ffp, x1, D.dp, g.w1, D.d, g.b1, BIG, BIG, D.ff, BIG, BIG, D.d);
+    if (plan.at[0]) {
+      TF_TRY(side_fork(c, sd, EV_FORK0), "fork 0");
+      TF_TRY(wgrad_launch(c, sd, jobs, plan.at[0], false), "wgrad (after the FFN-down dgrad)");
+    }
     TF_TRY(gemm(c, du, c.wgt(w + c.W.w1T, D.dp, D.ffp), dxb, nullptr, dz, NOBUF, D.dp, D.ffp, TF_EPI_ADD, none), "dgrad ffn_up");
     // ---- LN1 backward: dxb -> dzb (= d z1), dyb (= dropout1-masked) ----
     const Drop d1 = drop_for(e, e->p_token, site_of(l, SITE_DROP1));
-    TF_TRY(guard(c, sd, 1), "guard I");                      // previous layer's out_proj / in_proj wgrads read dyb / dzb / dqkv
     {
       TfLnArgs n{};
       ln_rows(c, n, z1, p.n1_w, (float*)(b + c.A.mean1), (float*)(b + c.A.rstd1));
@@ -777,16 +822,12 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "ln1_bwd");
     }
     const Buf dy1 = d1.thr ? dyb : dzb;
-    if (fork_a_pos == 1) TF_TRY(fork_a(), "wgrad w2 / w1");
-    auto fork_o = [&]() -> int {
-      int rc = side_fork(c, sd, EV_FORK_O);
-      if (rc == 0) rc = wgrad(c, sd, dy1, D.dp, o, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d);
-      return rc;
-    };
-    if (fork_o_pos == 0) TF_TRY(fork_o(), "wgrad out_proj");
+    jobs[2] = wjob(c, dy1, D.dp, o, D.dp, g.out_w, D.d, g.out_b, BIG, BIG, D.d, D.hd, D.hdp, D.d);
+    if (plan.at[1]) {
+      TF_TRY(side_fork(c, sd, EV_FORK1), "fork 1");
+      TF_TRY(wgrad_launch(c, sd, jobs, plan.at[1], false), "wgrad (after the LN1 backward)");
+    }
     TF_TRY(gemm(c, dy1, c.wgt(w + c.W.woT, D.dp, D.dp), d_o, nullptr, NOBUF, NOBUF, D.dp, D.dp, TF_EPI_NONE, none), "dgrad out_proj");
-    if (fork_a_pos == 2) TF_TRY(fork_a(), "wgrad w2 / w1");
-    if (fork_o_pos == 1) TF_TRY(fork_o(), "wgrad out_proj");
     {
       TfAttnArgs a{};
       a.qkv = qkv.p; a.qkv_lo = qkv.lo; a.ld_qkv = D.ldq; a.out = (void*)o.p; a.out_lo = (void*)o.lo; a.ld_out = D.dp; a.lse = (float*)(b + c.A.lse);
@@ -795,32 +836,15 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
       a.ds_work = D.split ? nullptr : (void*)(c.wk + c.A.dsw);
-      // TF_SPLIT_INPROJ (0 off, 1 last layer of the backward only, 2 every layer): the Q third of the in-proj weight gradient needs dQ
-      // only, so it can start under the dK / dV kernel instead of after it -- which shortens the un-overlapped tail behind layer 0
-      static const int split_inproj = getenv("TF_SPLIT_INPROJ") ? atoi(getenv("TF_SPLIT_INPROJ")) : 0;
-      const bool split_q = sd.st != nullptr && (split_inproj == 2 || (split_inproj == 1 && l == 0));
-      if (split_q) {
-        const int hq = D.nqkv / 3;
-        TF_TRY(tf_launch_attn_bwd_part(&a, 1, c.st), "attn_bwd dq");
-        TF_TRY(side_fork(c, sd, EV_FORK_Q), "fork Q");
-        TF_TRY(wgrad(c, sd, dqkv, hq, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, D.d, BIG, BIG, D.d), "wgrad in_proj (Q)");
-        TF_TRY(tf_launch_attn_bwd_part(&a, 2, c.st), "attn_bwd dkv");
-        TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
-        Buf dkv = dqkv;
-        dkv.p = (const unsigned char*)dqkv.p + (size_t)hq * 2;
-        if (dqkv.lo != nullptr) dkv.lo = (const unsigned char*)dqkv.lo + (size_t)hq * 2;
-        TF_TRY(wgrad(c, sd, dkv, 2 * hq, x, D.dp, g.in_w + (size_t)D.d * D.d, D.d, g.in_b + D.d, D.hd, D.hdp, 2 * D.d, BIG, BIG, D.d, l == 0),
-               "wgrad in_proj (K, V)");
-        TF_TRY(side_done(sd, 1), "done I");
-      } else {
-        TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
-      }
-      if (!split_q) {
-        TF_TRY(side_fork(c, sd, EV_FORK_I), "fork I");
-        TF_TRY(wgrad(c, sd, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d, l == 0), "wgrad in_proj");
-        TF_TRY(side_done(sd, 1), "done I");
-      }
+      TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
+    jobs[3] = wjob(c, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d);
+    if (plan.at[2]) {
+      TF_TRY(side_fork(c, sd, EV_FORK2), "fork 2");
+      // (the last launch of a whole backward has the chip to itself apart from one dgrad and the assemble kernel)
+      TF_TRY(wgrad_launch(c, sd, jobs, plan.at[2], tail && l == l_lo), "wgrad (after the attention backward)");
+    }
+    TF_TRY(side_done(sd, par), "done");
     TF_TRY(gemm(c, dqkv, c.wgt(w + c.W.winT, D.dp, D.ldq), dxa, nullptr, dzb, NOBUF, D.dp, D.ldq, TF_EPI_ADD, none), "dgrad in_proj");
   }
   if (tail) {
@@ -838,11 +862,11 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
   }
   if (sd.st != nullptr && e->defer_join) {
     e->overlap->pending = (sd.pending[0] ? 1u : 0u) | (sd.pending[1] ? 2u : 0u);      // the next call / tf_overlap_join takes over
+    e->overlap->reserved = (unsigned)sd.last;
     return 0;
   }
-  // join: the side stream is FIFO, so its last recorded event covers everything before it -- one wait, not one per group
-  if (sd.pending[1]) { sd.pending[0] = false; TF_TRY(guard(c, sd, 1), "join"); }
-  TF_TRY(guard(c, sd, 0), "join");
+  // join: the side stream is FIFO, so its last recorded event covers everything before it -- one wait, not one per layer
+  if (sd.pending[0] || sd.pending[1]) { sd.pending[sd.last] = true; sd.pending[sd.last ^ 1] = false; TF_TRY(guard(c, sd, sd.last), "join"); }
   if (sd.st != nullptr) e->overlap->pending = 0u;
   return 0;
 }

@@ -9,6 +9,7 @@ extern "C" {
 void tf_set_error_msg(const char* msg);                             // sets this thread's tf_last_error() text (tf_api.hip)
 int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream);
 int tf_launch_wgrad_tn(const TfWgradArgs* a, hipStream_t stream);
+int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, hipStream_t stream);   // wgrad_multi.hip
 int tf_wgrad_tiles(int N, int K, int caller_sized);                // output tiles of the wgrad kernel that will run
 int tf_launch_attn_fwd(const TfAttnArgs* a, hipStream_t stream);
 int tf_launch_attn_bwd(const TfAttnArgs* a, hipStream_t stream);

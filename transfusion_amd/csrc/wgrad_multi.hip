@@ -1,0 +1,325 @@
+// Weight gradients of SEVERAL linears in ONE launch (gfx950):  dW_p[N_p, K_p] += dY_p[M_p, N_p]^T . X_p[M_p, K_p],  p = 0 .. count-1.
+//
+// Why one launch: a layer's four weight gradients (in-proj, out-proj, FFN-up, FFN-down: 54 + 18 + 36 + 36 output tiles of 256 x 128 at
+// d = 768) each had to fill the chip BY ITSELF, which meant splitting the reduction (the token rows M) 5 - 14 ways and merging the
+// partial tiles with fp32 atomics: 34 MB of atomic traffic per launch against 2.4 - 7.1 MB of gradient, at the chip's ~1.3 TB/s atomic
+// rate.  Together the 144 tiles fill 256 CUs at TWO row chunks each: a quarter of the atomic bytes, a quarter of the launches, one
+// prologue and one flush per ~260 reduction steps instead of per 40 - 100.
+//
+// Work item = (row chunk c, output tile t of problem p), chunk-major: the workgroups that run together walk the SAME rows of dY / X
+// (an XCD owns a contiguous range of items, k-tile fastest, so the tiles that share a dY column panel share an L2).
+// Tile 256 (n) x 128 (k), 4 waves (2 x 2) of 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_bf16 per 16-row substep.  Both operands have the
+// reduction index on the slow axis in memory, so fragments come from ds_read_b64_tr_b16 (hardware transpose) on row-major LDS tiles
+// (dY [32][256] | X [32][128] per 32-row step, 16-B chunk ^= (row & 3) << 2: conflict-free for the transposed reads).
+// Staging: LDS-DMA through BUFFER loads (buffer_load_dwordx4 ... lds): per lane six loop-invariant 32-bit offsets, the step advances
+// one scalar offset per operand, and rows past the chunk's end arrive as zeros (no ragged path, no clamps, no 64-bit address
+// arithmetic in the loop).  The six transfers of a step are issued BETWEEN the step's MFMAs (an LDS-DMA costs its wave 60 - 180 issue
+// cycles: in front of the MFMAs, at one wave per SIMD, the matrix pipe idles for all of them).  3-slot ring, counted vmcnt, raw
+// s_barrier; transposed reads from inline asm (hipcc otherwise orders every LDS-DMA before any later ds_read with vmcnt(0)).
+// Bias gradients (column sums of dY): one extra accumulator per wave, D += SEL_nb . dYfrag_nb with SEL_nb[i][m] = (i >> 3 == nb); the
+// duty rotates over the waves that share an n-range (k-tile blocks x wave columns), every (2 tiles_k)-th 16-row substep each.
+// SPLIT (fp32-accuracy mode): three passes over the chunk's rows -- (dY_hi, X_hi), (dY_lo, X_hi), (dY_hi, X_lo) -- into the same
+// accumulators; the bias gradient takes passes 0 and 1.
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include "tf_common.h"
+#include "tf_kernels.h"
+
+namespace {
+
+constexpr int WG_MAX = TF_WGRAD_MULTI_MAX;
+
+struct WgProb {                                   // one problem as the kernel sees it (112 B)
+  const unsigned char* dY; const unsigned char* X; float* dW; float* db;
+  const unsigned char* dY_lo; const unsigned char* X_lo;
+  int ldy, ldx, lddw, M, N, K;
+  int rg, rgp, n_src, cg, cgp, k_src;
+  int tiles_k, tile0, m_chunk, pad;               // k-tiles per n-tile row; first global tile index; rows per chunk (multiple of 32)
+};
+struct WgMulti { int count, chunks, tiles_total, pad; WgProb p[WG_MAX]; };
+
+template <int N, class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+// INTL: 0 = the step's transfers in front of its MFMAs (the form of wgrad_tn2_kernel), 1 = one transfer after every second MFMA
+template <bool SPLIT, int NS, int INTL>
+__global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
+  constexpr int WN = 2, WK = 2, NB = 4, KB = 2;
+  constexpr int NWV = WN * WK, TN = WN * NB * 32, TK = WK * KB * 32;
+  constexpr int STEP = 32, YROW = TN * 2, XROW = TK * 2, YB = STEP * YROW, XB = STEP * XROW, SLOT = YB + XB;
+  constexpr int NPY = YB / 1024 / NWV, NPX = XB / 1024 / NWV, NPW = NPY + NPX;     // 1-KiB transfers per wave and step: 4 + 2
+  constexpr int YLPR = YROW / 16, XLPR = XROW / 16;                                 // lanes per tile row of a transfer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WK, wc = wave % WK;
+
+  // ---- work item -> (chunk, problem, tile) ----
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = logical / a.tiles_total, gt = logical - chunk * a.tiles_total;
+  int pi = 0;
+  for (int i = 1; i < a.count; ++i) pi = gt >= a.p[i].tile0 ? i : pi;
+  const WgProb& P = a.p[pi];
+  const int tiles_k = P.tiles_k, tile = gt - P.tile0;
+  const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
+  const int m_begin = chunk * P.m_chunk;
+  const int m_end = min(P.M, m_begin + P.m_chunk);
+  if (m_begin >= m_end) return;                                   // a problem with fewer rows than the launch's chunk count covers
+  const int rows = m_end - m_begin;
+  const int nsteps0 = (rows + STEP - 1) / STEP;
+  const int nsteps = SPLIT ? 3 * nsteps0 : nsteps0;
+  const int ldy = P.ldy, ldx = P.ldx, N = P.N, K = P.K;
+
+  // ---- buffer resources over the chunk's rows: offsets past the last row read zeros ----
+  const __amdgpu_buffer_rsrc_t rYh = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY + (size_t)m_begin * ldy * 2), 0, rows * ldy * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rXh = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X + (size_t)m_begin * ldx * 2), 0, rows * ldx * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t rYl = rYh, rXl = rXh;
+  if constexpr (SPLIT) {
+    rYl = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY_lo + (size_t)m_begin * ldy * 2), 0, rows * ldy * 2, 0x00020000);
+    rXl = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X_lo + (size_t)m_begin * ldx * 2), 0, rows * ldx * 2, 0x00020000);
+  }
+  // per-lane source offsets of this wave's transfers inside one 32-row step (tile swizzle folded in; columns clamped: never stored)
+  int vy[NPY], vx[NPX];
+#pragma unroll
+  for (int i = 0; i < NPY; ++i) {
+    const int j = i * NWV + wave;
+    const int r = j * (1024 / YROW) + lane / YLPR;
+    const int c = (lane % YLPR) ^ ((r & 3) << 2);
+    vy[i] = r * ldy * 2 + min(n0 + c * 8, N - 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) {
+    const int j = i * NWV + wave;
+    const int r = j * (1024 / XROW) + lane / XLPR;
+    const int c = (lane % XLPR) ^ ((r & 3) << 2);
+    vx[i] = r * ldx * 2 + min(k0 + c * 8, K - 8) * 2;
+  }
+  const int step_y = STEP * ldy * 2, step_x = STEP * ldx * 2;
+  // transfer q (0 .. NPW-1: first the dY pieces, then the X pieces) of reduction step `step` into ring slot `slot`
+  auto piece = [&](auto Q, int slot, int step) {
+    constexpr int q = decltype(Q)::value;
+    int st = step;
+    bool ylo = false, xlo = false;
+    if constexpr (SPLIT) {
+      const int seg = step >= 2 * nsteps0 ? 2 : (step >= nsteps0 ? 1 : 0);
+      st = step - seg * nsteps0;
+      ylo = seg == 1; xlo = seg == 2;
+    }
+    unsigned char* base = smem + slot * SLOT;
+    if constexpr (q < NPY) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(SPLIT && ylo ? rYl : rYh, TF_LDS_PTR(base + (q * NWV + wave) * 1024), 16, vy[q], st * step_y, 0, 0);
+    } else {
+      constexpr int i = q - NPY;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(SPLIT && xlo ? rXl : rXh, TF_LDS_PTR(base + YB + (i * NWV + wave) * 1024), 16, vx[i], st * step_x, 0, 0);
+    }
+  };
+  auto stage = [&](int slot, int step) { sfor<NPW>([&](auto Q) { piece(Q, slot, step); }); };
+
+  f32x16 acc[NB][KB], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int k = 0; k < KB; ++k) acc[i][k][r] = 0.f;
+  }
+  const bool has_bias = P.db != nullptr;
+  const int bias_mod = WK * tiles_k;                           // k-tile blocks x wave columns share one n-range: take turns
+  int bias_cnt = WK * (tile % tiles_k) + wc;
+  const int sel_nb = (lane & 31) / (32 / NB);
+
+  const int grp = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  const int h = grp >> 1, cb = grp & 1;
+  const int sw = q4 << 2, o8 = (p4 & 1) * 8;
+  const int yoff = (8 * h + q4) * YROW + (((wr * NB * 4 + cb * 2 + (p4 >> 1)) ^ sw) << 4) + o8;         // n-block nb: ^ (nb * 64)
+  const int xoff = YB + (8 * h + q4) * XROW + (((wc * KB * 4 + cb * 2 + (p4 >> 1)) ^ sw) << 4) + o8;    // k-block kb: ^ (kb * 64)
+
+  const unsigned lds_base = lds_addr_of(smem);
+  stage(0, 0);
+  if constexpr (NS >= 3) stage(1, 1);
+  if constexpr (NS >= 4) stage(2, 2);
+  int slot = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    // retire step st's transfers (issued NS - 1 steps ago), make them visible, recycle slot (st + NS - 1) % NS
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * NPW) : "memory");
+    const unsigned sl = lds_base + slot * SLOT;
+    u64 y0[NB][2], x0[KB][2], y1[NB][2], x1[KB][2];             // [block][row half] of substep 0 / 1
+#define TF_RD(Y, Xv, MS)                                                                                          \
+    Y[0][0] = tr_read_asm<(MS) * 16 * YROW>(sl + yoff);           Y[0][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + yoff);           \
+    Xv[0][0] = tr_read_asm<(MS) * 16 * XROW>(sl + xoff);          Xv[0][1] = tr_read_asm<(MS) * 16 * XROW + 4 * XROW>(sl + xoff);          \
+    Y[1][0] = tr_read_asm<(MS) * 16 * YROW>(sl + (yoff ^ 64));    Y[1][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + (yoff ^ 64));    \
+    Xv[1][0] = tr_read_asm<(MS) * 16 * XROW>(sl + (xoff ^ 64));   Xv[1][1] = tr_read_asm<(MS) * 16 * XROW + 4 * XROW>(sl + (xoff ^ 64));   \
+    Y[2][0] = tr_read_asm<(MS) * 16 * YROW>(sl + (yoff ^ 128));   Y[2][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + (yoff ^ 128));   \
+    Y[3][0] = tr_read_asm<(MS) * 16 * YROW>(sl + (yoff ^ 192));   Y[3][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + (yoff ^ 192));
+    TF_RD(y0, x0, 0)
+    TF_RD(y1, x1, 1)
+#undef TF_RD
+    const int nslot = slot == 0 ? NS - 1 : slot - 1;           // (st + NS - 1) % NS given slot = st % NS
+    const int nstep = st + NS - 1;                             // steps past the end read zeros (never consumed)
+    slot = slot == NS - 1 ? 0 : slot + 1;
+    if constexpr (INTL == 0) stage(nslot, nstep);
+    int pq = 0;                                                // MFMAs issued so far in this step (compile-time after unrolling)
+    auto substep = [&](u64 (&Y)[NB][2], u64 (&Xv)[KB][2], auto MS) {
+      constexpr int ms = decltype(MS)::value;
+      bf16x8 af[NB], bfr[KB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) af[nb] = join_tr64(Y[nb][0], Y[nb][1]);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bfr[kb] = join_tr64(Xv[kb][0], Xv[kb][1]);
+      sfor<NB * KB>([&](auto I) {
+        constexpr int i = decltype(I)::value, nb = i / KB, kb = i % KB;
+        acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+        if constexpr (INTL == 1) {
+          constexpr int done = ms * NB * KB + i + 1;             // one transfer behind every second MFMA of the step
+          if constexpr (done % 2 == 0 && done / 2 - 1 < NPW) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(std::integral_constant<int, done / 2 - 1>{}, nslot, nstep);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      });
+      const bool my_turn = has_bias && bias_cnt == 0 && (!SPLIT || st < 2 * nsteps0);          // wave-uniform
+      bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
+      if (my_turn) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const unsigned w = sel_nb == nb ? 0x3F803F80u : 0u;          // two bf16 ones
+          const u32x4 sv = {w, w, w, w};
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(sv), af[nb], accb, 0, 0, 0);
+        }
+      }
+    };
+    (void)pq;
+    // substep 0 may start when its 12 reads are back (the 12 of substep 1 still in flight)
+    asm volatile("s_waitcnt lgkmcnt(12)"
+                 : "+v"(y0[0][0]), "+v"(y0[0][1]), "+v"(y0[1][0]), "+v"(y0[1][1]), "+v"(y0[2][0]), "+v"(y0[2][1]), "+v"(y0[3][0]),
+                   "+v"(y0[3][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]), "+v"(x0[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    substep(y0, x0, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(y1[0][0]), "+v"(y1[0][1]), "+v"(y1[1][0]), "+v"(y1[1][1]), "+v"(y1[2][0]), "+v"(y1[2][1]), "+v"(y1[3][0]),
+                   "+v"(y1[3][1]), "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    substep(y1, x1, std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the workgroup retires
+
+  // ---- flush: fp32 atomics into the (unpadded) parameter-layout gradient; a register of a 32x32 accumulator is two 128-B row segments ----
+  float* __restrict__ dW = P.dW;
+  const int lddw = P.lddw, rg = P.rg, rgp = P.rgp, n_src = P.n_src, cg = P.cg, cgp = P.cgp, k_src = P.k_src;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int np = n0 + wr * (NB * 32) + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int ng = np / rgp, ne = np - ng * rgp;
+      const int ns = ng * rg + ne;
+      const bool nok = (np < N) && (ne < rg) && (ns < n_src);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kp = k0 + wc * (KB * 32) + kb * 32 + (lane & 31);
+        const int kg = kp / cgp, ke = kp - kg * cgp;
+        const int ks = kg * cg + ke;
+        if (nok && kp < K && ke < cg && ks < k_src) atomicAdd(dW + (size_t)ns * lddw + ks, acc[nb][kb][r]);
+      }
+    }
+    if (has_bias && lane < 32) {                                 // column sums of n-block nb: accumulator rows (32 / NB) nb .. = register 16 nb / NB
+      const int np = n0 + wr * (NB * 32) + nb * 32 + lane;
+      const int ng = np / rgp, ne = np - ng * rgp;
+      const int ns = ng * rg + ne;
+      if (np < N && ne < rg && ns < n_src) atomicAdd(P.db + ns, accb[(16 / NB) * nb]);
+    }
+  }
+}
+
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
+
+}  // namespace
+
+// count problems (each a TfWgradArgs; `groups` expands into that many problems) as one launch.  blocks: the number of workgroups the
+// caller wants in flight (0: two per CU, a launch that has the chip to itself); the row chunks follow from it.
+extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, hipStream_t stream) {
+  if (probs == nullptr || count <= 0) return -1;
+  WgMulti m{};
+  int n = 0, tiles = 0, min_steps = 1 << 30, max_steps = 0;
+  bool split = false, any = false;
+  double flops = 0.0;
+  for (int i = 0; i < count; ++i) {
+    const TfWgradArgs& a = probs[i];
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) continue;
+    if (a.dY == nullptr || a.X == nullptr || a.dW == nullptr) return -1;
+    const int G = a.groups > 1 ? a.groups : 1;
+    if (a.M % G) return -7;
+    if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8)) return -2;
+    if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
+    const bool sp = a.dY_lo != nullptr;
+    if (sp && a.X_lo == nullptr) return -6;
+    if (any && sp != split) return -8;                        // one arithmetic mode per launch
+    split = sp; any = true;
+    const int Mg = a.M / G;
+    for (int g = 0; g < G; ++g) {
+      if (n >= WG_MAX) return -9;
+      WgProb& p = m.p[n++];
+      p.dY = (const unsigned char*)a.dY + (size_t)g * Mg * a.ldy * 2; p.X = (const unsigned char*)a.X + (size_t)g * Mg * a.ldx * 2;
+      p.dY_lo = sp ? (const unsigned char*)a.dY_lo + (size_t)g * Mg * a.ldy * 2 : nullptr;
+      p.X_lo = sp ? (const unsigned char*)a.X_lo + (size_t)g * Mg * a.ldx * 2 : nullptr;
+      p.dW = (float*)((unsigned char*)a.dW + (long long)g * a.dw_gstride);
+      p.db = a.db != nullptr ? (float*)((unsigned char*)a.db + (long long)g * a.dw_gstride) : nullptr;
+      p.ldy = a.ldy; p.ldx = a.ldx; p.lddw = a.lddw; p.M = Mg; p.N = a.N; p.K = a.K;
+      p.rg = a.rg; p.rgp = a.rgp; p.n_src = a.n_src; p.cg = a.cg; p.cgp = a.cgp; p.k_src = a.k_src;
+      p.tiles_k = (a.K + 127) / 128;
+      p.tile0 = tiles;
+      tiles += p.tiles_k * ((a.N + 255) / 256);
+      const int steps = (Mg + 31) / 32;
+      min_steps = steps < min_steps ? steps : min_steps;
+      max_steps = steps > max_steps ? steps : max_steps;
+      flops += 2.0 * Mg * a.N * a.K;
+    }
+  }
+  if (n == 0) return 0;
+  if (blocks <= 0) blocks = 2 * cu_count();
+  int chunks = (blocks + tiles / 2) / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > min_steps) chunks = min_steps;
+  // a chunk's rows are addressed with 32-bit byte offsets inside a buffer resource: keep every chunk under 2 GiB
+  for (;;) {
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const long long rows = (((long long)(m.p[i].M + 31) / 32 + chunks - 1) / chunks) * 32;
+      const int ld = m.p[i].ldy > m.p[i].ldx ? m.p[i].ldy : m.p[i].ldx;
+      if (rows * ld * 2 >= (1ll << 31)) ok = false;
+    }
+    if (ok) break;
+    chunks *= 2;
+  }
+  for (int i = 0; i < n; ++i) m.p[i].m_chunk = (((m.p[i].M + 31) / 32 + chunks - 1) / chunks) * 32;
+  m.count = n; m.chunks = chunks; m.tiles_total = tiles;
+  (void)max_steps;
+  constexpr int NS = 3, LDS = NS * (32 * 512 + 32 * 256);
+#ifdef TF_EXPERIMENTS
+  static const int intl = getenv("TF_WGM_INTL") ? atoi(getenv("TF_WGM_INTL")) : 1;
+#else
+  constexpr int intl = 1;
+#endif
+  dim3 grid((unsigned)tiles * (unsigned)chunks), block(256);
+  TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops);
+  static const hipError_t o0 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static const hipError_t o1 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static const hipError_t o2 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<true, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)o0; (void)o1; (void)o2;
+  if (split) hipLaunchKernelGGL((wgrad_multi_kernel<true, NS, 1>), grid, block, LDS, stream, m);
+  else if (intl == 0) hipLaunchKernelGGL((wgrad_multi_kernel<false, NS, 0>), grid, block, LDS, stream, m);
+  else hipLaunchKernelGGL((wgrad_multi_kernel<false, NS, 1>), grid, block, LDS, stream, m);
+  return (int)hipGetLastError();
+}

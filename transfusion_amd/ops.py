@@ -273,6 +273,21 @@ def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG
     L.call("tf_gemm_wgrad", w, _stream())
 
 
+def wgrad_args(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, dY_lo=None, X_lo=None, groups=1,
+               dw_gstride=0):
+    """One problem of ``wgrad_multi`` (a ``TfWgradArgs``; keeps no reference to the tensors)."""
+    return L.TfWgradArgs(dY=L.ptr(dY), ldy=dY.stride(0), X=L.ptr(X), ldx=X.stride(0), dW=L.ptr(dW), lddw=dW.stride(0), db=L.ptr(db),
+                         dY_lo=L.ptr(dY_lo), X_lo=L.ptr(X_lo), zeros=0, M=dY.shape[0], N=N, K=K, rg=rg, rgp=rgp,
+                         n_src=dW.shape[0] if n_src is None else n_src, cg=cg, cgp=cgp,
+                         k_src=dW.shape[1] if k_src is None else k_src, m_chunk=0, groups=int(groups), dw_gstride=int(dw_gstride))
+
+
+def wgrad_multi(problems, blocks=0):
+    """Several weight gradients (``wgrad_args`` results) as ONE launch on the current stream (tf_gemm_wgrad_multi)."""
+    arr = (L.TfWgradArgs * len(problems))(*problems)
+    L.check(L.load().tf_gemm_wgrad_multi(arr, C.c_int(len(problems)), C.c_int(int(blocks)), C.c_void_p(_stream())), "tf_gemm_wgrad_multi")
+
+
 # ------------------------------------------------------------------------------------------------------
 # K1 / K9 permutations
 # ------------------------------------------------------------------------------------------------------
