@@ -22,6 +22,28 @@ rnd = lambda *s: torch.randn(*s, generator=g).to(device=dev, dtype=bf)
 st = ops._stream()
 
 
+def traced(fn, reps=5):
+    """per-kernel mean duration of `fn`'s launches (the library's launch tracer: HIP event pairs on the launching stream)"""
+    import collections
+    import ctypes
+    lib = Lb.load()
+    fn()
+    torch.cuda.synchronize()
+    Lb.check(lib.tf_trace_start(), "tf_trace_start")
+    for _ in range(reps):
+        fn()
+    cap = 4096
+    recs = (Lb.TfTraceRecord * cap)()
+    n = lib.tf_trace_stop(ctypes.addressof(recs), cap)
+    acc, cnt = collections.OrderedDict(), collections.Counter()
+    for r in recs[:min(int(n), cap)]:
+        k = r.name.decode()
+        acc[k] = acc.get(k, 0.0) + r.us
+        cnt[k] += 1
+    for k, v in acc.items():
+        print(f"    {k:44s} {v / cnt[k]:8.1f} us x {cnt[k] / reps:.0f}", flush=True)
+
+
 def timeit(name, fn, flops):
     fn()
     torch.cuda.synchronize()
@@ -42,14 +64,23 @@ if which in ("attn", "all"):
     dQKV = torch.empty(M, 3 * D, device=dev, dtype=bf)
     km = torch.zeros(B, S, dtype=torch.uint8, device=dev)
     km[:, S - 100:] = 1
-    for p in (0.15, 0.0):
+    dsw = torch.empty(Lb.load().tf_attn_ds_bytes(B, H, S), dtype=torch.uint8, device=dev)
+    # the benchmark's ragged batch: 196 visual tokens + U{128..512} language tokens per sample, packed rows, longest sample first
+    lens = sorted((NV + torch.randint(128, 513, (B,), generator=g)).tolist(), reverse=True)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    pairs = sum(l * l for l in lens)
+    for p, packed in ((0.15, False), (0.15, True), (0.0, True)):
         drop = ops.drop_params(p, 1, 1)
         dbits = ops.attn_dropmask(B, H, S, p, 1, 1, dev) if p > 0 else None
-        att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * D, out=Lb.ptr(O), ld_out=D, lse=Lb.ptr(lse), key_mask=Lb.ptr(km), B=B, S=S, H=H, HDP=hd,
+        att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * D, out=Lb.ptr(O), ld_out=D, lse=Lb.ptr(lse), key_mask=0 if packed else Lb.ptr(km), B=B, S=S, H=H, HDP=hd,
                             scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=Lb.ptr(dbits),
-                            dout=Lb.ptr(Y), ld_dout=D, dqkv=Lb.ptr(dQKV), ld_dqkv=3 * D, delta=Lb.ptr(delta))
-        timeit(f"attn_fwd p={p}", lambda: Lb.call("tf_attn_fwd", att, st), 4.0 * B * S * S * D)
-        timeit(f"attn_bwd p={p}", lambda: Lb.call("tf_attn_bwd", att, st), 8.0 * B * S * S * D)
+                            dout=Lb.ptr(Y), ld_dout=D, dqkv=Lb.ptr(dQKV), ld_dqkv=3 * D, delta=Lb.ptr(delta), ds_work=Lb.ptr(dsw),
+                            cu_rows=Lb.ptr(cu) if packed else 0)
+        fl = 4.0 * (pairs * H * hd if packed else B * S * S * D)
+        tag = f"p={p} {'packed' if packed else 'dense'}"
+        timeit(f"attn_fwd {tag}", lambda: Lb.call("tf_attn_fwd", att, st), fl)
+        timeit(f"attn_bwd {tag}", lambda: Lb.call("tf_attn_bwd", att, st), 2.0 * fl)
+        traced(lambda: Lb.call("tf_attn_bwd", att, st))
 if which in ("wgrad", "all"):
     X, dYq, dYf = rnd(M, D), rnd(M, 3 * D), rnd(M, ff)
     dW, db = torch.zeros(3 * D, D, device=dev), torch.zeros(3 * D, device=dev)

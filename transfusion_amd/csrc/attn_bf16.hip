@@ -1097,6 +1097,337 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
 }
 
 // ================================================================================================
+// backward, dK / dV with ROLE-SPLIT wave pairs (head dims <= 192, with the dS workspace).
+// What bounded attn_bwd_dkv16_kernel: every wave owned 16 keys and did everything for them -- S, dP, the softmax / dS arithmetic, dV
+// and dK -- as one dependent chain per 32-query sub-tile (fragment reads -> 24 MFMAs -> ~150 VALU -> 24 MFMAs), reading the whole Q
+// and dO tile twice (by rows and transposed) for its 16 keys: the matrix pipe was busy a quarter of the time (profiles/r03_v4), and at
+// full rate the LDS would have had to deliver 250 B/clk.  Here waves w and w + 4 (the two waves of one SIMD) share 32 keys and split
+// the PRODUCTS:
+//   role A (waves 0-3): S = Q K^T -> P, Pd = dropout(P) ;  dV^T += dO^T Pd      reads Q by rows, dO transposed
+//   role B (waves 4-7): dP = dO V^T ; dS = P (keep/(1-p) dP - delta) ; dK^T += Q^T dS ; stores the dS tiles      reads dO by rows, Q transposed
+// so a fragment read from LDS feeds two 16-key blocks and each wave reads two of the four tile images: half the LDS bytes per MFMA, and
+// the K / V fragments and one accumulator set per wave leave the registers to run one tile AHEAD: in iteration i a wave issues the 24
+// MFMAs of S / dP for tile i + 1 and the 24 of dV / dK for tile i back to back, and the vector arithmetic of the two roles falls on
+// OPPOSITE sides of the iteration's one barrier -- B forms dS(i) right after it, while A's 48 MFMAs run; A forms P(i + 1) right before
+// the next one, under its own dV MFMAs and B's 48 -- so the SIMD's matrix pipe always has work queued.
+// P crosses from A to B through LDS as fp32 in the accumulator layout (the two roles hold the same (query, key) element in the same
+// lane and register: a lane-linear 16-B-per-lane image, written once and read once); dS leaves for the dQ kernel exactly as before.
+// Q / dO tiles of 32 query rows, three buffers (tiles i and i + 1 in use, i + 2 being written), staged through registers.
+// ================================================================================================
+constexpr int TF_DKV_PAIR_QT = 32;
+// bit `bit` (a per-lane register) of `word` as a sign-extended field: all ones or zero (v_bfe_i32)
+__device__ __forceinline__ int bit_mask(int word, int bit) {
+  int m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "v"(bit));
+  return m;
+}
+#ifndef TF_ABL_PAIR
+#define TF_ABL_PAIR 0      // timing ablations (variant builds only; results are wrong): 1 no tile transfers, 2 no softmax / dS arithmetic,
+#endif                     // 4 no S / dP MFMAs, 8 no dV / dK MFMAs, 16 no row scalars, 32 no tile loop, 64 no dK / dV stores, 128 no K / V loads
+// (a __device__ function: the LDS-DMA builtin inside a non-generic lambda of a kernel TEMPLATE makes the host pass drop the
+// instantiation silently -- the launch then fails to link)
+__device__ __forceinline__ void dma_piece16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TF_LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+template <int HDP, bool BLK>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  constexpr int QT = TF_DKV_PAIR_QT, NBUF = 3;
+  constexpr int KS = HDP / 32, DB = HDP / 16, TSTR = G::TSTR;
+  constexpr int PAIR = 2 * QT * TSTR;                     // Q tile + dO tile, back to back
+  constexpr int NPC = (PAIR + 1023) / 1024, NI = (NPC + 7) / 8;       // 1-KiB LDS-DMA pieces of a tile pair; pieces per wave
+  constexpr int ROWS_BYTES = 4 * QT * (2 + 4 + 4);        // lse[QT], delta[QT], keep words [4 pairs][QT], block words [4 pairs][QT]
+  constexpr int XCH = 4 * 4096;                           // one exchange image: 4 pairs x 64 lanes x 64 B
+  constexpr int BUFS = ((NBUF * PAIR + 1023) / 1024) * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const rows_base = smem + BUFS;
+  unsigned char* const xch_base = rows_base + NBUF * ROWS_BYTES;
+  unsigned char* const dummy = xch_base + 2 * XCH;        // where the surplus pieces of the 8 x NI transfers land (never read)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, n = lane & 15;
+  const int pr = wave & 3;
+  const bool role_b = wave >= 4;                          // wave-uniform
+  const int S = a.S;
+  const int nkb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int kblk = logical % nkb;
+  const int key0 = kblk * 128 + pr * 32;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len;
+  if (kblk * 128 >= Sb) return;                           // key blocks past the sample's end (workgroup-uniform)
+  const size_t ld = a.ld_qkv;
+  const u16* qkv = (const u16*)a.qkv;
+  const u16* qbase = qkv + sr.row0 * ld + (size_t)(0 * a.H + head) * HDP;
+  const u16* kvbase = qkv + sr.row0 * ld + (size_t)((role_b ? 2 : 1) * a.H + head) * HDP;     // A holds K fragments, B holds V fragments
+  const u16* dobase = (const u16*)a.dout + sr.row0 * a.ld_dout + (size_t)head * HDP;
+
+  // ---- tile staging by LDS-DMA: piece k of a tile pair is bytes [1024 k, 1024 k + 1024) of the image Q tile | dO tile; wave w issues
+  //      pieces NI w .. NI w + NI - 1.  The image is lane-linear, so the tile's swizzle sits on the SOURCE side; rows past the sample's
+  //      end read zeros (buffer bounds).  No staging registers: NI loop-invariant offsets per lane.
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(qbase, ld, Sb, HDP), rdo = make_rsrc(dobase, (size_t)a.ld_dout, Sb, HDP);
+  int voff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = wave * NI + i;
+    const int pos = (k * 1024 + lane * 16) % (QT * TSTR);              // byte inside the Q or the dO tile
+    const int r = pos / TSTR, cp = (pos % TSTR) >> 4;
+    const int col = cp < HDP / 8 ? ((cp ^ swz16(r)) << 4) : 0;          // (row padding re-fetches chunk 0: never read)
+    const bool is_do = k * 1024 >= QT * TSTR;
+    voff[i] = k < NPC ? r * (int)((is_do ? (size_t)a.ld_dout : ld) * 2) + col : 0;
+  }
+  auto dma = [&](int t) {                                  // tile pair t -> its buffer
+    unsigned char* img = smem + (t % NBUF) * PAIR;
+    const int soq = t * QT * (int)(ld * 2), sod = t * QT * (int)(a.ld_dout * 2);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = wave * NI + i;                          // wave-uniform
+      const bool is_do = k * 1024 >= QT * TSTR;
+      unsigned char* dst = k < NPC ? img + k * 1024 : dummy + (k - NPC) * 1024;
+      dma_piece16(is_do ? rdo : rq, dst, voff[i], is_do ? sod : soq);
+    }
+  };
+
+  bool key_ok[2];
+  int okm[2];                     // all ones where the lane's key of block kb may be attended
+  bf16x8 bfrag[2][KS];            // B operands: key 16 kb + n, hd elements 32 ks + 8 g .. + 7 of K (role A) / V (role B)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int key = key0 + 16 * kb + n;
+    const int kr_ = min(key, Sb - 1);
+    key_ok[kb] = key < Sb;
+    if (key_ok[kb] && a.key_mask != nullptr) key_ok[kb] = a.key_mask[(size_t)b * S + key] == 0;
+    okm[kb] = key_ok[kb] ? -1 : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (TF_ABL_PAIR & 128) bfrag[kb][ks] = as_bf16x8(u32x4{(unsigned)kr_, 1u, 2u, 3u});
+      else bfrag[kb][ks] = as_bf16x8(*(const u32x4*)(kvbase + (size_t)kr_ * ld + ks * 32 + 8 * g));
+    }
+  }
+  f32x4 acc[2][DB];               // dV^T (role A) / dK^T (role B) of the wave pair's 32 keys
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) acc[kb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 sacc[2][2];               // S (A) / dP (B) of the tile one ahead: [key block][16-query block]
+  bf16x8 of[2];                   // Pd (A) / dS (B) of the current tile, as B operands of the accumulating product
+  of[0] = of[1] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});
+  const float sc = a.scale * LOG2E;
+  const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
+  // B: the pair's two rows of dS chunks (one chunk per 32-query tile), already offset to the lane's 16-B slot
+  unsigned char* ds_row = (unsigned char*)a.ds_work + (((size_t)bh * ds_nkb(S) + (key0 >> 4)) * ds_nqb(S)) * 1024 + 64 * n + 16 * g;
+  const size_t ds_kb_stride = (size_t)ds_nqb(S) * 1024;
+
+  const int rbase = n * TSTR + ((g ^ swz16(n)) << 4);                 // row read: + 16j * TSTR + 64 * ks
+  const int q4 = n >> 2, p = n & 3, fz = swz16(4 * g);
+  const int tbase = (4 * g + q4) * TSTR + 8 * (p & 1);                 // transposed read: + 16t * TSTR + 64 * (db>>1) + xe|xo
+  const int xe = ((p >> 1) ^ fz) << 4, xo = ((2 + (p >> 1)) ^ fz) << 4;
+  const int row_sel = role_b ? QT * TSTR : 0;                          // tile read by rows: Q (A) / dO (B); transposed: the other one
+  const int tr_sel = role_b ? 0 : QT * TSTR;
+
+  const int ntiles = (kblk * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sb + QT - 1) / QT;
+  const int dw_ld = 2 * ((S + 63) / 64);
+  // row scalars of tile t (threads 0 .. 4 QT - 1): lse / delta of row t & 31 (threads < QT); keep / block word of (row t & 31, pair t >> 5)
+  const int wsel = min(4 * kblk + (tid >> 5), dw_ld - 1);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + wsel;
+  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + wsel : nullptr;
+  float lse_n = 1.0e30f, del_n = 0.f;
+  unsigned dw_n = 0xffffffffu, bw_n = 0u;
+  auto rows_load = [&](int t) {
+    if (tid < 4 * QT) {
+      const int q = min(t * QT + (tid & (QT - 1)), Sb - 1);
+      if (tid < QT) { lse_n = a.lse[(size_t)bh * S + q]; del_n = a.delta[(size_t)bh * S + q]; }
+      if (a.drop_thr) dw_n = dbits[(size_t)q * dw_ld];
+      if (BLK) bw_n = bbits[(size_t)q * dw_ld];
+    }
+  };
+  auto rows_store = [&](int t) {
+    if (tid < 4 * QT) {
+      float* lse_w = (float*)(rows_base + (t % NBUF) * ROWS_BYTES);
+      unsigned* dw_w = (unsigned*)(lse_w + 2 * QT);
+      const bool in = t * QT + (tid & (QT - 1)) < Sb;
+      if (tid < QT) {
+        lse_w[tid] = in ? lse_n : 1.0e30f;                 // P = 0 for rows past the end
+        lse_w[QT + tid] = in ? del_n : 0.f;
+      }
+      dw_w[tid] = (!a.drop_thr || in) ? dw_n : 0u;
+      if (BLK) dw_w[4 * QT + tid] = bw_n;
+    }
+  };
+  // S (A) / dP (B) of tile t: rows of Q / dO against the resident K / V fragments; a row fragment feeds both key blocks
+  auto sx = [&](int t) {
+    const unsigned char* rt = smem + (t % NBUF) * PAIR + row_sel;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sacc[kb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 rf[2 * KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) rf[j * KS + ks] = *(const bf16x8*)(rt + rbase + 16 * j * TSTR + 64 * ks);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sacc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[j * KS + ks], bfrag[0][ks], sacc[0][j], 0, 0, 0);
+        sacc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[j * KS + ks], bfrag[1][ks], sacc[1][j], 0, 0, 0);
+      }
+    constexpr int NR = 2 * KS, AHEAD = NR < 4 ? NR : 4;
+    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+    for (int i = 0; i < NR - AHEAD; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * AHEAD, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // dV^T += dO^T Pd (A) / dK^T += Q^T dS (B) of tile t: a transposed fragment feeds both key blocks.  The transposed reads come from
+  // inline asm, AH fragments ahead of their MFMAs behind counted waits: as intrinsics hipcc puts s_waitcnt vmcnt(0) in front of the first
+  // of them (it cannot tell the tile being read from the tile in flight) and the transfers of tile t + 2 drain in mid-iteration.
+  const unsigned tr_lds = lds_addr_of(smem) + tr_sel + tbase;
+  auto accum = [&](int t) {
+    constexpr int AH = 4;
+    const unsigned ae = tr_lds + (t % NBUF) * PAIR + xe, ao = tr_lds + (t % NBUF) * PAIR + xo;
+    __builtin_amdgcn_sched_barrier(0);
+    u64 fa[DB], fb[DB];
+    static_for<(AH < DB ? AH : DB)>([&](auto I) {
+      constexpr int d = decltype(I)::value;
+      fa[d] = tr_read_asm<64 * (d >> 1)>((d & 1) ? ao : ae);
+      fb[d] = tr_read_asm<64 * (d >> 1) + 16 * TSTR>((d & 1) ? ao : ae);
+    });
+    static_for<DB>([&](auto I) {
+      constexpr int d = decltype(I)::value;
+      constexpr int pend = (DB - 1 - d) < (AH - 1) ? (DB - 1 - d) : (AH - 1);          // fragments issued after fragment d
+      lgkm_wait<2 * pend>(fa[d], fb[d]);
+      const bf16x8 f = join_tr64(fa[d], fb[d]);
+      acc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, of[0], acc[0][d], 0, 0, 0);
+      acc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, of[1], acc[1][d], 0, 0, 0);
+      if constexpr (d + AH < DB) {
+        constexpr int e = d + AH;
+        fa[e] = tr_read_asm<64 * (e >> 1)>((e & 1) ? ao : ae);
+        fb[e] = tr_read_asm<64 * (e >> 1) + 16 * TSTR>((e & 1) ? ao : ae);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // role A: P and Pd of tile t from S; P goes to the exchange image, Pd stays as the next accumulating product's operand
+  auto softmax_a = [&](int t) {
+    const float* lse_s = (const float*)(rows_base + (t % NBUF) * ROWS_BYTES);
+    const unsigned* dw_s = (const unsigned*)(lse_s + 2 * QT) + pr * QT;
+    unsigned char* xw = xch_base + (t & 1) * XCH + pr * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 l4 = *(const f32x4*)(lse_s + 16 * j + 4 * g);
+      const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
+      u32x4 b4 = {0u, 0u, 0u, 0u};
+      if (BLK) b4 = *(const u32x4*)(dw_s + 4 * QT + 16 * j + 4 * g);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int kbit = 16 * kb + n;
+        f32x4 pv;
+        float pd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // (masks ANDed into the value: a sign-extended one-bit field per key costs two VALU ops, a compare + select three and a VCC hazard)
+          float prob = fast_exp2(fmaf(sacc[kb][j][i], sc, -l4[i]));
+          prob = __builtin_bit_cast(float, __builtin_bit_cast(int, prob) & okm[kb]);
+          if (BLK) prob = __builtin_bit_cast(float, __builtin_bit_cast(int, prob) & ~bit_mask((int)b4[i], kbit));
+          pv[i] = prob;
+          pd[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, prob * dscale) & bit_mask((int)w4[i], kbit));      // Pd
+        }
+        *(f32x4*)(xw + (kb * 2 + j) * 1024) = pv;
+        u32x4 o = __builtin_bit_cast(u32x4, of[kb]);
+        o[2 * j] = cvt_pk_bf16(pd[0], pd[1]); o[2 * j + 1] = cvt_pk_bf16(pd[2], pd[3]);
+        of[kb] = as_bf16x8(o);
+      }
+    }
+  };
+  // role B: dS of tile t from P (exchange image) and dP; stored for the dQ kernel and kept as the next accumulating product's operand
+  auto ds_b = [&](int t) {
+    const float* lse_s = (const float*)(rows_base + (t % NBUF) * ROWS_BYTES);
+    const unsigned* dw_s = (const unsigned*)(lse_s + 2 * QT) + pr * QT;
+    const unsigned char* xr = xch_base + (t & 1) * XCH + pr * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 d4 = *(const f32x4*)(lse_s + QT + 16 * j + 4 * g);
+      const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int kbit = 16 * kb + n;
+        const f32x4 pv = *(const f32x4*)(xr + (kb * 2 + j) * 1024);
+        float ds[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep_scale = __builtin_bit_cast(float, __builtin_bit_cast(int, dscale) & bit_mask((int)w4[i], kbit));
+          ds[i] = pv[i] * fmaf(sacc[kb][j][i], keep_scale, -d4[i]);                                      // dS
+        }
+        u32x4 o = __builtin_bit_cast(u32x4, of[kb]);
+        o[2 * j] = cvt_pk_bf16(ds[0], ds[1]); o[2 * j + 1] = cvt_pk_bf16(ds[2], ds[3]);
+        of[kb] = as_bf16x8(o);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const u32x4 v = __builtin_bit_cast(u32x4, of[kb]);
+      const bool swp = ((n >> 2) & 1) != 0;
+      const u32x4 w = {swp ? v[2] : v[0], swp ? v[3] : v[1], swp ? v[0] : v[2], swp ? v[1] : v[3]};
+      *(u32x4*)(ds_row + kb * ds_kb_stride + (size_t)t * 1024) = w;
+    }
+  };
+  // every transfer and LDS store of this wave has landed, then the workgroup meets (vmcnt counts the dS stores too)
+  auto barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  if (ntiles > 0) {
+    dma(0);
+    rows_load(0);
+    rows_store(0);
+    if (ntiles > 1) dma(1);
+  }
+  // (the builtin, not only the asm wait inside barrier(): hipcc must KNOW that the K / V fragment loads have landed, or it waits for them
+  // -- vmcnt(0), and with them for the tile transfers in flight -- in front of the MFMAs of every iteration)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  barrier();
+  if (ntiles > 0) {
+    if (ntiles > 1) rows_load(1);
+    sx(0);
+    if (!role_b) softmax_a(0);
+    if (ntiles > 1) rows_store(1);
+  }
+  barrier();
+  for (int t = 0; t < ((TF_ABL_PAIR & 32) ? 0 : ntiles); ++t) {
+    // tiles t, t + 1 are in LDS (tile t + 1's S / dP is done); buffer (t + 2) % 3 is free: everyone has left iteration t - 1
+    if (t + 2 < ntiles) { if (!(TF_ABL_PAIR & 1)) dma(t + 2); if (!(TF_ABL_PAIR & 16)) rows_load(t + 2); }
+    if (role_b && !(TF_ABL_PAIR & 2)) ds_b(t);
+    if (t + 1 < ntiles && !(TF_ABL_PAIR & 4)) sx(t + 1);
+    if (!(TF_ABL_PAIR & 8)) accum(t);
+    if (!role_b && t + 1 < ntiles && !(TF_ABL_PAIR & 2)) softmax_a(t + 1);
+    if (t + 2 < ntiles && !(TF_ABL_PAIR & 16)) rows_store(t + 2);
+    barrier();
+  }
+  // ---- dV (A) / dK (B) rows.  A lane holds 4 consecutive head-dim elements per 16-element block (8 bytes): stored as they stand that is
+  //      24 dwordx2 stores per lane, and the epilogue was store-ISSUE bound (21 of the kernel's 113 us).  Lanes g and g ^ 1 hold adjacent
+  //      groups: they swap one group per PAIR of blocks (ds_swizzle, lane ^ 16), so that every lane stores 16 contiguous bytes -- the even
+  //      lane of block 2m, the odd lane of block 2m + 1 -- and an instruction writes 64 contiguous bytes of each of its 16 rows.
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int key = key0 + 16 * kb + n;
+    const bool ok = key < Sb && !((TF_ABL_PAIR & 64) && acc[kb][0][0] != 12345.f);
+    u16* row = (u16*)a.dqkv + (sr.row0 + min(key, Sb - 1)) * a.ld_dqkv + (size_t)((role_b ? 1 : 2) * a.H + head) * HDP;      // B: dK (scaled), A: dV
+    const float f = role_b ? a.scale : 1.0f;
+    const bool odd = (g & 1) != 0;
+#pragma unroll
+    for (int m = 0; m < DB / 2; ++m) {
+      const unsigned lo0 = cvt_pk_bf16(acc[kb][2 * m][0] * f, acc[kb][2 * m][1] * f), hi0 = cvt_pk_bf16(acc[kb][2 * m][2] * f, acc[kb][2 * m][3] * f);
+      const unsigned lo1 = cvt_pk_bf16(acc[kb][2 * m + 1][0] * f, acc[kb][2 * m + 1][1] * f), hi1 = cvt_pk_bf16(acc[kb][2 * m + 1][2] * f, acc[kb][2 * m + 1][3] * f);
+      // even lanes give away their group of block 2m + 1, odd lanes theirs of block 2m
+      const unsigned rlo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(odd ? lo0 : lo1), 0x401F);      // lane ^ 16
+      const unsigned rhi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(odd ? hi0 : hi1), 0x401F);
+      const u32x4 v = odd ? u32x4{rlo, rhi, lo1, hi1} : u32x4{lo0, hi0, rlo, rhi};
+      if (ok) *(u32x4*)(row + (2 * m + (odd ? 1 : 0)) * 16 + 4 * (g & 2)) = v;
+    }
+  }
+}
+
+// ================================================================================================
 // delta[b, h, q] = rowsum(dO . O) over the head's columns, one wave per token row (both tensors are read once, 16 B per lane)
 // ================================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const TfAttnArgs a) {
@@ -1155,9 +1486,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
   const u16* kbase = (const u16*)a.qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
   const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
   const int qb32 = 4 * qblk + wave;
-  // the dK / dV kernel walks the queries in tiles of TF_DKV16_QT rows: sub-tiles at or beyond ceil(Sb / QT) * QT were never written --
-  // and hold no query of this sample, so a wave that owns one has nothing to compute (it still takes part in the barriers)
-  const bool active = qb32 * 32 < ((Sb + TF_DKV16_QT - 1) / TF_DKV16_QT) * TF_DKV16_QT;
+  // the dK / dV kernels walk the queries in tiles of 32 (pair kernel) or TF_DKV16_QT rows: sub-tiles at or beyond ceil(Sb / 32) * 32 hold no
+  // query of this sample (and the pair kernel never wrote them), so a wave that owns one has nothing to compute (it still takes part in
+  // the barriers)
+  const bool active = qb32 * 32 < ((Sb + 31) / 32) * 32;
   const unsigned char* ds_col = (const unsigned char*)a.ds_work + (((size_t)bh * ds_nkb(S)) * ds_nqb(S) + qb32) * 1024 + 16 * lane;
   const size_t ds_kstride = (size_t)ds_nqb(S) * 1024;     // from one 16-key block to the next
 
@@ -1277,7 +1609,24 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
         TfTraceScope tr("attn_delta_kernel", st, 0.0, 4.0 * a->B * a->S * a->H * HDP);
         hipLaunchKernelGGL(attn_delta_kernel, dim3(a->B * ((a->S + 3) / 4)), dim3(256), 0, st, *a);
       }
+#ifdef TF_EXPERIMENTS
+      static const int use_pair = [] { const char* e = getenv("TF_ATTN_PAIR"); return e ? atoi(e) : 1; }();
+#else
+      constexpr int use_pair = 1;
+#endif
       if constexpr (HAS16) {
+        if (use_pair) {
+          constexpr int PQ = TF_DKV_PAIR_QT;
+          constexpr int PAIRB = 2 * PQ * Geo<HDP>::TSTR, NPCP = (PAIRB + 1023) / 1024;
+          const size_t lds_pair = ((3 * PAIRB + 1023) / 1024) * 1024 + 3 * (4 * PQ * 10) + 2 * (4 * 4096) + (8 * ((NPCP + 7) / 8) - NPCP) * 1024;
+          static const hipError_t p1 = hipFuncSetAttribute((const void*)attn_bwd_dkv_pair_kernel<HDP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+          static const hipError_t p2 = hipFuncSetAttribute((const void*)attn_bwd_dkv_pair_kernel<HDP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair);
+          (void)p1; (void)p2;
+          snprintf(nm, sizeof(nm), "attn_bwd_dkv_pair_kernel<%d>", HDP);
+          TfTraceScope tr(nm, st, 1.5 * fl);               // credited: dP, dV, dK (the S recompute is not)
+          if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_pair_kernel<HDP, true>), grid, dim3(512), lds_pair, st, *a);
+          else hipLaunchKernelGGL((attn_bwd_dkv_pair_kernel<HDP, false>), grid, dim3(512), lds_pair, st, *a);
+        } else {
         static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
         static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
         (void)o1; (void)o2;
@@ -1285,6 +1634,7 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
         TfTraceScope tr(nm, st, 1.5 * fl);                 // credited: dP, dV, dK (the S recompute is not)
         if (a->block_bits != nullptr) hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, true, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
         else hipLaunchKernelGGL((attn_bwd_dkv16_kernel<HDP, false, QT, true>), grid, dim3(512), lds_kv16d, st, *a);
+        }
       } else {
         static const hipError_t o1 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, false, QT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
         static const hipError_t o2 = hipFuncSetAttribute((const void*)attn_bwd_dkv16_kernel<HDP, true, QT, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv16d);
