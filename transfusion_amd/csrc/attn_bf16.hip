@@ -1309,17 +1309,36 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
     });
     __builtin_amdgcn_sched_barrier(0);
   };
-  // role A: P and Pd of tile t from S; P goes to the exchange image, Pd stays as the next accumulating product's operand
-  auto softmax_a = [&](int t) {
+  // The vector phases read their LDS inputs (row scalars; B: the P image) AHEAD, into registers, from a point where the wave has other
+  // work to issue -- A before its dV MFMAs, B before the iteration's tile transfers -- instead of at the head of a dependent chain.
+  f32x4 rs4[2]; u32x4 rw4[2], rb4[1]; f32x4 rp4[2][2];
+  auto rows_a = [&](int t) {                               // role A: lse, keep words (block words) of tile t
     const float* lse_s = (const float*)(rows_base + (t % NBUF) * ROWS_BYTES);
     const unsigned* dw_s = (const unsigned*)(lse_s + 2 * QT) + pr * QT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rs4[j] = *(const f32x4*)(lse_s + 16 * j + 4 * g);
+      rw4[j] = *(const u32x4*)(dw_s + 16 * j + 4 * g);
+    }
+  };
+  auto rows_b = [&](int t) {                               // role B: delta, keep words and the P image of tile t
+    const float* lse_s = (const float*)(rows_base + (t % NBUF) * ROWS_BYTES);
+    const unsigned* dw_s = (const unsigned*)(lse_s + 2 * QT) + pr * QT;
+    const unsigned char* xr = xch_base + (t & 1) * XCH + pr * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rs4[j] = *(const f32x4*)(lse_s + QT + 16 * j + 4 * g);
+      rw4[j] = *(const u32x4*)(dw_s + 16 * j + 4 * g);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) rp4[kb][j] = *(const f32x4*)(xr + (kb * 2 + j) * 1024);
+    }
+  };
+  // role A: P and Pd of tile t from S; P goes to the exchange image, Pd stays as the next accumulating product's operand
+  auto softmax_a = [&](int t) {
     unsigned char* xw = xch_base + (t & 1) * XCH + pr * 4096 + lane * 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const f32x4 l4 = *(const f32x4*)(lse_s + 16 * j + 4 * g);
-      const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
-      u32x4 b4 = {0u, 0u, 0u, 0u};
-      if (BLK) b4 = *(const u32x4*)(dw_s + 4 * QT + 16 * j + 4 * g);
+      if (BLK) rb4[0] = *(const u32x4*)(rows_base + (t % NBUF) * ROWS_BYTES + 4 * (2 * QT + pr * QT + 4 * QT + 16 * j + 4 * g));   // (in phase: registers)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int kbit = 16 * kb + n;
@@ -1328,11 +1347,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           // (masks ANDed into the value: a sign-extended one-bit field per key costs two VALU ops, a compare + select three and a VCC hazard)
-          float prob = fast_exp2(fmaf(sacc[kb][j][i], sc, -l4[i]));
+          float prob = fast_exp2(fmaf(sacc[kb][j][i], sc, -rs4[j][i]));
           prob = __builtin_bit_cast(float, __builtin_bit_cast(int, prob) & okm[kb]);
-          if (BLK) prob = __builtin_bit_cast(float, __builtin_bit_cast(int, prob) & ~bit_mask((int)b4[i], kbit));
+          if (BLK) prob = __builtin_bit_cast(float, __builtin_bit_cast(int, prob) & ~bit_mask((int)rb4[0][i], kbit));
           pv[i] = prob;
-          pd[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, prob * dscale) & bit_mask((int)w4[i], kbit));      // Pd
+          pd[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, prob * dscale) & bit_mask((int)rw4[j][i], kbit));      // Pd
         }
         *(f32x4*)(xw + (kb * 2 + j) * 1024) = pv;
         u32x4 o = __builtin_bit_cast(u32x4, of[kb]);
@@ -1343,22 +1362,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
   };
   // role B: dS of tile t from P (exchange image) and dP; stored for the dQ kernel and kept as the next accumulating product's operand
   auto ds_b = [&](int t) {
-    const float* lse_s = (const float*)(rows_base + (t % NBUF) * ROWS_BYTES);
-    const unsigned* dw_s = (const unsigned*)(lse_s + 2 * QT) + pr * QT;
-    const unsigned char* xr = xch_base + (t & 1) * XCH + pr * 4096 + lane * 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const f32x4 d4 = *(const f32x4*)(lse_s + QT + 16 * j + 4 * g);
-      const u32x4 w4 = *(const u32x4*)(dw_s + 16 * j + 4 * g);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int kbit = 16 * kb + n;
-        const f32x4 pv = *(const f32x4*)(xr + (kb * 2 + j) * 1024);
         float ds[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float keep_scale = __builtin_bit_cast(float, __builtin_bit_cast(int, dscale) & bit_mask((int)w4[i], kbit));
-          ds[i] = pv[i] * fmaf(sacc[kb][j][i], keep_scale, -d4[i]);                                      // dS
+          const float keep_scale = __builtin_bit_cast(float, __builtin_bit_cast(int, dscale) & bit_mask((int)rw4[j][i], kbit));
+          ds[i] = rp4[kb][j][i] * fmaf(sacc[kb][j][i], keep_scale, -rs4[j][i]);                          // dS
         }
         u32x4 o = __builtin_bit_cast(u32x4, of[kb]);
         o[2 * j] = cvt_pk_bf16(ds[0], ds[1]); o[2 * j + 1] = cvt_pk_bf16(ds[2], ds[3]);
@@ -1388,6 +1401,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
   barrier();
   if (ntiles > 0) {
     if (ntiles > 1) rows_load(1);
+    if (!role_b) rows_a(0);
     sx(0);
     if (!role_b) softmax_a(0);
     if (ntiles > 1) rows_store(1);
@@ -1396,8 +1410,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
   for (int t = 0; t < ((TF_ABL_PAIR & 32) ? 0 : ntiles); ++t) {
     // tiles t, t + 1 are in LDS (tile t + 1's S / dP is done); buffer (t + 2) % 3 is free: everyone has left iteration t - 1
     if (t + 2 < ntiles) { if (!(TF_ABL_PAIR & 1)) dma(t + 2); if (!(TF_ABL_PAIR & 16)) rows_load(t + 2); }
-    if (role_b && !(TF_ABL_PAIR & 2)) ds_b(t);
+    if (role_b && !(TF_ABL_PAIR & 2)) { rows_b(t); ds_b(t); }
     if (t + 1 < ntiles && !(TF_ABL_PAIR & 4)) sx(t + 1);
+    if (!role_b && t + 1 < ntiles && !(TF_ABL_PAIR & 2)) rows_a(t + 1);
     if (!(TF_ABL_PAIR & 8)) accum(t);
     if (!role_b && t + 1 < ntiles && !(TF_ABL_PAIR & 2)) softmax_a(t + 1);
     if (t + 2 < ntiles && !(TF_ABL_PAIR & 16)) rows_store(t + 2);
