@@ -121,3 +121,32 @@ def test_comm_entries_validate_arguments_without_a_gpu(lib):
         assert any(buf.raw)                                                # an id was drawn
     else:
         assert b"librccl" in lib.tf_last_error()
+
+
+def test_shipped_library_reads_no_experiment_switch(lib):
+    """The TF_* environment switches of the launch planners and the ablation blocks exist in EXPERIMENTS builds only
+    (-DTF_EXPERIMENTS: `python -m transfusion_amd.build --exp`, tools/build_variant.sh): the shipped library does not reference
+    getenv and none of the switch names is in the binary, so no environment variable can change what training computes."""
+    import re
+    from transfusion_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(m.group(0).decode() for m in re.finditer(rb"TF_[A-Z][A-Z0-9_]{3,}", blob))
+    assert not names, sorted(names)
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    assert " getenv" not in syms
+    # the switches are still in the sources (behind the macro), i.e. this test would notice one that bypasses it
+    src = "".join(open(os.path.join(ROOT, "transfusion_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "transfusion_amd", "csrc"))
+                  if f.endswith((".hip", ".h")))
+    assert "TF_ENV_INT(\"TF_" in src
+    assert not re.search(r"[^_a-z]getenv\(\"TF_", src)
+
+
+def test_dense_rows_warning_is_said_once():
+    import warnings
+    from transfusion_amd.modeling.cross_fusion.ego_fusion import cross_f_box_layers as m
+    m._warned_dense_rows = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m._warn_dense_rows_once()
+        m._warn_dense_rows_once()
+    assert len(w) == 1 and "lang_valid_rows" in str(w[0].message)

@@ -226,7 +226,7 @@ def test_slowfast_pooling_against_reference_fixture(golden_dir, name, precision)
     layer.precision = precision
     tx = [torch.from_numpy(x).to(dev).requires_grad_(True) for x in xs]
     tokens, none, att = layer(tx, pad_mask=True)
-    assert none is None and torch.equal(att.cpu(), torch.from_numpy(g["att_mask"])) and att.tf_valid_tokens == cfg["B"] * cfg["T"]
+    assert none is None and torch.equal(att.cpu(), torch.from_numpy(g["att_mask"])) and layer.valid_tokens == cfg["B"] * cfg["T"]
     ftol, gtol = (1e-5, 1e-5) if not cfg["out_mlp"] else ((1e-2, 3e-2) if precision == "bf16" else (1e-3, 1e-3))
     assert tokens.dtype == torch.float32 and rel(tokens, g["tokens"]) < ftol
     (tokens * torch.from_numpy(cot).to(dev)).sum().backward()

@@ -7,7 +7,7 @@ name=$1; src=$2; shift 2
 out=build/variants/$name; mkdir -p $out
 python -m transfusion_amd.build >/dev/null
 obj=$out/${src%.hip}.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result "$@" -c transfusion_amd/csrc/$src -o $obj
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result -DTF_EXPERIMENTS "$@" -c transfusion_amd/csrc/$src -o $obj
 objs=""
 for f in gemm_bf16 wgrad_multi attn_bf16 attn_x3 rowops heads comm tf_api; do
   if [ "$f.hip" == "$src" ]; then objs="$objs $obj"; else objs="$objs transfusion_amd/csrc/_obj/$f.o"; fi

@@ -22,6 +22,16 @@
 #include "tf_kernels.h"
 #include "attn_common.h"
 
+// Ablation / variant macros (TF_ABL_FWD, TF_FWD_PRIO, TF_FWD_NO_DMA, TF_ABL_PAIR, TF_DKV16_QT) act in experiments builds only
+// (-DTF_EXPERIMENTS: tools/build_variant.sh); without it they are forced off -- no flag changes what the shipped library computes.
+#ifndef TF_EXPERIMENTS
+#undef TF_ABL_FWD
+#undef TF_FWD_PRIO
+#undef TF_FWD_NO_DMA
+#undef TF_ABL_PAIR
+#undef TF_DKV16_QT
+#endif
+
 namespace {
 
 // ================================================================================================
@@ -1609,12 +1619,12 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
   // do not fit 256 registers.  With a dS workspace those widths still run at two waves per SIMD -- dV and dK as two passes of the
   // 16-row kernel (WHICH = 0 / 1) and the thin dQ kernel; without one they take the 32-row kernels (one wave per SIMD).
   constexpr bool HAS16 = HDP <= 192;
-  static const int dq16 = [] { const char* e = getenv("TF_ATTN_DQ16"); return e ? atoi(e) : 1; }();
-  static const int dkv16 = [] { const char* e = getenv("TF_ATTN_DKV16"); return e ? atoi(e) : 1; }();
+  static const int dq16 = TF_ENV_INT("TF_ATTN_DQ16", 1);
+  static const int dkv16 = TF_ENV_INT("TF_ATTN_DKV16", 1);
   bool done_q = part == 2, done_kv = part == 1;
   {
     constexpr int QT = TF_DKV16_QT;
-    static const int use_ds = [] { const char* e = getenv("TF_ATTN_DS"); return e ? atoi(e) : 1; }();     // A/B switch
+    static const int use_ds = TF_ENV_INT("TF_ATTN_DS", 1);     // A/B switch
     if (part == 0 && use_ds && dq16 && dkv16 && !cross && a->ds_work != nullptr) {
       // S and dP once: delta -> dK / dV (+ dS tiles) -> dQ = dS . K
       const size_t lds_kv16d = 4 * QT * Geo<HDP>::TSTR + 2 * (72 * QT), lds_qd = 64 * Geo<HDP>::TSTR + 4 * 4096;
@@ -1624,11 +1634,7 @@ template <int HDP> int launch_bwd(const TfAttnArgs* a, hipStream_t st, int part)
         TfTraceScope tr("attn_delta_kernel", st, 0.0, 4.0 * a->B * a->S * a->H * HDP);
         hipLaunchKernelGGL(attn_delta_kernel, dim3(a->B * ((a->S + 3) / 4)), dim3(256), 0, st, *a);
       }
-#ifdef TF_EXPERIMENTS
-      static const int use_pair = [] { const char* e = getenv("TF_ATTN_PAIR"); return e ? atoi(e) : 1; }();
-#else
-      constexpr int use_pair = 1;
-#endif
+      static const int use_pair = TF_ENV_INT("TF_ATTN_PAIR", 1);
       if constexpr (HAS16) {
         if (use_pair) {
           constexpr int PQ = TF_DKV_PAIR_QT;

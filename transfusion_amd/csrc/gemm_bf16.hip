@@ -1127,7 +1127,7 @@ int plan_cus();
 int pick_mi(int M, int N, int G = 1) {
   const int slots = 2 * plan_cus();
   const int tn = (N + BN - 1) / BN;
-  static const int env_lo = getenv("TF_GEMM_MI_MIN") ? atoi(getenv("TF_GEMM_MI_MIN")) : 2;       // experiment switch
+  static const int env_lo = TF_ENV_INT("TF_GEMM_MI_MIN", 2);       // experiment switch
   // half-filled chips: the time is one tile's, so the shortest tile that still leaves every CU at most one workgroup wins
   int best = 6; double best_cost = -1.0;
   for (int mi = 6; mi >= (env_lo < 2 ? 2 : env_lo); --mi) {
@@ -1235,7 +1235,7 @@ int num_cus() {
 // the height that makes the tile grid an exact number of rounds changes from step to step; fp8 / fp32-accuracy operands keep 8 / 9.
 int pick_mf(int M, int N, int mf_lo = 5, int G = 1) {
   const int tn = (N + BIG_BN - 1) / BIG_BN, slots = plan_cus();
-  static const int env_lo = getenv("TF_GEMM_MF_MIN") ? atoi(getenv("TF_GEMM_MF_MIN")) : 0;      // experiment switch
+  static const int env_lo = TF_ENV_INT("TF_GEMM_MF_MIN", 0);      // experiment switch
   if (env_lo > mf_lo) mf_lo = env_lo > 9 ? 9 : env_lo;
   int best = 9; long best_cost = -1;
   for (int mf = 9; mf >= mf_lo; --mf) {                 // ties go to the taller tile (fewer W re-stagings)
@@ -1267,7 +1267,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->groups > 1 && (a->M % a->groups) != 0) return -7;          // equal row ranges
   if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
-  static const int big = getenv("TF_GEMM_BIG") ? atoi(getenv("TF_GEMM_BIG")) : 1;
+  static const int big = TF_ENV_INT("TF_GEMM_BIG", 1);
   const double fl = 2.0 * a->M * a->N * a->K;          // algorithmic (the fp32-accuracy mode executes three bf16 passes of it)
   const bool split = a->A_lo != nullptr;
   if (split) {
@@ -1299,17 +1299,17 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     const long rs = (ts + 2 * pc - 1) / (2 * pc);
     const double sh = (ts - (rs - 1) * 2 * pc) * 2 <= 2 * pc ? 0.62 : 1.0;         // (see pick_mi)
     const double t_small = ((double)(rs - 1) + sh) * (8.0 + 0.021 * a->K) * ((mi + 2) / 6.0);
-    static const int model = getenv("TF_GEMM_MODEL") ? atoi(getenv("TF_GEMM_MODEL")) : 1;      // experiment switch
+    static const int model = TF_ENV_INT("TF_GEMM_MODEL", 1);      // experiment switch
     if (model && t_small < t_big) use_big = false;
   }
   // Two workgroups per CU (144 x 256 tiles) for launches of two or more rounds (QKV, FFN-up, FFN-down dgrad at the benchmark shape):
   // see the kernel's header.  TF_GEMM_DUO=0 turns it off, TF_GEMM_DUO_MIN sets the tile threshold, TF_GEMM_DUO_US the stagger.
-  static const int duo = getenv("TF_GEMM_DUO") ? atoi(getenv("TF_GEMM_DUO")) : 1;
-  static const int duo_min = getenv("TF_GEMM_DUO_MIN") ? atoi(getenv("TF_GEMM_DUO_MIN")) : 0;
-  static const double duo_us = getenv("TF_GEMM_DUO_US") ? atof(getenv("TF_GEMM_DUO_US")) : -1.0;
+  static const int duo = TF_ENV_INT("TF_GEMM_DUO", 1);
+  static const int duo_min = TF_ENV_INT("TF_GEMM_DUO_MIN", 0);
+  static const double duo_us = TF_ENV_DBL("TF_GEMM_DUO_US", -1.0);
   if (use_big && duo && !split) {
     const long td = row_tiles(a, 144) * ((a->N + BIG_BN - 1) / BIG_BN);
-    static const int duo_1r = getenv("TF_GEMM_DUO_1R") ? atoi(getenv("TF_GEMM_DUO_1R")) : 0;   // experiment: epilogue bitmask -> also single-round launches
+    static const int duo_1r = TF_ENV_INT("TF_GEMM_DUO_1R", 0);   // experiment: epilogue bitmask -> also single-round launches
     const long need = duo_min > 0 ? duo_min : (((duo_1r >> a->epilogue) & 1) ? num_cus() + 1 : 2L * num_cus() + 1);
     if (td >= need) {
       const double us = duo_us >= 0 ? duo_us : 0.0;
@@ -1336,14 +1336,14 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   const int mi_sel = pick_mi(a->M, a->N, a->groups);
   // at most about one workgroup per CU: the 4-slot ring form (see the kernel's header).  TF_GEMM_RING = percent of the CU count up
   // to which a grid takes it (0 = never).
-  static const int ring_pct = getenv("TF_GEMM_RING") ? atoi(getenv("TF_GEMM_RING")) : 100;
+  static const int ring_pct = TF_ENV_INT("TF_GEMM_RING", 100);
   if (ring_pct > 0 && mi_sel <= 5) {
     const long tiles = row_tiles(a, 32 * mi_sel) * ((a->N + BN - 1) / BN);
     if (tiles * 100 <= (long)ring_pct * num_cus()) {
       char nm[56];
       snprintf(nm, sizeof(nm), "gemm_nt_kernel<%d, %d, 64, ring>", a->epilogue, mi_sel);
       TfTraceScope tr(nm, stream, fl);
-      static const int ring_slots = getenv("TF_GEMM_RING_SLOTS") ? atoi(getenv("TF_GEMM_RING_SLOTS")) : 4;
+      static const int ring_slots = TF_ENV_INT("TF_GEMM_RING_SLOTS", 4);
       if (ring_slots == 3) {
         switch (mi_sel) {
           case 2: return launch_gemm_mi<2, 64, false, 3>(a, stream);
@@ -1378,7 +1378,7 @@ namespace {
 // samples/s; a wgrad that has the chip to itself needs more, smaller blocks to keep two workgroups on every CU (isolated:
 // qkv 121 us with 128x128 vs 161 us with 256x128) and keeps the 128x128 kernel.
 int wgrad_version(bool caller_sized) {
-  static const int v = getenv("TF_WGRAD_V") ? atoi(getenv("TF_WGRAD_V")) : 0;
+  static const int v = TF_ENV_INT("TF_WGRAD_V", 0);
   return v ? v : (caller_sized ? 2 : 1);
 }
 }  // namespace
@@ -1401,8 +1401,8 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   const int steps = (a.M + 31) / 32;
   // Every split adds one full fp32 |dW| of atomic traffic (chip-wide ~1.3 TB/s), so use the FEWEST splits that
   // still give one resident wave of blocks: 256 CUs x 2 blocks.
-  static const int env_slots = getenv("TF_WGRAD_SLOTS") ? atoi(getenv("TF_WGRAD_SLOTS")) : 0;   // experiment switches
-  static const int env_splits = getenv("TF_WGRAD_SPLITS") ? atoi(getenv("TF_WGRAD_SPLITS")) : 0;
+  static const int env_slots = TF_ENV_INT("TF_WGRAD_SLOTS", 0);   // experiment switches
+  static const int env_splits = TF_ENV_INT("TF_WGRAD_SPLITS", 0);
   // Measured on MI355X (M = 22656, 128x128 tiles): the best block count grows with the tile count -- 36 tiles: ~6 splits
   // (216 blocks), 72: 5-6 (360-432), 108: 4 (432) -- i.e. about 200 + 2.15 * tiles blocks, never more than one resident wave.
   int target = env_slots > 0 ? env_slots : (v2 ? 288 : (int)(200 + 2.15 * tiles));
@@ -1426,7 +1426,7 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
     static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     static const hipError_t once3 = hipFuncSetAttribute((const void*)wgrad_tn2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     (void)once; (void)once3;
-    static const int ring = getenv("TF_WGRAD_RING") ? atoi(getenv("TF_WGRAD_RING")) : 3;      // experiment switch (2: 48 KiB)
+    static const int ring = TF_ENV_INT("TF_WGRAD_RING", 3);      // experiment switch (2: 48 KiB)
     if (split) hipLaunchKernelGGL(wgrad_tn2_kernel<true>, grid, block, LDS2, stream, a);
     else if (ring == 2) hipLaunchKernelGGL((wgrad_tn2_kernel<false, 2>), grid, block, LDS2 / 3 * 2, stream, a);
     else hipLaunchKernelGGL(wgrad_tn2_kernel<false>, grid, block, LDS2, stream, a);

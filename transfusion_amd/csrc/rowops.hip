@@ -1085,7 +1085,7 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   const int width = max(a->d, max(a->lddx, a->dx_drop != nullptr ? a->lddxd : 0));
   if (width > 64 * MAXC_MAX * 8) return -2;
   constexpr int nw = 8;        // waves per workgroup (16 measured slower: 39.9 vs 38.3 us; its instantiations spilled and are gone)
-  static const int env_g = getenv("TF_LNB_GRID") ? atoi(getenv("TF_LNB_GRID")) : 512;     // experiment switch
+  static const int env_g = TF_ENV_INT("TF_LNB_GRID", 512);     // experiment switch
   const int pg = a->pgroups > 1 ? a->pgroups : 1;
   if (a->rows % pg) return -2;
   const dim3 grid(grid_for(a->rows / pg, nw, max(1, env_g / pg)), pg);       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
@@ -1240,7 +1240,7 @@ extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStrea
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
   if (total <= 0) return 0;
-  static const int tiled = getenv("TF_PATCH_TILED") ? atoi(getenv("TF_PATCH_TILED")) : 1;
+  static const int tiled = TF_ENV_INT("TF_PATCH_TILED", 1);
   const int cc = tiled ? patch_chunk(a) : 0;
   if (cc > 0) {
     const int nch = (a->C + cc - 1) / cc;

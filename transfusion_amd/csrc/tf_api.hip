@@ -236,19 +236,10 @@ int ncus() {
   }();
   return n;
 }
-int env_int(const char* name, int dflt) {
-#ifdef TF_EXPERIMENTS
-  const char* v = getenv(name);
-  return v != nullptr ? (int)strtol(v, nullptr, 0) : dflt;
-#else
-  (void)name;
-  return dflt;
-#endif
-}
 WPlan wgrad_plan(bool last_layer) {
   // hex digits, lowest first: the products started at positions 0, 1, 2.  A product can start only where its operands exist (W2 | W1
   // from position 0, WO from position 1, WI at position 2); whatever the digits leave out starts at position 2.
-  static const int body = env_int("TF_WGM_BODY", 0x000), tail = env_int("TF_WGM_TAIL", 0x843);
+  static const int body = TF_ENV_INT("TF_WGM_BODY", 0x000), tail = TF_ENV_INT("TF_WGM_TAIL", 0x843);
   const int v = last_layer ? tail : body;
   WPlan p{{v & (W_W2 | W_W1), (v >> 4) & (W_W2 | W_W1 | W_WO), 0}};
   p.at[1] &= ~p.at[0];
@@ -288,7 +279,7 @@ int wgrad_launch(const Ctx& c, Side& sd, const TfWgradArgs* jobs, int mask, bool
   if (sd.st != nullptr && !alone) {
     // Beside the chain: ~1.7 workgroups per CU (three row chunks for a d = 768 layer's 144 tiles: 172 us alone against 210 at two and 207
     // at four), and fewer when M is small, so that a workgroup keeps a few dozen 32-row steps to amortise its prologue and flush
-    static const int per_cu_x10 = env_int("TF_WGM_BLOCKS_X10", 17), min_steps = env_int("TF_WGM_MIN_STEPS", 40);
+    static const int per_cu_x10 = TF_ENV_INT("TF_WGM_BLOCKS_X10", 17), min_steps = TF_ENV_INT("TF_WGM_MIN_STEPS", 40);
     int tiles = 0;
     for (int i = 0; i < n; ++i) tiles += ((sel[i].N + 255) / 256) * ((sel[i].K + 127) / 128) * c.D.G;
     const int steps = (c.D.M / c.D.G + 31) / 32;
@@ -348,7 +339,7 @@ int tf_overlap_create(TfOverlap* o) {
   // TF_SIDE_PRIORITY (experiment): -1 = the device's highest stream priority, 1 = its lowest, unset / 0 = default.  The lowest priority
   // is worth -0.6 % on the single-encoder benchmark (4.235 vs 4.26 ms, same box) and is a disaster for the wrapper, whose four level
   // streams then starve their four side streams (B = 4: 11.5 vs 6.35 ms per step): the default priority stays.
-  static const int prio_sel = getenv("TF_SIDE_PRIORITY") ? atoi(getenv("TF_SIDE_PRIORITY")) : 0;
+  static const int prio_sel = TF_ENV_INT("TF_SIDE_PRIORITY", 0);
   if (prio_sel != 0) {
     int least = 0, greatest = 0;
     TF_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest), "tf_overlap_create(priority range)");

@@ -55,6 +55,19 @@ int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t stream); 
 #endif
 
 #ifdef __cplusplus
+// Experiment switches (TF_* environment variables read by the launch planners) exist in EXPERIMENTS builds only (-DTF_EXPERIMENTS:
+// `python -m transfusion_amd.build --exp`, tools/build_variant.sh -> build/variants/, selected with TFUSION_LIB).  In the shipped
+// library the macros are their defaults: no environment variable can change what it computes, and the names are not even in the binary.
+#ifdef TF_EXPERIMENTS
+#include <cstdlib>
+static inline int tf_env_int_(const char* name, int dflt) { const char* v = getenv(name); return v != nullptr ? (int)strtol(v, nullptr, 0) : dflt; }
+static inline double tf_env_dbl_(const char* name, double dflt) { const char* v = getenv(name); return v != nullptr ? atof(v) : dflt; }
+#define TF_ENV_INT(name, dflt) tf_env_int_(name, dflt)
+#define TF_ENV_DBL(name, dflt) tf_env_dbl_(name, dflt)
+#else
+#define TF_ENV_INT(name, dflt) (dflt)
+#define TF_ENV_DBL(name, dflt) (dflt)
+#endif
 // Launch tracer hook (see tf_trace_start in tfusion.h): a scope object around one kernel launch.  Costs one predictable
 // branch when tracing is off.
 struct TfTraceScope {

@@ -307,11 +307,7 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
   m.count = n; m.chunks = chunks; m.tiles_total = tiles;
   (void)max_steps;
   constexpr int NS = 3, LDS = NS * (32 * 512 + 32 * 256);
-#ifdef TF_EXPERIMENTS
-  static const int intl = getenv("TF_WGM_INTL") ? atoi(getenv("TF_WGM_INTL")) : 1;
-#else
-  constexpr int intl = 1;
-#endif
+  static const int intl = TF_ENV_INT("TF_WGM_INTL", 1);
   dim3 grid((unsigned)tiles * (unsigned)chunks), block(256);
   TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops);
   static const hipError_t o0 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

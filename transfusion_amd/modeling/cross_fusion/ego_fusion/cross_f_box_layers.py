@@ -157,6 +157,21 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, d_vis, d_lang, None) + tuple(grads)
 
 
+_warned_dense_rows = False
+
+
+def _warn_dense_rows_once():
+    """A masked batch reached an encoder in training without ``lang_valid_rows``: the call is the reference's dense computation (every
+    padded token is carried through every row-wise kernel).  Said once, because nothing else would: the results are the same."""
+    global _warned_dense_rows
+    if not _warned_dense_rows:
+        _warned_dense_rows = True
+        import warnings
+        warnings.warn("transfusion_amd: a language padding mask was given without lang_valid_rows -- the encoder runs on dense rows "
+                      "(padded tokens included).  Pass lang_valid_rows=<number of un-masked tokens> (the pooling layer's valid_tokens) "
+                      "to drop them from the row-wise kernels.", RuntimeWarning, stacklevel=3)
+
+
 class CrossTransformerModuleBox(nn.Module):
     def __init__(
         self,
@@ -453,6 +468,8 @@ class CrossTransformerModuleBox(nn.Module):
         self._packed_rows = 0
         if lang_valid_rows is not None and language_tokens_att_maks is not None and self.pack_tokens:
             self._packed_rows = x.shape[0] * x.shape[1] + int(lang_valid_rows)
+        elif language_tokens_att_maks is not None and self.pack_tokens and self.training:
+            _warn_dense_rows_once()
         self._block_bits = None
         if vis_tokens_mask is not None:
             self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)

@@ -172,8 +172,9 @@ class CrossFusionBoxWrapper(nn.Module):
         if att_mask is None:
             raise RuntimeError("the pooling layer returned no attention mask (IdentityLayer trap, narr_pooling_layers.py:409-414)")
         pad_mask = ~(att_mask.type(torch.bool))     # HF mask (1 = token) -> torch convention (True = ignore), reference :196
-        # host-side count of real language tokens, when the pooling layer knows it: the encoders then run on the packed token rows
-        n_valid = getattr(att_mask, "tf_valid_tokens", None)
+        # host-side count of real language tokens, when the pooling layer knows it (SlowFastPooling.valid_tokens, set by the call
+        # above): the encoders then run on the packed token rows
+        n_valid = getattr(self.narr_pooling_layer, "valid_tokens", None)
         fused_l_features = None
         mscale_l_features = []
         # The feature levels are independent of each other unless language_f is forwarded from level to level (forward_language_f,

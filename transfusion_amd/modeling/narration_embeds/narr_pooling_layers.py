@@ -64,8 +64,10 @@ class SlowFastPooling(nn.Module):
         p_out = float(self.out_dropout.p) if self.training else 0.0
         tensor = ops.pool_norm(tensor, lens_t if min(lens) != T else None, self.use_out_tanh, p_out)
         # the number of real tokens in the batch, known here on the host: with it the fusion encoders drop the padded tokens from their
-        # row-wise kernels (CrossTransformerModuleBox.forward(..., lang_valid_rows=...)) instead of carrying them as dead rows
-        att_mask.tf_valid_tokens = int(sum(lens))
+        # row-wise kernels (CrossTransformerModuleBox.forward(..., lang_valid_rows=...)) instead of carrying them as dead rows.  It is
+        # kept on the LAYER (the reference's three-value return stays as it is; an attribute hung on the mask tensor would be lost by
+        # the first op applied to the mask): the wrapper reads `valid_tokens` right after this call.
+        self.valid_tokens = int(sum(lens))
         return tensor, None, att_mask
 
 
