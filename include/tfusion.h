@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 4
+#define TF_ABI_VERSION 5
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -220,6 +220,9 @@ typedef struct TfRadamArgs {
   // step_size, rectified are formed on the device from it (degenerated_to_sgd: radam_optim.py:31,80-84)
   const uint32_t* step_clock; long long step0; int degenerated_to_sgd;
   int zero_grad;                                  // != 0: g[i] = 0 after it has been read (the next step's zero fill, fused: g is writable then)
+  const float* lr_dev;                            // optional device scalar: the learning rate is *lr_dev instead of lr -- a step captured in
+                                                  // a HIP graph would otherwise replay the rate it was captured with under the reference's
+                                                  // warm-up / multi-step schedulers (runner/nao/abc_nao_trainer.py:197-212)
 } TfRadamArgs;
 
 // language auxiliary head, pooling stage (modeling/cross_fusion/ego_fusion/lm_layers.py:59-72, PoolPredictor.forward):

@@ -376,3 +376,21 @@ def test_lr_scale_builds_contiguous_ranges_with_their_own_rate():
         p = g["params"][0]
         assert p.data_ptr() == tr.flat.flat.data_ptr() + 4 * lo and p.numel() == hi - lo
         assert p.grad.data_ptr() == tr.flat.grad.data_ptr() + 4 * lo
+
+
+def test_graph_capture_guard_names_the_nested_stream_fork():
+    """runner.trainer.check_capturable: a wrapper that ran its levels on level streams while the encoders fork weight-gradient side
+    streams cannot be captured (hipStreamEndCapture crashes on the nested fork, ROCm 7.2) -- a ValueError, not a core dump."""
+    import torch
+    from transfusion_amd.runner.trainer import check_capturable
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, path):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 2)
+            self._last_path = path
+    tree = torch.nn.Sequential(torch.nn.Linear(2, 2), Wrapper("streams"))
+    with pytest.raises(ValueError, match="TF_LEVEL_STREAMS=0"):
+        check_capturable(tree, True)
+    check_capturable(tree, False)                                  # no side streams: one fork level, capturable
+    check_capturable(torch.nn.Sequential(Wrapper("grouped"), Wrapper("loop")), True)

@@ -209,3 +209,62 @@ def test_lr_scale_ranges_equal_parameter_groups():
     torch.cuda.synchronize()
     for (n, p), q in zip(a.named_parameters(), b.parameters()):
         assert (p - q).abs().max().item() < 1e-6, n
+
+
+def test_replays_follow_the_lr_scheduler():
+    """A captured step reads its learning rate from a device scalar (TfRadamArgs.lr_dev) that replay() refreshes from
+    ``param_groups``: replays under a schedule that moves the rate equal eager steps under the same schedule (dropout off, one batch)."""
+    dev = _dev()
+    from transfusion_amd import ops
+    from transfusion_amd.optim import FusedRAdam
+    from transfusion_amd.runner.trainer import FusionTrainStep, GraphedTrainStep
+    opt_cls = lambda params, lr, weight_decay: FusedRAdam(params, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+    rates = [0.05, 0.05, 0.01, 0.002, 0.03]
+    finals = []
+    for graphed in (False, True):
+        ops.clock_set(0)
+        enc = _encoder(dev)
+        enc.token_dropout = enc.patch_dropout = 0.0
+        for m in enc.modules():
+            if hasattr(m, "pack_tokens"):
+                m.pack_tokens = False
+        tr = FusionTrainStep(enc, lr=rates[0], weight_decay=1e-3, grad_clip=1.0, optimizer_cls=opt_cls)
+        batch = _batch(dev, 0)
+        if graphed:
+            gs = GraphedTrainStep(tr, batch, _loss, warmup=1)               # step 1 at rates[0]
+            for r in rates[1:]:
+                for g in tr.opt.param_groups:
+                    g["lr"] = r
+                gs.replay()
+            gs.finish()
+        else:
+            for r in rates:
+                for g in tr.opt.param_groups:
+                    g["lr"] = r
+                ops.clock_advance()
+                tr.step([batch], _loss, on_clock=True)
+        torch.cuda.synchronize()
+        finals.append(tr.flat.flat.detach().cpu().clone())
+    ops.clock_set(0)
+    assert (finals[0] - finals[1]).abs().max().item() < 2e-5
+    # ... and the schedule mattered: constant-rate steps end elsewhere
+    assert (finals[0] - _constant_rate_reference(dev, rates[0], len(rates), opt_cls)).abs().max().item() > 1e-3
+
+
+def _constant_rate_reference(dev, lr, steps, opt_cls):
+    from transfusion_amd import ops
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    ops.clock_set(0)
+    enc = _encoder(dev)
+    enc.token_dropout = enc.patch_dropout = 0.0
+    for m in enc.modules():
+        if hasattr(m, "pack_tokens"):
+            m.pack_tokens = False
+    tr = FusionTrainStep(enc, lr=lr, weight_decay=1e-3, grad_clip=1.0, optimizer_cls=opt_cls)
+    batch = _batch(dev, 0)
+    for _ in range(steps):
+        ops.clock_advance()
+        tr.step([batch], _loss, on_clock=True)
+    torch.cuda.synchronize()
+    ops.clock_set(0)
+    return tr.flat.flat.detach().cpu().clone()

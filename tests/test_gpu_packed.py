@@ -219,6 +219,22 @@ def test_wrong_count_is_reported_and_harmless(dev):
         assert enc.packed_row_error() == 0
         enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()) - 3)
         assert enc.packed_row_error() == true_rows
+        # ... and the host hears about it without asking: the word travels behind every packed forward, the next call (or an explicit
+        # check) raises
+        from transfusion_amd._lib import TfError
+        from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import check_packed_row_errors
+        with pytest.raises(TfError, match="lang_valid_rows"):
+            check_packed_row_errors(sync=True)
+        # a count that is too LARGE: rows no token maps to are zero rows, nothing is read or written out of range, outputs stay finite
+        vis, lo, _, _ = enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()) + 5)
+        torch.cuda.synchronize()
+        assert torch.isfinite(vis).all() and torch.isfinite(lo).all()
+        assert enc.packed_row_error() == true_rows
+        with pytest.raises(TfError, match="lang_valid_rows"):
+            enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()))       # raised by the NEXT packed call
+        enc(t(x), t(lang), t(mask), lang_valid_rows=int((~mask).sum()))
+        assert enc.packed_row_error() == 0
+        check_packed_row_errors(sync=True)
     with pytest.raises(ValueError):
         enc(t(x), t(lang), t(mask), lang_valid_rows=cfg["B"] * cfg["Nl"] + 1)
     enc.pack_tokens = False                                    # the switch: the count is then ignored

@@ -214,6 +214,13 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   const int row = blockIdx.x * 4 + wave;
   if (row >= (a.row_map != nullptr ? a.rows : a.B * S)) return;
   const int dense = a.row_map != nullptr ? a.row_map[row] : row;       // packed batches: the (sample, position) this row is gathered from
+  if (dense < 0) {                                                      // a row no token maps to (the host's row count exceeded the mask's): zeros
+    for (int c = lane * 8; c < a.ld_out; c += 512) {
+      *(u32x4*)((u16*)a.out + (size_t)row * a.ld_out + c) = u32x4{0, 0, 0, 0};
+      if (a.out_lo != nullptr) *(u32x4*)((u16*)a.out_lo + (size_t)row * a.ld_out + c) = u32x4{0, 0, 0, 0};
+    }
+    return;
+  }
   const int b = dense / S, s = dense - b * S;
   // parameter groups (TfAssembleArgs.pgroups): sample b belongs to group b / (B / pgroups); its kind embeddings sit p_gstride bytes apart
   const long long poff = a.pgroups > 1 ? (long long)(b / (a.B / a.pgroups)) * a.p_gstride : 0;
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
   const long long poff = (long long)blockIdx.y * a.p_gstride;
   for (int row = row_lo + blockIdx.x * 4 + wave; row < row_lo + nrows_g; row += gridDim.x * 4) {
     const int dense = a.row_map != nullptr ? a.row_map[row] : row;
+    if (dense < 0) continue;                                           // (wave-uniform) a row no token maps to: see assemble_fwd_kernel
     const int b = dense / S, s = dense - b * S;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -440,11 +448,17 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
 //   dense_of[m]      b * S + s of packed row m
 //   packed_of_lang[b * Nl + j]   packed row of language token j of sample b, or -1 when it is masked
 // One workgroup (B is a few dozen samples of a few hundred tokens): a wave per sample counts, every thread ranks one sample, thread 0
-// scans the positions, a wave per sample fills.  err[0] is set to the mask's total when it differs from the host's `expected`.
+// scans the positions, a wave per sample fills.
+// The host passes the row COUNT (`expected`: it sizes every grid and the workspace); the maps come from the mask.  When the two
+// disagree (err[0] = the mask's total; with groups: also when a group's rows are not expected / groups) the maps are still made SAFE
+// for a launch sequence of `expected` rows: no sample extends past row `expected` (cu and start_of are clamped, tokens past it map
+// to -1 in packed_of_lang: they come back as zero rows), and rows no token maps to hold dense_of = -1, which the assemble kernels
+// turn into zero rows.  Such a step computes garbage for the truncated samples -- and the host raises on the error word at its next
+// call -- but every access stays inside the `expected`-row tensors.
 __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
                                                        int* __restrict__ start_of, int* __restrict__ dense_of, int* __restrict__ packed_of_lang,
                                                        int expected, int* __restrict__ err, int groups) {
-  extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position)
+  extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position) | total
   int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int S = Nv + Nl;
@@ -470,14 +484,22 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int p = 0; p < B; ++p) { const int c = start[p + 1]; start[p] = run; cu[p] = run; run += c; }
-    start[B] = run; cu[B] = run;
-    if (run != expected) err[0] = run;
+    bool bad = false;
+    const int Bg = B / groups;
+    for (int p = 0; p < B; ++p) {
+      const int c = start[p + 1];
+      if (groups > 1 && p % Bg == 0 && run != (p / Bg) * (expected / groups)) bad = true;      // every group owns expected / groups rows
+      start[p] = run; cu[p] = min(run, expected); run += c;
+    }
+    start[B] = run; cu[B] = min(run, expected);
+    err[0] = (run != expected || bad) ? run : 0;                    // (this forward's verdict: the word does not accumulate)
   }
   __syncthreads();
+  const int total = start[B];
+  for (int i = total + (int)threadIdx.x; i < expected; i += blockDim.x) dense_of[i] = -1;       // rows no token maps to
   for (int b = wave; b < B; b += nw) {
     const int base = start[pos_of[b]];
-    if (lane == 0) start_of[b] = base;
+    if (lane == 0) start_of[b] = max(0, min(base, expected - Nv));
     for (int i = lane; i < Nv; i += 64) dense_of[base + i] = b * S + i;
     int run = base + Nv;
     for (int j0 = 0; j0 < Nl; j0 += 64) {
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
       const unsigned long long m = __ballot(ok);
       const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
       if (ok) dense_of[pos] = b * S + Nv + j;
-      if (j < Nl) packed_of_lang[(size_t)b * Nl + j] = ok ? pos : -1;
+      if (j < Nl) packed_of_lang[(size_t)b * Nl + j] = (ok && pos < expected) ? pos : -1;
       run += __popcll(m);
     }
   }
@@ -551,6 +573,7 @@ __global__ void cast_bf16_f32_kernel(const u16* __restrict__ s, float* __restric
 // normally computes (radam_optim.py:64-84; optim.radam_schedule) are formed here, in double, by every thread alike.
 __global__ __launch_bounds__(256) void radam_kernel(const TfRadamArgs a_in) {
   TfRadamArgs a = a_in;
+  if (a.lr_dev != nullptr) a.lr = *a.lr_dev;
   if (a.step_clock != nullptr) {
     const double t = (double)(a.step0 + (long long)*a.step_clock);
     const double b2t = pow((double)a.beta2, t), b1t = pow((double)a.beta1, t);

@@ -97,9 +97,13 @@ class _EncoderFn(torch.autograd.Function):
         desc.vis_out, desc.vis_out_is_f32 = L.ptr(vis_out), ops._is_f32(vis_out)
         desc.lang_out, desc.lang_out_is_f32 = L.ptr(lang_out), ops._is_f32(lang_out)
         st = ops._stream()
+        if desc.packed_rows > 0:
+            check_packed_row_errors(sync=False)          # an earlier call whose lang_valid_rows disagreed with its mask raises here
         desc.repack = 1 if mod._wpack_dirty() else 0     # bf16 weight shadows are refreshed inside the forward call
         L.call("tf_encoder_fwd", desc, st)
         desc.repack = 0
+        if desc.packed_rows > 0 and not torch.cuda.is_current_stream_capturing():
+            _watch_packed_rows(desc, st, x.device)
         ctx.mod, ctx.desc, ctx.keep, ctx.gen = mod, desc, keep, keep["gen"]
         ctx.group_mods = list(mod._group_mods) if mod._group_mods else None
         mod._last_desc = desc               # debug / test hooks (packed_row_error, peek)
@@ -155,6 +159,42 @@ class _EncoderFn(torch.autograd.Function):
         if direct:
             return (None, None, d_vis, d_lang, None) + (None,) * ctx.nparams
         return (None, None, d_vis, d_lang, None) + tuple(grads)
+
+
+# ---- packed batches: the host's row count against the mask's, read back lazily ------------------------------------------------------
+# The device finds a `lang_valid_rows` that disagrees with the mask (row_map_kernel: it then keeps every access inside the tensors the
+# host sized, and the step computes garbage for the truncated samples).  The error word travels to pinned host memory behind the
+# forward, on its stream, with an event -- no host synchronisation in the step -- and the NEXT packed forward whose copy has landed
+# raises (``check_packed_row_errors(sync=True)`` waits for all of them: end of an epoch, tests).
+_packed_flags = []
+
+
+def _watch_packed_rows(desc, stream, device):
+    host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+    L.check(L.load().tf_encoder_packed_error(C.byref(desc), C.c_void_p(host.data_ptr()), C.c_void_p(stream)), "tf_encoder_packed_error")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _packed_flags.append((host, ev, int(desc.packed_rows)))
+    if len(_packed_flags) > 64:
+        check_packed_row_errors(sync=False)
+        del _packed_flags[:-64]
+
+
+def check_packed_row_errors(sync: bool = True):
+    """Raises TfError for any earlier packed forward whose ``lang_valid_rows`` disagreed with its padding mask."""
+    while _packed_flags:
+        host, ev, want = _packed_flags[0]
+        if not sync and not ev.query():
+            break
+        if sync:
+            ev.synchronize()
+        _packed_flags.pop(0)
+        got = int(host[0])
+        if got != 0:
+            _packed_flags.clear()
+            raise L.TfError(f"lang_valid_rows: an earlier forward was told {want} token rows, its padding mask holds {got} "
+                            "(the count must be B * Nv + the number of un-masked language tokens; with grouped levels every group must "
+                            "drop the same tokens).  That step's outputs and gradients are wrong.")
 
 
 _warned_dense_rows = False

@@ -196,6 +196,8 @@ class CrossFusionBoxWrapper(nn.Module):
             fused_l_features = grouped[1][-1]
         parallel = (grouped is None and main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
                     and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
+        # which way the levels went (read by runner.trainer.check_capturable: level streams + side streams cannot be graph-captured)
+        self._last_path = "grouped" if grouped is not None else ("streams" if parallel else "loop")
         if main is not None:
             # the GEMMs plan their tile grids for their share of the chip while the levels run side by side (backward included:
             # autograd replays the levels on the same streams)

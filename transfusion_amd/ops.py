@@ -213,6 +213,11 @@ def overlap_handle(device):
     return _overlap_cache[_overlap_key(device)]
 
 
+def wgrad_overlap_enabled() -> bool:
+    """Whether encoder calls fork a side stream for their weight gradients (``TF_WGRAD_OVERLAP=0`` keeps one stream)."""
+    return os.environ.get("TF_WGRAD_OVERLAP", "1") != "0"
+
+
 def wgrad_overlap(device):
     """Address of the ``TfOverlap`` (side stream + events on which ``tf_encoder_bwd`` issues its weight-gradient GEMMs) that belongs to
     the CURRENT stream of ``device``, created on first use: encoders that run concurrently on different streams (the wrapper's feature

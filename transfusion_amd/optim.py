@@ -50,6 +50,24 @@ class FusedRAdam(torch.optim.Optimizer):
         self.degenerated_to_sgd = degenerated_to_sgd
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def lr_device(self, group, device):
+        """The group's learning rate as a one-element device tensor (created on first use, holding the current ``group['lr']``): what
+        ``step(on_clock=True)`` hands to the kernel, so that a step replayed from a HIP graph follows the LR scheduler."""
+        t = group.get("_lr_dev")
+        if t is None or t.device != device:
+            t = torch.full((1,), float(group["lr"]), dtype=torch.float32, device=device)
+            group["_lr_dev"], group["_lr_dev_val"] = t, float(group["lr"])
+        return t
+
+    def refresh_lr(self):
+        """Copies every group's current ``lr`` into its device scalar (no-op for groups whose rate has not changed).  Call OUTSIDE a graph
+        capture, before a replay: GraphedTrainStep.replay() does."""
+        for g in self.param_groups:
+            t = g.get("_lr_dev")
+            if t is not None and g.get("_lr_dev_val") != float(g["lr"]):
+                t.fill_(float(g["lr"]))
+                g["_lr_dev_val"] = float(g["lr"])
+
     def grad_sumsq(self, out: torch.Tensor):
         """Accumulates sum(g^2) of every gradient into the 1-element fp32 tensor ``out`` (device side)."""
         lib = L.load()
@@ -71,6 +89,8 @@ class FusedRAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         st = ops._stream()
+        if on_clock and not torch.cuda.is_current_stream_capturing():
+            self.refresh_lr()             # eager calls on the clock read the rate from the device scalar too: keep it current
         for g in self.param_groups:
             beta1, beta2 = g["betas"]
             for p in g["params"]:
@@ -94,6 +114,7 @@ class FusedRAdam(torch.optim.Optimizer):
                                   clip=float(clip), zero_grad=1 if zero_grad else 0)
                 if on_clock:      # step = step0 + *clock: right now, and after every advance of the clock (one per replay)
                     a.step_clock, a.step0, a.degenerated_to_sgd = ops.clock_ptr(), step - ops.clock_value(), int(self.degenerated_to_sgd)
+                    a.lr_dev = L.ptr(self.lr_device(g, p.device))     # ... and the rate is read from the device (refresh_lr())
                 L.call("tf_radam_step", a, st)
                 # the kernel wrote through a raw pointer: tell autograd / the encoders' bf16 weight-shadow cache
                 # (CrossTransformerModuleBox._wpack_dirty keys on (data_ptr, _version)) that the tensor changed

@@ -489,6 +489,23 @@ class FusionTrainStep:
             m.mark_weights_updated()
 
 
+def check_capturable(module, overlap_on: bool):
+    """Raises ValueError for a module tree whose step cannot be captured in a HIP graph on this runtime: a wrapper whose last forward
+    ran its feature levels on LEVEL STREAMS (``_last_path == "streams"``) while the encoders fork a side stream of their own for the weight
+    gradients.  Every fork of that step is joined (an encoder call waits for its side stream's done event on the level stream it ran on;
+    the wrapper makes the origin wait for every level stream), so the capture is legal by the API's rules and each fork level alone
+    captures and replays correctly -- but ending a capture with the SECOND level of forks present crashes inside hipStreamEndCapture
+    (ROCm 7.2: a segmentation fault in the runtime, gpurun_out/wg.txt of round 3, not an error code).  Refusing here turns a core dump
+    into an exception that names the two ways out."""
+    for m in module.modules():
+        if getattr(m, "_last_path", None) == "streams" and overlap_on:
+            raise ValueError(
+                f"GraphedTrainStep: {type(m).__name__} runs its feature levels on their own streams and every level's encoder forks a side "
+                "stream for its weight gradients; hipStreamEndCapture crashes on that nested fork (ROCm 7.2).  Capture with the levels on "
+                "one stream (TF_LEVEL_STREAMS=0), without the side streams (TF_WGRAD_OVERLAP=0), or with the levels as one grouped call "
+                "(parameters in FusionTrainStep's flat layout, equal token grids).")
+
+
 class GraphedTrainStep:
     """A whole training step of a ``FusionTrainStep`` -- forward, backward, clip, fused RAdam -- captured ONCE in a HIP graph and
     replayed: one host call per step instead of several hundred kernel launches, event records and autograd nodes.  For the
@@ -525,6 +542,7 @@ class GraphedTrainStep:
                 trainer.step([batch], loss_fn, on_clock=True)
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        check_capturable(trainer.module, ops.wgrad_overlap_enabled())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
             ops.clock_advance()
@@ -550,7 +568,10 @@ class GraphedTrainStep:
         copy(self.batch, batch)
 
     def replay(self):
-        """One optimiser step.  Returns the (static) loss tensor of that step."""
+        """One optimiser step.  Returns the (static) loss tensor of that step.  The learning rate of every parameter group is read from
+        a device scalar that is refreshed here (an LR scheduler may have moved ``param_groups[i]['lr']`` since the last replay)."""
+        if hasattr(self.trainer.opt, "refresh_lr"):
+            self.trainer.opt.refresh_lr()                # (on the current stream: the one graph.replay() launches on)
         self.graph.replay()
         self.replays += 1
         self._ops._clock_host[0] += 1                    # the graph advanced the device word
