@@ -31,6 +31,26 @@ LEVEL_CASES = {
 }
 
 
+# The wrapper's level loop over SEVERAL FPN levels with the reference's real token geometry (cross_fusion_config_sym_ego_res50.yml:8-17:
+# patches of 4, 4, 2, 1 on maps of stride 4 / 8 / 16 / 32 -> level 0 holds four times the tokens of levels 1 - 3), one shared narration
+# input with padding, every level with its own encoder / patch embedding / back-projection (cross_f_box_wrapper.py:177-212).
+MLEVEL_CASES = {
+    "mlevel_4n_n_n_n": dict(B=2, d=64, h=4, L=2, Nl=7, mask_lens=[7, 3], seed=401,
+                            levels=[dict(C=16, H=8, W=8, p=2), dict(C=16, H=4, W=4, p=2), dict(C=64, H=2, W=2, p=1), dict(C=64, H=2, W=2, p=1)]),
+}
+
+
+def make_mlevel_case(cfg):
+    """-> (lang [B, Nl, d], mask [B, Nl] bool (True = pad), per level: dict(params, feat, conv_w, reg_w, reg_b, gout))"""
+    B, d, L = cfg["B"], cfg["d"], cfg["L"]
+    _, lang, mask, _, _ = make_encoder_inputs(cfg["seed"], B, 1, cfg["Nl"], d, cfg["mask_lens"])
+    levels = []
+    for i, lv in enumerate(cfg["levels"]):
+        feat, conv_w, reg_w, reg_b, gout = make_level_extras(cfg["seed"] + 10 * (i + 1), B, lv["C"], lv["H"], lv["W"], lv["p"], d)
+        levels.append(dict(params=make_encoder_params(cfg["seed"] + 10 * (i + 1), d, L), feat=feat, conv_w=conv_w, reg_w=reg_w, reg_b=reg_b, gout=gout))
+    return lang, mask, levels
+
+
 def encoder_param_shapes(d: int, L: int, ff_mult: int = 2):
     ff = int(d * ff_mult)
     shapes = {

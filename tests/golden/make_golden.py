@@ -24,9 +24,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (ASYM_CASES, ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, POOL_CASES, QKV_CASES, RADAM_CASES,  # noqa: E402
-                   make_asym_case, make_encoder_inputs, make_encoder_params, make_heads_case, make_level_extras, make_lm_case,
-                   make_pool_case, make_qkv_case, make_radam_case)
+from cases import (ASYM_CASES, ENCODER_CASES, HEADS_CASES, IGNORE_VERB_IDX_BG, LEVEL_CASES, LM_CASES, MLEVEL_CASES, POOL_CASES, QKV_CASES,  # noqa: E402
+                   RADAM_CASES, make_asym_case, make_encoder_inputs, make_encoder_params, make_heads_case, make_level_extras, make_lm_case,
+                   make_mlevel_case, make_pool_case, make_qkv_case, make_radam_case)
 
 REF = os.environ.get("TF_REFERENCE", "/root/reference")
 
@@ -152,6 +152,57 @@ def run_level_case(name, cfg, Enc, ref_utils):
             out["gradp/" + k] = p_.grad.numpy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "ok", fused.shape)
+
+
+def run_mlevel_case(name, cfg, Enc, ref_utils):
+    """The wrapper's level loop (cross_f_box_wrapper.py:177-212) over several levels of unequal token count, driven through the importable
+    reference pieces in the wrapper's order; the narration tokens and their padding mask are shared by the levels
+    (forward_language_f: False), the loss takes every level's fused feature map.  Records per level: the fused map, the gradient of its
+    feature map, of its patch embedding / back-projection and of EVERY encoder parameter; and the gradient of the shared narration
+    tokens (the sum over the levels)."""
+    lang, mask, levels = make_mlevel_case(cfg)
+    B, d = cfg["B"], cfg["d"]
+    tl = torch.from_numpy(lang).requires_grad_(True)
+    tm = torch.from_numpy(mask)
+    out = {"in_lang": lang, "in_mask": mask}
+    loss = 0.0
+    keep = []
+    for i, (lv, data) in enumerate(zip(cfg["levels"], levels)):
+        C, H, W, p = lv["C"], lv["H"], lv["W"], lv["p"]
+        pe = ref_utils.PositionalEmbeddingLayer("sin1d", 8192, d)
+        enc = Enc(no_patches=8192, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=cfg["L"], patch_dropout=0.0,
+                  num_heads=cfg["h"], fforward_multiplier=2, token_dropout=0.0, back_to_img_fn="regroup", activ_f="gelu", final_norm="ln",
+                  input_f_size=d)
+        missing, unexpected = enc.load_state_dict({k: torch.from_numpy(v) for k, v in data["params"].items()}, strict=False)
+        assert set(missing) == {"padding_mask", "pos_embedding_layer.pos_embedding"} and not unexpected
+        conv = torch.nn.Conv2d(C, d, kernel_size=(p, p), stride=(p, p), bias=False)     # wrapper :268-274
+        conv.weight.data.copy_(torch.from_numpy(data["conv_w"]))
+        reg = ref_utils.RegroupPatchesLayerBox(d, 1, 1, p, p, C, 0.0, None)              # wrapper :126-137
+        reg.linear.weight.data.copy_(torch.from_numpy(data["reg_w"]))
+        reg.linear.bias.data.copy_(torch.from_numpy(data["reg_b"]))
+        enc.train(); conv.train(); reg.train()
+        tf = torch.from_numpy(data["feat"]).requires_grad_(True)
+        reg.init_h, reg.init_w = H, W                                                    # wrapper :180-181
+        tok = ref_utils.patchify_image(conv(tf), 1, 1)                                   # wrapper :183-185
+        vis, lang_out, _, _ = enc(tok, tl, tm, vis_tokens_mask=None)                     # the SAME language tokens on every level
+        fused = reg(vis)                                                                 # wrapper :211
+        loss = loss + (fused * torch.from_numpy(data["gout"])).sum()
+        keep.append((tf, conv, reg, enc, fused, lang_out))
+        for k, v_ in data["params"].items():
+            out[f"l{i}/param/{k}"] = v_
+        out.update({f"l{i}/in_feat": data["feat"], f"l{i}/cot_out": data["gout"], f"l{i}/conv_w": data["conv_w"], f"l{i}/reg_w": data["reg_w"],
+                    f"l{i}/reg_b": data["reg_b"]})
+    loss.backward()
+    for i, (tf, conv, reg, enc, fused, lang_out) in enumerate(keep):
+        out.update({f"l{i}/fused": fused.detach().numpy(), f"l{i}/lang_out": lang_out.detach().numpy(), f"l{i}/grad_feat": tf.grad.numpy(),
+                    f"l{i}/grad_conv_w": conv.weight.grad.numpy(), f"l{i}/grad_reg_w": reg.linear.weight.grad.numpy(),
+                    f"l{i}/grad_reg_b": reg.linear.bias.grad.numpy()})
+        for k, p_ in enc.named_parameters():
+            if p_.grad is not None:
+                out[f"l{i}/gradp/{k}"] = p_.grad.numpy()
+    out["grad_lang"] = tl.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", [tuple(k[4].shape) for k in keep])
 
 
 def run_lm_case(name, cfg):
@@ -425,6 +476,9 @@ def main():
     for name, cfg in LEVEL_CASES.items():
         if want(name):
             run_level_case(name, cfg, Enc, ref_utils)
+    for name, cfg in MLEVEL_CASES.items():
+        if want(name):
+            run_mlevel_case(name, cfg, Enc, ref_utils)
     for name, cfg in LM_CASES.items():
         if want(name):
             run_lm_case(name, cfg)

@@ -148,8 +148,9 @@ def test_wrapper_levels_grouped_equal_level_loop(monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("TF_GROUP_LEVELS", mode)
         tr.zero_grad()
-        for f in feats:
-            f.grad = None
+        # fresh leaves per mode: a leaf's AccumulateGrad node remembers the stream of its first use, and the two modes deliver the
+        # feature-map gradients on different streams (level streams / the grouped call's) -- in training one mode runs for good
+        feats = [f.detach().clone().requires_grad_(True) for f in feats]
         out = model({"image": feats, "language_f": lang})
         fs = [out["features"][str(i)] for i in range(4)]
         if gouts is None:

@@ -424,3 +424,89 @@ def test_three_levels_in_one_forward_against_oracle(monkeypatch, precision, stre
                 assert rel(prm.grad, sd[k].grad) < gtol, (i, k)
     valid = ~torch.from_numpy(mask)
     assert rel(lang_dev.grad.cpu()[valid], lang_ref.grad[valid]) < gtol          # sum over the three levels (valid rows; padded rows get none)
+
+
+@pytest.mark.parametrize("precision,packed", [(16, True), (16, False), (32, True)])
+def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, packed):
+    """The reference's level loop over four levels with its real token geometry (Nv = 4N, N, N, N; one shared, padded narration input)
+    against the REFERENCE-generated fixture, through the path the training step takes: parameters in FusionTrainStep's flat layout, so
+    that levels 1 - 3 run as ONE grouped encoder call and level 0 beside them on its own stream.  Every level's fused map, the gradient
+    of every feature map, of the shared narration tokens (summed over the levels) and of EVERY parameter; bf16 and fp32-accuracy mode,
+    packed and dense rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from cases import MLEVEL_CASES
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    dev = torch.device("cuda:0")
+    name = "mlevel_4n_n_n_n"
+    cfg = MLEVEL_CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    B, d, lv = cfg["B"], cfg["d"], cfg["levels"]
+    n = len(lv)
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": list(range(n)), "replace_fpn_features": True, "patch_h": [l["p"] for l in lv], "patch_w": [l["p"] for l in lv],
+                   "backproj_dropout": 0.0})
+    fusion["args"].update({"num_layers": [cfg["L"]] * n, "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": precision,
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in lv], [l["C"] for l in lv]), {}, run_cfg, None).to(dev).train()
+    for i in range(n):
+        pre = f"l{i}/"
+        model.cross_fusion_encoders[i].load_state_dict({k[len(pre) + 6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre + "param/")},
+                                                       strict=False)
+        model.patches_to_token[i].weight.data.copy_(torch.from_numpy(g[pre + "conv_w"]))
+        model.tokens_to_features[i].linear.weight.data.copy_(torch.from_numpy(g[pre + "reg_w"]))
+        model.tokens_to_features[i].linear.bias.data.copy_(torch.from_numpy(g[pre + "reg_b"]))
+    lens = [int((~g["in_mask"][b]).sum()) for b in range(B)]
+
+    class PassThroughPooling(torch.nn.Module):           # the fixture starts at the language tokens (the pooling layer has its own fixtures)
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, k in enumerate(lens):
+                m[b, k:] = 0
+            if packed:
+                self.valid_tokens = sum(lens)             # what SlowFastPooling leaves for the wrapper: the encoders run on packed rows
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    tr = FusionTrainStep(model, lr=0.0, weight_decay=0.0, grad_clip=None)          # lr 0: the step leaves parameters and gradients to read
+    feats = [torch.from_numpy(g[f"l{i}/in_feat"]).to(dev).requires_grad_(True) for i in range(n)]
+    lang = torch.from_numpy(g["in_lang"]).to(dev).requires_grad_(True)
+    got = {}
+
+    def loss_fn(m, _):
+        out = m({"image": feats, "language_f": [lang[b] for b in range(B)]})
+        got["fused"] = [out["features"][str(i)] for i in range(n)]
+        return sum((got["fused"][i].float() * torch.from_numpy(g[f"l{i}/cot_out"]).to(dev)).sum() for i in range(n))
+
+    tr.step([None], loss_fn)
+    torch.cuda.synchronize()
+    # the path under test: levels 1 - 3 as one grouped call, level 0 beside it
+    assert int(model.cross_fusion_encoders[1]._last_desc.groups) == 3 and int(model.cross_fusion_encoders[0]._last_desc.groups) in (0, 1)
+    assert (int(model.cross_fusion_encoders[1]._last_desc.packed_rows) > 0) == packed
+    ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
+    for i in range(n):
+        pre = f"l{i}/"
+        assert rel(got["fused"][i], g[pre + "fused"]) < ftol, i
+        assert rel(feats[i].grad, g[pre + "grad_feat"]) < gtol, i
+        assert rel(model.patches_to_token[i].weight.grad, g[pre + "grad_conv_w"]) < gtol, i
+        assert rel(model.tokens_to_features[i].linear.weight.grad, g[pre + "grad_reg_w"]) < gtol, i
+        assert rel(model.tokens_to_features[i].linear.bias.grad, g[pre + "grad_reg_b"]) < gtol, i
+        params = dict(model.cross_fusion_encoders[i].named_parameters())
+        checked = 0
+        for k, v in g.items():
+            if k.startswith(pre + "gradp/"):
+                pname = k[len(pre) + 6:]
+                if float(np.abs(v).max()) == 0.0:
+                    continue                                    # (lang_kind_embedding etc. when nothing flows: compared by value below)
+                assert rel(params[pname].grad, v) < gtol, (i, pname)
+                checked += 1
+        assert checked >= 12 * cfg["L"] + 2, checked
+    assert rel(lang.grad, g["grad_lang"]) < gtol                 # the shared narration tokens: the sum over the four levels

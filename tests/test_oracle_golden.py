@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from cases import (ENCODER_CASES, LEVEL_CASES, make_encoder_inputs, make_encoder_params)
+from cases import (ENCODER_CASES, LEVEL_CASES, MLEVEL_CASES, make_encoder_inputs, make_encoder_params)
 from oracle import fusion_oracle as O
 
 TOL = 2e-5
@@ -115,6 +115,40 @@ def test_level_cases(golden_dir, name):
     for k, v in g.items():
         if k.startswith("gradp/"):
             _close(sd[k[6:]].grad, v, tol=5e-5, what=k)
+
+
+@pytest.mark.parametrize("name", list(MLEVEL_CASES))
+def test_multi_level_loop(golden_dir, name):
+    """The wrapper's level loop over levels of unequal token count with one shared narration input (cross_f_box_wrapper.py:177-212):
+    the oracle's per-level restatement, looped, against the reference's fused maps and gradients -- the summed gradient of the shared
+    language tokens included."""
+    cfg = MLEVEL_CASES[name]
+    g = _load(golden_dir, name)
+    lang = torch.from_numpy(g["in_lang"]).requires_grad_(True)
+    mask = torch.from_numpy(g["in_mask"])
+    loss, keep = 0.0, []
+    for i, lv in enumerate(cfg["levels"]):
+        pre = f"l{i}/"
+        sd = _sd({k[len(pre) + 6:]: v for k, v in g.items() if k.startswith(pre + "param/")}, cfg["d"])
+        feat = torch.from_numpy(g[pre + "in_feat"]).requires_grad_(True)
+        conv_w = torch.from_numpy(g[pre + "conv_w"]).requires_grad_(True)
+        reg_w = torch.from_numpy(g[pre + "reg_w"]).requires_grad_(True)
+        reg_b = torch.from_numpy(g[pre + "reg_b"]).requires_grad_(True)
+        fused, lo = O.fusion_level_forward(feat, conv_w, sd, lang, mask, cfg["h"], cfg["L"], reg_w, reg_b, lv["p"], lv["p"])
+        _close(fused, g[pre + "fused"], what=pre + "fused")
+        _close(lo, g[pre + "lang_out"], what=pre + "lang_out")
+        loss = loss + (fused * torch.from_numpy(g[pre + "cot_out"])).sum()
+        keep.append((pre, sd, feat, conv_w, reg_w, reg_b))
+    loss.backward()
+    _close(lang.grad, g["grad_lang"], tol=5e-5, what="grad_lang")
+    for pre, sd, feat, conv_w, reg_w, reg_b in keep:
+        _close(feat.grad, g[pre + "grad_feat"], tol=5e-5, what=pre + "grad_feat")
+        _close(conv_w.grad, g[pre + "grad_conv_w"], tol=5e-5, what=pre + "grad_conv_w")
+        _close(reg_w.grad, g[pre + "grad_reg_w"], tol=5e-5, what=pre + "grad_reg_w")
+        _close(reg_b.grad, g[pre + "grad_reg_b"], tol=5e-5, what=pre + "grad_reg_b")
+        for k, v in g.items():
+            if k.startswith(pre + "gradp/"):
+                _close(sd[k[len(pre) + 6:]].grad, v, tol=5e-5, what=k)
 
 
 def test_sin1d_and_local_mask(golden_dir):

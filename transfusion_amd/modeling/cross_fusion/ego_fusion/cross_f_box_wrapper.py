@@ -197,11 +197,12 @@ class CrossFusionBoxWrapper(nn.Module):
         parallel = (grouped is None and main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
                     and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
         # which way the levels went (read by runner.trainer.check_capturable: level streams + side streams cannot be graph-captured)
-        self._last_path = "grouped" if grouped is not None else ("streams" if parallel else "loop")
+        others_on_streams = grouped is not None and getattr(self, "_grouped_others", 0) > 0 and os.environ.get("TF_LEVEL_STREAMS", "1") != "0"
+        self._last_path = ("streams" if others_on_streams else "grouped") if grouped is not None else ("streams" if parallel else "loop")
         if main is not None:
             # the GEMMs plan their tile grids for their share of the chip while the levels run side by side (backward included:
             # autograd replays the levels on the same streams)
-            ops.set_gemm_concurrency(len(self.fpn_features_idx) if parallel else 1)
+            ops.set_gemm_concurrency(len(self.fpn_features_idx) if parallel else (1 + getattr(self, "_grouped_others", 0) if grouped is not None else 1))
         if parallel and (self._level_streams is None or self._level_streams[0].device != language_f.device):
             # TF_LEVEL_STREAMS = n > 1: n streams shared round-robin by the levels (default: one per level)
             n_st = int(os.environ.get("TF_LEVEL_STREAMS", "1"))
@@ -259,20 +260,31 @@ class CrossFusionBoxWrapper(nn.Module):
         return rcnn_outs
 
     def _grouped_levels(self, features_dict, language_f, pad_mask, n_valid):
-        """All levels through ONE grouped encoder call, or None when they cannot be grouped (then the level loop runs).  -> (fused
-        feature maps per level, fused language tokens per level)."""
+        """The levels that share a token grid through ONE grouped encoder call (TfEncoderDesc.groups), the others beside it on their own
+        streams; None when no two levels can be grouped (then the level loop runs).  The reference's real FPN geometry -- patches of
+        4, 4, 2, 1 on maps of stride 4 / 8 / 16 / 32 (cross_fusion_config_sym_ego_res50.yml:8-17) -- gives level 0 four times the tokens
+        of levels 1 - 3: the grouped call then covers levels 1 - 3 and level 0 runs concurrently.
+        -> (fused feature maps per level, fused language tokens per level)."""
         encs = list(self.cross_fusion_encoders)
-        lead = encs[0]
-        if not hasattr(lead, "group_stride") or self.vis_mask_type != "global":          # (a local visual mask: per-level block bits)
+        if not hasattr(encs[0], "group_stride") or self.vis_mask_type != "global":          # (a local visual mask: per-level block bits)
             return None
         keys = [str(k) for k in self.fpn_features_idx]
         feats = [features_dict["features"][k] for k in keys]
-        G, B = len(encs), language_f.shape[0]
-        n_tok = set()
-        for i, feat in enumerate(feats):
-            n_tok.add((feat.shape[2] // self.patches_to_token[i].patch_h) * (feat.shape[3] // self.patches_to_token[i].patch_w))
-        if len(n_tok) != 1 or any(f.shape[0] != B for f in feats) or lead.group_stride(encs) is None:
+        nlev, B = len(encs), language_f.shape[0]
+        if any(f.shape[0] != B for f in feats):
             return None
+        n_tok = [(f.shape[2] // self.patches_to_token[i].patch_h) * (f.shape[3] // self.patches_to_token[i].patch_w) for i, f in enumerate(feats)]
+        # the largest class of levels with one token count whose encoders sit at a common stride (ties: the first)
+        members = None
+        for cnt in sorted(set(n_tok), key=lambda c: -n_tok.count(c)):
+            idx = [i for i in range(nlev) if n_tok[i] == cnt]
+            if len(idx) >= 2 and encs[idx[0]].group_stride([encs[i] for i in idx]) is not None:
+                members = idx
+                break
+        if members is None:
+            return None
+        others = [i for i in range(nlev) if i not in members]
+        lead, G = encs[members[0]], len(members)
         # the per-level pieces either side of the grouped call (patch embedding, back-projection + fold: different shapes per level) run
         # side by side on the level streams, forward and -- autograd replays a node on its forward stream -- backward
         main = torch.cuda.current_stream(language_f.device)
@@ -280,31 +292,54 @@ class CrossFusionBoxWrapper(nn.Module):
         if use_streams and (self._level_streams is None or self._level_streams[0].device != language_f.device):
             self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
 
-        def per_level(fn, args):
+        def per_level(fn, levels, args):
             if not use_streams:
-                return [fn(i, a) for i, a in enumerate(args)]
+                return [fn(i, a) for i, a in zip(levels, args)]
             res = []
-            for i, a in enumerate(args):
+            for i, a in zip(levels, args):
                 st = self._level_streams[i]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     r = fn(i, a)
                 r.record_stream(main)
                 res.append(r)
-            for st in self._level_streams[:len(args)]:
-                main.wait_stream(st)
+            for i in levels:
+                main.wait_stream(self._level_streams[i])
             return res
         for i, feat in enumerate(feats):
             self.tokens_to_features[i].init_h, self.tokens_to_features[i].init_w = feat.shape[2], feat.shape[3]
-        # ... each side as ONE autograd node when the shapes allow it (level_ops: the host issues a level's two or three kernels instead of
-        # four autograd nodes and a dozen torch / stream calls per level and direction); TF_LEVEL_OPS=0 keeps the per-level modules
+        outs, fused_ls = [None] * nlev, [None] * nlev
+        # ---- the levels outside the group: a whole level each (patch embedding, encoder, back-projection) on its stream, started first so
+        #      that it runs beside the grouped call
+        self._grouped_others = len(others)
+        if others:
+            ops.set_gemm_concurrency(1 + len(others))
+        for i in others:
+            def whole_level(i=i):
+                vis_tokens = self.patches_to_token[i](feats[i])
+                fused_features, fl, _, _ = self.cross_fusion_encoders[i](vis_tokens, language_f, pad_mask, vis_tokens_mask=None,
+                                                                         **self._pack_kw(i, n_valid))
+                return self.tokens_to_features[i](fused_features), fl
+            if use_streams:
+                st = self._level_streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs[i], fused_ls[i] = whole_level()
+                outs[i].record_stream(main)
+                fused_ls[i].record_stream(main)
+            else:
+                outs[i], fused_ls[i] = whole_level()
+        # ... each side of the grouped call as ONE autograd node when the shapes allow it (level_ops: the host issues a level's two or three
+        # kernels instead of four autograd nodes and a dozen torch / stream calls per level and direction); TF_LEVEL_OPS=0 keeps the
+        # per-level modules
         from transfusion_amd import level_ops
         fused_ops = os.environ.get("TF_LEVEL_OPS", "1") != "0"
-        sts = self._level_streams if use_streams else None
-        if fused_ops and level_ops.k1_supported(self.patches_to_token, feats, self.token_dim):
-            x = level_ops.levels_patch_embed(self.patches_to_token, feats, sts)
+        p2t, t2f, gfeats = [self.patches_to_token[i] for i in members], [self.tokens_to_features[i] for i in members], [feats[i] for i in members]
+        sts = [self._level_streams[i] for i in members] if use_streams else None
+        if fused_ops and level_ops.k1_supported(p2t, gfeats, self.token_dim):
+            x = level_ops.levels_patch_embed(p2t, gfeats, sts)
         else:
-            toks = per_level(lambda i, feat: self.patches_to_token[i](feat), feats)
+            toks = per_level(lambda i, feat: self.patches_to_token[i](feat), members, gfeats)
             if len({t.dtype for t in toks}) != 1:
                 return None
             x = torch.cat(toks, dim=0)                             # [G * B, Nv, d], group-major
@@ -312,12 +347,17 @@ class CrossFusionBoxWrapper(nn.Module):
         kw = {}
         if n_valid is not None and getattr(lead, "pack_tokens", False):
             kw["lang_valid_rows"] = G * n_valid
-        fused, fused_l, _, _ = lead.forward_grouped(encs, x, lang_g, pad_g, **kw)
-        if fused_ops and level_ops.k9_supported(self.tokens_to_features, self.token_dim):
-            outs = level_ops.levels_back_project(self.tokens_to_features, fused, sts)
+        fused, fused_l, _, _ = lead.forward_grouped([encs[i] for i in members], x, lang_g, pad_g, **kw)
+        if fused_ops and level_ops.k9_supported(t2f, self.token_dim):
+            gouts = level_ops.levels_back_project(t2f, fused, sts)
         else:
-            outs = per_level(lambda i, f: self.tokens_to_features[i](f), [fused[i * B:(i + 1) * B] for i in range(G)])
-        return outs, list(fused_l.chunk(G, dim=0))
+            gouts = per_level(lambda i, f: self.tokens_to_features[i](f), members, [fused[k * B:(k + 1) * B] for k in range(G)])
+        for k, (i, fl) in enumerate(zip(members, fused_l.chunk(G, dim=0))):
+            outs[i], fused_ls[i] = gouts[k], fl
+        if use_streams:
+            for i in others:
+                main.wait_stream(self._level_streams[i])
+        return outs, fused_ls
 
     def _pack_kw(self, i, n_valid):
         """``lang_valid_rows`` for encoders that can drop masked tokens (the joint-attention encoder; the asymmetric variant attends over
