@@ -269,44 +269,43 @@ def traced_kernels(step, nsteps):
 
 
 def wgrad_alone(B, device, reps=20):
-    """The overlapped weight-gradient kernel with the chip to itself: the four wgrad shapes of a layer, sized exactly as the encoder
-    runtime sizes them on its side stream (caller-sized M-splits, M/44 blocks capped at 256), back to back on one stream."""
+    """The dominant kernel with the chip to itself: a layer's four weight-gradient products as ONE launch (tf_gemm_wgrad_multi), sized as
+    the encoder runtime sizes it on its side stream (~1.7 workgroups per CU: three row chunks of the 144 output tiles), back to back on
+    one stream, at the packed row count the benchmark's batches average (196 + 320 tokens per sample)."""
     from transfusion_amd import ops
-    M, d, ff = B * (NV + NL), D, D * FF_MULT
+    M, d, ff = B * (NV + (NL // 4 + NL) // 2), D, D * FF_MULT
     g = torch.Generator().manual_seed(2)
     rnd = lambda *s: torch.randn(*s, generator=g).to(device=device, dtype=torch.bfloat16)
-    X, Xf, dYq, dYd, dYf = rnd(M, d), rnd(M, ff), rnd(M, 3 * d), rnd(M, d), rnd(M, ff)
-    dW, db = torch.zeros(3 * d, max(d, ff), device=device), torch.zeros(3 * d, device=device)
-    target = min(256, max(32, M // 44))
-
-    def chunk(N, K):
-        tiles = ((N + 255) // 256) * ((K + 127) // 128)
-        steps = (M + 31) // 32
-        splits = max(1, min(steps, (target + tiles // 2) // tiles))
-        return ((steps + splits - 1) // splits) * 32
-
-    cases = [(dYq, 3 * d, X, d), (dYd, d, X, d), (dYf, ff, X, d), (dYd, d, Xf, ff)]        # in_proj, out_proj, linear1, linear2
-    tot_us, tot_fl = 0.0, 0.0
-    for dY, N, Xin, K in cases:
-        fn = lambda: ops.wgrad(dY, N, Xin, K, dW[:N, :K], db[:N], m_chunk=chunk(N, K))
+    x, o, x1, hh = rnd(M, d), rnd(M, d), rnd(M, d), rnd(M, ff)
+    dqkv, dy1, dy2, du = rnd(M, 3 * d), rnd(M, d), rnd(M, d), rnd(M, ff)
+    pairs = [(dqkv, x), (dy1, o), (du, x1), (dy2, hh)]                                        # in_proj, out_proj, linear1, linear2
+    dWs = [torch.zeros(a.shape[1], b.shape[1], device=device) for a, b in pairs]
+    dbs = [torch.zeros(a.shape[1], device=device) for a, _ in pairs]
+    probs = [ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v) for (a, b), w, v in zip(pairs, dWs, dbs)]
+    tiles = sum(((a.shape[1] + 255) // 256) * ((b.shape[1] + 127) // 128) for a, b in pairs)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    blocks = max(1, (cus * 17 // 10 + tiles // 2) // tiles) * tiles
+    fn = lambda: ops.wgrad_multi(probs, blocks)
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
         fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        tot_us += e0.elapsed_time(e1) * 1e3 / reps
-        tot_fl += 2.0 * M * N * K
-    return dict(avg_launch_us=round(tot_us / len(cases), 1), achieved=round(tot_fl / tot_us / 1e6, 1),
-                frac=round(tot_fl / tot_us / 1e6 / PEAK_BF16_TFLOPS, 4),
-                note="same kernel and sizing, launched alone back to back (mean over the four wgrad shapes of a layer)")
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    fl = sum(2.0 * M * a.shape[1] * b.shape[1] for a, b in pairs)
+    return dict(avg_launch_us=round(us, 1), achieved=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4),
+                flops_per_launch=fl, rows=M, workgroups=blocks,
+                note="one layer's four products as one launch, the encoder runtime's sizing, alone back to back")
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (a port of the reference arithmetic) timed on this host: forward + backward of the same
-    4-layer encoder with dropout masks drawn on the host (as the reference does), B=2 samples per step."""
+def cpu_baseline(seconds_budget=12.0):
+    """The CPU oracle (a port of the reference arithmetic) timed on this host: forward + backward of the same 4-layer encoder, dropout
+    masks drawn on the host (as the reference does).  SURVEY.md 8(d) asks for config 1 (B = 2) and the north-star shape (B = 32), dropout
+    on and p = 0: the headline object is B = 2 with dropout (best of a few steps), `variants` holds the other three on a bounded sample
+    (one warm-up + one or two timed steps each; ~30 s of CPU work in all)."""
     from oracle import fusion_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
@@ -314,40 +313,53 @@ def cpu_baseline(seconds_budget=25.0):
         avail = os.cpu_count() or 1
     nthreads = max(1, min(avail, 16))            # a one-GPU box owns a 16-core share of the host
     torch.set_num_threads(nthreads)
-    B = 2
     enc = make_encoder("cpu")
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "pos_embedding" not in k and "heatmap" not in k)
           for k, v in enc.state_dict().items()}
-    x, lang, pad = make_batch(B, "cpu", 0)[:3]
     S = NV + NL
 
-    def step():
-        masks = {"patch": (torch.rand(B, NV, D) >= P_PATCH).float()}
-        for l in range(L):
-            pre = f"t_encoder.layers.{l}."
-            masks[pre + "attn"] = (torch.rand(B, H, S, S) >= P_TOKEN).float()
-            masks[pre + "dropout1"] = (torch.rand(B, S, D) >= P_TOKEN).float()
-            masks[pre + "dropout"] = (torch.rand(B, S, D * FF_MULT) >= P_TOKEN).float()
-            masks[pre + "dropout2"] = (torch.rand(B, S, D) >= P_TOKEN).float()
-        for v in sd.values():
-            v.grad = None
-        vis, lo = O.encoder_forward(sd, x, lang, pad, H, L, masks=masks, token_dropout=P_TOKEN, patch_dropout=P_PATCH)
-        valid = (~pad).unsqueeze(-1).float()
-        loss = vis.pow(2).mean() + (lo.pow(2) * valid).sum() / (valid.sum() * D)
-        loss.backward()
+    def measure(B, dropout, budget, max_steps, warm_up=True):
+        x, lang, pad = make_batch(B, "cpu", 0)[:3]
 
-    t0 = time.perf_counter()
-    step()                                  # warm-up
-    warm = time.perf_counter() - t0
-    times = []
-    while len(times) < 3 or (sum(times) + warm < seconds_budget and len(times) < 12):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return dict(value=round(B / best, 3), unit="samples/s", cores=nthreads, kind="port",
-                sample=f"oracle/fusion_oracle.py fwd+bwd, dropout on, B={B} x [{NV}+{NL}] tokens, d={D}, {L} layers, fp32, "
-                       f"best of {len(times)} steps after 1 warm-up ({best * 1e3:.0f} ms/step)")
+        def step():
+            masks, pt, pp = None, 0.0, 0.0
+            if dropout:
+                pt, pp = P_TOKEN, P_PATCH
+                masks = {"patch": (torch.rand(B, NV, D) >= P_PATCH).float()}
+                for l in range(L):
+                    pre = f"t_encoder.layers.{l}."
+                    masks[pre + "attn"] = (torch.rand(B, H, S, S) >= P_TOKEN).float()
+                    masks[pre + "dropout1"] = (torch.rand(B, S, D) >= P_TOKEN).float()
+                    masks[pre + "dropout"] = (torch.rand(B, S, D * FF_MULT) >= P_TOKEN).float()
+                    masks[pre + "dropout2"] = (torch.rand(B, S, D) >= P_TOKEN).float()
+            for v in sd.values():
+                v.grad = None
+            vis, lo = O.encoder_forward(sd, x, lang, pad, H, L, masks=masks, token_dropout=pt, patch_dropout=pp)
+            valid = (~pad).unsqueeze(-1).float()
+            loss = vis.pow(2).mean() + (lo.pow(2) * valid).sum() / (valid.sum() * D)
+            loss.backward()
+
+        warm = 0.0
+        if warm_up:
+            t0 = time.perf_counter()
+            step()
+            warm = time.perf_counter() - t0
+        times = []
+        while len(times) < 1 or (sum(times) + warm < budget and len(times) < max_steps):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        best = min(times)
+        return dict(value=round(B / best, 3), ms_per_step=round(best * 1e3, 1), steps=len(times), batch=B, dropout=bool(dropout))
+
+    head = measure(2, True, seconds_budget, 12)
+    variants = {"b2_p0": measure(2, False, 3.0, 6), "b32_dropout": measure(32, True, 0.0, 1, warm_up=False),
+                "b32_p0": measure(32, False, 0.0, 1, warm_up=False)}
+    return dict(value=head["value"], unit="samples/s", cores=nthreads, kind="port",
+                sample=f"oracle/fusion_oracle.py fwd+bwd, dropout on, B=2 x [{NV}+{NL}] tokens, d={D}, {L} layers, fp32, "
+                       f"best of {head['steps']} steps after 1 warm-up ({head['ms_per_step']:.0f} ms/step); variants: the same at B = 32 "
+                       f"(ONE step, no warm-up: a bounded sample) and with every dropout p = 0",
+                variants=variants)
 
 
 class _Comm:
@@ -516,7 +528,7 @@ class _PassThroughDetector(torch.nn.Module):
         pass
 
 
-def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4):
+def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False, reducer=False):
     """The reference's REAL module around the hot path, at its own per-GPU batch: CrossFusionBoxWrapper over four FPN levels (level maps
     14p x 14p, p = 4, 4, 2, 1; C = 256 .. 2048; patch-embedding GEMM, 4-layer encoder on [196 + 512] tokens, back-projection + fold per
     level) with a pass-through detector, full training step (FusionTrainStep: flat buffers, clip, fused RAdam).  Host-bound at this size
@@ -526,9 +538,16 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4):
     from transfusion_amd.runner.config import load_fusion_config
     from transfusion_amd.runner.trainer import FusionTrainStep
     obj = {}
+    saved_force = os.environ.get("TF_FORCE_LAYERWISE")
     try:
         ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]
-        shapes = [(14 * p, 14 * p) for p in ps]
+        # `real`: the reference's FPN geometry (patches of 4, 4, 2, 1 on maps of stride 4 / 8 / 16 / 32 of a 448-pixel frame,
+        # cross_fusion_config_sym_ego_res50.yml:8-17): token grids 28 x 28, 14 x 14, 14 x 14, 14 x 14 -- level 0 holds four times the
+        # tokens of the others; levels 1 - 3 run as one grouped encoder call, level 0 beside them.  Otherwise 14 x 14 on every level.
+        grids = [28, 14, 14, 14] if real else [14, 14, 14, 14]
+        shapes = [(n * p, n * p) for n, p in zip(grids, ps)]
+        if reducer:
+            os.environ["TF_FORCE_LAYERWISE"] = "1"       # the data-parallel path at world 1: layer-by-layer backward, per-unit hooks, no-op reduce
         fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
         fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})
         fusion["args"].update({"input_f_size": D})
@@ -561,13 +580,22 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4):
         loss = float(last["loss"].item())
         if not math.isfinite(loss):
             raise SystemExit(f"leg wrapper_b{batch}: non-finite loss {loss}")
+        vis_tokens = [n * n for n in grids]
         out = dict(ms_per_step=round(dt * 1e3, 3), samples_s=round(comm.world * batch / dt, 1), host_enqueue_ms=round(t_host * 1e3, 3),
-                   batch_per_gpu=batch, levels=4, layers_per_level=L, tokens=[NV, NL], d=D, dtype="bf16", steps=steps, warmup=warmup,
-                   final_loss=round(loss, 5), module="CrossFusionBoxWrapper (4 FPN levels) + pass-through detector, full training step")
+                   batch_per_gpu=batch, levels=4, layers_per_level=L, tokens=[NV, NL], vis_tokens_per_level=vis_tokens, d=D, dtype="bf16",
+                   steps=steps, warmup=warmup, final_loss=round(loss, 5),
+                   us_per_visual_token=round(dt * 1e6 / (batch * sum(vis_tokens)), 3),
+                   reducer=type(obj["trainer"].layerwise).__name__ if obj["trainer"].layerwise is not None else None,
+                   module="CrossFusionBoxWrapper (4 FPN levels) + pass-through detector, full training step")
         if rank == 0:
-            log(f"  leg wrapper_b{batch:<3d} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  (host enqueue {out['host_enqueue_ms']:.2f} ms/step)")
+            tag = "wrapper_b%d%s%s" % (batch, "_real" if real else "", "_dp" if reducer else "")
+            log(f"  leg {tag:16s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  (host enqueue {out['host_enqueue_ms']:.2f} ms/step)")
         return out
     finally:
+        if saved_force is None:
+            os.environ.pop("TF_FORCE_LAYERWISE", None)
+        else:
+            os.environ["TF_FORCE_LAYERWISE"] = saved_force
         obj.clear()
         gc.collect()
         torch.cuda.empty_cache()
@@ -604,7 +632,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,fp8,b4,b4_dense,b4_graph,wrapper_b4,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,b4_graph,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -752,7 +780,7 @@ def main():
                                   "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                                   "us_per_step": dom["us_per_step"],
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
-        if dom["kernel"].startswith("wgrad_tn2") and "roofline" in result:
+        if dom["kernel"].startswith("wgrad_multi") and "roofline" in result:
             # the dominant kernel runs on the side stream and SHARES the chip with the backward chain in situ; its own rate too:
             result["roofline"]["alone"] = wgrad_alone(args.batch, device)
         result["kernels"] = [{k: r[k] for k in ("kernel", "avg_us", "launches_per_step", "us_per_step", "tflops", "tflops_valid", "gbs", "side_stream")} for r in rows]
@@ -777,11 +805,11 @@ def main():
                 "no_padding": dict(padded=False),                                                     # 196 + 512 real tokens each
             }
             for name in [n.strip() for n in args.legs.split(",") if n.strip()]:
-                if name == "wrapper_b4":
-                    legs[name] = run_wrapper_leg(device, rank, comm, batch=4)
+                if name in ("wrapper_b4", "wrapper_b4_real", "wrapper_b4_dp"):
+                    legs[name] = run_wrapper_leg(device, rank, comm, batch=4, real=name.endswith("_real"), reducer=name.endswith("_dp"))
                     continue
                 if name not in specs:
-                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4)")
+                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4, wrapper_b4_real, wrapper_b4_dp)")
                 legs[name if name not in legs else f"{name}#{len(legs)}"] = run_leg(name, device, rank, comm, **specs[name])
         else:
             # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32

@@ -29,7 +29,7 @@ for i in (1, 2):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        if not any(t in k for t in ("gemm_nt", "wgrad_tn", "attn_fwd", "attn_bwd", "ln_bwd")): continue
+        if not any(t in k for t in ("gemm_nt", "wgrad_", "attn_fwd", "attn_bwd", "ln_bwd")): continue
         k = re.sub(r"^void ", "", k).replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVE_CYCLES": n[k] += 1
