@@ -53,8 +53,11 @@ class BucketComm:
             raise L.TfError("tf_allreduce_bucket needs a contiguous fp32 CUDA tensor")
         if t.device != self.device:
             raise L.TfError(f"communicator lives on {self.device}, tensor on {t.device}")
-        st = (stream if stream is not None else torch.cuda.current_stream(t.device)).cuda_stream
-        L.check(self.lib.tf_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), st), "tf_allreduce_bucket")
+        stream = stream if stream is not None else torch.cuda.current_stream(t.device)
+        L.check(self.lib.tf_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), stream.cuda_stream), "tf_allreduce_bucket")
+        # the collective reads and writes the raw pointer later, on `stream`: tell the caching allocator, so that the block is not
+        # handed to another tensor before that work has run (a view of a long-lived flat buffer today; a temporary tomorrow)
+        t.record_stream(stream)
 
     def stats(self):
         w, r, calls, elems = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
