@@ -434,7 +434,7 @@ def allreduce_busbw(trainer, comm, reps=10):
 
 
 def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
-            steps=8, warmup=3, grad_clip=1.0, graph=False):
+            steps=8, warmup=3, grad_clip=1.0):
     """One more BASELINE configuration in the same process, after the headline: its own encoder, trainer and batches, `warmup` untimed +
     `steps` timed training steps between barrier + sync pairs (the headline's protocol), max over ranks.  Returns the leg's numbers;
     everything it allocated is released before the next leg."""
@@ -457,17 +457,6 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         def step(i):
             last["loss"] = obj["trainer"].step([obj["batches"][i % 2]], loss_fn)
 
-        if graph:
-            # the whole step captured once in a HIP graph (runner.trainer.GraphedTrainStep; dense rows, one GPU): per step one copy of the
-            # next batch into the static tensors + one replay
-            from transfusion_amd.runner.trainer import GraphedTrainStep
-            static = [t.clone() for t in obj["batches"][0][:5]] + [None]
-            obj["graphed"] = GraphedTrainStep(obj["trainer"], static, loss_fn, warmup=2)
-
-            def step(i):
-                obj["graphed"].load(obj["batches"][i % 2][:5] + (None,))
-                last["loss"] = obj["graphed"].replay()
-
         for i in range(warmup):
             step(i)
         comm.sync()
@@ -488,8 +477,6 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
                    layers=layers, dtype="fp32" if precision == "fp32" else ("fp8 projections + bf16" if fp8 else "bf16"),
                    block_tflops_per_gpu=round(fl / dt / 1e12, 1), block_mfma_util=round(fl / dt / 1e12 / peak, 4), peak_used=round(peak, 1),
                    packed_rows=bool(pack), padded=bool(padded), steps=steps, warmup=warmup, final_loss=round(loss, 5))
-        if graph:
-            out["hip_graph"] = True
         if rank == 0:
             log(f"  leg {name:10s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  {out['block_tflops_per_gpu']:7.1f} TFLOP/s/GPU "
                 f"({100 * out['block_mfma_util']:.1f} % of {peak:.0f})")
@@ -632,7 +619,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,b4_graph,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -798,8 +785,7 @@ def main():
                 "stress": dict(batch=8, d=1024, h=4, nv=784, nl=1024, steps=6, warmup=2),             # configs[3]: 64 samples / 8 GPUs
                 "fp8": dict(fp8=True),                                                                # configs[4]
                 "b4": dict(batch=4, steps=16, warmup=4),                                              # the reference's own per-GPU batch (32 / 8)
-                "b4_dense": dict(batch=4, steps=16, warmup=4, pack=False),                            # ... dense rows, eager: what b4_graph compares with
-                "b4_graph": dict(batch=4, steps=16, warmup=4, pack=False, graph=True),                # ... the whole step replayed from a HIP graph
+                "b4_dense": dict(batch=4, steps=16, warmup=4, pack=False),                            # ... on dense rows
                 "b16": dict(batch=16),                                                                # configs[1]: Ego4Dv1, batch 16, one GPU
                 "dense_rows": dict(pack=False),                                                       # masked tokens carried as dead rows
                 "no_padding": dict(padded=False),                                                     # 196 + 512 real tokens each

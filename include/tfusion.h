@@ -339,8 +339,8 @@ const char* tf_last_error(void);
 void tf_set_gemm_concurrency(int n);
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
-/* probs[0 .. count): see TF_WGRAD_MULTI_MAX.  blocks: workgroups the caller wants in flight (sizes the row chunks); 0 = a launch that
- * has the chip to itself (two per CU) */
+/* probs[0 .. count): see TF_WGRAD_MULTI_MAX.  blocks > 0: that many workgroups (256 x 128 output tiles x row chunks) in flight;
+ * 0 = sized by the library for a launch that has the chip to itself; -1 = sized for a launch that runs beside other kernels */
 int tf_gemm_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, tf_stream_t s);
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);
 int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* dQ (which also fills `delta`), then dK, dV */

@@ -379,10 +379,10 @@ def test_lr_scale_builds_contiguous_ranges_with_their_own_rate():
 
 
 def test_graph_capture_guard_names_the_nested_stream_fork():
-    """runner.trainer.check_capturable: a wrapper that ran its levels on level streams while the encoders fork weight-gradient side
+    """graph_step.check_capturable: a wrapper that ran its levels on level streams while the encoders fork weight-gradient side
     streams cannot be captured (hipStreamEndCapture crashes on the nested fork, ROCm 7.2) -- a ValueError, not a core dump."""
     import torch
-    from transfusion_amd.runner.trainer import check_capturable
+    from graph_step import check_capturable
 
     class Wrapper(torch.nn.Module):
         def __init__(self, path):

@@ -1,4 +1,4 @@
-"""A training step captured in a HIP graph (runner.trainer.GraphedTrainStep) and the pieces that make its replays NEW steps:
+"""A training step captured in a HIP graph (tests/graph_step.py: test infrastructure since round 4) and the pieces that make its replays NEW steps:
 the library's step clock folded into every dropout key (tf_clock_ptr), RAdam's schedule formed on the device from that clock.
 The eager path -- the reference semantics, the one every other test exercises -- is the yardstick: eager steps on the same clock
 and replays of the captured step must leave the same parameters."""
@@ -97,7 +97,8 @@ def test_replays_equal_eager_steps_on_the_same_clock(monkeypatch):
     dev = _dev()
     from transfusion_amd import ops
     from transfusion_amd.optim import FusedRAdam
-    from transfusion_amd.runner.trainer import FusionTrainStep, GraphedTrainStep
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    from graph_step import GraphedTrainStep
     monkeypatch.setattr(ops, "next_seed", lambda: 0x1234ABCD)    # eager calls draw a new seed per forward; the graph bakes one
     # five steps in all: RAdam's rectified branch starts at step 6, and there sqrt(v) normalises the update of entries whose true
     # gradient is zero (the K third of in_proj_bias) by their rounding noise -- no two runs agree on those, eager or not; the branch
@@ -150,7 +151,8 @@ def test_replays_equal_eager_steps_on_the_same_clock(monkeypatch):
 def test_replays_draw_new_masks(monkeypatch):
     dev = _dev()
     from transfusion_amd import ops
-    from transfusion_amd.runner.trainer import FusionTrainStep, GraphedTrainStep
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    from graph_step import GraphedTrainStep
     ops.clock_set(0)
     enc = _encoder(dev)
     tr = FusionTrainStep(enc, lr=0.0, weight_decay=0.0, grad_clip=None)       # lr 0: the weights stay, only the masks change
@@ -217,7 +219,8 @@ def test_replays_follow_the_lr_scheduler():
     dev = _dev()
     from transfusion_amd import ops
     from transfusion_amd.optim import FusedRAdam
-    from transfusion_amd.runner.trainer import FusionTrainStep, GraphedTrainStep
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    from graph_step import GraphedTrainStep
     opt_cls = lambda params, lr, weight_decay: FusedRAdam(params, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
     rates = [0.05, 0.05, 0.01, 0.002, 0.03]
     finals = []

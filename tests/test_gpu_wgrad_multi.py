@@ -29,12 +29,12 @@ def _problem(g, M, N, K, dev, scale=1.0):
     return dY, X, dY.double().cpu().t() @ X.double().cpu(), dY.double().cpu().sum(0)
 
 
-@pytest.mark.parametrize("blocks", [0, 1, 40, 97, 512])
+@pytest.mark.parametrize("blocks", [0, -1, 1, 40, 97, 512])
 def test_layer_shaped_problems(dev, blocks):
     """four problems with a layer's operand relations (shared rows, different N / K, one without a bias) at a small width"""
     from transfusion_amd import ops
-    g = torch.Generator().manual_seed(11 + blocks)
-    M, d = 1000 + 7 * (blocks % 5), 136                                   # ragged last 32-row step
+    g = torch.Generator().manual_seed(11 + abs(blocks))
+    M, d = 1000 + 7 * (abs(blocks) % 5), 136                                   # ragged last 32-row step
     shapes = [(3 * d, d, True), (d, d, True), (2 * d, d, False), (d, 2 * d, True)]
     probs, outs, keep = [], [], []
     for N, K, bias in shapes:
@@ -68,10 +68,14 @@ def test_benchmark_layer(dev):
     pairs = [(dqkv, x), (dy1, o), (du, x1), (dy2, hh)]
     dWs = [torch.zeros(a.shape[1], b.shape[1], device=dev) for a, b in pairs]
     dbs = [torch.zeros(a.shape[1], device=dev) for a, _ in pairs]
-    ops.wgrad_multi([ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v) for (a, b), w, v in zip(pairs, dWs, dbs)], 256)
-    for (a, b), w, v in zip(pairs, dWs, dbs):
-        assert rel(w, a.float().t() @ b.float()) < 2e-5
-        assert rel(v, a.float().sum(0)) < 2e-5
+    refs = [(a.float().t() @ b.float(), a.float().sum(0)) for a, b in pairs]
+    for blocks in (256, 0, -1):                  # an explicit count; the launcher's own sizing alone / beside a chain
+        for w, v in zip(dWs, dbs):
+            w.zero_(); v.zero_()
+        ops.wgrad_multi([ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v) for (a, b), w, v in zip(pairs, dWs, dbs)], blocks)
+        for (rw, rv), w, v in zip(refs, dWs, dbs):
+            assert rel(w, rw) < 2e-5, blocks
+            assert rel(v, rv) < 2e-5, blocks
 
 
 def test_different_row_counts_and_tile_tails(dev):
@@ -86,7 +90,7 @@ def test_different_row_counts_and_tile_tails(dev):
         probs.append(ops.wgrad_args(dY, N, X, K, dW, db))
         outs.append((dW, db, ref, refb))
         keep += [dY, X]
-    for blocks in (0, 64):
+    for blocks in (0, 64, -1):
         for dW, db, _, _ in outs:
             dW.zero_(); db.zero_()
         ops.wgrad_multi(probs, blocks)
@@ -111,10 +115,12 @@ def test_padded_groups_and_leading_dimensions(dev):
     dW2 = torch.zeros(K, n_src, device=dev)
     probs = [ops.wgrad_args(dY, N, X, K, dW, db, rg=rg, rgp=rgp, n_src=n_src),
              ops.wgrad_args(X, K, dY, N, dW2, None, cg=rg, cgp=rgp, k_src=n_src)]
-    ops.wgrad_multi(probs, 48)
-    assert rel(dW, ref[idx]) < 1e-4
-    assert rel(db, refb[idx]) < 1e-4
-    assert rel(dW2, ref[idx].t()) < 1e-4
+    for blocks in (48, -1):
+        dW.zero_(); db.zero_(); dW2.zero_()
+        ops.wgrad_multi(probs, blocks)
+        assert rel(dW, ref[idx]) < 1e-4
+        assert rel(db, refb[idx]) < 1e-4
+        assert rel(dW2, ref[idx].t()) < 1e-4
 
 
 def test_groups_expand(dev):
@@ -128,6 +134,8 @@ def test_groups_expand(dev):
     store = torch.zeros(G * blk, dtype=torch.float32, device=dev)
     p = ops.wgrad_args(dy, N, x, K, store[: N * K].view(N, K), store[N * K: N * K + N], groups=G, dw_gstride=blk * 4)
     ops.wgrad_multi([p], 30)
+    ops.wgrad_multi([p], -1)                                               # the launcher's own sizing adds the same again
+    store *= 0.5
     for k in range(G):
         dW = store[k * blk: k * blk + N * K].view(N, K)
         db = store[k * blk + N * K: k * blk + N * K + N]
@@ -152,10 +160,13 @@ def test_split_mode(dev):
         Y64, X64 = joined(Yh, Yl).cpu()[:, :N], joined(Xh, Xl).cpu()[:, :K]
         outs.append((dW, db, Y64.t() @ X64, Y64.sum(0)))
         keep += [Yh, Yl, Xh, Xl]
-    ops.wgrad_multi(probs, 24)
-    for dW, db, ref, refb in outs:
-        assert rel(dW, ref) < KTOL
-        assert rel(db, refb) < KTOL
+    for blocks in (24, -1):
+        for dW, db, _, _ in outs:
+            dW.zero_(); db.zero_()
+        ops.wgrad_multi(probs, blocks)
+        for dW, db, ref, refb in outs:
+            assert rel(dW, ref) < KTOL
+            assert rel(db, refb) < KTOL
 
 
 def test_argument_errors(dev):

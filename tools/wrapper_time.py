@@ -68,7 +68,7 @@ if os.environ.get("TRAINER") == "1":
 
     if os.environ.get("GRAPH") == "1":
         # the same step captured once in a HIP graph and replayed (dense rows; fresh dropout masks per replay through the step clock)
-        from transfusion_amd.runner.trainer import GraphedTrainStep
+        from graph_step import GraphedTrainStep
         for f in feats:
             f.grad = None
         gs = GraphedTrainStep(trainer, None, _loss, warmup=3)

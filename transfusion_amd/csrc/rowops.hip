@@ -462,12 +462,30 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
   int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int S = Nv + Nl;
+  // fast path: a lane reads 8 mask bytes with one load (a row of 512 tokens = one load per lane: the byte-per-lane loop below made 8
+  // dependent trips per sample and pass, 23 us for 32 samples)
+  const bool wide = lm != nullptr && (Nl & 7) == 0 && (((size_t)lm) & 7) == 0;
+  auto ok_bits = [&](int b, int j8) -> unsigned {                  // bit k: token j8 + k of sample b is attended (j8 < Nl, multiple of 8)
+    const unsigned long long v = *(const unsigned long long*)(lm + (size_t)b * Nl + j8);
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m |= (((v >> (8 * k)) & 0xffull) == 0ull ? 1u : 0u) << k;
+    return m;
+  };
   for (int b = wave; b < B; b += nw) {
     int c = 0;
-    for (int j0 = 0; j0 < Nl; j0 += 64) {
-      const int j = j0 + lane;
-      const bool ok = j < Nl && (lm == nullptr || lm[(size_t)b * Nl + j] == 0);
-      c += __popcll(__ballot(ok));
+    if (wide) {
+      for (int j0 = 0; j0 < Nl; j0 += 512) {
+        const int j8 = j0 + lane * 8;
+        c += j8 < Nl ? __popc(ok_bits(b, j8)) : 0;
+      }
+      c = (int)wave_sum((float)c);                               // (exact: at most Nl <= 2^24)
+    } else {
+      for (int j0 = 0; j0 < Nl; j0 += 64) {
+        const int j = j0 + lane;
+        const bool ok = j < Nl && (lm == nullptr || lm[(size_t)b * Nl + j] == 0);
+        c += __popcll(__ballot(ok));
+      }
     }
     if (lane == 0) cnt[b] = Nv + c;
   }
@@ -502,6 +520,35 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
     if (lane == 0) start_of[b] = max(0, min(base, expected - Nv));
     for (int i = lane; i < Nv; i += 64) dense_of[base + i] = b * S + i;
     int run = base + Nv;
+    if (wide) {
+      for (int j0 = 0; j0 < Nl; j0 += 512) {
+        const int j8 = j0 + lane * 8;
+        const unsigned m = j8 < Nl ? ok_bits(b, j8) : 0u;
+        const int c = __popc(m);
+        // exclusive prefix of c (0 .. 8) over the lanes below: one ballot per bit plane
+        int before = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) before += __popcll(__ballot((c >> p) & 1) & ((1ull << lane) - 1ull)) << p;
+        int tot = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) tot += __popcll(__ballot((c >> p) & 1)) << p;
+        if (j8 < Nl) {
+          int out[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const bool ok = (m >> k) & 1u;
+            const int pos = run + before + __popc(m & ((1u << k) - 1u));
+            if (ok) dense_of[pos] = b * S + Nv + j8 + k;
+            out[k] = (ok && pos < expected) ? pos : -1;
+          }
+          int* dst = packed_of_lang + (size_t)b * Nl + j8;         // 8 ints: 32-B aligned when the table is (Nl % 8 == 0)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dst[k] = out[k];
+        }
+        run += tot;
+      }
+      continue;
+    }
     for (int j0 = 0; j0 < Nl; j0 += 64) {
       const int j = j0 + lane;
       const bool ok = j < Nl && (lm == nullptr || lm[(size_t)b * Nl + j] == 0);
@@ -664,9 +711,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
+    // the partial is the ONLY datum published, and an agent-scope atomic store is written through (sc1): once it has completed
+    // (vmcnt 0) the ticket may follow -- no release fence, whose L2 write-back per block made this kernel 32 us for 75 MB at 512 blocks
+    // and 109 us at 2048 (cdna_hip_programming.md, the split-K combine: "sc1 stores ... need no release fence")
     __hip_atomic_store(&g_sumsq_part[slot][blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the release's write-back must be complete before the ticket: MI355X_MICROARCH.md)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(&g_sumsq_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = t == gridDim.x - 1;
   }

@@ -275,21 +275,10 @@ int wgrad_launch(const Ctx& c, Side& sd, const TfWgradArgs* jobs, int mask, bool
   for (int i = 0; i < 4; ++i) if ((mask >> i) & 1) sel[n++] = jobs[i];
   if (n == 0) return 0;
   hipStream_t st = sd.st != nullptr ? sd.st : c.st;
-  int blocks = 0;                                              // nothing beside it: two workgroups per CU
-  if (sd.st != nullptr && !alone) {
-    // Beside the chain: ~1.7 workgroups per CU (three row chunks for a d = 768 layer's 144 tiles: 172 us alone against 210 at two and 207
-    // at four), and fewer when M is small, so that a workgroup keeps a few dozen 32-row steps to amortise its prologue and flush
-    static const int per_cu_x10 = TF_ENV_INT("TF_WGM_BLOCKS_X10", 17), min_steps = TF_ENV_INT("TF_WGM_MIN_STEPS", 40);
-    int tiles = 0;
-    for (int i = 0; i < n; ++i) tiles += ((sel[i].N + 255) / 256) * ((sel[i].K + 127) / 128) * c.D.G;
-    const int steps = (c.D.M / c.D.G + 31) / 32;
-    int chunks = (ncus() * per_cu_x10 / 10 + tiles / 2) / tiles;
-    if (chunks > steps / min_steps) chunks = steps / min_steps;
-    if (chunks < 1) chunks = 1;
-    blocks = chunks * tiles;
-  }
+  // sizing is the launcher's: 0 = the launch has the chip to itself, -1 = it runs beside the chain
+  const int blocks = (sd.st != nullptr && !alone) ? -1 : 0;
   if (n * c.D.G > TF_WGRAD_MULTI_MAX) {                        // more groups than one launch takes: one launch per product
-    for (int i = 0; i < n; ++i) { const int rc = tf_launch_wgrad_multi(&sel[i], 1, blocks > 0 ? blocks / n : 0, st); if (rc != 0) return rc; }
+    for (int i = 0; i < n; ++i) { const int rc = tf_launch_wgrad_multi(&sel[i], 1, blocks, st); if (rc != 0) return rc; }
     return 0;
   }
   return tf_launch_wgrad_multi(sel, n, blocks, st);

@@ -26,6 +26,15 @@
 #include "tf_common.h"
 #include "tf_kernels.h"
 
+// timing ablations of the K loop (experiments builds only: wrong results): 2 one MFMA in eight, 4 fragment reads in the first step
+// only, 16 no flush.  Measured with them (tools/experiments/wgrad_multi_kloop_ablations.txt): see DESIGN.md, "What bounds the step now".
+#ifndef TF_EXPERIMENTS
+#undef TF_ABL_WGM
+#endif
+#ifndef TF_ABL_WGM
+#define TF_ABL_WGM 0
+#endif
+
 namespace {
 
 constexpr int WG_MAX = TF_WGRAD_MULTI_MAX;
@@ -44,6 +53,11 @@ template <int N, class F, int... I> __device__ __forceinline__ void sfor_impl(F&
 }
 template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
+// (a __device__ function: the LDS-DMA builtin inside a lambda of a kernel TEMPLATE can make hipcc's host pass drop the instantiation
+// silently -- the library then fails to load with an undefined __device_stub__; it did when a fourth template parameter was tried)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TF_LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
 // INTL: 0 = the step's transfers in front of its MFMAs (the form of wgrad_tn2_kernel), 1 = one transfer after every second MFMA
 template <bool SPLIT, int NS, int INTL>
 __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
@@ -110,10 +124,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
     }
     unsigned char* base = smem + slot * SLOT;
     if constexpr (q < NPY) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(SPLIT && ylo ? rYl : rYh, TF_LDS_PTR(base + (q * NWV + wave) * 1024), 16, vy[q], st * step_y, 0, 0);
+      dma16(SPLIT && ylo ? rYl : rYh, base + (q * NWV + wave) * 1024, vy[q], st * step_y);
     } else {
       constexpr int i = q - NPY;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(SPLIT && xlo ? rXl : rXh, TF_LDS_PTR(base + YB + (i * NWV + wave) * 1024), 16, vx[i], st * step_x, 0, 0);
+      dma16(SPLIT && xlo ? rXl : rXh, base + YB + (i * NWV + wave) * 1024, vx[i], st * step_x);
     }
   };
   auto stage = [&](int slot, int step) { sfor<NPW>([&](auto Q) { piece(Q, slot, step); }); };
@@ -155,8 +169,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
     Xv[1][0] = tr_read_asm<(MS) * 16 * XROW>(sl + (xoff ^ 64));   Xv[1][1] = tr_read_asm<(MS) * 16 * XROW + 4 * XROW>(sl + (xoff ^ 64));   \
     Y[2][0] = tr_read_asm<(MS) * 16 * YROW>(sl + (yoff ^ 128));   Y[2][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + (yoff ^ 128));   \
     Y[3][0] = tr_read_asm<(MS) * 16 * YROW>(sl + (yoff ^ 192));   Y[3][1] = tr_read_asm<(MS) * 16 * YROW + 4 * YROW>(sl + (yoff ^ 192));
+    if (!(TF_ABL_WGM & 4) || st == 0) {
     TF_RD(y0, x0, 0)
     TF_RD(y1, x1, 1)
+    }
 #undef TF_RD
     const int nslot = slot == 0 ? NS - 1 : slot - 1;           // (st + NS - 1) % NS given slot = st % NS
     const int nstep = st + NS - 1;                             // steps past the end read zeros (never consumed)
@@ -172,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
       for (int kb = 0; kb < KB; ++kb) bfr[kb] = join_tr64(Xv[kb][0], Xv[kb][1]);
       sfor<NB * KB>([&](auto I) {
         constexpr int i = decltype(I)::value, nb = i / KB, kb = i % KB;
-        acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+        if constexpr (!(TF_ABL_WGM & 2) || i == 0) acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+        else asm volatile("" :: "v"(af[nb]), "v"(bfr[kb]));
         if constexpr (INTL == 1) {
           constexpr int done = ms * NB * KB + i + 1;             // one transfer behind every second MFMA of the step
           if constexpr (done % 2 == 0 && done / 2 - 1 < NPW) {
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
         const int kp = k0 + wc * (KB * 32) + kb * 32 + (lane & 31);
         const int kg = kp / cgp, ke = kp - kg * cgp;
         const int ks = kg * cg + ke;
+        if ((TF_ABL_WGM & 16) && (r != 0 || (lane & 31) != 0)) { asm volatile("" :: "v"(acc[nb][kb][r])); continue; }
         if (nok && kp < K && ke < cg && ks < k_src) atomicAdd(dW + (size_t)ns * lddw + ks, acc[nb][kb][r]);
       }
     }
@@ -247,8 +265,9 @@ int cu_count() {
 
 }  // namespace
 
-// count problems (each a TfWgradArgs; `groups` expands into that many problems) as one launch.  blocks: the number of workgroups the
-// caller wants in flight (0: two per CU, a launch that has the chip to itself); the row chunks follow from it.
+// count problems (each a TfWgradArgs; `groups` expands into that many problems) as one launch.  blocks > 0: that many workgroups in
+// flight (the row chunks follow from it); 0: sized here for a launch that has the chip to itself (two workgroups per CU); -1: for a
+// launch that runs beside a dependent chain of other kernels.
 extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, hipStream_t stream) {
   if (probs == nullptr || count <= 0) return -1;
   WgMulti m{};
@@ -288,8 +307,16 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
     }
   }
   if (n == 0) return 0;
-  if (blocks <= 0) blocks = 2 * cu_count();
-  int chunks = (blocks + tiles / 2) / tiles;
+  if (blocks == 0) blocks = 2 * cu_count();
+  int chunks;
+  if (blocks > 0) chunks = (blocks + tiles / 2) / tiles;
+  else {
+    // Beside the chain: ~1.7 workgroups per CU (three row chunks for a d = 768 layer's 144 tiles: 172 us alone against 210 at two and 207
+    // at four), and fewer when M is small, so that a workgroup keeps a few dozen 32-row steps to amortise its prologue and flush
+    static const int per_cu_x10 = TF_ENV_INT("TF_WGM_BLOCKS_X10", 17), steps_per_chunk = TF_ENV_INT("TF_WGM_MIN_STEPS", 40);
+    chunks = (cu_count() * per_cu_x10 / 10 + tiles / 2) / tiles;
+    if (chunks > min_steps / steps_per_chunk) chunks = min_steps / steps_per_chunk;
+  }
   if (chunks < 1) chunks = 1;
   if (chunks > min_steps) chunks = min_steps;
   // a chunk's rows are addressed with 32-bit byte offsets inside a buffer resource: keep every chunk under 2 GiB

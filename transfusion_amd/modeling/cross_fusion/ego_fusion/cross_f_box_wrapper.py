@@ -196,7 +196,7 @@ class CrossFusionBoxWrapper(nn.Module):
             fused_l_features = grouped[1][-1]
         parallel = (grouped is None and main is not None and not self.forward_language_f and len(self.fpn_features_idx) > 1
                     and os.environ.get("TF_LEVEL_STREAMS", "1") != "0")
-        # which way the levels went (read by runner.trainer.check_capturable: level streams + side streams cannot be graph-captured)
+        # which way the levels went (read by tests/graph_step.py: check_capturable: level streams + side streams cannot be graph-captured)
         others_on_streams = grouped is not None and getattr(self, "_grouped_others", 0) > 0 and os.environ.get("TF_LEVEL_STREAMS", "1") != "0"
         self._last_path = ("streams" if others_on_streams else "grouped") if grouped is not None else ("streams" if parallel else "loop")
         if main is not None:

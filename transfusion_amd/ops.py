@@ -166,7 +166,7 @@ def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
 
 
 # ---- the step clock (tf_clock_ptr): what makes a step captured in a HIP graph draw fresh dropout masks on every replay ----
-_clock_host = [0]          # host mirror of the device word (graph replays advance the device side; GraphedTrainStep keeps this in step)
+_clock_host = [0]          # host mirror of the device word (graph replays advance the device side; a capturing caller keeps this in step: tests/graph_step.py)
 
 
 def clock_ptr() -> int:
@@ -188,7 +188,7 @@ def clock_set(value: int):
 
 
 def clock_value() -> int:
-    """The clock as the host last left it (plus the replays GraphedTrainStep has counted)."""
+    """The clock as the host last left it (plus the replays a capturing caller has counted)."""
     return _clock_host[0]
 
 

@@ -61,7 +61,7 @@ class FusedRAdam(torch.optim.Optimizer):
 
     def refresh_lr(self):
         """Copies every group's current ``lr`` into its device scalar (no-op for groups whose rate has not changed).  Call OUTSIDE a graph
-        capture, before a replay: GraphedTrainStep.replay() does."""
+        capture, before a replay: the replay helper of tests/graph_step.py does."""
         for g in self.param_groups:
             t = g.get("_lr_dev")
             if t is not None and g.get("_lr_dev_val") != float(g["lr"]):
@@ -82,7 +82,7 @@ class FusedRAdam(torch.optim.Optimizer):
         """``sumsq`` (1-element device tensor holding sum(g^2) over ALL gradients) + ``clip`` > 0 apply torch's
         clip_grad_norm_ coefficient on the device, with no host synchronisation.  ``on_clock``: the step number is read from the
         library's step clock on the device (``ops.clock_*``) and the schedule terms are formed there -- what a step captured in a
-        HIP graph needs, since its host-computed terms would be frozen into the graph (GraphedTrainStep).  ``zero_grad``: every gradient
+        HIP graph needs, since its host-computed terms would be frozen into the graph (tests/graph_step.py).  ``zero_grad``: every gradient
         is zeroed by the kernel once it has been read (the next step's zero fill, fused into this pass)."""
         loss = None
         if closure is not None:
