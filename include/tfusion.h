@@ -124,6 +124,7 @@ typedef struct TfAttnArgs {
   // Backward, optional workspace of tf_attn_ds_bytes(B, H, S) bytes.  With it (head dims <= 192, self attention) S and dP are computed
   // ONCE: a small kernel forms delta, the dK / dV kernel writes its dS tiles here (bf16, one coalesced 1-KiB chunk per 16 keys x 32
   // queries) and a thin kernel forms dQ = dS . K from them -- instead of a dQ kernel that recomputes S and dP.  null: the two-kernel form.
+  // fp32-accuracy mode (qkv_lo != null): 2 x tf_attn_ds_bytes(B, H, S) bytes -- a hi and a lo plane of dS, any head dim the mode serves.
   void* ds_work;
 } TfAttnArgs;
 

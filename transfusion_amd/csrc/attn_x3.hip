@@ -11,6 +11,11 @@
 //   * dK and dV are two launches of one kernel (WHICH): a wave that kept K, V (hi + lo) resident AND both accumulators would need
 //     ~450 registers at head dim 192.  The dV launch needs only K resident, the dK launch K and V.
 // The bf16 kernels' tuning (two waves per SIMD, register prefetch, read-ahead pipelines) is deliberately absent here.
+//
+// With a dS workspace (TfAttnArgs.ds_work, 2 x tf_attn_ds_bytes: a hi and a lo plane; self attention) the backward computes S and dP
+// for dQ no longer: a small kernel forms delta, the dK launch writes its dS tiles -- per (batch, head) a [key][query] bf16 matrix of
+// side 128 ceil(S / 128) stored as 32 x 32 tiles of 2 KiB (a wave of the dK launch fills one per query tile, contiguously), twice --
+// and attn_bwd_dq_ds_x3_kernel forms dQ = scale dS . K from them with one product instead of three (eight products per layer -> six).
 #include "tf_common.h"
 #include <cstdio>
 #include "tf_kernels.h"
@@ -72,6 +77,11 @@ __device__ __forceinline__ void stage_quad(cu16p a_hi, cu16p a_lo, size_t lda, b
   r2.store(lb_hi, tid);
   r3.store(lb_lo, tid);
 }
+
+// dS workspace of the fp32-accuracy backward: per (batch, head) a [side][side] bf16 matrix, side = 128 ceil(S / 128); the lo plane
+// follows the hi plane (plane = tf_attn_ds_bytes(B, H, S) bytes = B H side^2 elements + slack)
+__host__ __device__ inline size_t ds_side_x3(int S) { return (size_t)128 * ((S + 127) / 128); }
+__host__ __device__ inline size_t ds_plane_x3(int B, int H, int S) { return (size_t)B * H * ds_side_x3(S) * ds_side_x3(S) + 2048; }   // elements
 
 // ================================================================================================
 // forward: St[key][q] = K . Q^T (3 passes), online softmax in fp32, O^T += V^T . Pt (3 passes)
@@ -342,6 +352,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
 
 // ================================================================================================
 // backward, dV (WHICH = 0) or dK (WHICH = 1): key on the lane, loop over query tiles of 32 (see attn_bwd_dkv_kernel)
+// (dV and dK in ONE pass -- S and dP once for both, four products per tile instead of five -- was built and works up to head dim 160:
+// two accumulator sets + the K fragments are 288 registers at head dim 192, so the V rows have to come from LDS, and 128 V rows in
+// both planes (147 KB at the dual-use tile stride, 100 KB packed) do not fit beside the 74 KB of Q / dO tiles.  The benchmark's and
+// the reference's fp32 configurations have head dims 192 and 224: the variant is not in the tree.)
 //   S[q][key] = Q.K^T -> P ;  dP = dO.V^T ;  Pd = P*keep/(1-p) ;  dS = P*(keep/(1-p)*dP - delta)
 //   dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key] ; dK *= scale
 // ================================================================================================
@@ -402,6 +416,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const float sc = a.scale * LOG2E;
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const bool blk = a.block_bits != nullptr;
+  // dS rows of this lane's key in the workspace planes (WHICH == 1 with TfAttnArgs.ds_work, self attention): see the file header
+  u16* ds_h = nullptr; u16* ds_l = nullptr;
+  if constexpr (WHICH == 1) {
+    if (a.ds_work != nullptr && !cross) {
+      const size_t nb = ds_side_x3(S) / 32;                        // 32 x 32 tiles per side
+      // tile (key0 / 32, query tile t) of this (batch, head); inside it row (lane & 31), the 16-B chunk this lane stores (see the loop)
+      ds_h = (u16*)a.ds_work + (((size_t)bh * nb + (key0 >> 5)) * nb) * 1024 + (lane & 31) * 32;
+      ds_l = ds_h + ds_plane_x3(a.B, a.H, S);
+    }
+  }
 
   const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sqb + 31) / 32;
   const int dw_ld = 2 * ((S + 63) / 64);
@@ -457,6 +481,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
         else st[r] = p * fmaf(dp[r], keep_scale, -d4[i]);                              // dS
       }
     }
+    if constexpr (WHICH == 1) {
+      if (ds_h != nullptr) {              // (workgroup-uniform) this wave's 32 keys x 32 queries of dS: one contiguous 2-KiB tile per plane
+        // registers 4g..4g+3 are queries 8g + 4h + (0..3): lanes l and l ^ 32 hold the two halves of every 16-B chunk (8 queries) of
+        // their key's row.  Lane half h keeps chunks h and h + 2 and gets the other lane's half of them: 16-B stores, whole rows.
+        u32x2 hi[4], lo[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          hi[g4][0] = pack2bf(st[4 * g4], st[4 * g4 + 1]); hi[g4][1] = pack2bf(st[4 * g4 + 2], st[4 * g4 + 3]);
+          lo[g4][0] = pack2bf(st[4 * g4] - bf2f((u16)(hi[g4][0] & 0xffffu)), st[4 * g4 + 1] - bf2f((u16)(hi[g4][0] >> 16)));
+          lo[g4][1] = pack2bf(st[4 * g4 + 2] - bf2f((u16)(hi[g4][1] & 0xffffu)), st[4 * g4 + 3] - bf2f((u16)(hi[g4][1] >> 16)));
+        }
+        u16* th = ds_h + (size_t)t * 1024;
+        u16* tl = ds_l + (size_t)t * 1024;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {                              // chunk 2 c2 + h is this lane's; it gives away chunk 2 c2 + (1 - h)
+          const u32x2 mine_h = h ? hi[2 * c2 + 1] : hi[2 * c2], give_h = h ? hi[2 * c2] : hi[2 * c2 + 1];
+          const u32x2 mine_l = h ? lo[2 * c2 + 1] : lo[2 * c2], give_l = h ? lo[2 * c2] : lo[2 * c2 + 1];
+          u32x2 got_h, got_l;
+          got_h[0] = (unsigned)__shfl_xor((int)give_h[0], 32, 64); got_h[1] = (unsigned)__shfl_xor((int)give_h[1], 32, 64);
+          got_l[0] = (unsigned)__shfl_xor((int)give_l[0], 32, 64); got_l[1] = (unsigned)__shfl_xor((int)give_l[1], 32, 64);
+          const u32x4 vh = h ? u32x4{got_h[0], got_h[1], mine_h[0], mine_h[1]} : u32x4{mine_h[0], mine_h[1], got_h[0], got_h[1]};
+          const u32x4 vl = h ? u32x4{got_l[0], got_l[1], mine_l[0], mine_l[1]} : u32x4{mine_l[0], mine_l[1], got_l[0], got_l[1]};
+          *(u32x4*)(th + 8 * (2 * c2 + h)) = vh;
+          *(u32x4*)(tl + 8 * (2 * c2 + h)) = vl;
+        }
+      }
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 f_h, f_l;
@@ -483,6 +534,127 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   }
 }
 
+// ================================================================================================
+// delta[b, h, q] = rowsum(dO . O) in fp32 from both planes of both tensors, one wave per token row (the dS path: the dQ kernel that
+// used to form it is not launched)
+// ================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_x3_kernel(const TfAttnArgs a) {
+  __shared__ float part[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, nrb = (S + 3) / 4;
+  const int b = blockIdx.x / nrb, q = (blockIdx.x % nrb) * 4 + wave;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  if (q >= sr.len) return;                                 // (no barrier below: waves are independent)
+  const int cph = a.HDP / 8, nch = a.H * cph;             // 16-B chunks per head / per row (<= 256)
+  const size_t oo = (sr.row0 + q) * a.ld_out, od = (sr.row0 + q) * a.ld_dout;
+  for (int c = lane; c < nch; c += 64) {
+    float of[8], df[8];
+    load8_split(a.out, a.out_lo, oo + c * 8, of);
+    load8_split(a.dout, a.dout_lo, od + c * 8, df);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(of[e], df[e], s);
+    part[wave][c] = s;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS writes have landed (wave-private rows of `part`)
+  __builtin_amdgcn_wave_barrier();
+  if (lane < a.H) {
+    float s = 0.f;
+    for (int c = 0; c < cph; ++c) s += part[wave][lane * cph + c];
+    a.delta[((size_t)b * a.H + lane) * S + q] = s;
+  }
+}
+
+// ================================================================================================
+// backward, dQ from the dS planes the dK launch wrote:  dQ^T[d][q] += K^T[d][key] . dS^T[key][q]  (3 passes);  dQ = scale * dQ^T^T.
+// 4 waves x 32 queries per workgroup; per 64-key tile the K tile (both planes) and the [64 keys][128 queries] block of dS (both planes)
+// are staged for the workgroup, the next tile's loads in flight during the matrix work; a wave's B operand is the transposed read of
+// ITS 32 query columns -- tr_frag hands lane (query n) the 8 keys of a k-step in the order the A operand's K^T fragment uses.
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_ds_x3_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  using GD = Geo<128>;                                          // the dS block as a tile of 128 columns
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kt_h = smem;
+  unsigned char* kt_l = smem + 64 * G::TSTR;
+  unsigned char* dt_h = smem + 128 * G::TSTR;
+  unsigned char* dt_l = dt_h + 64 * GD::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int S = a.S;
+  const int nqb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nqb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int qblk = logical % nqb;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len;
+  if (qblk * 128 >= Sb) return;                                 // query blocks past the sample's end (workgroup-uniform)
+  const size_t ld = a.ld_qkv;
+  cu16p k_h = (const u16*)a.qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
+  const size_t nb = ds_side_x3(S) / 32;                          // 32 x 32 tiles (2 KiB) per side
+  cu16p d_h = (const u16*)a.ds_work + ((size_t)bh * nb * nb + (size_t)qblk * 4) * 1024, d_l = d_h + ds_plane_x3(a.B, a.H, S);
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
+
+  f32x16 dq[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+  TileRegs<64, HDP> rk_h, rk_l;
+  // the [64 keys][128 queries] block of dS = 2 x 4 tiles of 2 KiB per plane: piece id = i * 256 + tid -> tile id >> 7 (key half kbl = tile
+  // >> 2, query tile qt = tile & 3), row (id & 127) >> 2, 16-B piece id & 3: a tile is read by 128 consecutive threads, contiguously
+  u32x4 rd_h[4], rd_l[4];
+  unsigned d_off[4];                                            // element offset of piece i inside key tile 0 (a key tile further: 2 nb tiles)
+  int d_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + tid, tile = id >> 7, kbl = tile >> 2, qt = tile & 3, row = (id & 127) >> 2, pc = id & 3;
+    d_off[i] = (unsigned)((kbl * nb + qt) * 1024 + row * 32 + pc * 8);
+    d_lds[i] = tile_off(kbl * 32 + row, qt * 4 + pc, GD::TSTR);
+  }
+  auto fetch = [&](int t) {
+    rk_h.load(k_h, ld, t * 64, Sb - 1, false, tid);
+    rk_l.load(k_l, ld, t * 64, Sb - 1, false, tid);
+    const size_t tb = (size_t)t * 2 * nb * 1024;                // (the dK launch wrote every tile a key tile reads: whole 128-key workgroups)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rd_h[i] = *(const u32x4*)(d_h + tb + d_off[i]); rd_l[i] = *(const u32x4*)(d_l + tb + d_off[i]); }
+  };
+  if (ntiles > 0) fetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                                            // every wave is done with the previous tiles
+    rk_h.store(kt_h, tid); rk_l.store(kt_l, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { *(u32x4*)(dt_h + d_lds[i]) = rd_h[i]; *(u32x4*)(dt_l + d_lds[i]) = rd_l[i]; }
+    __syncthreads();
+    if (t + 1 < ntiles) fetch(t + 1);
+#pragma unroll 1
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 ds_hi = tr_frag<128>(dt_h, kb * 32 + 16 * s, wave * 32, lane);
+        const bf16x8 ds_lo = tr_frag<128>(dt_l, kb * 32 + 16 * s, wave * 32, lane);
+#pragma unroll
+        for (int d = 0; d < G::DBLK; ++d)
+          dq[d] = mfma3(tr_frag<HDP>(kt_h, kb * 32 + 16 * s, d * 32, lane), tr_frag<HDP>(kt_l, kb * 32 + 16 * s, d * 32, lane), ds_hi, ds_lo, dq[d]);
+      }
+    }
+  }
+  const int qrow = qblk * 128 + wave * 32 + (lane & 31);
+  if (qrow < Sb) {
+    const size_t off = (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+    u16* r_h = (u16*)a.dqkv + off;
+    u16* r_l = (u16*)a.dqkv_lo + off;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = d * 32 + 8 * g4 + 4 * h;
+        store4_split(r_h + c, r_l + c, dq[d][4 * g4] * a.scale, dq[d][4 * g4 + 1] * a.scale, dq[d][4 * g4 + 2] * a.scale, dq[d][4 * g4 + 3] * a.scale);
+      }
+  }
+}
+
 template <int HDP> int launch_fwd_x3(const TfAttnArgs* a, hipStream_t st) {
   const size_t lds = 256 * Geo<HDP>::TSTR;
   static const hipError_t once = hipFuncSetAttribute((const void*)attn_fwd_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -504,7 +676,11 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
   const dim3 grid(((a->S + 127) / 128) * a->B * a->H), grid_q(((Sq + 127) / 128) * a->B * a->H);
   const double fl = 4.0 * a->B * a->H * (double)Sq * a->S * HDP;       // credited as in attn_bf16.hip: backward = 2x forward over dq + dkv
   char nm[56];
-  {
+  const bool ds = a->ds_work != nullptr && a->q == nullptr;            // S and dP once: delta, dV, dK (+ dS planes), dQ from dS
+  if (ds) {
+    TfTraceScope tr("attn_delta_x3_kernel", st);
+    hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(a->B * ((a->S + 3) / 4)), dim3(256), 0, st, *a);
+  } else {
     snprintf(nm, sizeof(nm), "attn_bwd_dq_x3_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
@@ -518,6 +694,14 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dK>", HDP);
     TfTraceScope tr(nm, st, fl / 2);
     hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<HDP, 1>), grid, dim3(256), lds_kv, st, *a);
+  }
+  if (ds) {
+    const size_t lds_ds = 128 * Geo<HDP>::TSTR + 128 * Geo<128>::TSTR;
+    static const hipError_t o4 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ds);
+    (void)o4;
+    snprintf(nm, sizeof(nm), "attn_bwd_dq_ds_x3_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl / 2);
+    hipLaunchKernelGGL(attn_bwd_dq_ds_x3_kernel<HDP>, grid_q, dim3(256), lds_ds, st, *a);
   }
   return (int)hipGetLastError();
 }

@@ -99,7 +99,7 @@ struct AOff {   // byte offsets inside work
   size_t meanf, rstdf;
   size_t dxa, dxb, dz, dy, dzb, dyb, du, d_o, dqkv, delta;
   size_t dz1, dy1, dzb1, dyb1, du1, dqkv1;        // the same six for odd layers
-  size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work), bf16 mode
+  size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work)
   size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
   size_t total;
 };
@@ -134,7 +134,7 @@ AOff make_aoff(const Dims& D) {
   // gradients of layer l are launched together at the end of the layer's backward and run beside the chain of layer l - 1, which
   // fills the other set.
   a.dz1 = take2(md); a.dy1 = take2(md); a.dzb1 = take2(md); a.dyb1 = take2(md); a.du1 = take2(mf); a.dqkv1 = take2(mq);
-  a.dsw = take(D.split ? 256 : tf_attn_ds_bytes(D.B, D.H, D.S));
+  a.dsw = take((D.split ? 2 : 1) * tf_attn_ds_bytes(D.B, D.H, D.S));      // fp32-accuracy mode: a hi and a lo plane
   a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
   return a;
@@ -815,7 +815,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
-      a.ds_work = D.split ? nullptr : (void*)(c.wk + c.A.dsw);
+      a.ds_work = (void*)(c.wk + c.A.dsw);
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
     jobs[3] = wjob(c, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d);
