@@ -154,5 +154,11 @@ def test_out_of_range_labels_select_nothing_and_are_reported(dev):
     with pytest.raises(IndexError):
         ops.check_label_errors(sync=True)
     ops.check_label_errors(sync=True)                       # reported once
+    # the trainer's entry: FusionTrainStep.step() looks (without waiting) at the start of every step, check_errors(sync=True) waits
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    run(n3, v3)
+    with pytest.raises(IndexError):
+        FusionTrainStep.check_errors(sync=True)
+    FusionTrainStep.check_errors(sync=True)
     with pytest.raises(RuntimeError):                       # class-weight vector shorter than the class count
         ops.nao_head_losses(cls, box, None, Cn, Cv, t(noun), t(verb), None, t(reg), t(noun_w[:-1]), t(verb_w), IGNORE_VERB_IDX_BG)

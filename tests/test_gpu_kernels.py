@@ -606,3 +606,20 @@ def test_wgrad_grouped_rows(dev, G, Mg, N, K, chunk):
         assert rel(dW, yk.t() @ xk) < 2e-5, k
         assert rel(db, yk.sum(0)) < 2e-5, k
     assert float(store.view(G, blk)[:, N * K + N:].abs().max()) == 0.0       # nothing written between the groups' tensors
+
+
+def test_backward_through_repacked_weight_shadows_raises(dev):
+    """ops.linear keeps bf16 shadows of a weight and re-packs them IN PLACE after an optimiser step.  forward, step, forward again and
+    then the FIRST graph's backward would form dgrad with the new weights: the re-pack bumps the shadows' autograd version, so that
+    backward raises torch's in-place-modification error."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(9)
+    w = torch.nn.Parameter(torch.randn(64, 64, generator=g).to(dev))
+    x = torch.randn(16, 64, generator=g).to(dev).requires_grad_(True)
+    y1 = ops.linear(x, w)
+    with torch.no_grad():
+        w.add_(0.5)                                    # an optimiser step (bumps w's version -> the shadows are re-packed in place)
+    y2 = ops.linear(x, w)
+    y2.float().sum().backward()                        # the current graph is fine
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y1.float().sum().backward()

@@ -89,6 +89,10 @@ def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, w
     w = w.detach().contiguous().float()
     if into is not None and into[0].shape == (rows_p, ld) and (not want_t or (into[1] is not None and into[1].shape == (cols_p, ld_t))):
         dst, dst_t = into[0], into[1] if want_t else None
+        # the kernel rewrites them through raw pointers: tell autograd, so that a backward whose forward saved the OLD contents (forward,
+        # optimiser step, forward again, then the first graph's backward) raises torch's in-place-modification error instead of
+        # silently forming dgrad with the new weights
+        torch._C._increment_version([t for t in (dst, dst_t) if t is not None])
     else:
         dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
         dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
@@ -392,8 +396,8 @@ def _weight_shadows(weight, N8, Kp, Np, planes=False, sources=None):
     if hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[1] == key:
         return hit[2]
     # same owners, new version (the optimiser stepped): re-pack into the entry's tensors instead of zero-filling two fresh ones per
-    # weight and step.  (As with the encoders' shadow blocks, a forward whose backward is still pending must not be followed by an
-    # optimiser step and another forward of the same weight before that backward runs.)
+    # weight and step.  (A forward whose backward is still pending must not be followed by an optimiser step and another forward of the
+    # same weight before that backward runs: pack_weight bumps the shadows' autograd version, so that backward RAISES.)
     reuse = hit[2][:2] if (hit is not None and not planes and all(r() is o for r, o in zip(hit[0], owners))
                           and hit[2][0].device == w2.device) else None
     wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np, into=reuse)
@@ -759,6 +763,8 @@ _label_flags = []        # (pinned host copy of sums[7], event recorded behind t
 
 
 def _watch_label_flag(sums):
+    if torch.cuda.is_current_stream_capturing():      # a pinned copy + an event query do not belong in a captured sequence
+        return
     host = torch.empty(1, dtype=torch.float32, pin_memory=True)
     host.copy_(sums[7:8], non_blocking=True)
     ev = torch.cuda.Event()

@@ -447,6 +447,7 @@ class FusionTrainStep:
 
     def step(self, micro_batches: List, loss_fn, on_clock: bool = False):
         """``loss_fn(module, batch) -> scalar``; returns the last loss (detached).  ``on_clock``: see FusedRAdam.step."""
+        self.check_errors(sync=False)                  # deferred device-side findings of EARLIER steps that have reached the host
         if not (self.zero_in_opt and self._grads_clean):
             self.zero_grad()
         self.flat.check_bound()
@@ -477,6 +478,20 @@ class FusionTrainStep:
         self._grads_clean = self.zero_in_opt
         self.mark_parameters_updated()
         return loss.detach()
+
+    @staticmethod
+    def check_errors(sync: bool = True):
+        """What the kernels found wrong WITHOUT stopping the stream: noun / verb labels outside their class range (the loss kernel
+        drops such samples; torch's cross_entropy would have raised IndexError -- ``ops.check_label_errors``) and a ``lang_valid_rows``
+        that disagreed with its padding mask (``check_packed_row_errors``).  ``step()`` looks at what has already reached the host
+        (``sync=False``: no stall) at the start of every step, so a bad batch raises one or two steps later; call this with
+        ``sync=True`` where a wait is cheap -- the end of an epoch, before a checkpoint, at teardown -- so that none stays unseen."""
+        from transfusion_amd import ops
+        from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import check_packed_row_errors
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        ops.check_label_errors(sync=sync)
+        check_packed_row_errors(sync=sync)
 
     def mark_parameters_updated(self):
         """The fused optimiser wrote through the FLAT buffer: it bumped that tensor's version counter, but a re-homed parameter
