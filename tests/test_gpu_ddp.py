@@ -187,7 +187,8 @@ if not single:
 grouped = int(getattr(model.cross_fusion_encoders[0], "_last_desc").groups)
 if rank == 0:
     extra = dict(grouped=grouped) if single else dict(grouped=grouped, agreed=tr.layerwise.agreed, collectives=tr.layerwise.collectives, nunits=len(tr.layerwise.units),
-                                          keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order)
+                                          keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order,
+                                          ranges=[(u["lo"], u["hi"]) for u in tr.layerwise.units])
     torch.save(dict(hist=hist, **extra), {out!r})
 if not single:
     dist.barrier()
@@ -235,9 +236,12 @@ def test_two_ranks_grouped_levels_under_the_ordered_reducer(tmp_path):
     assert two["grouped"] == 2 and one["grouped"] == 2, (two["grouped"], one["grouped"])
     assert two["agreed"] is True
     assert two["nunits"] == 8 and two["collectives"] == 1 + 2 * 8, (two["nunits"], two["collectives"], two["keys"])
-    for st2, st1 in zip(two["hist"], one["hist"]):
+    for step, (st2, st1) in enumerate(zip(two["hist"], one["hist"])):
         err = ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item()
-        assert err < 5e-3, err
+        # (seen ONCE in ~15 full-suite runs of round 4: 0.37 here, never in a targeted run -- if it comes back, say WHERE: per reducer unit)
+        where = [(k, round(((st2["grad"][lo:hi] - st1["grad"][lo:hi]).norm() / st1["grad"][lo:hi].norm().clamp_min(1e-30)).item(), 4))
+                 for k, (lo, hi) in zip(two["keys"], two["ranges"])] if err >= 5e-3 else None
+        assert err < 5e-3, (step, err, where)
     m2 = two["hist"][0]["param"] - two["hist"][0]["before"]
     m1 = one["hist"][0]["param"] - one["hist"][0]["before"]
     assert float(m1.abs().max()) > 0 and ((m2 - m1).norm() / m1.norm()).item() < 2e-2
