@@ -619,7 +619,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,v1_d712,v2_d896_fp32,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -787,6 +787,10 @@ def main():
                 "b4": dict(batch=4, steps=16, warmup=4),                                              # the reference's own per-GPU batch (32 / 8)
                 "b4_dense": dict(batch=4, steps=16, warmup=4, pack=False),                            # ... on dense rows
                 "b16": dict(batch=16),                                                                # configs[1]: Ego4Dv1, batch 16, one GPU
+                # the widths the reference's two YAMLs really give the fusion block ("ref-true alt"): input_f_size = the RoI
+                # head's representation size, 712 (Ego4Dv1: head dim 178, padded to 192 columns) and 896 (Ego4Dv2, fp32: head dim 224)
+                "v1_d712": dict(batch=16, d=712),
+                "v2_d896_fp32": dict(precision="fp32", d=896, steps=6, warmup=2),
                 "dense_rows": dict(pack=False),                                                       # masked tokens carried as dead rows
                 "no_padding": dict(padded=False),                                                     # 196 + 512 real tokens each
             }
