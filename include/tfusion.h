@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 5
+#define TF_ABI_VERSION 6
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -126,6 +126,9 @@ typedef struct TfAttnArgs {
   // queries) and a thin kernel forms dQ = dS . K from them -- instead of a dQ kernel that recomputes S and dP.  null: the two-kernel form.
   // fp32-accuracy mode (qkv_lo != null): 2 x tf_attn_ds_bytes(B, H, S) bytes -- a hi and a lo plane of dS, any head dim the mode serves.
   void* ds_work;
+  // how many tf_attn_ds_bytes-sized planes ds_work holds.  0 = the mode's minimum (1 in bf16, 2 in the fp32-accuracy mode).  4 in the
+  // fp32-accuracy mode: the dK launch also leaves Pd = P . keep / (1 - p) there (hi + lo), and dV is formed from it without recomputing S.
+  int ds_planes;
 } TfAttnArgs;
 
 

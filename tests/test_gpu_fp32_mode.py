@@ -123,12 +123,13 @@ def test_split_wgrad(dev, m_chunk):
     assert rel(dWb, Y64.t() @ X64) > 20 * rel(dW, Y64.t() @ X64)
 
 
-@pytest.mark.parametrize("ds", [False, True])
+@pytest.mark.parametrize("ds", [0, 2, 4])
 @pytest.mark.parametrize("hd,S,p", [(64, 200, 0.0), (192, 333, 0.15), (224, 130, 0.1)])
 def test_split_attention_against_fp64(dev, hd, S, p, ds):
     """tf_attn_fwd / tf_attn_bwd with lo planes against fp64 attention on the same (hi + lo) values: key-padding mask, dropout
-    bits replayed, LSE, dQ / dK / dV.  ``ds``: with a dS workspace (2 x tf_attn_ds_bytes) the backward is delta -> dV -> dK (+ the dS
-    planes) -> dQ = dS . K; the workspace starts NaN-filled: what the dK launch does not write must not reach a stored dQ row."""
+    bits replayed, LSE, dQ / dK / dV.  ``ds`` = planes of workspace: 2 (dS hi + lo): delta -> dV -> dK (+ the dS planes) -> dQ = dS . K;
+    4 (+ Pd hi + lo): delta -> dK (+ dS, Pd) -> dV = dO^T . Pd -> dQ.  The workspace starts NaN-filled: what the dK launch does not write
+    must not reach a stored row."""
     from transfusion_amd import _lib as L, ops
     B, H = 2, 2
     g = torch.Generator().manual_seed(hd + S)
@@ -152,8 +153,9 @@ def test_split_attention_against_fp64(dev, hd, S, p, ds):
                      key_mask=L.ptr(kmd), B=B, S=S, H=H, HDP=hd, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1],
                      drop_scale=drop[2], drop_bits=L.ptr(bits), dout=L.ptr(dh), dout_lo=L.ptr(dl), ld_dout=H * hd, dqkv=L.ptr(gh),
                      dqkv_lo=L.ptr(gl), ld_dqkv=3 * H * hd, delta=L.ptr(delta))
-    dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S),), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
+    dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S) * ds // 2,), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
     a.ds_work = L.ptr(dsw)
+    a.ds_planes = ds
     L.call("tf_attn_fwd", a, ops._stream())
     L.call("tf_attn_bwd", a, ops._stream())
     torch.cuda.synchronize()

@@ -16,6 +16,9 @@
 // for dQ no longer: a small kernel forms delta, the dK launch writes its dS tiles -- per (batch, head) a [key][query] bf16 matrix of
 // side 128 ceil(S / 128) stored as 32 x 32 tiles of 2 KiB (a wave of the dK launch fills one per query tile, contiguously), twice --
 // and attn_bwd_dq_ds_x3_kernel forms dQ = scale dS . K from them with one product instead of three (eight products per layer -> six).
+// With 4 x tf_attn_ds_bytes the dK launch (which then runs FIRST) also writes Pd = P . keep / (1 - p), in the register layout the
+// dV product consumes it in (a lane's 16-byte B fragments side by side: 1-KiB stores, no transposition), and attn_bwd_dv_pd_x3_kernel
+// forms dV^T += dO^T . Pd from it without recomputing S: five products per layer.
 #include "tf_common.h"
 #include <cstdio>
 #include "tf_kernels.h"
@@ -417,13 +420,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   const float dscale = a.drop_thr ? a.drop_scale : 1.0f;
   const bool blk = a.block_bits != nullptr;
   // dS rows of this lane's key in the workspace planes (WHICH == 1 with TfAttnArgs.ds_work, self attention): see the file header
-  u16* ds_h = nullptr; u16* ds_l = nullptr;
+  u16* ds_h = nullptr; u16* ds_l = nullptr; u16* pd_h = nullptr; u16* pd_l = nullptr;
   if constexpr (WHICH == 1) {
     if (a.ds_work != nullptr && !cross) {
       const size_t nb = ds_side_x3(S) / 32;                        // 32 x 32 tiles per side
       // tile (key0 / 32, query tile t) of this (batch, head); inside it row (lane & 31), the 16-B chunk this lane stores (see the loop)
       ds_h = (u16*)a.ds_work + (((size_t)bh * nb + (key0 >> 5)) * nb) * 1024 + (lane & 31) * 32;
       ds_l = ds_h + ds_plane_x3(a.B, a.H, S);
+      if (a.ds_planes >= 4) {               // Pd tiles: [k-step s2][lane][8 values], hi plane 2, lo plane 3
+        pd_h = (u16*)a.ds_work + 2 * ds_plane_x3(a.B, a.H, S) + (((size_t)bh * nb + (key0 >> 5)) * nb) * 1024 + lane * 8;
+        pd_l = pd_h + ds_plane_x3(a.B, a.H, S);
+      }
     }
   }
 
@@ -445,6 +452,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
   float n_lse = 0.f, n_del = 0.f;
   unsigned n_dw = 0u, n_bw = 0u;
   if (ntiles > 0) row_scalars(0, n_lse, n_del, n_dw, n_bw);
+  // DEFER (the dK launch that stores dS / Pd tiles, head dims <= 192): the 8 tile stores of tile t are ISSUED at the start of tile
+  // t + 1's matrix phase.  vmcnt retires in issue order, so the staging wait of the next tile (global loads -> LDS) also waits for
+  // every older store: issued right behind the softmax they had only the 36 MFMAs of the dK product to complete in, and the wait
+  // exposed the rest -- 391 us per launch against 293 with the stores ablated.  Deferred they get a whole tile's matrix work.
+  // 32 registers carry the packed tiles across the staging (head dim 224 has none to spare: it stores at once).
+  constexpr bool DEFER = WHICH == 1 && HDP <= 192;
+  u32x4 pend[8];
+  auto flush_pending = [&](int tp) {          // tile tp's dS chunks (hi, lo) x 2 and Pd fragments (hi, lo) x 2
+    u16* th = ds_h + (size_t)tp * 1024;
+    u16* tl = ds_l + (size_t)tp * 1024;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      *(u32x4*)(th + 8 * (2 * c2 + h)) = pend[2 * c2];
+      *(u32x4*)(tl + 8 * (2 * c2 + h)) = pend[2 * c2 + 1];
+    }
+    if (pd_h != nullptr) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        *(u32x4*)(pd_h + (size_t)tp * 1024 + s2 * 512) = pend[4 + 2 * s2];
+        *(u32x4*)(pd_l + (size_t)tp * 1024 + s2 * 512) = pend[5 + 2 * s2];
+      }
+    }
+  };
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = t * 32;
     __syncthreads();
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks)
       st = mfma3(row_frag<HDP>(qt_h, 0, ks, lane), row_frag<HDP>(qt_l, 0, ks, lane), kf_h[ks], kf_l[ks], st);
+    if constexpr (DEFER) { if (ds_h != nullptr && t > 0) flush_pending(t - 1); }      // (between the S and the dP product: see DEFER)
     if constexpr (WHICH == 1) {
 #pragma unroll
       for (int ks = 0; ks < G::KSTEPS; ++ks)
@@ -478,7 +509,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
         const float p = att ? fast_exp2(fmaf(st[r], sc, -l4[i])) : 0.f;
         const float keep_scale = ((w4[i] >> (lane & 31)) & 1u) ? dscale : 0.f;
         if constexpr (WHICH == 0) st[r] = p * keep_scale;                              // Pd
-        else st[r] = p * fmaf(dp[r], keep_scale, -d4[i]);                              // dS
+        else {
+          st[r] = p * fmaf(dp[r], keep_scale, -d4[i]);                                 // dS
+          dp[r] = p * keep_scale;                                                      // Pd (dP is spent): stored below for the dV kernel
+        }
+      }
+    }
+    if constexpr (WHICH == 1) {
+      if (pd_h != nullptr) {              // (workgroup-uniform) the two B fragments of the dV product, as they sit in this lane
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 f_h, f_l;
+          acc_frag_split(dp, s2, f_h, f_l);
+          if constexpr (DEFER) {
+            pend[4 + 2 * s2] = __builtin_bit_cast(u32x4, f_h); pend[5 + 2 * s2] = __builtin_bit_cast(u32x4, f_l);
+          } else {
+            *(bf16x8*)(pd_h + (size_t)t * 1024 + s2 * 512) = f_h;
+            *(bf16x8*)(pd_l + (size_t)t * 1024 + s2 * 512) = f_l;
+          }
+        }
       }
     }
     if constexpr (WHICH == 1) {
@@ -503,8 +552,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
           got_l[0] = (unsigned)__shfl_xor((int)give_l[0], 32, 64); got_l[1] = (unsigned)__shfl_xor((int)give_l[1], 32, 64);
           const u32x4 vh = h ? u32x4{got_h[0], got_h[1], mine_h[0], mine_h[1]} : u32x4{mine_h[0], mine_h[1], got_h[0], got_h[1]};
           const u32x4 vl = h ? u32x4{got_l[0], got_l[1], mine_l[0], mine_l[1]} : u32x4{mine_l[0], mine_l[1], got_l[0], got_l[1]};
-          *(u32x4*)(th + 8 * (2 * c2 + h)) = vh;
-          *(u32x4*)(tl + 8 * (2 * c2 + h)) = vl;
+          if constexpr (DEFER) { pend[2 * c2] = vh; pend[2 * c2 + 1] = vl; }
+          else {
+            *(u32x4*)(th + 8 * (2 * c2 + h)) = vh;
+            *(u32x4*)(tl + 8 * (2 * c2 + h)) = vl;
+          }
         }
       }
     }
@@ -519,6 +571,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
         acc[d] = mfma3(tr_frag<HDP>(th, 16 * s2, d * 32, lane), tr_frag<HDP>(tl, 16 * s2, d * 32, lane), f_h, f_l, acc[d]);
     }
   }
+  if constexpr (DEFER) { if (ds_h != nullptr && ntiles > 0) flush_pending(ntiles - 1); }
   if (key < Sb) {
     const size_t off = (sr.row0 + key) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
     u16* r_h = (u16*)a.dqkv + off;
@@ -530,6 +583,78 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
       for (int g4 = 0; g4 < 4; ++g4) {
         const int c = d * 32 + 8 * g4 + 4 * h;
         store4_split(r_h + c, r_l + c, acc[d][4 * g4] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc);
+      }
+  }
+}
+
+// ================================================================================================
+// backward, dV from the Pd tiles the dK launch wrote:  dV^T[d][key] += dO^T[d][q] . Pd[q][key]  (3 passes), key on the lane.
+// One product instead of the two of attn_bwd_dkv_x3_kernel<.., 0> (no S, no softmax, no Q tile, no K fragments): per 32-query tile
+// the dO tile (both planes) is staged for the workgroup, the next tile's loads in flight during the matrix work, and a lane's two B
+// fragments per plane are two 16-byte loads from the tile the producer lane of the same index stored.
+// ================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dv_pd_x3_kernel(const TfAttnArgs a) {
+  using G = Geo<HDP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dot_h = smem;
+  unsigned char* dot_l = smem + 32 * G::TSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int S = a.S;
+  const int nkb = (S + 127) / 128;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = pair_of_group(logical / nkb, a.B * a.H), b = bh / a.H, head = bh % a.H;
+  const int key0 = (logical % nkb) * 128 + wave * 32;
+  const SampleRows sr = sample_rows(a.cu_rows, b, S);
+  const int Sb = sr.len;
+  if ((logical % nkb) * 128 >= Sb) return;                      // key blocks past the sample's end (workgroup-uniform)
+  const size_t dooff = sr.row0 * a.ld_dout + (size_t)head * HDP;
+  cu16p do_h = (const u16*)a.dout + dooff, do_l = (const u16*)a.dout_lo + dooff;
+  const size_t nb = ds_side_x3(S) / 32;
+  cu16p pd_h = (const u16*)a.ds_work + 2 * ds_plane_x3(a.B, a.H, S) + (((size_t)bh * nb + (key0 >> 5)) * nb) * 1024 + lane * 8;
+  cu16p pd_l = pd_h + ds_plane_x3(a.B, a.H, S);
+  f32x16 acc[G::DBLK];
+#pragma unroll
+  for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  // (the dK launch ran the same tile loop: it wrote a tile for every t below, zeros where keys or queries are masked or past the end)
+  const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sb + 31) / 32;
+  TileRegs<32, HDP> r_h, r_l;
+  bf16x8 f_h[2], f_l[2];
+  auto fetch = [&](int t) {
+    r_h.load(do_h, a.ld_dout, t * 32, Sb - 1, true, tid);       // dO rows past the end: zeros
+    r_l.load(do_l, a.ld_dout, t * 32, Sb - 1, true, tid);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f_h[s2] = *(const bf16x8*)(pd_h + (size_t)t * 1024 + s2 * 512);
+      f_l[s2] = *(const bf16x8*)(pd_l + (size_t)t * 1024 + s2 * 512);
+    }
+  };
+  if (ntiles > 0) fetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();                                            // every wave is done with the previous tile
+    r_h.store(dot_h, tid); r_l.store(dot_l, tid);
+    const bf16x8 c_h0 = f_h[0], c_h1 = f_h[1], c_l0 = f_l[0], c_l1 = f_l[1];
+    __syncthreads();
+    if (t + 1 < ntiles) fetch(t + 1);
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d) {
+      acc[d] = mfma3(tr_frag<HDP>(dot_h, 0, d * 32, lane), tr_frag<HDP>(dot_l, 0, d * 32, lane), c_h0, c_l0, acc[d]);
+      acc[d] = mfma3(tr_frag<HDP>(dot_h, 16, d * 32, lane), tr_frag<HDP>(dot_l, 16, d * 32, lane), c_h1, c_l1, acc[d]);
+    }
+  }
+  const int key = key0 + (lane & 31);
+  if (key < Sb) {
+    const size_t off = (sr.row0 + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+    u16* o_h = (u16*)a.dqkv + off;
+    u16* o_l = (u16*)a.dqkv_lo + off;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = d * 32 + 8 * g4 + 4 * h;
+        store4_split(o_h + c, o_l + c, acc[d][4 * g4], acc[d][4 * g4 + 1], acc[d][4 * g4 + 2], acc[d][4 * g4 + 3]);
       }
   }
 }
@@ -685,7 +810,8 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
     TfTraceScope tr(nm, st, fl);
     hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<HDP>, grid_q, dim3(256), lds_q, st, *a);
   }
-  {
+  const bool pd = ds && a->ds_planes >= 4;                             // ... and Pd for the dV product: the dK launch goes first
+  if (!pd) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dV>", HDP);
     TfTraceScope tr(nm, st, fl / 2);
     hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<HDP, 0>), grid, dim3(256), lds_kv, st, *a);
@@ -694,6 +820,14 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
     snprintf(nm, sizeof(nm), "attn_bwd_dkv_x3_kernel<%d, dK>", HDP);
     TfTraceScope tr(nm, st, fl / 2);
     hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<HDP, 1>), grid, dim3(256), lds_kv, st, *a);
+  }
+  if (pd) {
+    const size_t lds_pd = 64 * Geo<HDP>::TSTR;
+    static const hipError_t o6 = hipFuncSetAttribute((const void*)attn_bwd_dv_pd_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pd);
+    (void)o6;
+    snprintf(nm, sizeof(nm), "attn_bwd_dv_pd_x3_kernel<%d>", HDP);
+    TfTraceScope tr(nm, st, fl / 2);
+    hipLaunchKernelGGL(attn_bwd_dv_pd_x3_kernel<HDP>, grid, dim3(256), lds_pd, st, *a);
   }
   if (ds) {
     const size_t lds_ds = 128 * Geo<HDP>::TSTR + 128 * Geo<128>::TSTR;

@@ -134,7 +134,7 @@ AOff make_aoff(const Dims& D) {
   // gradients of layer l are launched together at the end of the layer's backward and run beside the chain of layer l - 1, which
   // fills the other set.
   a.dz1 = take2(md); a.dy1 = take2(md); a.dzb1 = take2(md); a.dyb1 = take2(md); a.du1 = take2(mf); a.dqkv1 = take2(mq);
-  a.dsw = take((D.split ? 2 : 1) * tf_attn_ds_bytes(D.B, D.H, D.S));      // fp32-accuracy mode: a hi and a lo plane
+  a.dsw = take((D.split ? 4 : 1) * tf_attn_ds_bytes(D.B, D.H, D.S));      // fp32-accuracy mode: hi + lo planes of dS and of Pd
   a.a8 = take((size_t)D.M * (D.ffp > D.dp ? D.ffp : D.dp)); a.sa8 = take(mr);
   a.total = o;
   return a;
@@ -815,7 +815,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
-      a.ds_work = (void*)(c.wk + c.A.dsw);
+      a.ds_work = (void*)(c.wk + c.A.dsw); a.ds_planes = D.split ? 4 : 1;
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
     }
     jobs[3] = wjob(c, dqkv, D.nqkv, x, D.dp, g.in_w, D.d, g.in_b, D.hd, D.hdp, 3 * D.d, BIG, BIG, D.d);
