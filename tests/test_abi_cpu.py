@@ -56,7 +56,7 @@ def test_plan_and_dropout_helpers_are_host_side(lib):
     assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p0)) == 0
     e.precision = 1
     assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p1)) == 0
-    assert (p0.wpack_bytes, p0.work_bytes) == (plan0_w, plan0_k) and 1.8 * p0.work_bytes < p1.work_bytes < 2.0 * p0.work_bytes
+    assert (p0.wpack_bytes, p0.work_bytes) == (plan0_w, plan0_k) and 1.8 * p0.work_bytes < p1.work_bytes < 2.2 * p0.work_bytes      # plane pairs of everything; FOUR planes of attention workspace (dS and Pd) against one
     assert 1.5 * p0.wpack_bytes < p1.wpack_bytes < 2.0 * p0.wpack_bytes and p1.hdp == 192      # the fp8 shadows and fp32 biases have no lo plane
     e.d, e.H, e.ff = 1024, 4, 2048                       # head dim 256: bf16 only
     assert lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(p1)) != 0
