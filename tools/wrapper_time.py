@@ -17,7 +17,8 @@ B, NL, D = int(os.environ.get("B", 8)), 512, 768
 dev = torch.device("cuda", 0)
 torch.manual_seed(42)
 ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]
-shapes = [(14 * p, 14 * p) for p in ps]
+grids = [28, 14, 14, 14] if os.environ.get("REAL") == "1" else [14, 14, 14, 14]        # REAL=1: the reference's FPN geometry (bench leg wrapper_b4_real)
+shapes = [(g * p, g * p) for g, p in zip(grids, ps)]
 fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
 fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})       # run.narr_fusion.* keys of the experiment YAML
 fusion["args"].update({"input_f_size": D})
