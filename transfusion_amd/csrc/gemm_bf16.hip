@@ -1246,7 +1246,15 @@ int pick_mf(int M, int N, int mf_lo = 5, int G = 1) {
   return best;
 }
 template <bool SPLIT> int launch_gemm_big_mf(int mf, const TfGemmArgs* a, hipStream_t stream) {
-  if constexpr (SPLIT) return mf == 9 ? launch_gemm_big<9, true>(a, stream) : launch_gemm_big<8, true>(a, stream);
+  if constexpr (SPLIT) {
+    switch (mf) {                                        // (the fp32-accuracy mode plans its tile height like the bf16 one since round 4)
+      case 5: return launch_gemm_big<5, true>(a, stream);
+      case 6: return launch_gemm_big<6, true>(a, stream);
+      case 7: return launch_gemm_big<7, true>(a, stream);
+      case 8: return launch_gemm_big<8, true>(a, stream);
+      default: return launch_gemm_big<9, true>(a, stream);
+    }
+  }
   else {
     switch (mf) {
       case 5: return launch_gemm_big<5>(a, stream);
@@ -1288,9 +1296,10 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   // per CU) once the chip is full, but at small M its grid is a fraction of a round -- M = 5664, N = 768 is 69 tiles for 256
   // CUs, 76 us for 20 GFLOP.  Estimated time = rounds x (fixed + per-K cost of one tile), constants from the K-sweeps on
   // MI355X (large: 13.3 us + 26.4 us per 1000 K; 128-wide at two per CU: ~8 us + 21 us per 1000 K).
+  static const int split_mf_lo = TF_ENV_INT("TF_GEMM_SPLIT_MF_MIN", 5);     // experiment switch (8: the two heights the mode had before)
   bool use_big = big && a->M >= 1024 && a->N >= 256;
   if (use_big) {
-    const int mfp = pick_mf(a->M, a->N, split ? 8 : 5, a->groups);
+    const int mfp = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups);
     const long tb = row_tiles(a, 32 * mfp) * ((a->N + BIG_BN - 1) / BIG_BN);
     const int mi = split ? 4 : pick_mi(a->M, a->N, a->groups);            // (the fp32-accuracy mode has one tile height of this kernel)
     const long ts = row_tiles(a, 32 * mi) * ((a->N + BN - 1) / BN);
@@ -1320,7 +1329,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     }
   }
   if (use_big) {
-    const int mf = pick_mf(a->M, a->N, split ? 8 : 5, a->groups);
+    const int mf = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups);
     char nm[56];
     snprintf(nm, sizeof(nm), split ? "gemm_nt_big_kernel<%d, %d, x3>" : "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
