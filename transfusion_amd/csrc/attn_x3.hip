@@ -696,15 +696,16 @@ __global__ __launch_bounds__(256) void attn_delta_x3_kernel(const TfAttnArgs a) 
 // are staged for the workgroup, the next tile's loads in flight during the matrix work; a wave's B operand is the transposed read of
 // ITS 32 query columns -- tr_frag hands lane (query n) the 8 keys of a k-step in the order the A operand's K^T fragment uses.
 // ================================================================================================
-template <int HDP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_ds_x3_kernel(const TfAttnArgs a) {
+// KT = keys per staged tile: 32 halves the LDS of a workgroup (57 KB at head dim 192) so that TWO share a CU (252 registers)
+template <int HDP, int KT>
+__global__ __launch_bounds__(256, (KT == 32 && HDP <= 192) ? 2 : 1) void attn_bwd_dq_ds_x3_kernel(const TfAttnArgs a) {
   using G = Geo<HDP>;
   using GD = Geo<128>;                                          // the dS block as a tile of 128 columns
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kt_h = smem;
-  unsigned char* kt_l = smem + 64 * G::TSTR;
-  unsigned char* dt_h = smem + 128 * G::TSTR;
-  unsigned char* dt_l = dt_h + 64 * GD::TSTR;
+  unsigned char* kt_l = smem + KT * G::TSTR;
+  unsigned char* dt_h = smem + 2 * KT * G::TSTR;
+  unsigned char* dt_l = dt_h + KT * GD::TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int S = a.S;
   const int nqb = (S + 127) / 128;
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_ds_x3_kernel(const TfAttnA
   cu16p k_h = (const u16*)a.qkv + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP, k_l = (const u16*)a.qkv_lo + sr.row0 * ld + (size_t)(1 * a.H + head) * HDP;
   const size_t nb = ds_side_x3(S) / 32;                          // 32 x 32 tiles (2 KiB) per side
   cu16p d_h = (const u16*)a.ds_work + ((size_t)bh * nb * nb + (size_t)qblk * 4) * 1024, d_l = d_h + ds_plane_x3(a.B, a.H, S);
-  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;
+  const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + KT - 1) / KT;
 
   f32x16 dq[G::DBLK];
 #pragma unroll
@@ -726,35 +727,36 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_ds_x3_kernel(const TfAttnA
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-  TileRegs<64, HDP> rk_h, rk_l;
+  TileRegs<KT, HDP> rk_h, rk_l;
+  constexpr int NP = KT / 16;                                   // 16-byte pieces of the dS block per thread and plane
   // the [64 keys][128 queries] block of dS = 2 x 4 tiles of 2 KiB per plane: piece id = i * 256 + tid -> tile id >> 7 (key half kbl = tile
   // >> 2, query tile qt = tile & 3), row (id & 127) >> 2, 16-B piece id & 3: a tile is read by 128 consecutive threads, contiguously
-  u32x4 rd_h[4], rd_l[4];
-  unsigned d_off[4];                                            // element offset of piece i inside key tile 0 (a key tile further: 2 nb tiles)
-  int d_lds[4];
+  u32x4 rd_h[NP], rd_l[NP];
+  unsigned d_off[NP];                                            // element offset of piece i inside key tile 0 (a key tile further: 2 nb tiles)
+  int d_lds[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NP; ++i) {
     const int id = i * 256 + tid, tile = id >> 7, kbl = tile >> 2, qt = tile & 3, row = (id & 127) >> 2, pc = id & 3;
     d_off[i] = (unsigned)((kbl * nb + qt) * 1024 + row * 32 + pc * 8);
     d_lds[i] = tile_off(kbl * 32 + row, qt * 4 + pc, GD::TSTR);
   }
   auto fetch = [&](int t) {
-    rk_h.load(k_h, ld, t * 64, Sb - 1, false, tid);
-    rk_l.load(k_l, ld, t * 64, Sb - 1, false, tid);
-    const size_t tb = (size_t)t * 2 * nb * 1024;                // (the dK launch wrote every tile a key tile reads: whole 128-key workgroups)
+    rk_h.load(k_h, ld, t * KT, Sb - 1, false, tid);
+    rk_l.load(k_l, ld, t * KT, Sb - 1, false, tid);
+    const size_t tb = (size_t)t * (KT / 32) * nb * 1024;                // (the dK launch wrote every tile a key tile reads: whole 128-key workgroups)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { rd_h[i] = *(const u32x4*)(d_h + tb + d_off[i]); rd_l[i] = *(const u32x4*)(d_l + tb + d_off[i]); }
+    for (int i = 0; i < NP; ++i) { rd_h[i] = *(const u32x4*)(d_h + tb + d_off[i]); rd_l[i] = *(const u32x4*)(d_l + tb + d_off[i]); }
   };
   if (ntiles > 0) fetch(0);
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();                                            // every wave is done with the previous tiles
     rk_h.store(kt_h, tid); rk_l.store(kt_l, tid);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { *(u32x4*)(dt_h + d_lds[i]) = rd_h[i]; *(u32x4*)(dt_l + d_lds[i]) = rd_l[i]; }
+    for (int i = 0; i < NP; ++i) { *(u32x4*)(dt_h + d_lds[i]) = rd_h[i]; *(u32x4*)(dt_l + d_lds[i]) = rd_l[i]; }
     __syncthreads();
     if (t + 1 < ntiles) fetch(t + 1);
 #pragma unroll 1
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < KT / 32; ++kb) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 ds_hi = tr_frag<128>(dt_h, kb * 32 + 16 * s, wave * 32, lane);
@@ -830,12 +832,20 @@ template <int HDP> int launch_bwd_x3(const TfAttnArgs* a, hipStream_t st) {
     hipLaunchKernelGGL(attn_bwd_dv_pd_x3_kernel<HDP>, grid, dim3(256), lds_pd, st, *a);
   }
   if (ds) {
-    const size_t lds_ds = 128 * Geo<HDP>::TSTR + 128 * Geo<128>::TSTR;
-    static const hipError_t o4 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_x3_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ds);
-    (void)o4;
+    static const int kt = TF_ENV_INT("TF_X3_DQ_KT", 32);              // experiment switch: 64 = one workgroup per CU
     snprintf(nm, sizeof(nm), "attn_bwd_dq_ds_x3_kernel<%d>", HDP);
     TfTraceScope tr(nm, st, fl / 2);
-    hipLaunchKernelGGL(attn_bwd_dq_ds_x3_kernel<HDP>, grid_q, dim3(256), lds_ds, st, *a);
+    if (kt == 64 || HDP > 192) {                                    // (head dim 224: 300 registers, one workgroup per CU either way)
+      const size_t lds_ds = 128 * Geo<HDP>::TSTR + 128 * Geo<128>::TSTR;
+      static const hipError_t o4 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_x3_kernel<HDP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ds);
+      (void)o4;
+      hipLaunchKernelGGL((attn_bwd_dq_ds_x3_kernel<HDP, 64>), grid_q, dim3(256), lds_ds, st, *a);
+    } else {
+      const size_t lds_ds = 64 * Geo<HDP>::TSTR + 64 * Geo<128>::TSTR;
+      static const hipError_t o7 = hipFuncSetAttribute((const void*)attn_bwd_dq_ds_x3_kernel<HDP, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ds);
+      (void)o7;
+      hipLaunchKernelGGL((attn_bwd_dq_ds_x3_kernel<HDP, 32>), grid_q, dim3(256), lds_ds, st, *a);
+    }
   }
   return (int)hipGetLastError();
 }
