@@ -63,6 +63,17 @@ def make_batch(B, device, rank, d=D, nv=NV, nl=NL, variant=0, padded=True):
     return x.to(device), lang.to(device), pad.to(device), valid.to(device), km.to(device), lens.tolist()
 
 
+def _sumsq(t):
+    """sum(t^2) of a contiguous fp32 CUDA tensor through the library's own tf_sumsq (the optimiser's norm kernel): the timed region
+    holds no vendor-library kernel, the harness's loss included (torch.dot is rocBLAS)."""
+    from transfusion_amd import ops
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    out = torch.zeros(1, dtype=torch.float32, device=t.device)
+    ops.sumsq(t, out)
+    return out[0]
+
+
 class _MaskedSquareLoss(torch.autograd.Function):
     """mean(vis^2) + mean(lang[valid]^2) with a hand-written backward: 3 elementwise passes and 2 dot products per step
     instead of autograd's ~10 (the harness's own loss was ~1 GB/step of fp32 traffic next to the block it is timing); the mask
@@ -74,8 +85,7 @@ class _MaskedSquareLoss(torch.autograd.Function):
         kv = 1.0 / vis.numel()
         ctx.save_for_backward(vis, m, km)
         ctx.kv = kv
-        v1, m1 = vis.reshape(-1), m.reshape(-1)
-        return torch.dot(v1, v1) * kv + torch.dot(m1, m1) * km
+        return _sumsq(vis) * kv + _sumsq(m) * km
 
     @staticmethod
     def backward(ctx, g):
@@ -107,8 +117,7 @@ class _SquareMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f):
         ctx.save_for_backward(f)
-        v = f.reshape(-1)
-        return torch.dot(v, v) / v.numel() if f.dtype == torch.float32 else v.float().pow(2).mean()
+        return _sumsq(f) / f.numel() if f.dtype == torch.float32 else f.reshape(-1).float().pow(2).mean()
 
     @staticmethod
     def backward(ctx, g):
@@ -262,7 +271,7 @@ def traced_kernels(step, nsteps):
     for name, a in by.items():
         rows.append(dict(kernel=name, avg_us=round(a["us"] / a["launches"], 2), launches_per_step=round(a["launches"] / nsteps, 2),
                          us_per_step=round(a["us"] / nsteps, 1), tflops=round(a["flops"] / a["us"] / 1e6, 1) if a["flops"] else None,
-                         gbs=round(a["bytes"] / a["us"] / 1e3, 1) if a["bytes"] else None, side_stream=a["side"] > 0,
+                         gbs=round(a["bytes"] / a["us"] / 1e3, 1) if (a["bytes"] and not a["flops"]) else None, side_stream=a["side"] > 0,
                          flops_per_launch=a["flops"] / a["launches"], bytes_per_launch=a["bytes"] / a["launches"]))
     rows.sort(key=lambda r: -r["us_per_step"])
     return rows
@@ -433,6 +442,40 @@ def allreduce_busbw(trainer, comm, reps=10):
                 note="all-reduce alone, back to back (not overlapped with the backward)")
 
 
+def rccl_probe(trainer, comm, device, rank):
+    """N > 1 over RCCL: what the exchange ran on -- the process group's backend and size -- and the library's OWN communicator
+    (tf_comm_create / tf_allreduce_bucket, csrc/comm.hip) exercised WITH its peers: one all-reduce compared with the process group's
+    result, then its tf_comm_stats (world, rank, calls, elements).  Collective: every rank calls it.  A failure is reported, not raised
+    (the headline line does not depend on it)."""
+    out = {"backend": dist.get_backend(), "group_world": dist.get_world_size()}
+    if out["backend"] != "nccl":
+        return out                                   # (the one-GPU rehearsal over gloo: RCCL refuses two ranks on one device)
+    try:
+        from transfusion_amd.comm import BucketComm
+        bc = trainer.bucket_comm if trainer.bucket_comm is not None else BucketComm.from_process_group(device)
+        n = 1 << 22
+        t = torch.arange(n, dtype=torch.float32, device=device) * (1.0 / n) + float(rank + 1)
+        ref = t.clone()
+        bc.all_reduce_(t)
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        comm.sync()
+        same = bool(torch.equal(t, ref))
+        big = torch.zeros(16 << 20, dtype=torch.float32, device=device)            # 64 MB, ten times
+        comm.sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            bc.all_reduce_(big)
+        comm.sync()
+        dt = comm.max(time.perf_counter() - t0) / 10
+        w = dist.get_world_size()
+        out["rccl"] = dict(bc.stats(), matches_process_group=same, busbw_gbs_64mb=round(big.numel() * 4 / dt / 1e9 * 2 * (w - 1) / w, 1))
+        if trainer.bucket_comm is None:
+            bc.close()
+    except Exception as e:                           # noqa: BLE001 -- reported on the line
+        out["rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
             steps=8, warmup=3, grad_clip=1.0):
     """One more BASELINE configuration in the same process, after the headline: its own encoder, trainer and batches, `warmup` untimed +
@@ -469,13 +512,16 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         if not math.isfinite(loss):
             raise SystemExit(f"leg {name}: non-finite loss {loss}")
         S = nv + nl
-        fl = 3 * layers * flops_per_sample_layer(S, d) * batch                     # per GPU, dense S
+        fl_dense = 3 * layers * flops_per_sample_layer(S, d) * batch               # per GPU, dense S
+        # executed work: the nv + len_b real tokens of each sample, averaged over the leg's batches (utilisation is quoted on THIS)
+        fl = sum(3 * layers * sum(flops_per_sample_layer(nv + n, d) for n in b[5]) for b in obj["batches"]) / len(obj["batches"])
         # peak the leg is priced against: dense bf16 MFMA; a third of it in the fp32-accuracy mode (three bf16 passes per product).
         # The fp8 leg runs its forward projections on fp8 operands and everything else in bf16: priced against the bf16 peak.
         peak = PEAK_BF16_TFLOPS / 3.0 if precision == "fp32" else PEAK_BF16_TFLOPS
         out = dict(ms_per_step=round(dt * 1e3, 3), samples_s=round(comm.world * batch / dt, 1), batch_per_gpu=batch, tokens=[nv, nl], d=d, heads=h,
                    layers=layers, dtype="fp32" if precision == "fp32" else ("fp8 projections + bf16" if fp8 else "bf16"),
                    block_tflops_per_gpu=round(fl / dt / 1e12, 1), block_mfma_util=round(fl / dt / 1e12 / peak, 4), peak_used=round(peak, 1),
+                   block_mfma_util_dense_credit=round(fl_dense / dt / 1e12 / peak, 4),
                    packed_rows=bool(pack), padded=bool(padded), steps=steps, warmup=warmup, final_loss=round(loss, 5))
         if rank == 0:
             log(f"  leg {name:10s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  {out['block_tflops_per_gpu']:7.1f} TFLOP/s/GPU "
@@ -600,6 +646,27 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`
+    as a child process (rank 0's JSON line goes to our stdout, everything else to stderr) and return its exit code.
+    TF_BENCH_LAUNCHER (tests): another launcher command line in place of `python -m torch.distributed.run`."""
+    import shlex
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    launcher = shlex.split(os.environ["TF_BENCH_LAUNCHER"]) if os.environ.get("TF_BENCH_LAUNCHER") else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                      os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"  bench.py --gpus {n}: launching {' '.join(cmd[:len(launcher) + 7])} ...")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -636,9 +703,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called bare (`python bench.py --gpus N`): start the N ranks ourselves, as Lightning's strategy="ddp" does for the reference
+        # (runner/run_experiment.py:437-454) -- a CHILD process (no exec), started before this process touches the GPU
+        faulthandler.cancel_dump_traceback_later()
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product kernels")
@@ -713,10 +783,12 @@ def main():
                                f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding"
                                f"{' (masked tokens dropped from the row-wise kernels)' if PACK_TOKENS else ' (masked tokens carried as dead rows)'}",
                    "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "comm": args.comm if world > 1 else None},
-        "block_mfma_util": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "block_tflops_per_gpu": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
-        "block_mfma_util_valid_tokens": round(train_flops_valid / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "block_tflops_valid_tokens": round(train_flops_valid / (ms * 1e-3) / 1e12, 1),
+        # utilisation on EXECUTED work: only the Nv + len_b real tokens of each sample (what the kernels compute with the masked tokens
+        # dropped); the dense-S credit of BASELINE.md section 3 (padded tokens counted) beside it
+        "block_mfma_util": round(train_flops_valid / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "block_tflops_per_gpu": round(train_flops_valid / (ms * 1e-3) / 1e12, 1),
+        "block_mfma_util_dense_credit": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "block_tflops_dense_credit": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
         "mean_valid_tokens": round(sum(sum(vs) for vs in valid_S) / (len(valid_S) * args.batch), 1),
         "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if world > 1 else 0.0,
         "final_loss": round(final_loss, 5),
@@ -728,12 +800,13 @@ def main():
         peak = PEAK_BF16_TFLOPS / 3.0
         result["dtype_note"] = ("fp32-accuracy mode: hi + lo bf16 operand planes, 3 bf16 MFMA passes per product, fp32 accumulation, "
                                 "epilogues and statistics; results within 1e-3 of the fp32 reference (tests/test_gpu_fp32_mode.py)")
-        result["block_mfma_util"] = round(train_flops_step / (ms * 1e-3) / 1e12 / peak, 4)
-        result["block_mfma_util_valid_tokens"] = round(train_flops_valid / (ms * 1e-3) / 1e12 / peak, 4)
+        result["block_mfma_util"] = round(train_flops_valid / (ms * 1e-3) / 1e12 / peak, 4)
+        result["block_mfma_util_dense_credit"] = round(train_flops_step / (ms * 1e-3) / 1e12 / peak, 4)
         result["peak_tflops_used"] = round(peak, 1)
         result["peak_fp32_mfma_tflops"] = 157.3
     if world > 1:
         result["allreduce"] = allreduce_busbw(trainer, comm)          # every rank takes part; rank 0 prints
+        result["allreduce"].update(rccl_probe(trainer, comm, device, rank))
     if rank == 0 and rows is not None:
         # in-situ kernel table: the traced steps ran AFTER the timed region (two event records per launch would perturb it)
         total = sum(r["us_per_step"] for r in rows)
@@ -759,12 +832,15 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                                   "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                                   "algorithmic_flops_per_launch": dom["flops_per_launch"], "us_per_step": dom["us_per_step"],
+                                  "algorithmic_bytes_per_launch": dom["bytes_per_launch"] or None,
+                                  "traffic_ratio": round(traffic / dom["bytes_per_launch"], 3) if (traffic and dom["bytes_per_launch"]) else None,
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round((dom["gbs"] or 0.0) / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                                   "avg_launch_us": dom["avg_us"],
                                   "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                                  "traffic_ratio": round(traffic / dom["bytes_per_launch"], 3) if (traffic and dom["bytes_per_launch"]) else None,
                                   "us_per_step": dom["us_per_step"],
                                   "measured": f"HIP event pair per launch on its own stream over {args.trace_steps} training steps after the timed region"}
         if dom["kernel"].startswith("wgrad_multi") and "roofline" in result:
@@ -809,6 +885,9 @@ def main():
                                 "batch_per_gpu": per}
         if legs:
             result["legs"] = legs
+            if "fp32" in legs:            # BASELINE configs[2] (Ego4Dv2, run.precision: 32) names fp32: that leg's figure at top level too
+                result["value_fp32"] = legs["fp32"]["samples_s"]
+                result["ms_per_step_fp32"] = legs["fp32"]["ms_per_step"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()

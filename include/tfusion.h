@@ -527,6 +527,15 @@ typedef struct TfTraceRecord {
 int tf_trace_start(void);
 long long tf_trace_stop(TfTraceRecord* out, long long cap);   /* device sync; returns the number of launches recorded (<= cap are written) */
 
+/* ---- stream-ordering probes (tests; no reference counterpart) ----
+ * The weight gradients of this library are produced on OTHER streams than the chain (TfOverlap side streams, the wrapper's level
+ * streams) and consumed by collectives and the optimiser behind events.  A missing event edge shows as a wrong gradient once in many
+ * runs; behind a spin it shows every time.  tf_debug_spin: a kernel that occupies stream s for `us` microseconds (one wave, capped at
+ * 50 ms, always terminates).  tf_debug_delay_wgrad: from now on every weight-gradient launch tf_encoder_bwd puts on a TfOverlap side
+ * stream is preceded by such a spin (process-wide; 0 = off, the default); returns the previous value. */
+int tf_debug_spin(int us, tf_stream_t s);
+int tf_debug_delay_wgrad(int us);
+
 #ifdef __cplusplus
 }
 #endif

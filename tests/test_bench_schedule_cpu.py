@@ -59,3 +59,32 @@ def test_every_rank_issues_the_same_collectives(bench, warmup, steps, trace_step
     assert logs[0].count("grad_allreduce") == warmup + steps + trace_steps
     assert logs[0].count("barrier") == 2 and logs[0].count("allreduce_max") == 1
     assert set(traced_on) <= {0}
+
+
+def test_bare_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 4` with no launcher around it (WORLD_SIZE unset) starts `<launcher> --nnodes=1 --nproc-per-node 4
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 4 ...` as a CHILD process before it touches a GPU, passes rank 0's JSON line
+    through on stdout and exits with the child's code -- what Lightning's strategy="ddp" does for the reference
+    (runner/run_experiment.py:437-454).  The launcher here is a recording fake (TF_BENCH_LAUNCHER)."""
+    import json
+    import subprocess
+    fake = tmp_path / "fake_launcher.py"
+    fake.write_text(
+        "import json, os, sys\n"
+        "json.dump({'argv': sys.argv[1:], 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), 'world': os.environ.get('WORLD_SIZE')},"
+        f" open({str(tmp_path / 'seen.json')!r}, 'w'))\n"
+        "print(json.dumps({'metric': 'fake', 'n_gpus': 4}))\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TF_BENCH_LAUNCHER"] = f"{sys.executable} {fake}"
+    for rc in (0, 3):
+        env["FAKE_RC"] = str(rc)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"], env=env,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == rc, r.stderr[-2000:]
+        assert json.loads(r.stdout.strip().splitlines()[-1]) == {"metric": "fake", "n_gpus": 4}
+        seen = json.load(open(tmp_path / "seen.json"))
+        a = seen["argv"]
+        assert a[:3] == ["--nnodes=1", "--nproc-per-node", "4"] and a[3:5] == ["--master-addr", "127.0.0.1"] and a[5] == "--master-port"
+        assert a[7].endswith("bench.py") and a[8:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+        assert seen["ipc"] == "0" and seen["world"] is None

@@ -36,6 +36,9 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+if int(os.environ.get("TF_TEST_WGRAD_DELAY_US", "0")):
+    from transfusion_amd import ops
+    ops.debug_delay_wgrad(int(os.environ["TF_TEST_WGRAD_DELAY_US"]))
 cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
 enc, _ = build(cfg, dev)
 enc.train()
@@ -65,8 +68,10 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("acc", [1, 2])
-def test_two_ranks_one_gpu_layerwise_reducer_on_the_real_encoder(tmp_path, acc):
+@pytest.mark.parametrize("acc,delay_us", [(1, 0), (2, 0), (1, 3000)])
+def test_two_ranks_one_gpu_layerwise_reducer_on_the_real_encoder(tmp_path, acc, delay_us):
+    """delay_us: every weight-gradient launch sits behind a spin of that many microseconds (ops.debug_delay_wgrad): a collective that
+    lacked an event edge to the side stream would reduce zeros, every time."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     out = str(tmp_path / "ddp.pt")
@@ -75,7 +80,8 @@ def test_two_ranks_one_gpu_layerwise_reducer_on_the_real_encoder(tmp_path, acc):
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   TF_TEST_WGRAD_DELAY_US=str(delay_us))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -148,6 +154,11 @@ if not single:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+if int(os.environ.get("TF_TEST_WGRAD_DELAY_US", "0")):
+    from transfusion_amd import ops
+    ops.debug_delay_wgrad(int(os.environ["TF_TEST_WGRAD_DELAY_US"]))
+if os.environ.get("TF_TEST_BREAK_EDGE"):                    # negative control: the reducer WITHOUT one of its event edges
+    OrderedRangeReducer._debug_break_edge = os.environ["TF_TEST_BREAK_EDGE"]
 d, h, L = 64, 4, 2
 levels = {levels}
 fusion = load_fusion_config(os.path.join({root!r}, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
@@ -179,7 +190,7 @@ for step in range(3):
     tr.step([mine], loss_fn)
     torch.cuda.synchronize()
     hist.append(dict(before=before.cpu(), grad=tr.flat.grad.cpu().clone(), param=tr.flat.flat.cpu().clone()))
-if not single:
+if not single and not os.environ.get("TF_TEST_BREAK_EDGE"):      # (with an edge removed the ranks may well disagree: that IS the finding)
     chk = tr.flat.flat.double().sum().reshape(1).cpu()
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -200,15 +211,21 @@ _LEVELS_RAGGED = "[dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3)]"      
 _LEVELS_EQUAL = "[dict(C=16, H=12, W=12, p=2), dict(C=8, H=18, W=18, p=3)]"          # 36 and 36: ONE grouped encoder call
 
 
-def _run_tree(tmp_path, levels, tag):
+def _run_tree(tmp_path, levels, tag, delay_us=0, break_edge=None, single=True):
+    """Two ranks sharing the GPU over gloo, then (``single``) one process that sees all four samples.  ``delay_us``: every weight-gradient
+    launch of BOTH runs behind a spin (ops.debug_delay_wgrad); ``break_edge``: the two-rank run with one event edge of the reducer removed
+    (OrderedRangeReducer._debug_break_edge -- the negative control of the probe)."""
     out2, out1 = str(tmp_path / f"{tag}2.pt"), str(tmp_path / f"{tag}1.pt")
     s2, s1 = tmp_path / f"{tag}_w2.py", tmp_path / f"{tag}_w1.py"
     s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2, levels=levels))
     s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1, levels=levels))
     port = _free_port()
     procs = []
+    extra = {"TF_TEST_WGRAD_DELAY_US": str(delay_us)}
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        if break_edge:
+            env["TF_TEST_BREAK_EDGE"] = break_edge
         procs.append(subprocess.Popen([sys.executable, str(s2)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -220,73 +237,74 @@ def _run_tree(tmp_path, levels, tag):
             pytest.fail("two-rank run hung (a rank issued a different collective sequence?)")
         outs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", TF_TREE_SINGLE="1")
+    if not single:
+        return torch.load(out2), None
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", TF_TREE_SINGLE="1", **extra)
     r = subprocess.run([sys.executable, str(s1)], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     return torch.load(out2), torch.load(out1)
 
 
-def test_two_ranks_grouped_levels_under_the_ordered_reducer(tmp_path):
-    """Levels with equal token counts run as ONE grouped encoder call (TfEncoderDesc.groups) -- also under a data-parallel reducer: the
-    grouped backward then goes layer by layer and reports each layer of EVERY member encoder to its hook.  Same checks as the level-loop
-    test below: rank-agreed order, one collective per unit from step 2 on, gradients equal to one process that sees all samples."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
-    two, one = _run_tree(tmp_path, _LEVELS_EQUAL, "grp")
-    assert two["grouped"] == 2 and one["grouped"] == 2, (two["grouped"], one["grouped"])
+def _unit_errors(two, st2, st1):
+    return [(k, round(((st2["grad"][lo:hi] - st1["grad"][lo:hi]).norm() / st1["grad"][lo:hi].norm().clamp_min(1e-30)).item(), 4))
+            for k, (lo, hi) in zip(two["keys"], two["ranges"])]
+
+
+def _check_tree(two, one, grouped):
+    """rank-agreed order, one collective per unit from step 2 on, gradients of every step equal to one process that sees all samples
+    (world 2 sums the two ranks' gradients of their own 2 samples; the single process saw all 4: same sum), same first movement (the
+    optimiser uses the MEAN over ranks, grad_scale 1 / world)."""
+    if grouped:
+        assert two["grouped"] == 2 and one["grouped"] == 2, (two["grouped"], one["grouped"])
     assert two["agreed"] is True
+    # 2 levels x (K1 + 2 encoder layers + K9) = 8 units; step 1: one collective, steps 2 and 3: one per unit
     assert two["nunits"] == 8 and two["collectives"] == 1 + 2 * 8, (two["nunits"], two["collectives"], two["keys"])
     for step, (st2, st1) in enumerate(zip(two["hist"], one["hist"])):
         err = ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item()
-        # (seen ONCE in ~15 full-suite runs of round 4: 0.37 here, never in a targeted run -- if it comes back, say WHERE: per reducer unit)
-        where = [(k, round(((st2["grad"][lo:hi] - st1["grad"][lo:hi]).norm() / st1["grad"][lo:hi].norm().clamp_min(1e-30)).item(), 4))
-                 for k, (lo, hi) in zip(two["keys"], two["ranges"])] if err >= 5e-3 else None
-        assert err < 5e-3, (step, err, where)
+        assert err < 5e-3, (step, err, _unit_errors(two, st2, st1))          # (a failure says WHERE: per reducer unit)
     m2 = two["hist"][0]["param"] - two["hist"][0]["before"]
     m1 = one["hist"][0]["param"] - one["hist"][0]["before"]
     assert float(m1.abs().max()) > 0 and ((m2 - m1).norm() / m1.norm()).item() < 2e-2
 
 
-def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path):
+@pytest.mark.parametrize("delay_us", [0, 3000])
+def test_two_ranks_grouped_levels_under_the_ordered_reducer(tmp_path, delay_us):
+    """Levels with equal token counts run as ONE grouped encoder call (TfEncoderDesc.groups) -- also under a data-parallel reducer: the
+    grouped backward then goes layer by layer and reports each layer of EVERY member encoder to its hook.  With ``delay_us`` every
+    producer of a gradient range that is NOT on the chain's stream -- the encoder's weight gradients (side stream), K1 / K9's (level
+    streams) -- starts 3 ms late: each consumer (the AccumulateGrad add, the unit's collective, the first step's whole-buffer reduce,
+    the optimiser) must then be held by its event edge, or it reads zeros.  DESIGN.md (e) lists writer x edge."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    two, one = _run_tree(tmp_path, _LEVELS_EQUAL, "grp", delay_us=delay_us)
+    _check_tree(two, one, grouped=True)
+
+
+@pytest.mark.parametrize("edge", ["side", "accum"])
+def test_the_delay_probe_sees_a_missing_edge(tmp_path, edge):
+    """Negative control of the probe above: the same two-rank run with ONE event edge of OrderedRangeReducer removed -- "side": a unit's
+    collective no longer waits for the weight-gradient side stream; "accum": no longer for the stream its K1 / K9 gradients were added
+    on -- must come out WRONG behind the spins (the delayed producers land after their range was reduced), in one run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    ok, one = _run_tree(tmp_path, _LEVELS_EQUAL, "ok", delay_us=3000)
+    bad, _ = _run_tree(tmp_path, _LEVELS_EQUAL, "bad", delay_us=3000, break_edge=edge, single=False)
+    worst = 0.0
+    for st2, st1 in zip(bad["hist"][1:], one["hist"][1:]):               # (step 1 reduces everything after the backward: no unit events)
+        worst = max(worst, ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item())
+    assert worst > 5e-2, (edge, worst)
+    _check_tree(ok, one, grouped=True)
+
+
+@pytest.mark.parametrize("delay_us", [0, 3000])
+def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path, delay_us):
     """The wrapper (two feature levels on their own HIP streams: patch embedding, 2-layer encoder, back-projection each) under
     FusionTrainStep with world 2: OrderedRangeReducer's CUDA branch -- unit events on the level streams and their wgrad side streams, a
     communication stream, collectives fired in the learnt order from inside the backward -- against ONE process that sees all four
     samples: same gradients (atomics order aside), same parameters after three steps, ranks bit-identical, identical packed-row counts."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    out2, out1 = str(tmp_path / "tree2.pt"), str(tmp_path / "tree1.pt")
-    s2, s1 = tmp_path / "w2.py", tmp_path / "w1.py"
-    s2.write_text(_TREE_WORKER.format(root=ROOT, out=out2, levels=_LEVELS_RAGGED))
-    s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1, levels=_LEVELS_RAGGED))
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(s2)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("two-rank run hung (a rank issued a different collective sequence?)")
-        outs.append(o)
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", TF_TREE_SINGLE="1")
-    r = subprocess.run([sys.executable, str(s1)], env=env, capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    two, one = torch.load(out2), torch.load(out1)
-    assert two["agreed"] is True
-    # 2 levels x (K1 + 2 encoder layers + K9) = 8 units; step 1: one collective, steps 2 and 3: one per unit
-    assert two["nunits"] == 8 and two["collectives"] == 1 + 2 * 8, (two["nunits"], two["collectives"], two["keys"])
+    two, one = _run_tree(tmp_path, _LEVELS_RAGGED, "tree", delay_us=delay_us)
+    _check_tree(two, one, grouped=False)
     keys = [two["keys"][u] for u in two["order"]]
     assert keys[0].startswith("tokens_to_features.1") and keys[-1].startswith("patches_to_token.0"), keys     # backward order: level 1 first
-    for st2, st1 in zip(two["hist"], one["hist"]):
-        # world 2 sums the two ranks' gradients of their own 2 samples; the single process saw all 4: same sum
-        err = ((st2["grad"] - st1["grad"]).norm() / st1["grad"].norm()).item()
-        assert err < 5e-3, err
-    # ... but the optimiser uses the MEAN over ranks (grad_scale 1 / world): compare the first step's movement
-    m2 = two["hist"][0]["param"] - two["hist"][0]["before"]
-    m1 = one["hist"][0]["param"] - one["hist"][0]["before"]
-    assert float(m1.abs().max()) > 0

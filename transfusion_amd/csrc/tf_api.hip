@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cmath>
 #include "tf_kernels.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -30,6 +31,27 @@ std::vector<hipStream_t> g_trace_sides;
 
 inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 constexpr int BIG = 1 << 28;
+
+// ---- stream-ordering probes (tf_debug_spin / tf_debug_delay_wgrad; tests) ----
+// A spin of a bounded number of microseconds, enqueued like any kernel: a consumer that lacks an edge to the producer behind the spin
+// reads the producer's target too early -- deterministically, instead of once in fifteen runs.
+std::atomic<int> g_delay_side_wgrad_us{0};
+constexpr int TF_SPIN_MAX_US = 50000;
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int launch_spin(int us, hipStream_t st) {
+  if (us <= 0) return 0;
+  if (us > TF_SPIN_MAX_US) us = TF_SPIN_MAX_US;
+  static const int khz = [] {
+    int dev = 0, r = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&r, hipDeviceAttributeWallClockRate, dev) != hipSuccess || r <= 0) r = 100000;
+    return r;
+  }();
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (long long)us * khz / 1000);
+  return (int)hipGetLastError();
+}
 
 uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -275,6 +297,7 @@ int wgrad_launch(const Ctx& c, Side& sd, const TfWgradArgs* jobs, int mask, bool
   for (int i = 0; i < 4; ++i) if ((mask >> i) & 1) sel[n++] = jobs[i];
   if (n == 0) return 0;
   hipStream_t st = sd.st != nullptr ? sd.st : c.st;
+  if (sd.st != nullptr) { const int rc = launch_spin(g_delay_side_wgrad_us.load(std::memory_order_relaxed), st); if (rc != 0) return rc; }
   // sizing is the launcher's: 0 = the launch has the chip to itself, -1 = it runs beside the chain
   const int blocks = (sd.st != nullptr && !alone) ? -1 : 0;
   if (n * c.D.G > TF_WGRAD_MULTI_MAX) {                        // more groups than one launch takes: one launch per product
@@ -358,6 +381,15 @@ int tf_overlap_destroy(TfOverlap* o) {
   for (int i = 0; i < 8; ++i) if (o->ev[i] != nullptr) { (void)hipEventDestroy((hipEvent_t)o->ev[i]); o->ev[i] = nullptr; }
   if (o->stream != nullptr) { (void)hipStreamSynchronize((hipStream_t)o->stream); (void)hipStreamDestroy((hipStream_t)o->stream); o->stream = nullptr; }
   return 0;
+}
+int tf_debug_spin(int us, tf_stream_t s) {
+  if (us < 0) return fail(-1, "tf_debug_spin");
+  TF_TRY(launch_spin(us, (hipStream_t)s), "tf_debug_spin");
+  return 0;
+}
+int tf_debug_delay_wgrad(int us) {
+  if (us < 0) return fail(-1, "tf_debug_delay_wgrad");
+  return g_delay_side_wgrad_us.exchange(us > TF_SPIN_MAX_US ? TF_SPIN_MAX_US : us, std::memory_order_relaxed);
 }
 const char* tf_last_error(void) { return g_err; }
 void tf_set_error_msg(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }

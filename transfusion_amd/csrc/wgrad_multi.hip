@@ -274,7 +274,7 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
   WgMulti m{};
   int n = 0, tiles = 0, min_steps = 1 << 30, max_steps = 0;
   bool split = false, any = false;
-  double flops = 0.0;
+  double flops = 0.0, abytes = 0.0;      // algorithmic work: 2 M N K; operands read once + the fp32 gradient
   for (int i = 0; i < count; ++i) {
     const TfWgradArgs& a = probs[i];
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) continue;
@@ -305,6 +305,7 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
       min_steps = steps < min_steps ? steps : min_steps;
       max_steps = steps > max_steps ? steps : max_steps;
       flops += 2.0 * Mg * a.N * a.K;
+      abytes += ((double)Mg * a.N + (double)Mg * a.K) * 2.0 * (sp ? 2.0 : 1.0) + (double)a.N * a.K * 4.0;
     }
   }
   if (n == 0) return 0;
@@ -337,7 +338,7 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
   constexpr int NS = 3, LDS = NS * (32 * 512 + 32 * 256);
   static const int intl = TF_ENV_INT("TF_WGM_INTL", 1);
   dim3 grid((unsigned)tiles * (unsigned)chunks), block(256);
-  TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops);
+  TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops, abytes);
   static const hipError_t o0 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   static const hipError_t o1 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   static const hipError_t o2 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<true, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -196,6 +196,14 @@ def clock_value() -> int:
     return _clock_host[0]
 
 
+def sumsq(x: torch.Tensor, out: torch.Tensor):
+    """out[0] += sum(x^2) (tf_sumsq: deterministic, no float atomics); x contiguous fp32, out a 1-element fp32 tensor."""
+    _require_cuda(x, out)
+    if x.dtype != torch.float32 or not x.is_contiguous() or out.dtype != torch.float32:
+        raise L.TfError("tf_sumsq needs contiguous fp32 tensors")
+    L.check(L.load().tf_sumsq(L.ptr(x), x.numel(), L.ptr(out), _stream()), "tf_sumsq")
+
+
 def set_gemm_concurrency(n: int):
     """Planning hint for the GEMM tile choice: ``n`` launch sequences share the chip (tf_set_gemm_concurrency)."""
     L.load().tf_set_gemm_concurrency(int(n))
@@ -272,8 +280,28 @@ def _zeros256(device):
     return z
 
 
+# ---- stream-ordering probe (tests/test_gpu_ddp.py): every weight-gradient launch -- the encoder runtime's on its side streams, K1 / K9 /
+# ops.linear's on the stream they are issued on -- behind a spin of `us` microseconds, so that a consumer (collective, optimiser,
+# AccumulateGrad) that lacks an event edge to its producer reads too early EVERY time instead of once in many runs
+_debug_wgrad_delay_us = 0
+
+
+def debug_delay_wgrad(us: int) -> int:
+    global _debug_wgrad_delay_us
+    prev = _debug_wgrad_delay_us
+    _debug_wgrad_delay_us = int(us)
+    L.load().tf_debug_delay_wgrad(int(us))
+    return prev
+
+
+def debug_spin(us: int, stream=None):
+    L.check(L.load().tf_debug_spin(int(us), C.c_void_p(_stream() if stream is None else stream)), "tf_debug_spin")
+
+
 def wgrad(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cgp=BIG, k_src=None, m_chunk=0, dY_lo=None, X_lo=None, groups=1,
           dw_gstride=0):
+    if _debug_wgrad_delay_us:
+        debug_spin(_debug_wgrad_delay_us)
     w = L.TfWgradArgs(dY=L.ptr(dY), ldy=dY.stride(0), X=L.ptr(X), ldx=X.stride(0), dW=L.ptr(dW), lddw=dW.stride(0), db=L.ptr(db),
                       dY_lo=L.ptr(dY_lo), X_lo=L.ptr(X_lo),
                       zeros=L.ptr(_zeros256(dY.device)), M=dY.shape[0], N=N, K=K, rg=rg, rgp=rgp,
@@ -293,6 +321,8 @@ def wgrad_args(dY, N, X, K, dW, db=None, rg=BIG, rgp=BIG, n_src=None, cg=BIG, cg
 
 def wgrad_multi(problems, blocks=0):
     """Several weight gradients (``wgrad_args`` results) as ONE launch on the current stream (tf_gemm_wgrad_multi)."""
+    if _debug_wgrad_delay_us:
+        debug_spin(_debug_wgrad_delay_us)
     arr = (L.TfWgradArgs * len(problems))(*problems)
     L.check(L.load().tf_gemm_wgrad_multi(arr, C.c_int(len(problems)), C.c_int(int(blocks)), C.c_void_p(_stream())), "tf_gemm_wgrad_multi")
 

@@ -183,6 +183,7 @@ class OrderedRangeReducer:
     What the reference gets from torch DDP's bucket order (runner/run_experiment.py:444-446, 452)."""
 
     joins_overlap = True
+    _debug_break_edge = None      # tests only ("side" / "accum"): drop one event edge, the negative control of tests/test_gpu_ddp.py's delay probe
 
     def __init__(self, flat: FlatParams, module: nn.Module, group=None, bucket_comm=None):
         self.flat, self.group, self.bucket_comm = flat, group, bucket_comm
@@ -293,7 +294,12 @@ class OrderedRangeReducer:
             from transfusion_amd import ops
             main = torch.cuda.current_stream(g.device)
             side = ops.side_stream(g.device)
-            self.units[u]["events"] = [main.record_event()] + ([side.record_event()] if side is not None else [])
+            evs = [main.record_event()] + ([side.record_event()] if side is not None else [])
+            if self._debug_break_edge == "side":
+                evs = evs[:1]
+            elif self._debug_break_edge == "accum" and u in self._pending_init:
+                evs = evs[1:]
+            self.units[u]["events"] = evs
         if self.order is None:
             return                           # first step: learn the order, reduce everything in finish()
         while self._next < len(self.order) and self._ready[self.order[self._next]]:
