@@ -561,7 +561,7 @@ class _PassThroughDetector(torch.nn.Module):
         pass
 
 
-def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False, reducer=False):
+def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False, reducer=False, d=D, precision=16):
     """The reference's REAL module around the hot path, at its own per-GPU batch: CrossFusionBoxWrapper over four FPN levels (level maps
     14p x 14p, p = 4, 4, 2, 1; C = 256 .. 2048; patch-embedding GEMM, 4-layer encoder on [196 + 512] tokens, back-projection + fold per
     level) with a pass-through detector, full training step (FusionTrainStep: flat buffers, clip, fused RAdam).  Host-bound at this size
@@ -583,16 +583,16 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
             os.environ["TF_FORCE_LAYERWISE"] = "1"       # the data-parallel path at world 1: layer-by-layer backward, per-unit hooks, no-op reduce
         fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
         fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})
-        fusion["args"].update({"input_f_size": D})
-        run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 16,
-                   "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": D,
+        fusion["args"].update({"input_f_size": d})
+        run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": precision,
+                   "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
                                                              "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
         torch.manual_seed(42)
         model = get_fusion_model(_PassThroughDetector(shapes, chans), {}, run_cfg, None).to(device).train()
         g = torch.Generator().manual_seed(4242 + 1000 * rank)
         feats = [torch.randn(batch, c, h, w, generator=g).to(device).requires_grad_(True) for c, (h, w) in zip(chans, shapes)]
         lens = torch.randint(NL // 4, NL + 1, (batch,), generator=g).tolist()
-        lang = [torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1).to(device) for n in lens]
+        lang = [torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(device) for n in lens]
         obj["trainer"] = FusionTrainStep(model, lr=1e-4, weight_decay=2e-4, grad_clip=1.0, zero_grads_in_optimizer=ZERO_IN_OPT)
         del model
 
@@ -614,14 +614,24 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
         if not math.isfinite(loss):
             raise SystemExit(f"leg wrapper_b{batch}: non-finite loss {loss}")
         vis_tokens = [n * n for n in grids]
+        # executed work of one step (train = 3 x forward): per level the encoder on its nv_l + len_b real tokens, plus the
+        # patch-embedding (K1: [B nv_l, C p^2] x [C p^2, d]) and back-projection (K9: [B nv_l, d] x [d, C p^2]) GEMMs
+        fl = 0.0
+        for nv_l, c, p in zip(vis_tokens, chans, ps):
+            fl += 3 * L * sum(flops_per_sample_layer(nv_l + n, d) for n in lens)
+            fl += 3 * 2 * (2.0 * batch * nv_l * c * p * p * d)
+        peak = PEAK_BF16_TFLOPS / 3.0 if str(precision) == "32" else PEAK_BF16_TFLOPS
         out = dict(ms_per_step=round(dt * 1e3, 3), samples_s=round(comm.world * batch / dt, 1), host_enqueue_ms=round(t_host * 1e3, 3),
-                   batch_per_gpu=batch, levels=4, layers_per_level=L, tokens=[NV, NL], vis_tokens_per_level=vis_tokens, d=D, dtype="bf16",
+                   batch_per_gpu=batch, levels=4, layers_per_level=L, tokens=[NV, NL], vis_tokens_per_level=vis_tokens, d=d,
+                   dtype="fp32" if str(precision) == "32" else "bf16",
+                   credited_tflop_per_step=round(fl / 1e12, 3), block_tflops_per_gpu=round(fl / dt / 1e12, 1),
+                   block_mfma_util=round(fl / dt / 1e12 / peak, 4), peak_used=round(peak, 1),
                    steps=steps, warmup=warmup, final_loss=round(loss, 5),
                    us_per_visual_token=round(dt * 1e6 / (batch * sum(vis_tokens)), 3),
                    reducer=type(obj["trainer"].layerwise).__name__ if obj["trainer"].layerwise is not None else None,
                    module="CrossFusionBoxWrapper (4 FPN levels) + pass-through detector, full training step")
         if rank == 0:
-            tag = "wrapper_b%d%s%s" % (batch, "_real" if real else "", "_dp" if reducer else "")
+            tag = "wrapper_b%d%s%s%s" % (batch, "_real" if real else "", "_dp" if reducer else "", "" if d == D and str(precision) != "32" else f"_d{d}_p{precision}")
             log(f"  leg {tag:16s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  (host enqueue {out['host_enqueue_ms']:.2f} ms/step)")
         return out
     finally:
@@ -686,7 +696,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_dp,b16,v1_d712,v2_d896_fp32,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_real_v1,wrapper_b4_real_v2,wrapper_b4_dp,b16,v1_d712,v2_d896_fp32,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -717,6 +727,10 @@ def main():
     backend = os.environ.get("TF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    if os.environ.get("TF_BENCH_STREAM") == "1":
+        # experiment hook: the whole run on a non-default (non-blocking) stream instead of the legacy null stream, which synchronises
+        # implicitly with every BLOCKING stream (hipExtStreamCreateWithCUMask makes those: TF_SIDE_CUS in experiments builds)
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -874,8 +888,15 @@ def main():
                 if name in ("wrapper_b4", "wrapper_b4_real", "wrapper_b4_dp"):
                     legs[name] = run_wrapper_leg(device, rank, comm, batch=4, real=name.endswith("_real"), reducer=name.endswith("_dp"))
                     continue
+                # the real module at the widths and precisions the reference's two YAMLs give it: Ego4Dv1 d = 712 at precision 16
+                # (ego_nao_res50_ego4d.yml:73,118), Ego4Dv2 d = 896 at precision 32 (ego_nao_res50_ego4dv2.yml:79,124)
+                if name in ("wrapper_b4_real_v1", "wrapper_b4_real_v2"):
+                    v2 = name.endswith("v2")
+                    legs[name] = run_wrapper_leg(device, rank, comm, batch=4, real=True, d=896 if v2 else 712, precision=32 if v2 else 16,
+                                                 steps=6 if v2 else 10, warmup=3)
+                    continue
                 if name not in specs:
-                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4, wrapper_b4_real, wrapper_b4_dp)")
+                    raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4, wrapper_b4_real, wrapper_b4_real_v1, wrapper_b4_real_v2, wrapper_b4_dp)")
                 legs[name if name not in legs else f"{name}#{len(legs)}"] = run_leg(name, device, rank, comm, **specs[name])
         else:
             # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32

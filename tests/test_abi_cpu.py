@@ -26,6 +26,16 @@ def test_exports_every_declared_symbol(lib):
     assert lib.tf_version() == _lib.CONSTS["TF_ABI_VERSION"]
 
 
+def test_exports_nothing_the_header_does_not_declare(lib):
+    """The dynamic symbol table of the library holds the header's entries and no other function of ours (the tf_launch_* / tf_tu_*
+    launchers the translation units call each other through are internal: a consumer cannot bind what the ABI does not promise)."""
+    from transfusion_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "t", "W")}
+    ours = {s for s in exported if s.startswith("tf_") or s.startswith("_Z")}
+    assert ours == set(_lib.FUNCTIONS), sorted(ours ^ set(_lib.FUNCTIONS))[:20]
+
+
 def test_struct_mirrors_match_c_layout(lib, tmp_path):
     from transfusion_amd import _lib
     names = sorted(_lib.STRUCTS)

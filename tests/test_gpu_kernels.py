@@ -543,6 +543,41 @@ def test_sumsq_is_a_pure_function_of_its_input(dev):
         assert abs(acc.item() - 3 * ref) <= 1e-5 * ref + 1e-30
 
 
+def test_sumsq_never_reads_a_stale_partial(dev):
+    """The hand-off inside tf_sumsq (block partials by sc1 stores, a ticket, the last arriver sums behind an agent acquire; no release
+    fence -- ADVICE r4) under the conditions that expose a stale read: 512 blocks, launches back to back with no host
+    synchronisation, an unrelated streaming kernel on another stream (uneven load), and every scratch row (16, round-robin) holding
+    the partials of a launch over DIFFERENT data of 1e6 times the magnitude.  One stale partial would change the small sums by many
+    orders of magnitude; every result must equal its own input's bits."""
+    from transfusion_amd import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    n = 18_912_000
+    big = (torch.randn(n, generator=g) * 1e3).to(dev)
+    small = (torch.randn(n, generator=g) * 1e-3).to(dev)
+    refs = {}
+    for name, x in (("big", big), ("small", small)):
+        out = torch.zeros(1, device=dev)
+        L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(out), ops._stream()), "tf_sumsq")
+        torch.cuda.synchronize()
+        refs[name] = out.clone()
+        assert abs(out.item() - x.double().pow(2).sum().item()) <= 2e-6 * x.double().pow(2).sum().item()
+    noise_a, noise_b = torch.empty(64 << 20, device=dev), torch.ones(64 << 20, device=dev)
+    side = torch.cuda.Stream()
+    outs = [torch.zeros(1, device=dev) for _ in range(96)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            noise_a.copy_(noise_b)
+    for i, out in enumerate(outs):                       # 16 launches over `big`, 16 over `small`, ...: launch i reuses the row of launch i - 16
+        x = big if (i // 16) % 2 == 0 else small
+        L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(out), ops._stream()), "tf_sumsq")
+    torch.cuda.synchronize()
+    for i, out in enumerate(outs):
+        want = refs["big"] if (i // 16) % 2 == 0 else refs["small"]
+        assert torch.equal(out, want), (i, out.item(), want.item())
+
+
 @pytest.mark.parametrize("G,Mg,N,K", [(4, 2083, 768, 768), (4, 2083, 2304, 768), (4, 2832, 768, 1536), (3, 300, 264, 128), (4, 5000, 1536, 768),
                                       (2, 8300, 768, 768)])     # 128-wide (ring and two-slot), large-tile and two-per-CU forms
 def test_gemm_grouped_rows(dev, G, Mg, N, K):

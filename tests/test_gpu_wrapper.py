@@ -510,3 +510,96 @@ def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, pac
                 checked += 1
         assert checked >= 12 * cfg["L"] + 2, checked
     assert rel(lang.grad, g["grad_lang"]) < gtol                 # the shared narration tokens: the sum over the four levels
+
+
+def _level_stream_step(dev, delay_us):
+    """One FusionTrainStep.step of a two-level wrapper whose levels run on their own streams (unequal token grids: the level loop) with
+    FROZEN inputs: feature maps and narration tokens need no gradient, so the last backward node on each level stream is K1's weight
+    gradient, written straight into the flat gradient buffer.  -> (parameters before, after, parameter ranges by name); with
+    ``delay_us`` None: (model, trainer) before any step."""
+    from transfusion_amd import ops
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.optim import FusedRAdam
+    from transfusion_amd.runner.config import load_fusion_config
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    d, h, L, B = 64, 4, 2, 4
+    levels = [dict(C=16, H=12, W=10, p=2), dict(C=8, H=9, W=9, p=3)]
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": [0, 1], "replace_fpn_features": True, "patch_h": [l["p"] for l in levels], "patch_w": [l["p"] for l in levels],
+                   "backproj_dropout": 0.0})
+    fusion["args"].update({"num_layers": [L] * 2, "num_heads": h, "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 16,
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    torch.manual_seed(5)
+    model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in levels], [l["C"] for l in levels]), {}, run_cfg, None).to(dev).train()
+    sgd = lambda ps, lr, weight_decay: FusedRAdam(ps, lr=lr, weight_decay=weight_decay, degenerated_to_sgd=True)
+    tr = FusionTrainStep(model, lr=2e-2, weight_decay=0.0, grad_clip=1.0, optimizer_cls=sgd)
+    if delay_us is None:
+        return model, tr
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.randn(B, l["C"], l["H"], l["W"], generator=g).to(dev) for l in levels]
+    lang = [torch.randn(n, d, generator=g).to(dev) for n in [9, 3, 11, 6]]
+    cots = [torch.randn(B, l["C"], l["H"], l["W"], generator=g).to(dev) for l in levels]
+
+    def loss_fn(m, _):
+        out = m({"image": feats, "language_f": lang})
+        return sum((out["features"][str(i)].float() * cots[i]).sum() for i in range(2))
+    before = tr.flat.flat.clone()
+    prev = ops.debug_delay_wgrad(delay_us)
+    try:
+        tr.step([None], loss_fn)
+        torch.cuda.synchronize()
+    finally:
+        ops.debug_delay_wgrad(prev)
+    assert model._last_path == "streams"
+    ranges = {n: (off, off + num) for n, _, off, num in tr.flat.slices}
+    return before.cpu(), tr.flat.flat.cpu().clone(), ranges
+
+
+def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen():
+    """One of the edges audited for round 4's intermittent two-rank mismatch: at world 1 the encoders and K1 / K9 add
+    their weight gradients straight into ``.grad`` on the LEVEL stream and hand autograd None; with frozen feature maps nothing
+    downstream of a level's K1 needs a gradient, so no tensor ever flows from the level stream back to the main stream.  What still
+    orders the optimiser behind it: the engine runs each parameter's AccumulateGrad node (a no-op for an undefined gradient) on the
+    stream the parameter was used on and joins every such "leaf stream" when backward() returns.  Probe: every weight-gradient launch
+    3 ms late (ops.debug_delay_wgrad) -- the step must move every parameter exactly as the undelayed step does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda:0")
+    b0, plain, ranges = _level_stream_step(dev, 0)
+    b1, late, _ = _level_stream_step(dev, 3000)
+    assert torch.equal(b0, b1)
+    m0, m1 = plain - b0, late - b0
+    for key in ("cross_fusion_encoders.0.t_encoder.layers.0.linear1.weight", "cross_fusion_encoders.1.t_encoder.layers.1.self_attn.in_proj_weight",
+                "patches_to_token.0.weight", "patches_to_token.1.weight", "tokens_to_features.0.linear.weight"):
+        lo, hi = ranges[key]
+        assert float(m0[lo:hi].abs().max()) > 0, key
+        assert ((m1[lo:hi] - m0[lo:hi]).norm() / m0[lo:hi].norm()).item() < 2e-2, (key, "the optimiser ran before this gradient was written")
+
+
+def test_capturing_level_streams_with_side_streams_raises_instead_of_crashing():
+    """ROCm 7.2's hipStreamEndCapture segfaults on a capture that holds level-stream forks WITH a side-stream fork inside each (round 3).
+    The product refuses such a capture before it launches anything (CrossFusionBoxWrapper._refuse_nested_fork_capture): a user who wraps
+    a step in torch.cuda.graph with the default settings gets a ValueError that names the ways out, not a core dump."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd import ops
+    dev = torch.device("cuda:0")
+    model, tr = _level_stream_step(dev, None)
+    assert ops.wgrad_overlap_enabled()
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.randn(4, c, h, w, generator=g).to(dev) for c, h, w in [(16, 12, 10), (8, 9, 9)]]
+    lang = [torch.randn(n, 64, generator=g).to(dev) for n in [9, 3, 11, 6]]
+    out = model({"image": feats, "language_f": lang})                   # eager: lazily created state settles, the path is "streams"
+    torch.cuda.synchronize()
+    assert model._last_path == "streams" and out["features"]["0"].shape == feats[0].shape
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(ValueError, match="nested fork"):
+        with torch.cuda.graph(graph, stream=side):
+            model({"image": feats, "language_f": lang})
+    torch.cuda.synchronize()
+    out2 = model({"image": feats, "language_f": lang})                  # the refusal left the runtime usable
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2["features"]["1"].float()).all()

@@ -66,8 +66,14 @@ def build_lib(force: bool = False, verbose: bool = True, experiments: bool = Fal
                 if verbose:
                     print(f"[transfusion_amd.build] compiled {os.path.basename(done)}", file=sys.stderr)
     objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(lib_path, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
+    if force or jobs or _stale(lib_path, objs + [os.path.join(CSRC, HEADERS[-1])]):
+        # exported = exactly the entries include/tfusion.h declares; the launchers the translation units call each other through
+        # (tf_launch_*, tf_tu_*) stay internal to the library
+        from transfusion_amd import _lib
+        vmap = os.path.join(obj_dir, "exports.map")
+        with open(vmap, "w") as f:
+            f.write("{\n  global:\n" + "".join(f"    {name};\n" for name in _lib.FUNCTIONS) + "  local:\n    *;\n};\n")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vmap}", "-o", lib_path] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -352,7 +352,14 @@ int tf_overlap_create(TfOverlap* o) {
   // is worth -0.6 % on the single-encoder benchmark (4.235 vs 4.26 ms, same box) and is a disaster for the wrapper, whose four level
   // streams then starve their four side streams (B = 4: 11.5 vs 6.35 ms per step): the default priority stays.
   static const int prio_sel = TF_ENV_INT("TF_SIDE_PRIORITY", 0);
-  if (prio_sel != 0) {
+  // TF_SIDE_CUS (experiment): the side stream confined to n of the 256 CUs by a CU mask (the KFD deals mask bits round-robin over
+  // the XCDs: the low n bits are n / 8 CUs of every XCD), so that the weight-gradient workgroups leave whole CUs to the chain
+  static const int side_cus = TF_ENV_INT("TF_SIDE_CUS", 0), side_cu0 = TF_ENV_INT("TF_SIDE_CU0", 0);
+  if (side_cus > 0 && side_cus < 256) {
+    uint32_t mask[8] = {};
+    for (int i = 0; i < side_cus; ++i) { const int b = (i + side_cu0) % 256; mask[b / 32] |= 1u << (b % 32); }
+    TF_TRY((int)hipExtStreamCreateWithCUMask(&st, 8, mask), "tf_overlap_create(CU-masked stream)");
+  } else if (prio_sel != 0) {
     int least = 0, greatest = 0;
     TF_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest), "tf_overlap_create(priority range)");
     TF_TRY((int)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_sel < 0 ? greatest : least), "tf_overlap_create(stream)");

@@ -177,24 +177,33 @@ def _watch_packed_rows(desc, stream, device):
     _packed_flags.append((host, ev, int(desc.packed_rows)))
     if len(_packed_flags) > 64:
         check_packed_row_errors(sync=False)
-        del _packed_flags[:-64]
+        while len(_packed_flags) > 64:                 # still too many in flight: WAIT for the oldest rather than dropping one unseen
+            _check_one_packed_flag(sync=True)
+
+
+def _check_one_packed_flag(sync: bool) -> bool:
+    """Looks at the oldest pending error word; False when its copy has not landed yet (and ``sync`` is off)."""
+    host, ev, want = _packed_flags[0]
+    if not sync and not ev.query():
+        return False
+    if sync:
+        ev.synchronize()
+    _packed_flags.pop(0)
+    got = int(host[0])
+    if got != 0:
+        _packed_flags.clear()
+        if got == want:                  # the total agrees, the split over the groups does not (row_map_kernel's `bad`)
+            raise L.TfError(f"lang_valid_rows: the {want} token rows of an earlier grouped forward are not shared equally by its groups "
+                            "(with grouped levels every group must drop the same tokens).  That step's outputs and gradients are wrong.")
+        raise L.TfError(f"lang_valid_rows: an earlier forward was told {want} token rows, its padding mask holds {got} "
+                        "(the count must be B * Nv + the number of un-masked language tokens).  That step's outputs and gradients are wrong.")
+    return True
 
 
 def check_packed_row_errors(sync: bool = True):
     """Raises TfError for any earlier packed forward whose ``lang_valid_rows`` disagreed with its padding mask."""
-    while _packed_flags:
-        host, ev, want = _packed_flags[0]
-        if not sync and not ev.query():
-            break
-        if sync:
-            ev.synchronize()
-        _packed_flags.pop(0)
-        got = int(host[0])
-        if got != 0:
-            _packed_flags.clear()
-            raise L.TfError(f"lang_valid_rows: an earlier forward was told {want} token rows, its padding mask holds {got} "
-                            "(the count must be B * Nv + the number of un-masked language tokens; with grouped levels every group must "
-                            "drop the same tokens).  That step's outputs and gradients are wrong.")
+    while _packed_flags and _check_one_packed_flag(sync):
+        pass
 
 
 _warned_dense_rows = False

@@ -203,6 +203,8 @@ class CrossFusionBoxWrapper(nn.Module):
             # the GEMMs plan their tile grids for their share of the chip while the levels run side by side (backward included:
             # autograd replays the levels on the same streams)
             ops.set_gemm_concurrency(len(self.fpn_features_idx) if parallel else (1 + getattr(self, "_grouped_others", 0) if grouped is not None else 1))
+        if parallel:
+            self._refuse_nested_fork_capture()
         if parallel and (self._level_streams is None or self._level_streams[0].device != language_f.device):
             # TF_LEVEL_STREAMS = n > 1: n streams shared round-robin by the levels (default: one per level)
             n_st = int(os.environ.get("TF_LEVEL_STREAMS", "1"))
@@ -259,6 +261,20 @@ class CrossFusionBoxWrapper(nn.Module):
             )
         return rcnn_outs
 
+    @staticmethod
+    def _refuse_nested_fork_capture():
+        """A step whose feature levels run on LEVEL STREAMS while every level's encoder forks a side stream of its own for the weight
+        gradients cannot be captured in a HIP graph on ROCm 7.2: every fork is joined -- the capture is legal by the API's rules, and
+        either fork level alone captures and replays -- but hipStreamEndCapture segfaults on the nested fork (round 3,
+        gpurun_out/wg.txt: a crash in the runtime, not an error code).  Raised BEFORE any level is launched, so that a user who wraps
+        FusionTrainStep.step in torch.cuda.graph with the defaults gets an exception that names the ways out instead of a core dump."""
+        if torch.cuda.is_current_stream_capturing() and ops.wgrad_overlap_enabled():
+            raise ValueError(
+                "CrossFusionBoxWrapper: this forward would run feature levels on their own streams while every level's encoder forks a side "
+                "stream for its weight gradients; hipStreamEndCapture crashes on that nested fork (ROCm 7.2).  Capture with the levels on "
+                "one stream (TF_LEVEL_STREAMS=0), without the side streams (TF_WGRAD_OVERLAP=0), or with ALL levels as one grouped call "
+                "(parameters in FusionTrainStep's flat layout, equal token grids).")
+
     def _grouped_levels(self, features_dict, language_f, pad_mask, n_valid):
         """The levels that share a token grid through ONE grouped encoder call (TfEncoderDesc.groups), the others beside it on their own
         streams; None when no two levels can be grouped (then the level loop runs).  The reference's real FPN geometry -- patches of
@@ -289,6 +305,20 @@ class CrossFusionBoxWrapper(nn.Module):
         # side by side on the level streams, forward and -- autograd replays a node on its forward stream -- backward
         main = torch.cuda.current_stream(language_f.device)
         use_streams = os.environ.get("TF_LEVEL_STREAMS", "1") != "0"
+        # ... each side of the grouped call as ONE autograd node when the shapes allow it (level_ops: the host issues a level's two or three
+        # kernels instead of four autograd nodes and a dozen torch / stream calls per level and direction); TF_LEVEL_OPS=0 keeps the
+        # per-level modules
+        from transfusion_amd import level_ops
+        fused_ops = os.environ.get("TF_LEVEL_OPS", "1") != "0"
+        p2t, t2f, gfeats = [self.patches_to_token[i] for i in members], [self.tokens_to_features[i] for i in members], [feats[i] for i in members]
+        k1_fused = fused_ops and level_ops.k1_supported(p2t, gfeats, self.token_dim)
+        # EVERY "cannot group" decision is taken here, before anything is launched (a level started on its stream and then abandoned
+        # would keep reading feats / language_f / pad_mask beside the fallback loop that recomputes it): the member levels' token
+        # dtypes must agree for the torch.cat of the per-level path (bf16 from the bf16 path, fp32 from the fp32-accuracy mode)
+        if not k1_fused and len({getattr(m, "precision", "bf16") for m in p2t}) != 1:
+            return None
+        if use_streams and others:
+            self._refuse_nested_fork_capture()
         if use_streams and (self._level_streams is None or self._level_streams[0].device != language_f.device):
             self._level_streams = [torch.cuda.Stream(device=language_f.device) for _ in self.fpn_features_idx]
 
@@ -329,19 +359,11 @@ class CrossFusionBoxWrapper(nn.Module):
                 fused_ls[i].record_stream(main)
             else:
                 outs[i], fused_ls[i] = whole_level()
-        # ... each side of the grouped call as ONE autograd node when the shapes allow it (level_ops: the host issues a level's two or three
-        # kernels instead of four autograd nodes and a dozen torch / stream calls per level and direction); TF_LEVEL_OPS=0 keeps the
-        # per-level modules
-        from transfusion_amd import level_ops
-        fused_ops = os.environ.get("TF_LEVEL_OPS", "1") != "0"
-        p2t, t2f, gfeats = [self.patches_to_token[i] for i in members], [self.tokens_to_features[i] for i in members], [feats[i] for i in members]
         sts = [self._level_streams[i] for i in members] if use_streams else None
-        if fused_ops and level_ops.k1_supported(p2t, gfeats, self.token_dim):
+        if k1_fused:
             x = level_ops.levels_patch_embed(p2t, gfeats, sts)
         else:
             toks = per_level(lambda i, feat: self.patches_to_token[i](feat), members, gfeats)
-            if len({t.dtype for t in toks}) != 1:
-                return None
             x = torch.cat(toks, dim=0)                             # [G * B, Nv, d], group-major
         lang_g, pad_g = language_f.repeat(G, 1, 1), pad_mask.repeat(G, 1)
         kw = {}

@@ -49,24 +49,38 @@ class FusedRAdam(torch.optim.Optimizer):
             raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
         self.degenerated_to_sgd = degenerated_to_sgd
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # device scalars of the learning rates, by group INDEX -- kept OUTSIDE param_groups: state_dict() stays what the reference's RAdam
+        # writes (no CUDA tensors in checkpoints), and load_state_dict(), which replaces the group dicts, leaves them -- and the pointer a
+        # captured graph holds -- in place
+        self._lr_dev = {}         # group index -> [tensor, value it holds]
 
     def lr_device(self, group, device):
         """The group's learning rate as a one-element device tensor (created on first use, holding the current ``group['lr']``): what
-        ``step(on_clock=True)`` hands to the kernel, so that a step replayed from a HIP graph follows the LR scheduler."""
-        t = group.get("_lr_dev")
-        if t is None or t.device != device:
-            t = torch.full((1,), float(group["lr"]), dtype=torch.float32, device=device)
-            group["_lr_dev"], group["_lr_dev_val"] = t, float(group["lr"])
-        return t
+        ``step(on_clock=True)`` hands to the kernel, so that a step replayed from a HIP graph follows the LR scheduler.  The tensor is
+        created once per group and refilled in place ever after; creating it inside a capture would bake the fill into the graph (every
+        replay would reset the rate), so that raises."""
+        gi = next(i for i, g in enumerate(self.param_groups) if g is group)
+        ent = self._lr_dev.get(gi)
+        if ent is None or ent[0].device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.TfError("FusedRAdam.lr_device: the rate's device scalar must exist before a capture (run one on_clock step eagerly first)")
+            ent = self._lr_dev[gi] = [torch.full((1,), float(group["lr"]), dtype=torch.float32, device=device), float(group["lr"])]
+        return ent[0]
 
     def refresh_lr(self):
         """Copies every group's current ``lr`` into its device scalar (no-op for groups whose rate has not changed).  Call OUTSIDE a graph
         capture, before a replay: the replay helper of tests/graph_step.py does."""
-        for g in self.param_groups:
-            t = g.get("_lr_dev")
-            if t is not None and g.get("_lr_dev_val") != float(g["lr"]):
-                t.fill_(float(g["lr"]))
-                g["_lr_dev_val"] = float(g["lr"])
+        for gi, ent in self._lr_dev.items():
+            lr = float(self.param_groups[gi]["lr"])
+            if ent[1] != lr:
+                ent[0].fill_(lr)
+                ent[1] = lr
+
+    def load_state_dict(self, state_dict):
+        """torch's load replaces the group dicts (and with them ``lr``): the device scalars are refilled IN PLACE from the loaded rates."""
+        super().load_state_dict(state_dict)
+        if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+            self.refresh_lr()
 
     def grad_sumsq(self, out: torch.Tensor):
         """Accumulates sum(g^2) of every gradient into the 1-element fp32 tensor ``out`` (device side)."""
