@@ -37,6 +37,15 @@ LEVEL_CASES = {
 MLEVEL_CASES = {
     "mlevel_4n_n_n_n": dict(B=2, d=64, h=4, L=2, Nl=7, mask_lens=[7, 3], seed=401,
                             levels=[dict(C=16, H=8, W=8, p=2), dict(C=16, H=4, W=4, p=2), dict(C=64, H=2, W=2, p=1), dict(C=64, H=2, W=2, p=1)]),
+    # the wrapper's two switches the shipped YAML leaves at their defaults (cross_f_box_wrapper.py:184, 202-209): vis_mask_type "local_k"
+    # (a visual token attends the visual tokens within k grid steps, utils.py:14-30) and forward_language_f "sum" / "direct" (the fused
+    # narration tokens of level i feed level i + 1: the levels are no longer independent)
+    "mlevel_local1": dict(B=2, d=64, h=4, L=2, Nl=7, mask_lens=[7, 3], seed=411, local_k=1,
+                          levels=[dict(C=16, H=10, W=8, p=2), dict(C=16, H=6, W=6, p=2), dict(C=32, H=3, W=4, p=1)]),
+    "mlevel_fwd_sum": dict(B=2, d=64, h=4, L=2, Nl=7, mask_lens=[5, 7], seed=421, fwd_lang="sum",
+                           levels=[dict(C=16, H=8, W=8, p=2), dict(C=16, H=4, W=4, p=2), dict(C=32, H=3, W=3, p=1)]),
+    "mlevel_fwd_direct_local1": dict(B=2, d=64, h=4, L=2, Nl=7, mask_lens=[7, 2], seed=431, fwd_lang="direct", local_k=1,
+                                     levels=[dict(C=16, H=8, W=6, p=2), dict(C=16, H=4, W=4, p=2), dict(C=32, H=3, W=3, p=1)]),
 }
 
 

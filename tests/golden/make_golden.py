@@ -167,6 +167,9 @@ def run_mlevel_case(name, cfg, Enc, ref_utils):
     out = {"in_lang": lang, "in_mask": mask}
     loss = 0.0
     keep = []
+    # cfg["fwd_lang"] ("sum" / "direct"): forward_language_f, wrapper :202-209 -- `language_f` is the pooling layer's output there (a
+    # non-leaf tensor the wrapper adds to IN PLACE); cfg["local_k"]: vis_mask_type "local_k", wrapper :184
+    language_f = tl * 1.0 if cfg.get("fwd_lang") else tl
     for i, (lv, data) in enumerate(zip(cfg["levels"], levels)):
         C, H, W, p = lv["C"], lv["H"], lv["W"], lv["p"]
         pe = ref_utils.PositionalEmbeddingLayer("sin1d", 8192, d)
@@ -183,8 +186,17 @@ def run_mlevel_case(name, cfg, Enc, ref_utils):
         enc.train(); conv.train(); reg.train()
         tf = torch.from_numpy(data["feat"]).requires_grad_(True)
         reg.init_h, reg.init_w = H, W                                                    # wrapper :180-181
-        tok = ref_utils.patchify_image(conv(tf), 1, 1)                                   # wrapper :183-185
-        vis, lang_out, _, _ = enc(tok, tl, tm, vis_tokens_mask=None)                     # the SAME language tokens on every level
+        tok4 = conv(tf)
+        vmask = None
+        if "local_k" in cfg:
+            ref_utils.cache_masks.clear()
+            vmask = ref_utils.get_visual_token_mask(tok4.shape[2:], f"local_{cfg['local_k']}")    # wrapper :184
+        tok = ref_utils.patchify_image(tok4, 1, 1)                                       # wrapper :183-185
+        vis, lang_out, _, _ = enc(tok, language_f, tm, vis_tokens_mask=vmask)            # (no forwarding: the SAME language tokens on every level)
+        if cfg.get("fwd_lang") == "direct":                                              # wrapper :202-209
+            language_f = lang_out
+        elif cfg.get("fwd_lang") == "sum":
+            language_f += lang_out
         fused = reg(vis)                                                                 # wrapper :211
         loss = loss + (fused * torch.from_numpy(data["gout"])).sum()
         keep.append((tf, conv, reg, enc, fused, lang_out))

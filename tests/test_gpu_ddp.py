@@ -221,7 +221,9 @@ def _run_tree(tmp_path, levels, tag, delay_us=0, break_edge=None, single=True):
     s1.write_text(_TREE_WORKER.format(root=ROOT, out=out1, levels=levels))
     port = _free_port()
     procs = []
-    extra = {"TF_TEST_WGRAD_DELAY_US": str(delay_us)}
+    # (GPU_MAX_HW_QUEUES: ROCm multiplexes streams onto a few hardware queues -- 4 by default -- and two streams that share one run in
+    # submission order, which would HIDE a missing event edge from the probe; with more queues than streams nothing is hidden)
+    extra = {"TF_TEST_WGRAD_DELAY_US": str(delay_us), "GPU_MAX_HW_QUEUES": "16"}
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         if break_edge:

@@ -512,6 +512,90 @@ def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, pac
     assert rel(lang.grad, g["grad_lang"]) < gtol                 # the shared narration tokens: the sum over the four levels
 
 
+@pytest.mark.parametrize("name", ["mlevel_local1", "mlevel_fwd_sum", "mlevel_fwd_direct_local1"])
+@pytest.mark.parametrize("precision,packed", [(16, True), (16, False), (32, True)])
+def test_wrapper_switches_against_reference_fixtures(golden_dir, name, precision, packed):
+    """The two switches of the wrapper's level loop that the shipped YAML leaves at their defaults, through the HIP path against
+    REFERENCE-generated fixtures: ``vis_mask_type: local_k`` (cross_f_box_wrapper.py:184 -> utils.py:14-30: a per-level block-bit mask in
+    the attention kernels) and ``forward_language_f: "sum" / "direct"`` (:202-209: level i's fused narration tokens feed level i + 1 --
+    with packed rows the masked positions travel as zero rows under the same mask).  Every level's fused map, the gradient of every
+    feature map, of the narration tokens and of every parameter; bf16 / fp32-accuracy mode, packed / dense rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from cases import MLEVEL_CASES
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    dev = torch.device("cuda:0")
+    cfg = MLEVEL_CASES[name]
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    B, d, lv = cfg["B"], cfg["d"], cfg["levels"]
+    n = len(lv)
+    fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+    fusion.update({"fpn_features": list(range(n)), "replace_fpn_features": True, "patch_h": [l["p"] for l in lv], "patch_w": [l["p"] for l in lv],
+                   "backproj_dropout": 0.0, "forward_language_f": cfg.get("fwd_lang", False),
+                   "vis_mask_type": f"local_{cfg['local_k']}" if "local_k" in cfg else "global"})
+    fusion["args"].update({"num_layers": [cfg["L"]] * n, "num_heads": cfg["h"], "patch_dropout": 0.0, "token_dropout": 0.0, "input_f_size": d})
+    run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": precision,
+               "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                         "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+    model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in lv], [l["C"] for l in lv]), {}, run_cfg, None).to(dev).train()
+    assert model.vis_mask_type == fusion["vis_mask_type"] and model.forward_language_f == fusion["forward_language_f"]
+    for i in range(n):
+        pre = f"l{i}/"
+        model.cross_fusion_encoders[i].load_state_dict({k[len(pre) + 6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre + "param/")},
+                                                       strict=False)
+        model.patches_to_token[i].weight.data.copy_(torch.from_numpy(g[pre + "conv_w"]))
+        model.tokens_to_features[i].linear.weight.data.copy_(torch.from_numpy(g[pre + "reg_w"]))
+        model.tokens_to_features[i].linear.bias.data.copy_(torch.from_numpy(g[pre + "reg_b"]))
+    lens = [int((~g["in_mask"][b]).sum()) for b in range(B)]
+
+    class PassThroughPooling(torch.nn.Module):
+        def forward(self, tensors, pad_mask=True):
+            x = torch.stack(tensors, 0)
+            m = torch.ones(x.shape[:2], device=x.device)
+            for b, k in enumerate(lens):
+                m[b, k:] = 0
+            if packed:
+                self.valid_tokens = sum(lens)
+            return x, None, m
+
+        def unfreeze_embeddings(self):
+            pass
+
+    model.narr_pooling_layer = PassThroughPooling()
+    feats = [torch.from_numpy(g[f"l{i}/in_feat"]).to(dev).requires_grad_(True) for i in range(n)]
+    lang = torch.from_numpy(g["in_lang"]).to(dev).requires_grad_(True)
+    out = model({"image": feats, "language_f": [lang[b] for b in range(B)]})
+    fused = [out["features"][str(i)] for i in range(n)]
+    sum((fused[i].float() * torch.from_numpy(g[f"l{i}/cot_out"]).to(dev)).sum() for i in range(n)).backward()
+    torch.cuda.synchronize()
+    assert model._last_path == ("loop" if cfg.get("fwd_lang") else "streams")      # forwarded tokens chain the levels; a local mask alone does not
+    assert (int(model.cross_fusion_encoders[0]._last_desc.packed_rows) > 0) == packed
+    if "local_k" in cfg:
+        assert int(model.cross_fusion_encoders[0]._last_desc.attn_block_bits or 0) != 0
+    ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
+    for i in range(n):
+        pre = f"l{i}/"
+        assert rel(fused[i], g[pre + "fused"]) < ftol, i
+        assert rel(feats[i].grad, g[pre + "grad_feat"]) < gtol, i
+        assert rel(model.patches_to_token[i].weight.grad, g[pre + "grad_conv_w"]) < gtol, i
+        assert rel(model.tokens_to_features[i].linear.weight.grad, g[pre + "grad_reg_w"]) < gtol, i
+        assert rel(model.tokens_to_features[i].linear.bias.grad, g[pre + "grad_reg_b"]) < gtol, i
+        params = dict(model.cross_fusion_encoders[i].named_parameters())
+        checked = 0
+        for k, v in g.items():
+            if k.startswith(pre + "gradp/"):
+                pname = k[len(pre) + 6:]
+                if float(np.abs(v).max()) == 0.0:
+                    continue
+                assert rel(params[pname].grad, v) < gtol, (i, pname)
+                checked += 1
+        assert checked >= 12 * cfg["L"], checked
+    valid = ~torch.from_numpy(g["in_mask"])
+    assert rel(lang.grad.cpu()[valid], torch.from_numpy(g["grad_lang"])[valid]) < gtol
+    assert float(torch.from_numpy(g["grad_lang"])[~valid].abs().max()) == 0.0 and float(lang.grad.cpu()[~valid].abs().max()) == 0.0
+
+
 def _level_stream_step(dev, delay_us):
     """One FusionTrainStep.step of a two-level wrapper whose levels run on their own streams (unequal token grids: the level loop) with
     FROZEN inputs: feature maps and narration tokens need no gradient, so the last backward node on each level stream is K1's weight

@@ -127,6 +127,7 @@ def test_multi_level_loop(golden_dir, name):
     lang = torch.from_numpy(g["in_lang"]).requires_grad_(True)
     mask = torch.from_numpy(g["in_mask"])
     loss, keep = 0.0, []
+    language_f = lang                     # forward_language_f (cross_f_box_wrapper.py:202-209): level i's fused tokens feed level i + 1
     for i, lv in enumerate(cfg["levels"]):
         pre = f"l{i}/"
         sd = _sd({k[len(pre) + 6:]: v for k, v in g.items() if k.startswith(pre + "param/")}, cfg["d"])
@@ -134,7 +135,14 @@ def test_multi_level_loop(golden_dir, name):
         conv_w = torch.from_numpy(g[pre + "conv_w"]).requires_grad_(True)
         reg_w = torch.from_numpy(g[pre + "reg_w"]).requires_grad_(True)
         reg_b = torch.from_numpy(g[pre + "reg_b"]).requires_grad_(True)
-        fused, lo = O.fusion_level_forward(feat, conv_w, sd, lang, mask, cfg["h"], cfg["L"], reg_w, reg_b, lv["p"], lv["p"])
+        vmask = None
+        if "local_k" in cfg:              # vis_mask_type "local_k" on this level's token grid (cross_f_box_wrapper.py:184; utils.py:14-30)
+            vmask = O.local_visual_mask(lv["H"] // lv["p"], lv["W"] // lv["p"], cfg["local_k"])
+        fused, lo = O.fusion_level_forward(feat, conv_w, sd, language_f, mask, cfg["h"], cfg["L"], reg_w, reg_b, lv["p"], lv["p"], vis_tokens_mask=vmask)
+        if cfg.get("fwd_lang") == "direct":
+            language_f = lo
+        elif cfg.get("fwd_lang") == "sum":
+            language_f = language_f + lo
         _close(fused, g[pre + "fused"], what=pre + "fused")
         _close(lo, g[pre + "lang_out"], what=pre + "lang_out")
         loss = loss + (fused * torch.from_numpy(g[pre + "cot_out"])).sum()
