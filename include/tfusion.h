@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 6
+#define TF_ABI_VERSION 7
 #define TF_MAX_LAYERS 16
 
 enum TfEpilogue {
@@ -64,6 +64,9 @@ typedef struct TfGemmArgs {
   // different weights): groups > 1 splits the M rows into `groups` equal ranges; range g multiplies by the weight / bias / scale_w
   // tensors that start g * w_gstride BYTES after W / bias / scale_w (W_lo likewise).  A, C, R, C2, scale_a are indexed by global row.
   int groups; long long w_gstride;
+  // fp32-accuracy mode, epilogues NONE / BIAS (ABI v7): c_is_f32 != 0 -> C is an fp32 [M, ldc] tensor written directly (C_lo unused):
+  // the tokens K1 hands the encoder and the gradient K9 hands back are fp32 tensors, not plane pairs
+  int c_is_f32;
 } TfGemmArgs;
 
 /* row-wise fp8 (e4m3) quantisation: dst[r][c] = fp8(src[r][c] / scale[r]), scale[r] = max|src[r][:]| / 448 (1 for an all-zero row);
@@ -303,7 +306,26 @@ typedef struct TfPatchArgs {
   const void* feat; int feat_is_f32;     // [B,C,H,W]
   void* cols; int ld_cols;               // [B*Hp*Wp, C*ph*pw (padded to ld_cols)] bf16
   int B, C, H, W, ph, pw;
+  // fp32-accuracy mode (ABI v7): cols as a hi + lo bf16 plane pair (value = hi + lo, 16 significant bits; same ld).  The gather
+  // (tf_patchify_fwd / tf_regroup_bwd) splits an fp32 feature map into the two planes, the scatter (tf_regroup_fwd / tf_patchify_bwd)
+  // adds them back: K1 / K9 at run.precision 32 without an fp32 im2col matrix in between
+  void* cols_lo;
 } TfPatchArgs;
+
+/* fp32 [rows, cols] -> the operand planes of the fp32-accuracy mode: hi = bf16(v), lo = bf16(v - hi), both [rows, ld_dst] with the
+ * columns [cols, ld_dst) zero-filled (ld_dst % 8 == 0; any cols, any row stride: 16-B accesses where the rows allow them) -- what torch
+ * spelt as three elementwise passes and two pads per GEMM operand.  Optional input
+ * dropout first (drop_thr != 0: element (r, c) is kept iff tf_dropout_mask says so at index r * drop_ld + c, kept values scaled by
+ * drop_scale -- BEFORE the split, so that the pair still carries 16 bits of the scaled value).  dst_f32 != null: the (dropped) fp32
+ * values are also / only written there (ld_f32; may alias src: the backward's in-place mask); hi / lo may then be null. */
+typedef struct TfPlanesArgs {
+  const float* src; int ld_src;
+  void* hi; void* lo; int ld_dst;
+  float* dst_f32; int ld_f32;
+  int rows, cols;
+  unsigned drop_thr, drop_key; float drop_scale; int drop_ld;
+} TfPlanesArgs;
+int tf_split_planes(const TfPlanesArgs* a, tf_stream_t s);
 
 
 /* ---- dropout key: every dropout site draws keep(i) = hash32(i, key) >= p * 2^32, key = f(seed, site) ---- */

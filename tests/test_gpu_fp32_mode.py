@@ -391,3 +391,80 @@ def test_linear_fp32_mode(dev, M, K, N):
         kept = y2 > 0
         assert (y2[~kept] == 0).all() and (y2[kept] - 1 / 0.75).abs().max().item() < 5e-5        # 16 significant bits of 4/3, not bf16(4/3)
         assert 0.6 < kept.float().mean().item() < 0.9
+
+
+@pytest.mark.parametrize("M,K,ld,p", [(300, 72, 128, 0.0), (4100, 768, 768, 0.0), (1000, 200, 256, 0.25), (500, 87, 128, 0.0)])
+def test_split_planes_kernel(dev, M, K, ld, p):
+    """tf_split_planes: fp32 [M, K] (strided) -> hi + lo bf16 planes [M, ld], zero pad, 16 significant bits; with input dropout the keep
+    mask is the one tf_dropout_mask replays at index row * ld + col and the kept values carry 1 / (1 - p) BEFORE the split; the in-place
+    fp32 form (the backward's mask) multiplies by the same mask."""
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(M + K)
+    full = torch.randn(M, K + 8, generator=g).to(dev)
+    x = full[:, :K]                                               # row stride K + 8: the kernel reads through ld_src
+    drop = ops.drop_params(p, 11, 7)
+    hi, lo = ops.planes_of(x, ld, drop, ld)
+    keep = torch.ones(M, ld, device=dev)
+    if p > 0:
+        m = torch.empty(M * ld, dtype=torch.uint8, device=dev)
+        L.check(L.load().tf_dropout_mask(L.ptr(m), M * ld, drop[1], drop[0], ops._stream()), "tf_dropout_mask")
+        keep = m.view(M, ld).float() * drop[2]
+        assert 0.65 < float(m.float().mean()) < 0.85
+    want = x.double() * keep[:, :K].double()
+    got = hi.double() + lo.double()
+    assert float((got[:, :K] - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max()) + 1e-30
+    assert torch.equal(hi[:, :K], want.float().to(torch.bfloat16))
+    if ld > K:
+        assert float(hi[:, K:].float().abs().max()) == 0.0 and float(lo[:, K:].float().abs().max()) == 0.0
+    if p > 0:
+        y = torch.zeros(M, ld, device=dev)
+        y[:, :K] = x
+        ops.dropout_f32_(y, K, drop, ld)
+        assert torch.equal(y[:, :K], (x * keep[:, :K]))
+
+
+@pytest.mark.parametrize("B,C,H,W,p,d", [(2, 16, 12, 10, 2, 64), (3, 8, 9, 9, 3, 72), (2, 256, 28, 28, 4, 128)])
+def test_k1_k9_fp32_mode_on_library_kernels(dev, B, C, H, W, p, d):
+    """K1 (ops.patch_embed_fp32) and K9 (ops.back_project_fp32) at run.precision 32 -- the gather / fold working on hi + lo planes
+    (TfPatchArgs.cols_lo), fp32 GEMM results (TfGemmArgs.c_is_f32), no torch elementwise op in between -- against fp64 conv / linear +
+    fold, outputs and every gradient, at 1e-4 (KTOL); maps that the patches do not tile (zero border), K = C p^2 = 72 (row padding)."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(B * C + H)
+    feat = torch.randn(B, C, H, W, generator=g).to(dev).requires_grad_(True)
+    K = C * p * p
+    w1 = (torch.randn(d, C, p, p, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+    Hp, Wp = H // p, W // p
+    tok = ops.patch_embed_fp32(feat, w1, p, p)
+    assert tok.dtype == torch.float32 and tok.shape == (B, Hp * Wp, d)
+    gt = torch.randn(B, Hp * Wp, d, generator=g).to(dev)
+    (tok * gt).sum().backward()
+    fr, wr = feat.detach().double().cpu().requires_grad_(True), w1.detach().double().cpu().requires_grad_(True)
+    tr = torch.nn.functional.conv2d(fr, wr, stride=p).flatten(2).transpose(1, 2)
+    (tr * gt.double().cpu()).sum().backward()
+    assert rel(tok, tr.detach()) < KTOL and rel(feat.grad, fr.grad) < KTOL and rel(w1.grad, wr.grad) < KTOL
+    if H % p or W % p:
+        assert float(feat.grad[:, :, Hp * p:, :].abs().max()) == 0.0 if H % p else True
+    # K9: tokens -> map
+    N = C * p * p
+    x = torch.randn(B, Hp * Wp, d, generator=g).to(dev).requires_grad_(True)
+    w9 = (torch.randn(N, d, generator=g) / d ** 0.5).to(dev).requires_grad_(True)
+    b9 = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    out = ops.back_project_fp32(x, w9, b9, 0.0, H, W, p, p)
+    assert out.dtype == torch.float32 and out.shape == (B, C, H, W)
+    go = torch.randn(B, C, H, W, generator=g).to(dev)
+    (out * go).sum().backward()
+    xr, w9r, b9r = (t.detach().double().cpu().requires_grad_(True) for t in (x, w9, b9))
+    yr = xr @ w9r.t() + b9r
+    fold = torch.nn.functional.fold(yr.transpose(1, 2), (Hp * p, Wp * p), kernel_size=p, stride=p)
+    ref = torch.nn.functional.pad(fold, (0, W - Wp * p, 0, H - Hp * p))
+    (ref * go.double().cpu()).sum().backward()
+    assert rel(out, ref.detach()) < KTOL
+    assert rel(x.grad, xr.grad) < KTOL and rel(w9.grad, w9r.grad) < KTOL and rel(b9.grad, b9r.grad) < KTOL
+    # ... with dropout in front of the linear: the forward and the backward use the same mask (dx is zero exactly where x was dropped)
+    x2 = torch.ones(B, Hp * Wp, d, device=dev, requires_grad=True)
+    out2 = ops.back_project_fp32(x2, w9, b9, 0.3, H, W, p, p)
+    out2.sum().backward()
+    want = (w9.detach().double().sum(0) / 0.7).expand(B, Hp * Wp, d)       # d out2.sum() / d x[b, t, k] = keep / (1 - p) * sum_n w9[n, k]
+    kept = x2.grad != 0
+    assert 0.6 < kept.float().mean().item() < 0.8
+    assert (x2.grad.double()[kept] - want[kept]).abs().max().item() < 1e-4 * want.abs().max().item()

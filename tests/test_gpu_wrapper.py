@@ -574,6 +574,10 @@ def test_wrapper_switches_against_reference_fixtures(golden_dir, name, precision
     if "local_k" in cfg:
         assert int(model.cross_fusion_encoders[0]._last_desc.attn_block_bits or 0) != 0
     ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
+    if precision == 16 and cfg.get("fwd_lang"):
+        # forwarded narration tokens chain the encoders: level i's inputs have been through i encoders' worth of bf16-stored activations
+        # (measured 1.1e-2 on the third level of the "direct" case against 0.6e-2 on the first); the fp32-accuracy mode keeps 1e-3
+        ftol, gtol = 2e-2, 5e-2
     for i in range(n):
         pre = f"l{i}/"
         assert rel(fused[i], g[pre + "fused"]) < ftol, i

@@ -149,6 +149,7 @@ if which in ("epi",):
     timeit("ffn_up DGELU p=0", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d0), fl)
     timeit("ffn_up DGELU p=.15", lambda: ops.gemm(X, W1, Hh, ff, D, Lb.TF_EPI_DGELU_DROP, R=U, drop=d15), fl)
 if which in ("ln",):
+    M = int(os.environ.get("KB_ROWS", M))
     X, DY = rnd(M, D), rnd(M, D)
     DX, DXD = torch.empty(M, D, device=dev, dtype=bf), torch.empty(M, D, device=dev, dtype=bf)
     mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)

@@ -148,7 +148,12 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
                                                         const u32x4* rhi = nullptr, const u32x4* rlo = nullptr) {
   const size_t oc = (size_t)gm * g.ldc + gn;
   if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
-    store8_split(g.C, g.C_lo, oc, f);
+    if (g.c_is_f32) {                                    // (uniform over the launch) fp32 result, no planes
+      *(f32x4*)((float*)g.C + oc) = f32x4{f[0], f[1], f[2], f[3]};
+      *(f32x4*)((float*)g.C + oc + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    } else {
+      store8_split(g.C, g.C_lo, oc, f);
+    }
   } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP || EPI == TF_EPI_BIAS_GELU_DROP_G) {
     const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
     float gd[8], hv[8];
@@ -1279,7 +1284,8 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   const double fl = 2.0 * a->M * a->N * a->K;          // algorithmic (the fp32-accuracy mode executes three bf16 passes of it)
   const bool split = a->A_lo != nullptr;
   if (split) {
-    if (a->fp8 || a->W_lo == nullptr || a->C_lo == nullptr) return -6;
+    if (a->fp8 || a->W_lo == nullptr || (a->C_lo == nullptr && !a->c_is_f32)) return -6;
+    if (a->c_is_f32 && a->epilogue != TF_EPI_NONE && a->epilogue != TF_EPI_BIAS) return -6;
     const int e = a->epilogue;
     const bool needs_r = e == TF_EPI_MUL || e == TF_EPI_BIAS_DROP_RES || e == TF_EPI_ADD || e == TF_EPI_DGELU_DROP;
     if (needs_r && (a->R == nullptr || a->R_lo == nullptr)) return -6;

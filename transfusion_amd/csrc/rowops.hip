@@ -753,7 +753,9 @@ __global__ void im2col_kernel(const TfPatchArgs a) {
       const size_t src = (((size_t)b * a.C + c) * a.H + hp * a.ph + i) * a.W + wp * a.pw + j;
       v = a.feat_is_f32 ? ((const float*)a.feat)[src] : bf2f(((const u16*)a.feat)[src]);
     }
-    ((u16*)a.cols)[t] = f2bf(v);
+    const u16 hi = f2bf(v);
+    ((u16*)a.cols)[t] = hi;
+    if (a.cols_lo != nullptr) ((u16*)a.cols_lo)[t] = f2bf(v - bf2f(hi));       // fp32-accuracy mode: the second operand plane
   }
 }
 // K9 scatter (F.fold with kernel == stride): the inverse permutation; the uncovered border is zero
@@ -766,7 +768,9 @@ __global__ void col2im_kernel(const TfPatchArgs a, int out_is_f32) {
     float v = 0.f;
     if (y < Hp * a.ph && x < Wp * a.pw) {
       const size_t tok = ((size_t)b * Hp + y / a.ph) * Wp + x / a.pw;
-      v = bf2f(((const u16*)a.cols)[tok * a.ld_cols + (c * a.ph + y % a.ph) * a.pw + x % a.pw]);
+      const size_t src = tok * a.ld_cols + (c * a.ph + y % a.ph) * a.pw + x % a.pw;
+      v = bf2f(((const u16*)a.cols)[src]);
+      if (a.cols_lo != nullptr) v += bf2f(((const u16*)a.cols_lo)[src]);
     }
     if (out_is_f32) ((float*)a.feat)[t] = v; else ((u16*)a.feat)[t] = f2bf(v);
   }
@@ -835,6 +839,43 @@ static int patch_chunk(const TfPatchArgs* a) {
   return cc < cpad ? cc : cpad;
 }
 
+// fp32 [rows, cols] -> hi + lo bf16 operand planes [rows, ld_dst] (zero-padded), optional input dropout first, optional fp32 copy of the
+// (dropped) values: include/tfusion.h, TfPlanesArgs.  A thread owns 8 consecutive columns of one row: two 16-B loads, 16-B stores.
+__global__ __launch_bounds__(256) void split_planes_kernel(const TfPlanesArgs a_in) {
+  TfPlanesArgs a = a_in;
+  a.drop_key = tf_salted(a.drop_key);                          // the step clock (tf_common.h)
+  const int width = a.hi != nullptr ? a.ld_dst : a.cols;       // columns a row's threads cover (payload + zeroed pad)
+  const int cpr = (width + 7) / 8;
+  const long long total = (long long)a.rows * cpr;
+  const bool vec = (a.ld_src & 3) == 0 && (((size_t)a.src) & 15) == 0;
+  const bool vec_out = a.dst_f32 != nullptr && (a.ld_f32 & 3) == 0 && (((size_t)a.dst_f32) & 15) == 0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int r = (int)(t / cpr), c = (int)(t - (long long)r * cpr) * 8;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < a.cols) {
+      const float* sp = a.src + (size_t)r * a.ld_src + c;
+      if (vec && c + 8 <= a.cols) load8_f32(sp, f);
+      else {                                                   // ragged last chunk / rows that are not 16-B aligned (class-count widths)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = c + e < a.cols ? sp[e] : 0.f;
+      }
+      if (a.drop_thr) {
+        const unsigned km = tf_keep8((unsigned)r * (unsigned)a.drop_ld + (unsigned)c, a.drop_key, a.drop_thr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = ((km >> e) & 1u) ? f[e] * a.drop_scale : 0.f;
+      }
+      if (a.dst_f32 != nullptr) {
+        float* dp = a.dst_f32 + (size_t)r * a.ld_f32 + c;
+        if (vec_out && c + 8 <= a.cols) store8_f32(dp, f);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (c + e < a.cols) dp[e] = f[e];
+        }
+      }
+    }
+    if (a.hi != nullptr) store8_split(a.hi, a.lo, (size_t)r * a.ld_dst + c, f);
+  }
+}
 // ------------------------------------------------------------------------------------------------
 // Row-wise fp8 (OCP e4m3) quantisation: one wave per row, 16-B lanes; scale[r] = max|row| / 448.
 // Feeds the fp8 operand variant of the large-tile GEMM (activations per token, weights per output channel).
@@ -1318,7 +1359,7 @@ extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
   if (total <= 0) return 0;
   static const int tiled = TF_ENV_INT("TF_PATCH_TILED", 1);
-  const int cc = tiled ? patch_chunk(a) : 0;
+  const int cc = (tiled && a->cols_lo == nullptr) ? patch_chunk(a) : 0;      // (the plane-pair form: element-per-thread kernel)
   if (cc > 0) {
     const int nch = (a->C + cc - 1) / cc;
     const dim3 grid((unsigned)((long long)a->B * (a->H / a->ph) * nch));
@@ -1331,6 +1372,17 @@ extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
+extern "C" int tf_launch_split_planes(const TfPlanesArgs* a, hipStream_t st) {
+  if (a->rows <= 0 || a->cols <= 0) return 0;
+  if (a->src == nullptr || (a->hi == nullptr && a->dst_f32 == nullptr) || (a->hi != nullptr && a->lo == nullptr)) return -1;
+  if (a->hi != nullptr && ((a->ld_dst % 8) || a->ld_dst < a->cols)) return -2;
+  const int width = a->hi != nullptr ? a->ld_dst : a->cols;
+  const long long total = (long long)a->rows * ((width + 7) / 8);
+  TfTraceScope tr("split_planes_kernel", st, 0.0, (double)a->rows * a->cols * (a->hi != nullptr ? 8.0 : 8.0));
+  hipLaunchKernelGGL(split_planes_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a);
+  return (int)hipGetLastError();
+}
+
 extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t st) {
   const long long total = (long long)a->B * a->C * a->H * a->W;
   if (total <= 0) return 0;

@@ -453,6 +453,7 @@ int tf_patchify_fwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_patchify_
 int tf_patchify_bwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_patchify_bwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
 int tf_regroup_fwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_regroup_fwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
 int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bwd", tf_launch_im2col(a, (hipStream_t)s)); }
+int tf_split_planes(const TfPlanesArgs* a, tf_stream_t s) { TF_WRAP("tf_split_planes", tf_launch_split_planes(a, (hipStream_t)s)); }
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
 // ---- the step clock -------------------------------------------------------------------------------------------------------

@@ -49,6 +49,7 @@ int tf_tu_set_clock_gemm(const unsigned* clock);                       // per tr
 int tf_tu_set_clock_rowops(const unsigned* clock);
 int tf_launch_im2col(const TfPatchArgs* a, hipStream_t stream);       // feat -> cols
 int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t stream);  // cols -> feat (fold; border zero)
+int tf_launch_split_planes(const TfPlanesArgs* a, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -60,8 +60,10 @@ class PatchToToken(nn.Module):
         B, Cc, H, W = feat.shape
         K = Cc * self.patch_h * self.patch_w
         if self.precision == "fp32":
-            # the gather stays in fp32 (an exact permutation, done by torch); the GEMM takes hi + lo planes of it
-            ph, pw = self.patch_h, self.patch_w
+            # run.precision 32: the gather splits the fp32 map into hi + lo operand planes itself, the GEMM returns fp32 tokens
+            if K % 8 == 0:
+                return ops.patch_embed_fp32(feat, self.weight, self.patch_h, self.patch_w)
+            ph, pw = self.patch_h, self.patch_w               # (odd C p^2: torch gathers, the GEMM still runs on planes)
             Hp, Wp = H // ph, W // pw
             rows = feat[:, :, : Hp * ph, : Wp * pw].float().reshape(B, Cc, Hp, ph, Wp, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * Hp * Wp, K)
             return ops.linear(rows, self.weight, None, precision="fp32").view(B, Hp * Wp, -1)

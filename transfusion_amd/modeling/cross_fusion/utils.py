@@ -110,14 +110,7 @@ class RegroupPatchesLayerBox(nn.Module):
     def forward(self, x, cls_f=None):
         p_drop = self.backproj_dropout if self.training else 0.0
         if self.precision == "fp32":
-            # fp32-accuracy GEMM; the fold stays in fp32 (an exact permutation with a zero border, done by torch)
-            y = ops.linear(x, self.linear.weight, self.linear.bias, p_drop_in=p_drop, precision="fp32")
-            B, Nv, _ = y.shape
-            ph, pw = self.patch_h, self.patch_w
-            Hp, Wp = self.init_h // ph, self.init_w // pw
-            if Hp * Wp != Nv:
-                raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {self.init_h}x{self.init_w} map with {ph}x{pw} patches")
-            img = y.view(B, Hp, Wp, self.out_channels, ph, pw).permute(0, 3, 1, 4, 2, 5).reshape(B, self.out_channels, Hp * ph, Wp * pw)
-            return torch.nn.functional.pad(img, (0, self.init_w - Wp * pw, 0, self.init_h - Hp * ph))
+            # run.precision 32: split (+ dropout) -> three-pass GEMM -> the fold adds the result's hi + lo planes into the fp32 map
+            return ops.back_project_fp32(x, self.linear.weight, self.linear.bias, p_drop, self.init_h, self.init_w, self.patch_h, self.patch_w)
         y = ops.linear(x, self.linear.weight, self.linear.bias, p_drop_in=p_drop, accumulate=self.accumulate_linear_grad)
         return ops.regroup(y, self.init_h, self.init_w, self.patch_h, self.patch_w, out_dtype=torch.float32)

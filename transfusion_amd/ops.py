@@ -154,8 +154,32 @@ def gemm(A, W, C_out, N, K, epilogue=None, bias=None, R=None, C2=None, drop=(0, 
                      drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
                      fp8=1 if fp8 else 0, scale_a=L.ptr(scale_a), scale_w=L.ptr(scale_w), act=act,
                      A_lo=L.ptr(A_lo), W_lo=L.ptr(W_lo), C_lo=L.ptr(C_lo), R_lo=L.ptr(R_lo), C2_lo=L.ptr(C2_lo),
-                     groups=int(groups), w_gstride=int(w_gstride))
+                     groups=int(groups), w_gstride=int(w_gstride),
+                     c_is_f32=1 if (A_lo is not None and C_out.dtype == torch.float32) else 0)   # fp32-accuracy mode: an fp32 result, no planes
     L.call("tf_gemm_fwd", g, _stream())
+
+
+def planes_of(x2d: torch.Tensor, ld: int, drop=(0, 0, 1.0), drop_ld: int = None):
+    """fp32 [M, K] (any row stride) -> the (hi, lo) bf16 operand planes [M, ld] of the fp32-accuracy mode, zero padded, with the
+    optional input dropout applied BEFORE the split (tf_split_planes: one kernel; torch spelt it as three elementwise passes and two
+    pads).  The keep mask is the function of (row * drop_ld + col) that tf_dropout_mask replays."""
+    _require_cuda(x2d)
+    M, K = x2d.shape
+    if x2d.dtype != torch.float32 or x2d.stride(1) != 1:
+        x2d = x2d.float().contiguous()
+    hi = torch.empty(M, ld, dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty(M, ld, dtype=torch.bfloat16, device=x2d.device)
+    a = L.TfPlanesArgs(src=L.ptr(x2d), ld_src=x2d.stride(0), hi=L.ptr(hi), lo=L.ptr(lo), ld_dst=ld, dst_f32=0, ld_f32=0, rows=M, cols=K,
+                       drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_ld=ld if drop_ld is None else drop_ld)
+    L.call("tf_split_planes", a, _stream())
+    return hi, lo
+
+
+def dropout_f32_(x2d: torch.Tensor, cols: int, drop, drop_ld: int):
+    """In place on the first ``cols`` columns of an fp32 [M, ld] tensor: x *= keep / (1 - p) with the mask of ``planes_of``."""
+    a = L.TfPlanesArgs(src=L.ptr(x2d), ld_src=x2d.stride(0), hi=0, lo=0, ld_dst=0, dst_f32=L.ptr(x2d), ld_f32=x2d.stride(0), rows=x2d.shape[0],
+                       cols=cols, drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_ld=drop_ld)
+    L.call("tf_split_planes", a, _stream())
 
 
 def quant_rows_fp8(x: torch.Tensor, ld_out: int = None):
@@ -446,7 +470,10 @@ def _weight_shadows(weight, N8, Kp, Np, planes=False, sources=None):
 
 
 def _planes_padded(x2d: torch.Tensor, ld: int):
-    """[M, K] (fp32 or bf16) -> (hi, lo) bf16 [M, ld], zero padded: hi + lo == x to 16 significant bits."""
+    """[M, K] (fp32 or bf16) -> (hi, lo) bf16 [M, ld], zero padded: hi + lo == x to 16 significant bits (tf_split_planes; a plane width
+    that is not a multiple of 8 -- the loss kernel's class-count logits -- takes the torch spelling)."""
+    if ld % 8 == 0:
+        return planes_of(x2d, ld)
     xf = x2d.float()
     hi = xf.to(torch.bfloat16)
     lo = (xf - hi.float()).to(torch.bfloat16)
@@ -456,9 +483,22 @@ def _planes_padded(x2d: torch.Tensor, ld: int):
     return hi.contiguous(), lo.contiguous()
 
 
+def _x3_forward(xh, xl, wsh, wsh_lo, bias, N, N8, Kp, Np):
+    """fp32 [M, Np] = (xh + xl) @ (W_hi + W_lo)^T + bias on three bf16 MFMA passes (columns >= N8 are never written)."""
+    M = xh.shape[0]
+    y = torch.empty(M, Np, dtype=torch.float32, device=xh.device)
+    bf = None if bias is None else bias.detach().float().contiguous()
+    if bf is not None and N8 != N:
+        bf = torch.nn.functional.pad(bf, (0, N8 - N))
+    gemm(xh, wsh, y, N8, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf, A_lo=xl, W_lo=wsh_lo)
+    return y
+
+
 class _LinearX3Fn(torch.autograd.Function):
     """``_LinearFn`` in the fp32-accuracy mode (include/tfusion.h, TfGemmArgs.A_lo): operands as hi + lo bf16 planes, three MFMA passes,
-    fp32 results -- K1 / K9 / the RoI heads when ``run.precision`` is 32."""
+    fp32 results -- K1 / K9 / the RoI heads when ``run.precision`` is 32.  Every step is a kernel of the library: the planes (and the
+    input dropout) come from tf_split_planes, the GEMMs write fp32 directly (TfGemmArgs.c_is_f32), the backward's mask is applied in
+    place by the same kernel -- no elementwise torch op, no float keep-mask tensor."""
 
     @staticmethod
     def forward(ctx, x2d, weight, bias, p_drop_in, seed, wsh, wsh_t, wsh_lo, wsh_t_lo):
@@ -466,48 +506,149 @@ class _LinearX3Fn(torch.autograd.Function):
         M, K = x2d.shape
         N = weight.shape[0]
         N8, Kp, Np = _up(N, 8), _up(K, 64), _up(N, 64)
-        xdtype = x2d.dtype
         drop = drop_params(p_drop_in, seed, 7)
-        keep = None
-        if drop[0]:
-            # dropout BEFORE the split (scaling each plane separately would round hi * 1/(1-p) to bf16 and lose the 16-bit property);
-            # the keep mask is the same function of the element index (row * Kp + col) the bf16 path's tf_dropout_apply uses
-            mask = torch.empty(M * Kp, dtype=torch.uint8, device=x2d.device)
-            L.check(L.load().tf_dropout_mask(L.ptr(mask), M * Kp, drop[1], drop[0], _stream()), "tf_dropout_mask")
-            keep = mask.view(M, Kp)[:, :K].float() * drop[2]
-            x2d = x2d.float() * keep
-        xh, xl = _planes_padded(x2d, Kp)
-        yh = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device)
-        yl = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device)
-        bf = None if bias is None else bias.detach().float().contiguous()
-        if bf is not None and N8 != N:
-            bf = torch.nn.functional.pad(bf, (0, N8 - N))
-        gemm(xh, wsh, yh, N8, Kp, L.TF_EPI_BIAS if bias is not None else L.TF_EPI_NONE, bias=bf, A_lo=xl, W_lo=wsh_lo, C_lo=yl)
-        ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo, keep)
-        ctx.meta = (M, K, N, N8, Kp, Np, bias is not None, weight.shape, xdtype)
-        return yh[:, :N].float() + yl[:, :N].float()
+        # dropout BEFORE the split (scaling each plane separately would round hi * 1/(1-p) to bf16 and lose the 16-bit property);
+        # the keep mask is the same function of the element index (row * Kp + col) the bf16 path's tf_dropout_apply uses
+        xh, xl = planes_of(x2d, Kp, drop, Kp)
+        y = _x3_forward(xh, xl, wsh, wsh_lo, bias, N, N8, Kp, Np)
+        ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo)
+        ctx.meta = (M, K, N, N8, Kp, Np, bias is not None, weight.shape, x2d.dtype, drop)
+        return y[:, :N] if Np != N else y
 
     @staticmethod
     def backward(ctx, gy):
-        xh, xl, wsh_t, wsh_t_lo, keep = ctx.saved_tensors
-        M, K, N, N8, Kp, Np, has_bias, wshape, xdtype = ctx.meta
-        gy = gy.reshape(M, N)
-        if N8 != N:
-            gy = torch.nn.functional.pad(gy, (0, N8 - N))
-        gh, gl = _planes_padded(gy, Np)
+        xh, xl, wsh_t, wsh_t_lo = ctx.saved_tensors
+        M, K, N, N8, Kp, Np, has_bias, wshape, xdtype, drop = ctx.meta
+        gh, gl = planes_of(gy.reshape(M, N), Np)              # (columns [N, Np) zero: the weight shadows' pad rows see nothing)
         dx = None
         if ctx.needs_input_grad[0]:
-            dh = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
-            dl = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
-            gemm(gh, wsh_t, dh, Kp, Np, L.TF_EPI_NONE, A_lo=gl, W_lo=wsh_t_lo, C_lo=dl)
-            dx = dh[:, :K].float() + dl[:, :K].float()
-            if keep is not None:
-                dx = dx * keep
-            dx = dx.to(xdtype)
+            dxf = torch.empty(M, Kp, dtype=torch.float32, device=gy.device)
+            gemm(gh, wsh_t, dxf, Kp, Np, L.TF_EPI_NONE, A_lo=gl, W_lo=wsh_t_lo)
+            if drop[0]:
+                dropout_f32_(dxf, K, drop, Kp)
+            dx = dxf[:, :K] if Kp != K else dxf
+            if xdtype != torch.float32:
+                dx = dx.to(xdtype)
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None
         wgrad(gh, N8, xh, Kp, dW.view(N, -1), db, dY_lo=gl, X_lo=xl)
         return dx, dW, db, None, None, None, None, None, None
+
+
+def _patch_args_planes(feat, hi, lo, B, Cc, H, W, ph, pw):
+    return L.TfPatchArgs(feat=L.ptr(feat), feat_is_f32=_is_f32(feat), cols=L.ptr(hi), ld_cols=hi.stride(0), B=B, C=Cc, H=H, W=W, ph=ph, pw=pw,
+                         cols_lo=L.ptr(lo))
+
+
+class _PatchEmbedX3Fn(torch.autograd.Function):
+    """K1 at run.precision 32 (cross_f_box_wrapper.py:266-274, 183-185): the k = s = p Conv2d as im2col + GEMM with the fp32 feature map
+    split into hi + lo planes BY THE GATHER (TfPatchArgs.cols_lo) -- no fp32 im2col matrix, no torch permute -- three MFMA passes, fp32
+    tokens out; the backward folds the plane pair of d(cols) straight back into an fp32 d(feat)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, ph, pw, wsh, wsh_t, wsh_lo, wsh_t_lo):
+        _require_cuda(feat, weight)
+        feat = feat.contiguous()
+        B, Cc, H, W = feat.shape
+        Hp, Wp = H // ph, W // pw
+        K, N = Cc * ph * pw, weight.shape[0]
+        N8, Kp, Np = _up(N, 8), _up(K, 64), _up(N, 64)
+        M = B * Hp * Wp
+        xh = torch.empty(M, Kp, dtype=torch.bfloat16, device=feat.device)
+        xl = torch.empty(M, Kp, dtype=torch.bfloat16, device=feat.device)
+        L.call("tf_patchify_fwd", _patch_args_planes(feat, xh, xl, B, Cc, H, W, ph, pw), _stream())
+        y = _x3_forward(xh, xl, wsh, wsh_lo, None, N, N8, Kp, Np)
+        ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo)
+        ctx.meta = (feat.shape, feat.dtype, ph, pw, M, K, N, N8, Kp, Np, weight.shape)
+        return (y[:, :N] if Np != N else y).view(B, Hp * Wp, N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, xl, wsh_t, wsh_t_lo = ctx.saved_tensors
+        shape, dtype, ph, pw, M, K, N, N8, Kp, Np, wshape = ctx.meta
+        gh, gl = planes_of(gy.reshape(M, N), Np)
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+            dl = torch.empty(M, Kp, dtype=torch.bfloat16, device=gy.device)
+            gemm(gh, wsh_t, dh, Kp, Np, L.TF_EPI_NONE, A_lo=gl, W_lo=wsh_t_lo, C_lo=dl)
+            dfeat = torch.empty(shape, dtype=dtype, device=gy.device)
+            L.call("tf_patchify_bwd", _patch_args_planes(dfeat, dh, dl, shape[0], shape[1], shape[2], shape[3], ph, pw), _stream(), _is_f32(dfeat))
+        dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
+        wgrad(gh, N8, xh, Kp, dW.view(N, -1), None, dY_lo=gl, X_lo=xl)
+        return dfeat, dW, None, None, None, None, None, None
+
+
+def patch_embed_fp32(feat, weight, ph, pw):
+    """[B, C, H, W] -> fp32 tokens [B, H' W', d] in the fp32-accuracy mode, entirely on the library's kernels."""
+    N = weight.shape[0]
+    K = feat.shape[1] * ph * pw
+    wsh, wsh_t, wsh_lo, wsh_t_lo = _weight_shadows(weight, _up(N, 8), _up(K, 64), _up(N, 64), planes=True)
+    return _PatchEmbedX3Fn.apply(feat, weight, ph, pw, wsh, wsh_t, wsh_lo, wsh_t_lo)
+
+
+class _BackProjectX3Fn(torch.autograd.Function):
+    """K9 at run.precision 32 (utils.py:84-119, 42-46): dropout -> Linear(d -> p^2 C) -> fold, with the GEMM result as a hi + lo plane
+    pair that the fold adds back into the fp32 feature map (TfPatchArgs.cols_lo), and the backward's gather splitting the fp32
+    cotangent into the plane pair the weight gradient and dgrad consume -- no fp32 [M, p^2 C] matrix, no torch permute."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, p_drop, seed, geom, wsh, wsh_t, wsh_lo, wsh_t_lo):
+        _require_cuda(x, weight)
+        B, Nv, d = x.shape
+        Cc, H, W, ph, pw = geom
+        N = weight.shape[0]
+        N8, Kp, Np = _up(N, 8), _up(d, 64), _up(N, 64)
+        M = B * Nv
+        drop = drop_params(p_drop, seed, 7)
+        xh, xl = planes_of(x.reshape(M, d), Kp, drop, Kp)
+        yh = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
+        yl = torch.empty(M, Np, dtype=torch.bfloat16, device=x.device)
+        bf = bias.detach().float().contiguous()
+        if N8 != N:
+            bf = torch.nn.functional.pad(bf, (0, N8 - N))
+        gemm(xh, wsh, yh, N8, Kp, L.TF_EPI_BIAS, bias=bf, A_lo=xl, W_lo=wsh_lo, C_lo=yl)
+        out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+        L.call("tf_regroup_fwd", _patch_args_planes(out, yh, yl, B, Cc, H, W, ph, pw), _stream(), 1)
+        ctx.save_for_backward(xh, xl, wsh_t, wsh_t_lo)
+        ctx.meta = (B, Nv, d, geom, M, N, N8, Kp, Np, weight.shape, x.dtype, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, xl, wsh_t, wsh_t_lo = ctx.saved_tensors
+        B, Nv, d, geom, M, N, N8, Kp, Np, wshape, xdtype, drop = ctx.meta
+        Cc, H, W, ph, pw = geom
+        g = g.contiguous()
+        gh = torch.empty(M, Np, dtype=torch.bfloat16, device=g.device)
+        gl = torch.empty(M, Np, dtype=torch.bfloat16, device=g.device)
+        L.call("tf_regroup_bwd", _patch_args_planes(g, gh, gl, B, Cc, H, W, ph, pw), _stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxf = torch.empty(M, Kp, dtype=torch.float32, device=g.device)
+            gemm(gh, wsh_t, dxf, Kp, Np, L.TF_EPI_NONE, A_lo=gl, W_lo=wsh_t_lo)
+            if drop[0]:
+                dropout_f32_(dxf, d, drop, Kp)
+            dx = (dxf[:, :d] if Kp != d else dxf).reshape(B, Nv, d)
+            if xdtype != torch.float32:
+                dx = dx.to(xdtype)
+        dW = torch.zeros(wshape, dtype=torch.float32, device=g.device)
+        db = torch.zeros(N, dtype=torch.float32, device=g.device)
+        wgrad(gh, N8, xh, Kp, dW.view(N, -1), db, dY_lo=gl, X_lo=xl)
+        return dx, dW, db, None, None, None, None, None, None, None
+
+
+def back_project_fp32(x, weight, bias, p_drop, init_h, init_w, ph, pw):
+    """tokens [B, Nv, d] -> fp32 feature map [B, C, init_h, init_w] in the fp32-accuracy mode (zero border where the patches do not
+    tile the map), entirely on the library's kernels."""
+    B, Nv, d = x.shape
+    N = weight.shape[0]
+    Cc = N // (ph * pw)
+    if (init_h // ph) * (init_w // pw) != Nv:
+        raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {init_h}x{init_w} map with {ph}x{pw} patches")
+    seed = next_seed() if p_drop > 0 else 0
+    wsh, wsh_t, wsh_lo, wsh_t_lo = _weight_shadows(weight, _up(N, 8), _up(d, 64), _up(N, 64), planes=True)
+    return _BackProjectX3Fn.apply(x, weight, bias, float(p_drop), seed, (Cc, init_h, init_w, ph, pw), wsh, wsh_t, wsh_lo, wsh_t_lo)
 
 
 class _LinearFn(torch.autograd.Function):
