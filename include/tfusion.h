@@ -132,7 +132,17 @@ typedef struct TfAttnArgs {
   // how many tf_attn_ds_bytes-sized planes ds_work holds.  0 = the mode's minimum (1 in bf16, 2 in the fp32-accuracy mode).  4 in the
   // fp32-accuracy mode: the dK launch also leaves Pd = P . keep / (1 - p) there (hi + lo), and dV is formed from it without recomputing S.
   int ds_planes;
+  // block-sparse tiles of a block mask (ABI v7; vis_mask_type "local_k", reference utils.py:14-30: a visual token attends a (2k+1)^2
+  // window, so most 64-key tiles of a visual query block are blocked for every one of its queries).  Derived from block_bits by
+  // tf_attn_block_skip; null = every tile is visited and masked element-wise (same results, bit for bit: a skipped tile holds only
+  // probabilities that are exactly 0).
+  //   block_skip_q [ceil(S/128)] u64: bit t of word qb = every query of block qb has all 64 keys of tile t blocked (forward, dQ);
+  //   block_skip_k [ceil(S/128)] u64: bit j of word kb = every key of block kb is blocked for all 32 queries of tile j (dK / dV).
+  // (S <= 4096 / 2048 respectively; beyond that the words are zero)
+  const void* block_skip_q; const void* block_skip_k;
 } TfAttnArgs;
+/* the two maps above from block_bits [S, ceil(S/64)] u64: skip_q and skip_k each ceil(S/128) u64 words (device memory) */
+int tf_attn_block_skip(const void* block_bits, int S, void* skip_q, void* skip_k, tf_stream_t s);
 
 
 // ---- row-wise kernels (rowops.hip) ----

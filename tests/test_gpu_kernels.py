@@ -493,6 +493,98 @@ def test_attention_block_mask(dev, B, S, H, hd, p):
         assert rel(g_hip[:, :, which, :, :hd], xr.grad[:, :, which]) < 1.5e-2, f"d{nm}"
 
 
+def _local_block(gh, gw, k, Nl):
+    """The reference's local_k mask (utils.py:14-30) on a gh x gw token grid, padded with Nl language tokens (nobody is blocked from
+    them, they block nobody): bool [S, S], True = blocked."""
+    Nv = gh * gw
+    r, c = torch.arange(Nv) // gw, torch.arange(Nv) % gw
+    near = ((r[:, None] - r[None, :]).abs() <= k) & ((c[:, None] - c[None, :]).abs() <= k)
+    blk = torch.zeros(Nv + Nl, Nv + Nl, dtype=torch.bool)
+    blk[:Nv, :Nv] = ~near
+    return blk
+
+
+@pytest.mark.parametrize("gh,gw,k,Nl,hd,packed", [(28, 28, 2, 100, 64, False), (28, 28, 4, 512, 192, True), (14, 14, 1, 70, 32, False), (40, 45, 1, 30, 64, False)])
+def test_attention_block_sparse_tiles(dev, gh, gw, k, Nl, hd, packed):
+    """TfAttnArgs.block_skip_q / block_skip_k (the local_k mask as block-sparse tiles): the maps tf_attn_block_skip derives
+    from the bit matrix are exactly the tiles a torch reduction of the mask finds fully blocked, a local mask on a 28 x 28 grid leaves a
+    visual query block with less than half of its visual key tiles, and forward and backward with the maps give the SAME BITS as
+    without them (a skipped tile holds only exact zeros) -- output, LSE, dQ, dK, dV; the last case has more than 64 query tiles of 32
+    (no dK / dV map: zero words)."""
+    from transfusion_amd import _lib as L, ops
+    lib = L.load()
+    B, H = 2, 2
+    Nv, S = gh * gw, gh * gw + Nl
+    blk = _local_block(gh, gw, k, Nl)
+    bits = _pack_bits(blk).to(dev)
+    nb, SW, nqt = (S + 127) // 128, (S + 63) // 64, (S + 31) // 32
+    skq = torch.full((nb,), -1, dtype=torch.int64, device=dev)
+    skk = torch.full((nb,), -1, dtype=torch.int64, device=dev)
+    L.check(lib.tf_attn_block_skip(L.ptr(bits), S, L.ptr(skq), L.ptr(skk), ops._stream()), "tf_attn_block_skip")
+    # the maps against a torch reduction of the mask (keys / rows past S count as blocked for the tile test only when the WHOLE word is:
+    # the bit matrix pads with zeros, so a ragged last tile is never skippable)
+    full = torch.zeros(nb * 128, SW * 64, dtype=torch.bool)
+    full[:S, :S] = blk
+    rows_exist = torch.arange(nb * 128) < S
+    want_q = []
+    for qb in range(nb):
+        rsel = rows_exist[qb * 128:(qb + 1) * 128]
+        t_all = full[qb * 128:(qb + 1) * 128][rsel].view(-1, SW, 64).all(-1).all(0)            # [SW]
+        want_q.append(sum(1 << t for t in range(SW) if bool(t_all[t])) if SW <= 64 else 0)
+    got_q = [int(v) & (2 ** 64 - 1) for v in skq.cpu().tolist()]
+    assert got_q == want_q
+    want_k = []
+    for kb in range(nb):
+        cols = full[:, kb * 128: min((kb + 1) * 128, SW * 64)]
+        word = 0
+        for j in range(nqt):
+            rsel = slice(j * 32, min((j + 1) * 32, S))
+            if bool(cols[rsel].all()):
+                word |= 1 << j
+        want_k.append(word if nqt <= 64 else 0)
+    got_k = [int(v) & (2 ** 64 - 1) for v in skk.cpu().tolist()]
+    assert got_k == want_k
+    if gh == 28:
+        vis_q = [bin(w).count("1") for w in want_q[: Nv // 128]]
+        assert min(vis_q) >= (Nv // 64) // 2 - 1, vis_q            # most visual key tiles of a visual query block are gone
+    # ---- same bits with and without the maps ----
+    hdp = (hd + 31) // 32 * 32
+    g = torch.Generator().manual_seed(S + hd)
+    ldq = (3 * H * hdp + 63) // 64 * 64
+    ldo = (H * hdp + 63) // 64 * 64
+    lens = [S, S - 37] if packed else [S, S]
+    rows = sum(lens) if packed else B * S
+    qkv = torch.zeros(rows, ldq)
+    qkv[:, : 3 * H * hdp].view(rows, 3, H, hdp)[..., :hd] = torch.randn(rows, 3, H, hd, generator=g)
+    qkv = bf(qkv).to(dev)
+    do = torch.zeros(rows, ldo)
+    do[:, : H * hdp].view(rows, H, hdp)[..., :hd] = torch.randn(rows, H, hd, generator=g)
+    do = bf(do).to(dev)
+    cu = torch.tensor([0, lens[0], lens[0] + lens[1]], dtype=torch.int32, device=dev) if packed else None
+    dsw = torch.empty(lib.tf_attn_ds_bytes(B, H, S), dtype=torch.uint8, device=dev)
+    res = {}
+    for use in (False, True):
+        out = torch.zeros(rows, ldo, dtype=torch.bfloat16, device=dev)
+        lse = torch.zeros(B * H * S, device=dev)
+        dqkv = torch.zeros(rows, ldq, dtype=torch.bfloat16, device=dev)
+        delta = torch.empty(B * H * S, device=dev)
+        dsw.fill_(0x7F)                                         # bf16 NaN patterns: a dS tile that is read without having been written shows
+        a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hdp,
+                         scale=1 / math.sqrt(hd), drop_thr=0, drop_key=0, drop_scale=1.0, block_bits=L.ptr(bits), dout=L.ptr(do), ld_dout=ldo,
+                         dqkv=L.ptr(dqkv), ld_dqkv=ldq, delta=L.ptr(delta), ds_work=L.ptr(dsw), cu_rows=L.ptr(cu),
+                         block_skip_q=L.ptr(skq) if use else 0, block_skip_k=L.ptr(skk) if use else 0)
+        L.call("tf_attn_fwd", a, ops._stream())
+        L.call("tf_attn_bwd", a, ops._stream())
+        torch.cuda.synchronize()
+        res[use] = (out.clone(), lse.clone(), dqkv.clone())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    valid = torch.zeros(B, H, S, dtype=torch.bool)
+    for b_, n_ in enumerate(lens):
+        valid[b_, :, :n_] = True
+    assert torch.equal(res[True][1].cpu().view(B, H, S)[valid], res[False][1].cpu().view(B, H, S)[valid])
+    assert torch.isfinite(res[True][2].float()).all() and float(res[True][2].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2500, 768, 768), (4096, 1536, 768), (700, 768, 1536),
                                    (900, 520, 192), (520, 264, 64), (1100, 776, 832)])     # odd counts of 64-value K-steps: the 128-deep MFMA's missing half is zeros
 def test_gemm_fp8_operands(dev, M, N, K):

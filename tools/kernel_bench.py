@@ -187,3 +187,60 @@ if which in ("small",):
                 Xk, Wk = rnd(Ms, K), rnd(N, K) * 0.03
                 O = torch.empty(Ms, N, device=dev, dtype=bf)
                 timeit(f"gemm M={Ms} N={N} K={K} (none)", lambda: ops.gemm(Xk, Wk, O, N, K, Lb.TF_EPI_NONE), 2.0 * Ms * N * K)
+if which in ("pack",):
+    # the per-step re-pack of a d = 768 encoder's fp32 weights into bf16 shadows (W and W^T): tf_encoder_pack = one launch per layer
+    import ctypes
+    e = Lb.TfEncoderDesc()
+    e.B, e.Nv, e.Nl, e.d, e.H, e.L, e.ff = 4, NV, NL, D, H, 4, ff
+    plan = Lb.TfEncoderPlan()
+    Lb.check(Lb.load().tf_encoder_plan_ex(ctypes.addressof(e), ctypes.addressof(plan)), "plan")
+    wpack = torch.zeros(plan.wpack_bytes, dtype=torch.uint8, device=dev)
+    work = torch.zeros(plan.work_bytes, dtype=torch.uint8, device=dev)
+    ps = []
+    for j in range(4):
+        t = dict(in_w=torch.randn(3 * D, D), in_b=torch.randn(3 * D), out_w=torch.randn(D, D), out_b=torch.randn(D), w1=torch.randn(ff, D), b1=torch.randn(ff),
+                 w2=torch.randn(D, ff), b2=torch.randn(D), n1_w=torch.ones(D), n1_b=torch.zeros(D), n2_w=torch.ones(D), n2_b=torch.zeros(D))
+        t = {k: v.to(dev) for k, v in t.items()}
+        ps.append(t)
+        for k, v in t.items():
+            setattr(e.p[j], k, v.data_ptr())
+    kv = torch.zeros(D, device=dev)
+    e.kind_v = e.kind_l = kv.data_ptr()
+    e.wpack, e.work = wpack.data_ptr(), work.data_ptr()
+    nbytes = 4 * (8 * D * D) * (4 + 2 + 2)
+    timeit("tf_encoder_pack, 4 layers (GB/s)", lambda: Lb.check(Lb.load().tf_encoder_pack(ctypes.byref(e), ctypes.c_void_p(st)), "pack"), nbytes * 1e3)
+if which in ("attnblk",):
+    # vis_mask_type local_k on a 28 x 28 token grid (+ 512 language tokens), head dim 192: forward / backward with and without the
+    # block-sparse tile maps (TfAttnArgs.block_skip_q / block_skip_k)
+    Bb, Hh, gh = 8, 4, 28
+    Nv_, Sx = gh * gh, gh * gh + 512
+    Mx = Bb * Sx
+    QKV, Y = rnd(Mx, 3 * D), rnd(Mx, D)
+    O = torch.empty(Mx, D, device=dev, dtype=bf)
+    lse, delta = torch.empty(Bb * Hh * Sx, device=dev), torch.empty(Bb * Hh * Sx, device=dev)
+    dQKV = torch.empty(Mx, 3 * D, device=dev, dtype=bf)
+    dsw = torch.empty(Lb.load().tf_attn_ds_bytes(Bb, Hh, Sx), dtype=torch.uint8, device=dev)
+    for k in (1, 2, 4, 8):
+        r, c = torch.arange(Nv_) // gh, torch.arange(Nv_) % gh
+        near = ((r[:, None] - r[None, :]).abs() <= k) & ((c[:, None] - c[None, :]).abs() <= k)
+        blk = torch.zeros(Sx, Sx, dtype=torch.bool)
+        blk[:Nv_, :Nv_] = ~near
+        SW = (Sx + 63) // 64
+        full = torch.zeros(Sx, SW * 64, dtype=torch.bool)
+        full[:, :Sx] = blk
+        bits = (full.view(Sx, SW, 64).to(torch.int64) << torch.arange(64, dtype=torch.int64)).sum(-1).contiguous().to(dev)
+        nb = (Sx + 127) // 128
+        skq, skk = torch.zeros(nb, dtype=torch.int64, device=dev), torch.zeros(nb, dtype=torch.int64, device=dev)
+        Lb.check(Lb.load().tf_attn_block_skip(Lb.ptr(bits), Sx, Lb.ptr(skq), Lb.ptr(skk), st), "skip")
+        torch.cuda.synchronize()
+        nq = sum(bin(int(v) & (2 ** 64 - 1)).count("1") for v in skq.cpu().tolist())
+        nk = sum(bin(int(v) & (2 ** 64 - 1)).count("1") for v in skk.cpu().tolist())
+        print(f"local_{k}: {nq} of {nb * SW} (128 q x 64 k) tiles and {nk} of {nb * ((Sx + 31) // 32)} (32 q x 128 k) tiles are fully blocked")
+        for use in (False, True):
+            att = Lb.TfAttnArgs(qkv=Lb.ptr(QKV), ld_qkv=3 * D, out=Lb.ptr(O), ld_out=D, lse=Lb.ptr(lse), key_mask=0, B=Bb, S=Sx, H=Hh, HDP=hd,
+                                scale=1 / math.sqrt(hd), drop_thr=0, drop_key=0, drop_scale=1.0, block_bits=Lb.ptr(bits),
+                                dout=Lb.ptr(Y), ld_dout=D, dqkv=Lb.ptr(dQKV), ld_dqkv=3 * D, delta=Lb.ptr(delta), ds_work=Lb.ptr(dsw),
+                                block_skip_q=Lb.ptr(skq) if use else 0, block_skip_k=Lb.ptr(skk) if use else 0)
+            fl = 4.0 * Bb * Sx * Sx * D
+            timeit(f"attn_fwd local_{k} skip={use}", lambda: Lb.call("tf_attn_fwd", att, st), fl)
+            timeit(f"attn_bwd local_{k} skip={use}", lambda: Lb.call("tf_attn_bwd", att, st), 2.0 * fl)

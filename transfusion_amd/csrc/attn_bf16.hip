@@ -85,6 +85,16 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
 
   const FragAddr<HDP> fk(lds_addr_of(kt), lane), fv(lds_addr_of(vt), lane);
   const int ntiles = (valid_key_limit(a.key_mask, b, Sb, lane) + 63) / 64;   // trailing all-padding key tiles are skipped
+  // the key tiles this workgroup visits: all of them, minus -- with a block mask -- those blocked for every query of the block
+  // (TfAttnArgs.block_skip_q: every probability there is exactly 0).  A scalar bit set; t = the tile in hand, tn = the next one.
+  const int nts = __builtin_amdgcn_readfirstlane(ntiles);          // (scalar: the tile index is an LDS-DMA's scalar offset)
+  unsigned long long act = nts >= 64 ? ~0ull : ((1ull << nts) - 1ull);
+  if (BLK && a.block_skip_q != nullptr && nts <= 64) {
+    const unsigned long long sk = ((const unsigned long long*)a.block_skip_q)[logical % nqb];
+    act &= ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sk >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sk));
+  }
+  const bool listed = BLK && nts <= 64;                   // (more than 64 tiles: S > 4096, no map; plain counting)
+  int t = listed ? (act ? __builtin_ctzll(act) : -1) : (nts > 0 ? 0 : -1);
 #ifndef TF_FWD_NO_DMA
   const TileDma<HDP, 4> dma(__builtin_amdgcn_readfirstlane(wave), lane, ld);
   const __amdgpu_buffer_rsrc_t krs = make_rsrc(kbase, ld, Sb, HDP), vrs = make_rsrc(vbase, ld, Sb, HDP);
@@ -96,9 +106,12 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
     if (BLK) blk_n = brow[tn];
     if (a.key_mask != nullptr) kmb_n = a.key_mask[(size_t)b * S + min(tn * 64 + lane, Sb - 1)];
   };
-  if (ntiles > 0) { fetch_words(0); dma.issue(krs, 0u, kt); }
+  if (t >= 0) { fetch_words(t); dma.issue(krs, (unsigned)t * tile_bytes, kt); }
 #endif
-  for (int t = 0; t < ntiles; ++t) {
+  while (t >= 0) {
+    int tn;
+    if (listed) { act &= act - 1ull; tn = act ? __builtin_ctzll(act) : -1; }
+    else tn = t + 1 < nts ? t + 1 : -1;
     const int kv0 = t * 64;
     // K / V staging is LDS-DMA (no staging registers: the kernel stays under 256 VGPRs, two workgroups per CU): V(t) travels
     // under S(t) + softmax, K(t+1) under PV(t); each buffer is rewritten only after the barrier that every wave reaches once it
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
 #endif
 #ifndef TF_FWD_NO_DMA
     dma_wait_barrier();                    // V(t) landed and visible; every wave has finished S(t)
-    if (t + 1 < ntiles) { fetch_words(t + 1); dma.issue(krs, (t + 1) * tile_bytes, kt); }     // K(t+1) travels under PV(t)
+    if (tn >= 0) { fetch_words(tn); dma.issue(krs, (unsigned)tn * tile_bytes, kt); }     // K(next) travels under PV(t)
 #endif
     // ---- O^T[d][q] += V^T . Pt ----  (transposed V fragments PF ahead of their MFMA)
     {
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
+    t = tn;
   }
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -1185,9 +1199,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
     const bool is_do = k * 1024 >= QT * TSTR;
     voff[i] = k < NPC ? r * (int)((is_do ? (size_t)a.ld_dout : ld) * 2) + col : 0;
   }
-  auto dma = [&](int t) {                                  // tile pair t -> its buffer
-    unsigned char* img = smem + (t % NBUF) * PAIR;
-    const int soq = t * QT * (int)(ld * 2), sod = t * QT * (int)(a.ld_dout * 2);
+  // (i = position in the sequence of VISITED query tiles: picks the LDS buffer; T = the tile itself: picks the rows.  Without a block
+  // mask the two are equal; with TfAttnArgs.block_skip_k the tiles whose 32 queries block all of this workgroup's keys are left out)
+  auto dma = [&](int i, int T) {                           // tile pair T -> buffer i % NBUF
+    unsigned char* img = smem + (i % NBUF) * PAIR;
+    const int soq = T * QT * (int)(ld * 2), sod = T * QT * (int)(a.ld_dout * 2);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = wave * NI + i;                          // wave-uniform
@@ -1250,11 +1266,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
       if (BLK) bw_n = bbits[(size_t)q * dw_ld];
     }
   };
-  auto rows_store = [&](int t) {
+  auto rows_store = [&](int i, int T) {
     if (tid < 4 * QT) {
-      float* lse_w = (float*)(rows_base + (t % NBUF) * ROWS_BYTES);
+      float* lse_w = (float*)(rows_base + (i % NBUF) * ROWS_BYTES);
       unsigned* dw_w = (unsigned*)(lse_w + 2 * QT);
-      const bool in = t * QT + (tid & (QT - 1)) < Sb;
+      const bool in = T * QT + (tid & (QT - 1)) < Sb;
       if (tid < QT) {
         lse_w[tid] = in ? lse_n : 1.0e30f;                 // P = 0 for rows past the end
         lse_w[QT + tid] = in ? del_n : 0.f;
@@ -1371,7 +1387,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
     }
   };
   // role B: dS of tile t from P (exchange image) and dP; stored for the dQ kernel and kept as the next accumulating product's operand
-  auto ds_b = [&](int t) {
+  auto ds_b = [&](int T) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -1393,40 +1409,71 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
       const u32x4 v = __builtin_bit_cast(u32x4, of[kb]);
       const bool swp = ((n >> 2) & 1) != 0;
       const u32x4 w = {swp ? v[2] : v[0], swp ? v[3] : v[1], swp ? v[0] : v[2], swp ? v[1] : v[3]};
-      *(u32x4*)(ds_row + kb * ds_kb_stride + (size_t)t * 1024) = w;
+      *(u32x4*)(ds_row + kb * ds_kb_stride + (size_t)T * 1024) = w;
     }
   };
   // every transfer and LDS store of this wave has landed, then the workgroup meets (vmcnt counts the dS stores too)
   auto barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  if (ntiles > 0) {
-    dma(0);
-    rows_load(0);
-    rows_store(0);
-    if (ntiles > 1) dma(1);
+  // ---- the query tiles this workgroup visits (a scalar bit set; T0 / T1 / T2 = the tiles at sequence positions t, t + 1, t + 2) ----
+  const int nts = __builtin_amdgcn_readfirstlane(ntiles);
+  unsigned long long act = nts >= 64 ? ~0ull : ((1ull << nts) - 1ull);
+  const bool listed = BLK && a.block_skip_k != nullptr && nts <= 64;
+  if (listed) {
+    const unsigned long long sk0 = ((const unsigned long long*)a.block_skip_k)[kblk];
+    const unsigned long long sk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sk0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sk0);
+    // the dQ kernel reads whole 64-key x 128-query regions of dS: a tile left out here is still part of regions it visits -- zeros
+    if (role_b) {
+      unsigned long long z = act & sk;
+      while (z) {
+        const int T = __builtin_ctzll(z);
+        z &= z - 1ull;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) *(u32x4*)(ds_row + kb * ds_kb_stride + (size_t)T * 1024) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    act &= ~sk;
+  }
+  const int nact = listed ? __builtin_popcountll(act) : nts;
+  int seq = 0;                                             // tiles handed out so far (unlisted: the next tile)
+  auto pop = [&]() -> int {
+    if (!listed) return seq++;
+    const int T = __builtin_ctzll(act);
+    act &= act - 1ull;
+    ++seq;
+    return T;
+  };
+  int T0 = 0, T1 = 0, T2 = 0;
+  if (nact > 0) {
+    T0 = pop();
+    dma(0, T0);
+    rows_load(T0);
+    rows_store(0, T0);
+    if (nact > 1) { T1 = pop(); dma(1, T1); }
   }
   // (the builtin, not only the asm wait inside barrier(): hipcc must KNOW that the K / V fragment loads have landed, or it waits for them
   // -- vmcnt(0), and with them for the tile transfers in flight -- in front of the MFMAs of every iteration)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   barrier();
-  if (ntiles > 0) {
-    if (ntiles > 1) rows_load(1);
+  if (nact > 0) {
+    if (nact > 1) rows_load(T1);
     if (!role_b) rows_a(0);
     sx(0);
     if (!role_b) softmax_a(0);
-    if (ntiles > 1) rows_store(1);
+    if (nact > 1) rows_store(1, T1);
   }
   barrier();
-  for (int t = 0; t < ((TF_ABL_PAIR & 32) ? 0 : ntiles); ++t) {
+  for (int t = 0; t < ((TF_ABL_PAIR & 32) ? 0 : nact); ++t) {
     // tiles t, t + 1 are in LDS (tile t + 1's S / dP is done); buffer (t + 2) % 3 is free: everyone has left iteration t - 1
-    if (t + 2 < ntiles) { if (!(TF_ABL_PAIR & 1)) dma(t + 2); if (!(TF_ABL_PAIR & 16)) rows_load(t + 2); }
-    if (role_b && !(TF_ABL_PAIR & 2)) { rows_b(t); ds_b(t); }
-    if (t + 1 < ntiles && !(TF_ABL_PAIR & 4)) sx(t + 1);
-    if (!role_b && t + 1 < ntiles && !(TF_ABL_PAIR & 2)) rows_a(t + 1);
+    if (t + 2 < nact) { T2 = pop(); if (!(TF_ABL_PAIR & 1)) dma(t + 2, T2); if (!(TF_ABL_PAIR & 16)) rows_load(T2); }
+    if (role_b && !(TF_ABL_PAIR & 2)) { rows_b(t); ds_b(T0); }
+    if (t + 1 < nact && !(TF_ABL_PAIR & 4)) sx(t + 1);
+    if (!role_b && t + 1 < nact && !(TF_ABL_PAIR & 2)) rows_a(t + 1);
     if (!(TF_ABL_PAIR & 8)) accum(t);
-    if (!role_b && t + 1 < ntiles && !(TF_ABL_PAIR & 2)) softmax_a(t + 1);
-    if (t + 2 < ntiles && !(TF_ABL_PAIR & 16)) rows_store(t + 2);
+    if (!role_b && t + 1 < nact && !(TF_ABL_PAIR & 2)) softmax_a(t + 1);
+    if (t + 2 < nact && !(TF_ABL_PAIR & 16)) rows_store(t + 2, T2);
     barrier();
+    T0 = T1; T1 = T2;
   }
   // ---- dV (A) / dK (B) rows.  A lane holds 4 consecutive head-dim elements per 16-element block (8 bytes): stored as they stand that is
   //      24 dwordx2 stores per lane, and the epilogue was store-ISSUE bound (21 of the kernel's 113 us).  Lanes g and g ^ 1 hold adjacent
@@ -1531,14 +1578,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
 
   TileRegs16<64, HDP, NT> kr;
   u32x4 cr[4];
-  if (ntiles > 0) {
-    kr.load(kbase, ld, 0, Sb - 1, tid);
+  // the key tiles this workgroup visits: with a block mask, not those blocked for every query of the block (TfAttnArgs.block_skip_q:
+  // their dS is exactly 0 -- the dK / dV kernel writes zeros or nothing there).  t = the tile in hand, tn = the next one.
+  const int nts = __builtin_amdgcn_readfirstlane(ntiles);
+  unsigned long long act = nts >= 64 ? ~0ull : ((1ull << nts) - 1ull);
+  const bool listed = a.block_skip_q != nullptr && nts <= 64;
+  if (listed) {
+    const unsigned long long sk = ((const unsigned long long*)a.block_skip_q)[qblk];
+    act &= ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sk >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sk));
+  }
+  int t = listed ? (act ? __builtin_ctzll(act) : -1) : (nts > 0 ? 0 : -1);
+  if (t >= 0) {
+    kr.load(kbase, ld, t * 64, Sb - 1, tid);
     if (active) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)c * ds_kstride);
+      for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)(4 * t + c) * ds_kstride);
     }
   }
-  for (int t = 0; t < ntiles; ++t) {
+  while (t >= 0) {
+    int tn;
+    if (listed) { act &= act - 1ull; tn = act ? __builtin_ctzll(act) : -1; }
+    else tn = t + 1 < nts ? t + 1 : -1;
     __syncthreads();                                     // every wave is done with the previous K tile
     kr.store(kt, tid);
     if (active) {
@@ -1546,11 +1606,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
       for (int c = 0; c < 4; ++c) *(u32x4*)(dsw + c * 1024 + 16 * lane) = cr[c];
     }
     __syncthreads();
-    if (t + 1 < ntiles) {
-      kr.load(kbase, ld, (t + 1) * 64, Sb - 1, tid);
+    if (tn >= 0) {
+      kr.load(kbase, ld, tn * 64, Sb - 1, tid);
       if (active) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)(4 * (t + 1) + c) * ds_kstride);
+        for (int c = 0; c < 4; ++c) cr[c] = *(const u32x4*)(ds_col + (size_t)(4 * tn + c) * ds_kstride);
       }
     }
     if (active) {
@@ -1571,6 +1631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
         }
       }
     }
+    t = tn;
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1586,6 +1647,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
       }
     }
   }
+}
+
+// ================================================================================================
+// block-sparse tile maps of a block mask (TfAttnArgs.block_skip_q / block_skip_k), one workgroup per 128-row / 128-key block
+// ================================================================================================
+__global__ __launch_bounds__(256) void attn_block_skip_kernel(const unsigned long long* __restrict__ bits, int S, unsigned long long* __restrict__ skip_q,
+                                                              unsigned long long* __restrict__ skip_k) {
+  __shared__ unsigned long long word;
+  const int SW = (S + 63) / 64, nb = (S + 127) / 128, nqt = (S + 31) / 32;
+  const int blk = blockIdx.x % nb;
+  const bool is_k = (int)blockIdx.x >= nb;
+  if (threadIdx.x == 0) word = 0ull;
+  __syncthreads();
+  if (!is_k) {
+    // bit t: all 64 keys of tile t blocked for every query row of this block (rows past S do not exist)
+    if (SW <= 64) {
+      for (int t = 0; t < SW; ++t) {
+        bool all = true;
+        for (int r = blk * 128 + (int)threadIdx.x; r < min(S, blk * 128 + 128); r += 256) all = all && bits[(size_t)r * SW + t] == ~0ull;
+        if (__syncthreads_and(all ? 1 : 0) && threadIdx.x == 0) word |= 1ull << t;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) skip_q[blk] = word;
+  } else {
+    // bit j: the (up to) 128 keys of this block -- words 2 blk, 2 blk + 1 -- blocked for all 32 query rows of tile j
+    if (nqt <= 64) {
+      const int w0 = 2 * blk, w1 = 2 * blk + 1;
+      for (int j0 = 0; j0 < nqt; j0 += 8) {                          // a half wave per query tile
+        const int j = j0 + ((int)threadIdx.x >> 5), r = j * 32 + ((int)threadIdx.x & 31);
+        bool ok = true;
+        if (j < nqt && r < S) ok = bits[(size_t)r * SW + w0] == ~0ull && (w1 >= SW || bits[(size_t)r * SW + w1] == ~0ull);
+        const unsigned long long bal = __ballot(ok);
+        const unsigned half = (threadIdx.x & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+        if ((threadIdx.x & 31) == 0 && j < nqt && half == 0xffffffffu) atomicOr(&word, 1ull << j);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) skip_k[blk] = word;
+  }
+}
+extern "C" int tf_launch_attn_block_skip(const void* block_bits, int S, void* skip_q, void* skip_k, hipStream_t st) {
+  if (block_bits == nullptr || skip_q == nullptr || skip_k == nullptr || S <= 0) return -1;
+  TfTraceScope tr("attn_block_skip_kernel", st);
+  hipLaunchKernelGGL(attn_block_skip_kernel, dim3(2 * ((S + 127) / 128)), dim3(256), 0, st, (const unsigned long long*)block_bits, S,
+                     (unsigned long long*)skip_q, (unsigned long long*)skip_k);
+  return (int)hipGetLastError();
 }
 
 template <int HDP> int launch_fwd(const TfAttnArgs* a, hipStream_t st) {

@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
 // consecutive columns of one row from four 16-B loads and writes them with two 16-B stores; the transpose goes through
 // the LDS tile and leaves as 16 consecutive source rows of one column, again two 16-B stores (2-B stores made this
 // kernel 0.8 TB/s).  The element-wise path serves odd head widths (hd = 18) and the fp32 bias copies.
-struct PackBatch { TfPackArgs a[8]; };
+// tile0[i]: first block of tensor i in the 1-D grid (tile0[n] = grid size), gx[i]: its tiles per tile row -- every block is a real
+// tile (a 3-D grid over the LARGEST tensor's extents launched 10 368 blocks for a d = 768 layer, 1 236 of them with work)
+struct PackBatch { TfPackArgs a[8]; int tile0[9]; int gx[8]; };
 __device__ __forceinline__ int pack_src_index(int p, int g, int gp, int n_src) {      // padded index -> source index or -1
   const int q = gp >= (1 << 28) ? 0 : p / gp, e = p - q * gp;
   const int s = q * g + e;
@@ -329,8 +331,12 @@ __device__ __forceinline__ int pack_src_index(int p, int g, int gp, int n_src) {
 }
 __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
   __shared__ __attribute__((aligned(16))) u16 tile[64][72];        // 144-B rows: 16-B aligned, 36 words (= 4 mod 32 banks)
-  const TfPackArgs& a = pb.a[blockIdx.z];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  int z = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) z = (int)blockIdx.x >= pb.tile0[i] ? i : z;      // (tile0 of unused slots = grid size)
+  const TfPackArgs& a = pb.a[z];
+  const int local = (int)blockIdx.x - pb.tile0[z];
+  const int r0 = (local / pb.gx[z]) * 64, c0 = (local % pb.gx[z]) * 64;
   if (r0 >= a.rows_p || c0 >= a.cols_p) return;        // block-uniform
   const bool fast = !a.dst_is_f32 && (a.cols & 3) == 0 && (((size_t)a.src) & 15) == 0 &&
                     (a.cgp >= (1 << 28) || (((a.cg | a.cgp) & 3) == 0)) && (a.cols_p & 15) == 0 && (a.ld_dst & 7) == 0;
@@ -1246,15 +1252,18 @@ extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) 
   if (n <= 0) return 0;
   if (n > 8) return -2;
   PackBatch pb;
-  int gx = 0, gy = 0;
+  int total = 0;
   for (int i = 0; i < n; ++i) {
     if (a[i].rg <= 0 || a[i].cg <= 0 || a[i].rgp < a[i].rg || a[i].cgp < a[i].cg || a[i].rows_p <= 0 || a[i].cols_p <= 0) return -2;
     pb.a[i] = a[i];
-    gx = max(gx, (a[i].cols_p + 63) / 64);
-    gy = max(gy, (a[i].rows_p + 63) / 64);
+    pb.gx[i] = (a[i].cols_p + 63) / 64;
+    pb.tile0[i] = total;
+    total += pb.gx[i] * ((a[i].rows_p + 63) / 64);
   }
+  for (int i = n; i < 8; ++i) { pb.a[i] = a[0]; pb.gx[i] = 1; pb.tile0[i] = total; }
+  pb.tile0[8] = total;
   TfTraceScope tr("pack_kernel", st);
-  hipLaunchKernelGGL(pack_kernel, dim3(gx, gy, n), dim3(256), 0, st, pb);
+  hipLaunchKernelGGL(pack_kernel, dim3(total), dim3(256), 0, st, pb);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_pack(const TfPackArgs* a, hipStream_t st) {

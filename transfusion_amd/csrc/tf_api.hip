@@ -123,6 +123,7 @@ struct AOff {   // byte offsets inside work
   size_t dz1, dy1, dzb1, dyb1, du1, dqkv1;        // the same six for odd layers
   size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work)
   size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
+  size_t bskip;                                   // block-sparse tile maps of attn_block_bits: skip_q | skip_k, ceil(S/128) u64 words each
   size_t total;
 };
 AOff make_aoff(const Dims& D) {
@@ -134,6 +135,7 @@ AOff make_aoff(const Dims& D) {
   // (everything up to x0 is sized by the DENSE shape: these offsets do not move with the packed row count)
   a.zeros = take(256);
   a.perr = take(256);
+  a.bskip = take((size_t)2 * ((D.S + 127) / 128) * 8);
   a.cu = take((size_t)(D.B + 1) * 4); a.starts = take((size_t)D.B * 4); a.dense_of = take((size_t)D.Md * 4); a.pol = take((size_t)D.B * (D.Nl > 0 ? D.Nl : 1) * 4);
   a.keymask = take((size_t)D.Md);
   a.x0 = o; a.x_stride = plane(md) * (size_t)(1 + D.split); o += a.x_stride * (D.L + 1);
@@ -453,6 +455,10 @@ int tf_patchify_fwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_patchify_
 int tf_patchify_bwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_patchify_bwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
 int tf_regroup_fwd(const TfPatchArgs* a, int f32, tf_stream_t s) { TF_WRAP("tf_regroup_fwd", tf_launch_col2im(a, f32, (hipStream_t)s)); }
 int tf_regroup_bwd(const TfPatchArgs* a, tf_stream_t s) { TF_WRAP("tf_regroup_bwd", tf_launch_im2col(a, (hipStream_t)s)); }
+int tf_attn_block_skip(const void* bits, int S, void* skip_q, void* skip_k, tf_stream_t s) {
+  TF_TRY(tf_launch_attn_block_skip(bits, S, skip_q, skip_k, (hipStream_t)s), "tf_attn_block_skip");
+  return 0;
+}
 int tf_split_planes(const TfPlanesArgs* a, tf_stream_t s) { TF_WRAP("tf_split_planes", tf_launch_split_planes(a, (hipStream_t)s)); }
 int tf_pack_weight(const TfPackArgs* a, tf_stream_t s) { TF_WRAP("tf_pack_weight", tf_launch_pack(a, (hipStream_t)s)); }
 int tf_copy_rows(const TfCopyRowsArgs* a, tf_stream_t s) { TF_WRAP("tf_copy_rows", tf_launch_copy_rows(a, (hipStream_t)s)); }
@@ -643,6 +649,8 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   } else if (e->repack) {
     for (int l = 0; l < c.D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
   }
+  if (e->attn_block_bits != nullptr)              // the block mask's skippable tiles, once per forward (the backward reads them too)
+    TF_TRY(tf_launch_attn_block_skip(e->attn_block_bits, D.S, c.wk + c.A.bskip, c.wk + c.A.bskip + (size_t)((D.S + 127) / 128) * 8, c.st), "block_skip");
   uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
@@ -685,6 +693,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.key_mask = km; a.cu_rows = c.cu(); a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
+      if (e->attn_block_bits != nullptr) { a.block_skip_q = c.wk + c.A.bskip; a.block_skip_k = c.wk + c.A.bskip + (size_t)((D.S + 127) / 128) * 8; }
       if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
       if (dr.thr && side != nullptr && l == 0) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(0)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
@@ -854,6 +863,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       a.key_mask = km; a.cu_rows = c.cu(); a.B = D.B; a.S = D.S; a.H = D.H; a.HDP = D.hdp; a.scale = scale;
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
+      if (e->attn_block_bits != nullptr) { a.block_skip_q = c.wk + c.A.bskip; a.block_skip_k = c.wk + c.A.bskip + (size_t)((D.S + 127) / 128) * 8; }
       a.dout = d_o.p; a.dout_lo = d_o.lo; a.ld_dout = D.dp; a.dqkv = (void*)dqkv.p; a.dqkv_lo = (void*)dqkv.lo; a.ld_dqkv = D.ldq; a.delta = delta;
       a.ds_work = (void*)(c.wk + c.A.dsw); a.ds_planes = D.split ? 4 : 1;
       TF_TRY(tf_launch_attn_bwd(&a, c.st), "attn_bwd");
