@@ -13,7 +13,7 @@ from transfusion_amd.modeling.model_factory import get_fusion_model
 from transfusion_amd.runner.config import load_fusion_config
 from transfusion_amd import _lib as Lb
 
-B, NL, D = int(os.environ.get("B", 8)), 512, 768
+B, NL, D = int(os.environ.get("B", 8)), 512, int(os.environ.get("D", 768))
 dev = torch.device("cuda", 0)
 torch.manual_seed(42)
 ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]

@@ -157,6 +157,7 @@ class _EncoderFn(torch.autograd.Function):
                 ops.join_overlap(dev)
         mod._release(keep)
         if direct:
+            ops.note_grad_writer(dev)                   # (ops.note_grad_writer: FusionTrainStep joins this stream before the optimiser)
             return (None, None, d_vis, d_lang, None) + (None,) * ctx.nparams
         return (None, None, d_vis, d_lang, None) + tuple(grads)
 

@@ -293,6 +293,32 @@ def side_stream(device):
     return s
 
 
+# ---- streams that wrote into .grad DIRECTLY ----------------------------------------------------------------------------------------------
+# A backward that adds its parameter gradients straight into ``.grad`` (the encoders under FusionTrainStep, ops.linear(accumulate=True))
+# hands autograd ``None`` for them.  When nothing downstream of it needs a gradient either (a wrapper level on its own stream whose
+# feature map comes from a frozen backbone) no tensor ever flows from that stream back to the one the optimiser runs on.  Under the
+# delay probe the optimiser is nevertheless ordered behind such a stream (attributed to the engine joining the "leaf stream" of the
+# parameter's AccumulateGrad node, which still runs as a no-op) -- but that edge cannot be removed for a negative control, and
+# hardware-queue aliasing can hide a missing edge.  So the product does not rely on it: such writers note their
+# stream here and FusionTrainStep.step() joins them explicitly before the exchange and the optimiser (a few event waits per step).
+_grad_writer_streams = {}
+
+
+def note_grad_writer(device=None):
+    st = torch.cuda.current_stream(device)
+    _grad_writer_streams[(st.device.index, st.cuda_stream)] = st
+
+
+def join_grad_writers(device):
+    """The current stream of ``device`` waits for every stream noted by ``note_grad_writer`` since the last call."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(idx)
+    for key in [k for k in _grad_writer_streams if k[0] == idx]:
+        st = _grad_writer_streams.pop(key)
+        if st.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(st)
+
+
 _zeros_cache = {}
 
 
@@ -693,6 +719,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.into is not None:
             gw, gb = ctx.into
             wgrad(gyb, N8, xb, Kp, gw.view(N, -1), gb)
+            note_grad_writer(gy.device)
             return dx, None, None, None, None, None, None, None
         dW = torch.zeros(wshape, dtype=torch.float32, device=gy.device)
         db = torch.zeros(N, dtype=torch.float32, device=gy.device) if has_bias else None

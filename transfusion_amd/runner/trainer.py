@@ -465,6 +465,11 @@ class FusionTrainStep:
                 self.layerwise.active = i == len(micro_batches) - 1
             loss = loss_fn(self.module, mb)
             (loss / len(micro_batches)).backward()
+        if self.flat.grad.is_cuda:
+            # streams whose backward added into the flat gradient buffer without handing autograd a gradient (ops.note_grad_writer): the
+            # exchange, the norm and the optimiser below are ordered behind them explicitly
+            from transfusion_amd import ops
+            ops.join_grad_writers(self.flat.grad.device)
         if self.layerwise is not None:
             self.layerwise.finish()
         else:
