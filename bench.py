@@ -820,7 +820,7 @@ def main():
         result["peak_fp32_mfma_tflops"] = 157.3
     if world > 1:
         result["allreduce"] = allreduce_busbw(trainer, comm)          # every rank takes part; rank 0 prints
-        result["allreduce"].update(rccl_probe(trainer, comm, device, rank))
+        result["allreduce"].update({"backend": dist.get_backend(), "group_world": dist.get_world_size()})
     if rank == 0 and rows is not None:
         # in-situ kernel table: the traced steps ran AFTER the timed region (two event records per launch would perturb it)
         total = sum(r["us_per_step"] for r in rows)
@@ -912,6 +912,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()
+    if world > 1 and os.environ.get("TF_RCCL_PROBE", "1") != "0":
+        # LAST, and under a timer: the library's own RCCL communicator exercised with its peers (a second communicator next to the
+        # process group's).  Its bootstrap has never run on a multi-GPU node, and a communicator that never forms cannot be cancelled --
+        # so if the probe is not back in time the line measured above is printed WITHOUT it and every rank leaves (exit 0): the
+        # benchmark result never depends on the probe.
+        import threading
+        line = dict(result)
+        line["allreduce"] = dict(result.get("allreduce", {}), rccl={"error": "probe did not return within 90 s"})
+
+        def bail():
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        timer = threading.Timer(float(os.environ.get("TF_RCCL_PROBE_TIMEOUT_S", "90")), bail)
+        timer.daemon = True
+        timer.start()
+        probe = rccl_probe(trainer, comm, device, rank)
+        timer.cancel()
+        result.setdefault("allreduce", {}).update(probe)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -140,6 +140,23 @@ def test_bench_two_ranks_on_one_gpu_does_not_hang(tmp_path):
     assert res["strong"]["global_batch"] == 32 and res["strong"]["batch_per_gpu"] == 16 and res["strong"]["samples_s"] > 0
 
 
+def test_bench_bare_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself as a child process and passes
+    rank 0's JSON line through (what the driver's SCALE run calls; on this one-GPU box both ranks share cuda:0 over gloo)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TF_FORCE_DEVICE="0", TF_DIST_BACKEND="gloo", TF_BENCH_WATCHDOG_S="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-census", "--no-legs"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["value"] > 0
+    assert res["allreduce"]["group_world"] == 2 and res["allreduce"]["backend"] == "gloo"
+    assert res["rank_sync"]["identical_on_ranks"] == 2
+
+
 _TREE_WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
