@@ -506,6 +506,7 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
+        t_host = (time.perf_counter() - t0) / steps        # the host has ENQUEUED the steps by now (no sync inside a step)
         comm.sync()
         dt = comm.max(time.perf_counter() - t0) / steps
         loss = float(last["loss"].item())
@@ -522,10 +523,11 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
                    layers=layers, dtype="fp32" if precision == "fp32" else ("fp8 projections + bf16" if fp8 else "bf16"),
                    block_tflops_per_gpu=round(fl / dt / 1e12, 1), block_mfma_util=round(fl / dt / 1e12 / peak, 4), peak_used=round(peak, 1),
                    block_mfma_util_dense_credit=round(fl_dense / dt / 1e12 / peak, 4),
-                   packed_rows=bool(pack), padded=bool(padded), steps=steps, warmup=warmup, final_loss=round(loss, 5))
+                   packed_rows=bool(pack), padded=bool(padded), steps=steps, warmup=warmup, final_loss=round(loss, 5),
+                   host_enqueue_ms=round(t_host * 1e3, 3))
         if rank == 0:
             log(f"  leg {name:10s} {out['ms_per_step']:8.3f} ms/step  {out['samples_s']:9.1f} samples/s  {out['block_tflops_per_gpu']:7.1f} TFLOP/s/GPU "
-                f"({100 * out['block_mfma_util']:.1f} % of {peak:.0f})")
+                f"({100 * out['block_mfma_util']:.1f} % of {peak:.0f}; host enqueue {out['host_enqueue_ms']:.2f} ms/step)")
         return out
     finally:
         PACK_TOKENS = saved
