@@ -390,6 +390,26 @@ class _Comm:
         return float(t.item())
 
 
+class _QuietGC:
+    """Around a timed region: a full collection of this process (torch, four model families, thousands of modules: ~1.5 M tracked
+    objects) takes 60 - 165 ms, and CPython starts one whenever its allocation counters say so -- inside a host-bound step
+    (B = 4: the host needs 1.1 ms per step) that is a stall of 50 - 100 steps' worth.  Measured in round 5 (TF_LEG_TRACE=1 logs every
+    collection): the outliers of `legs.b4_dense`, `v1_d712`, `wrapper_b4_dp` were exactly these.  gc.freeze() moves everything alive
+    after the warm-up into the permanent generation, so the collector still runs during the timed steps but only walks what they
+    created (< 1 ms) -- what a long-running trainer does for the same reason."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        gc.freeze()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        gc.unfreeze()
+        return False
+
+
 def run_schedule(step, comm, rank, warmup, steps, trace_steps, traced):
     """The benchmark's control flow, the same on EVERY rank: W untimed steps, barrier + sync, K timed steps, barrier + sync,
     max over ranks; then `trace_steps` further steps which rank 0 runs under the launch tracer (`traced(n)`) and every other rank
@@ -402,11 +422,12 @@ def run_schedule(step, comm, rank, warmup, steps, trace_steps, traced):
     comm.sync()
     if rank == 0:
         log(f"  warm-up done ({warmup} steps)")
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(i); i += 1
-    comm.sync()
-    elapsed = comm.max(time.perf_counter() - t0)
+    with _QuietGC():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(i); i += 1
+        comm.sync()
+        elapsed = comm.max(time.perf_counter() - t0)
     if rank == 0:
         log(f"  timed region done ({steps} steps, {elapsed / max(steps, 1) * 1e3:.3f} ms/step)")
     rows = None
@@ -503,12 +524,23 @@ def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, l
         for i in range(warmup):
             step(i)
         comm.sync()
+        quiet = _QuietGC().__enter__()
         t0 = time.perf_counter()
+        marks = []
         for i in range(steps):
+            if i == 0 and os.environ.get("TF_LEG_TRACE") == "1":
+                import faulthandler as _fh
+                _fh.dump_traceback_later(0.008, repeat=False)       # where is the host 8 ms into the first timed step?
             step(warmup + i)
+            if i == 0 and os.environ.get("TF_LEG_TRACE") == "1":
+                _fh.cancel_dump_traceback_later()
+            marks.append(time.perf_counter())
         t_host = (time.perf_counter() - t0) / steps        # the host has ENQUEUED the steps by now (no sync inside a step)
         comm.sync()
         dt = comm.max(time.perf_counter() - t0) / steps
+        quiet.__exit__()
+        if os.environ.get("TF_LEG_TRACE") == "1" and rank == 0:
+            log(f"  leg {name}: host ms per step " + " ".join(f"{1e3 * (b_ - a_):.2f}" for a_, b_ in zip([t0] + marks[:-1], marks)))
         loss = float(last["loss"].item())
         if not math.isfinite(loss):
             raise SystemExit(f"leg {name}: non-finite loss {loss}")
@@ -606,12 +638,13 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
         for _ in range(warmup):
             last["loss"] = obj["trainer"].step([None], wloss)
         comm.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            last["loss"] = obj["trainer"].step([None], wloss)
-        t_host = (time.perf_counter() - t0) / steps
-        comm.sync()
-        dt = comm.max(time.perf_counter() - t0) / steps
+        with _QuietGC():
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last["loss"] = obj["trainer"].step([None], wloss)
+            t_host = (time.perf_counter() - t0) / steps
+            comm.sync()
+            dt = comm.max(time.perf_counter() - t0) / steps
         loss = float(last["loss"].item())
         if not math.isfinite(loss):
             raise SystemExit(f"leg wrapper_b{batch}: non-finite loss {loss}")
@@ -709,6 +742,16 @@ def main():
     global PACK_TOKENS
     PACK_TOKENS = not args.dense_rows
 
+    if os.environ.get("TF_LEG_TRACE") == "1":
+        import gc
+        _gc_t = {}
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                _gc_t["t"] = time.perf_counter()
+            elif info.get("generation", 0) >= 1:
+                log(f"  [gc] generation {info['generation']} collection: {1e3 * (time.perf_counter() - _gc_t.get('t', 0.0)):.1f} ms, collected {info.get('collected')}")
+        gc.callbacks.append(_gc_cb)
     # a hang must end with a Python stack on stderr, not with the driver's silence timeout
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("TF_BENCH_WATCHDOG_S", "900")), exit=True)
