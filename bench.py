@@ -497,6 +497,27 @@ def rccl_probe(trainer, comm, device, rank):
     return out
 
 
+def probe_under_timer(result, probe, rank, timeout_s=None):
+    """Runs ``probe()`` LAST and under a timer and merges what it returns into ``result["allreduce"]``.  The probe is the library's own
+    RCCL communicator exercised with its peers (a second communicator next to the process group's): its bootstrap has never run on a
+    multi-GPU node, and a communicator that never forms cannot be cancelled -- so if the probe is not back in time, the line measured so
+    far is printed WITHOUT it (rank 0) and the process leaves with exit code 0: the benchmark result never depends on the probe."""
+    import threading
+    line = dict(result)
+    line["allreduce"] = dict(result.get("allreduce", {}), rccl={"error": "probe did not return in time"})
+
+    def bail():
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+    timer = threading.Timer(float(timeout_s if timeout_s is not None else os.environ.get("TF_RCCL_PROBE_TIMEOUT_S", "90")), bail)
+    timer.daemon = True
+    timer.start()
+    out = probe()
+    timer.cancel()
+    result.setdefault("allreduce", {}).update(out)
+
+
 def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
             steps=8, warmup=3, grad_clip=1.0):
     """One more BASELINE configuration in the same process, after the headline: its own encoder, trainer and batches, `warmup` untimed +
@@ -958,24 +979,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()
     if world > 1 and os.environ.get("TF_RCCL_PROBE", "1") != "0":
-        # LAST, and under a timer: the library's own RCCL communicator exercised with its peers (a second communicator next to the
-        # process group's).  Its bootstrap has never run on a multi-GPU node, and a communicator that never forms cannot be cancelled --
-        # so if the probe is not back in time the line measured above is printed WITHOUT it and every rank leaves (exit 0): the
-        # benchmark result never depends on the probe.
-        import threading
-        line = dict(result)
-        line["allreduce"] = dict(result.get("allreduce", {}), rccl={"error": "probe did not return within 90 s"})
-
-        def bail():
-            if rank == 0:
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-        timer = threading.Timer(float(os.environ.get("TF_RCCL_PROBE_TIMEOUT_S", "90")), bail)
-        timer.daemon = True
-        timer.start()
-        probe = rccl_probe(trainer, comm, device, rank)
-        timer.cancel()
-        result.setdefault("allreduce", {}).update(probe)
+        probe_under_timer(result, lambda: rccl_probe(trainer, comm, device, rank), rank)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -88,3 +88,29 @@ def test_bare_gpus_n_launches_its_own_ranks(tmp_path):
         assert a[:3] == ["--nnodes=1", "--nproc-per-node", "4"] and a[3:5] == ["--master-addr", "127.0.0.1"] and a[5] == "--master-port"
         assert a[7].endswith("bench.py") and a[8:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
         assert seen["ipc"] == "0" and seen["world"] is None
+
+
+def test_a_probe_that_never_returns_cannot_take_the_bench_line_with_it(tmp_path):
+    """bench.probe_under_timer: the own-RCCL probe of the N > 1 line runs last and under a timer.  A probe that hangs (a communicator
+    that never forms) must leave rank 0's JSON line printed -- without the probe's part -- and exit code 0; a probe that returns is
+    merged into the line."""
+    import json
+    import subprocess
+    script = tmp_path / "probe.py"
+    script.write_text(
+        "import importlib.util, json, os, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "res = {'metric': 'm', 'value': 1.0, 'allreduce': {'backend': 'nccl', 'group_world': 8}}\n"
+        "if sys.argv[1] == 'hang':\n"
+        "    b.probe_under_timer(res, lambda: time.sleep(3600), 0, timeout_s=1.0)\n"
+        "else:\n"
+        "    b.probe_under_timer(res, lambda: {'rccl': {'world': 8, 'calls': 11}}, 0, timeout_s=30.0)\n"
+        "print(json.dumps(res))\n")
+    r = subprocess.run([sys.executable, str(script), "hang"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.0 and line["allreduce"]["group_world"] == 8 and "error" in line["allreduce"]["rccl"]
+    r = subprocess.run([sys.executable, str(script), "ok"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["allreduce"]["rccl"] == {"world": 8, "calls": 11} and line["allreduce"]["backend"] == "nccl"
