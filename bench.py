@@ -374,16 +374,17 @@ def cpu_baseline(seconds_budget=12.0):
 class _Comm:
     """The collectives bench.py's control flow issues itself (the gradient all-reduces are issued by the trainer inside step())."""
 
-    def __init__(self, world, device):
+    def __init__(self, world, device, live=None):
         self.world, self.device = world, device
+        self.live = world > 1 if live is None else live       # (True also in the one-rank rehearsal of the RCCL path: REHEARSE)
 
     def sync(self):
-        if self.world > 1:
+        if self.live:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max(self, x: float) -> float:
-        if self.world == 1:
+        if not self.live:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -797,8 +798,21 @@ def main():
         # experiment hook: the whole run on a non-default (non-blocking) stream instead of the legacy null stream, which synchronises
         # implicitly with every BLOCKING stream (hipExtStreamCreateWithCUMask makes those: TF_SIDE_CUS in experiments builds)
         torch.cuda.set_stream(torch.cuda.Stream(device=device))
-    if world > 1:
+    # TF_REHEARSE_COLLECTIVES=1 (tests/test_gpu_ddp.py): the N > 1 code path -- process group over RCCL, layer-wise all-reduces on the
+    # communication stream, rank checks, bandwidth probe, the library's own communicator -- on ONE GPU in a ONE-rank group: everything
+    # but the peers, against the real backend (gloo, which the two-rank rehearsals use, has other stream semantics)
+    rehearse = world == 1 and os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"
+    live = world > 1 or rehearse
+    if live:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            sock.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -822,7 +836,7 @@ def main():
     batches = [make_batch(args.batch, device, rank, variant=v) for v in range(max(1, args.batches))]
     if args.with_heads:
         batches = [b + (make_heads_batch(args.batch, device, rank, v),) for v, b in enumerate(batches)]
-    comm = _Comm(world, device)
+    comm = _Comm(world, device, live)
     last = {}
 
     def step(i):
@@ -830,7 +844,7 @@ def main():
 
     elapsed, rows = run_schedule(step, comm, rank, args.warmup, args.steps, 0 if args.no_census else args.trace_steps, traced_kernels)
     final_loss = float(last["loss"].item())
-    if world > 1 and os.environ.get("TF_CHECK_SYNC", "1") != "0":
+    if live and os.environ.get("TF_CHECK_SYNC", "1") != "0":
         # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
         mine = trainer.flat.flat.double().sum().reshape(1)
         lo, hi = mine.clone(), mine.clone()
@@ -862,7 +876,7 @@ def main():
         "config": {"workload": f"fusion-encoder{' + RoI heads and losses (512 RoIs / image)' if args.with_heads else ''} train step (fwd+bwd+allreduce+clip+RAdam), B={args.batch}/GPU x [{NV} vis + {NL} txt] tokens, "
                                f"d={D}, heads={H}, ff={D * FF_MULT}, layers={L}, dropout {P_TOKEN}/{P_PATCH}, random right-padding"
                                f"{' (masked tokens dropped from the row-wise kernels)' if PACK_TOKENS else ' (masked tokens carried as dead rows)'}",
-                   "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "comm": args.comm if world > 1 else None},
+                   "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "comm": args.comm if live else None},
         # utilisation on EXECUTED work: only the Nv + len_b real tokens of each sample (what the kernels compute with the masked tokens
         # dropped); the dense-S credit of BASELINE.md section 3 (padded tokens counted) beside it
         "block_mfma_util": round(train_flops_valid / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -870,7 +884,7 @@ def main():
         "block_mfma_util_dense_credit": round(train_flops_step / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "block_tflops_dense_credit": round(train_flops_step / (ms * 1e-3) / 1e12, 1),
         "mean_valid_tokens": round(sum(sum(vs) for vs in valid_S) / (len(valid_S) * args.batch), 1),
-        "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if world > 1 else 0.0,
+        "grad_allreduce_mb": round(trainer.reducer.bytes_per_step / 1e6, 1) if live else 0.0,
         "final_loss": round(final_loss, 5),
     }
     peak = PEAK_BF16_TFLOPS
@@ -884,7 +898,7 @@ def main():
         result["block_mfma_util_dense_credit"] = round(train_flops_step / (ms * 1e-3) / 1e12 / peak, 4)
         result["peak_tflops_used"] = round(peak, 1)
         result["peak_fp32_mfma_tflops"] = 157.3
-    if world > 1:
+    if live:
         result["allreduce"] = allreduce_busbw(trainer, comm)          # every rank takes part; rank 0 prints
         result["allreduce"].update({"backend": dist.get_backend(), "group_world": dist.get_world_size()})
     if rank == 0 and rows is not None:
@@ -930,7 +944,7 @@ def main():
         if args.isolated_census:
             census = kernel_census(args.batch, device)
             result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
-    if world > 1 and os.environ.get("TF_CHECK_SYNC", "1") != "0":
+    if live and os.environ.get("TF_CHECK_SYNC", "1") != "0":
         result["rank_sync"] = rank_sync
     # ---- the other BASELINE configurations, in the same run (every rank takes part: each step holds the gradient collectives) ----
     if not args.no_legs and not args.with_heads and args.precision == "bf16" and args.batch == 32:
@@ -978,11 +992,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()
-    if world > 1 and os.environ.get("TF_RCCL_PROBE", "1") != "0":
+    if live and os.environ.get("TF_RCCL_PROBE", "1") != "0":
         probe_under_timer(result, lambda: rccl_probe(trainer, comm, device, rank), rank)
+    if rehearse:
+        result["rehearsal"] = "one-rank process group: the N > 1 code path against the real backend, without peers"
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if live:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,12 +33,19 @@ from test_gpu_encoder import build
 from transfusion_amd.optim import FusedRAdam
 from transfusion_amd.runner.trainer import FusionTrainStep
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
+rehearse = os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"          # ONE rank over RCCL with a phantom peer (trainer._phantom_peers)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+if rehearse:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 if int(os.environ.get("TF_TEST_WGRAD_DELAY_US", "0")):
     from transfusion_amd import ops
     ops.debug_delay_wgrad(int(os.environ["TF_TEST_WGRAD_DELAY_US"]))
+if os.environ.get("TF_TEST_BREAK_EDGE"):
+    from transfusion_amd.runner.trainer import LayerwiseReducer
+    LayerwiseReducer._debug_break_edge = os.environ["TF_TEST_BREAK_EDGE"]
 cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
 enc, _ = build(cfg, dev)
 enc.train()
@@ -47,7 +54,7 @@ tr = FusionTrainStep(enc, lr=5e-2, weight_decay=0.0, grad_clip=None, accumulate=
 assert tr.layerwise is not None and enc.layer_grad_hook is not None, "the default N > 1 path must be the layer-wise reducer"
 x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], [30, 11, 22, 30])
 t = lambda a: torch.from_numpy(a).to(dev)
-mine = slice(rank * 2, rank * 2 + 2)                       # this rank's two samples
+mine = slice(0, 4) if rehearse else slice(rank * 2, rank * 2 + 2)       # this rank's two samples (the rehearsal's one rank: all four)
 def loss_fn(m, b):
     sl = b
     v, l_, _, _ = m(t(x[sl]), t(lang[sl]), t(mask[sl]))
@@ -57,15 +64,36 @@ before = tr.flat.flat.clone()
 tr.step(mbs, loss_fn)
 torch.cuda.synchronize()
 # every rank must hold bit-identical parameters afterwards
-chk = tr.flat.flat.double().sum().reshape(1).cpu()
+chk = tr.flat.flat.double().sum().reshape(1)
+chk = chk if rehearse else chk.cpu()                       # (RCCL reduces device tensors, gloo is given host ones)
 lo, hi = chk.clone(), chk.clone()
 dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 assert lo.item() == hi.item(), (lo.item(), hi.item())
 if rank == 0:
-    torch.save({{"grad": tr.flat.grad.cpu(), "param": tr.flat.flat.cpu(), "before": before.cpu(), "collectives": tr.layerwise.collectives}}, {out!r})
+    torch.save({{"grad": tr.flat.grad.cpu(), "param": tr.flat.flat.cpu(), "before": before.cpu(), "collectives": tr.layerwise.collectives,
+                "backend": dist.get_backend(), "own_comm": tr.bucket_comm is not None}}, {out!r})
 dist.barrier()
 dist.destroy_process_group()
 '''
+
+
+def _encoder_reference_grad(before):
+    """single process, all four samples, same starting parameters"""
+    from test_gpu_encoder import build
+    from transfusion_amd.runner.trainer import FlatParams
+    dev = torch.device("cuda:0")
+    cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
+    enc, _ = build(cfg, dev)
+    enc.train()
+    flat = FlatParams(enc)
+    assert torch.equal(flat.flat.cpu(), before)
+    enc.accumulate_into_grad = True
+    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], [30, 11, 22, 30])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    v, l_, _, _ = enc(t(x), t(lang), t(mask))
+    ((v * t(gv)).sum() + (l_ * t(gl)).sum()).backward()
+    torch.cuda.synchronize()
+    return flat.grad.cpu()
 
 
 @pytest.mark.parametrize("acc,delay_us", [(1, 0), (2, 0), (1, 3000)])
@@ -95,22 +123,7 @@ def test_two_ranks_one_gpu_layerwise_reducer_on_the_real_encoder(tmp_path, acc, 
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
     got = torch.load(out)
     assert got["collectives"] == 3                               # one all-reduce per layer per optimiser step (also with accumulation)
-    # single process, all four samples, same starting parameters
-    from test_gpu_encoder import build
-    from transfusion_amd.runner.trainer import FlatParams
-    dev = torch.device("cuda:0")
-    cfg = dict(B=4, Nv=24, Nl=30, d=64, h=4, L=3, seed=91)
-    enc, _ = build(cfg, dev)
-    enc.train()
-    flat = FlatParams(enc)
-    assert torch.equal(flat.flat.cpu(), got["before"])
-    enc.accumulate_into_grad = True
-    x, lang, mask, gv, gl = make_encoder_inputs(cfg["seed"], cfg["B"], cfg["Nv"], cfg["Nl"], cfg["d"], [30, 11, 22, 30])
-    t = lambda a: torch.from_numpy(a).to(dev)
-    v, l_, _, _ = enc(t(x), t(lang), t(mask))
-    ((v * t(gv)).sum() + (l_ * t(gl)).sum()).backward()
-    torch.cuda.synchronize()
-    ref = flat.grad.cpu() / acc                                   # micro-batch losses are scaled by 1 / accumulate
+    ref = _encoder_reference_grad(got["before"]) / acc            # micro-batch losses are scaled by 1 / accumulate
     err = ((got["grad"] - ref).norm() / ref.norm()).item()
     assert err < 2e-3, err                                        # same products, different fp32 summation order (atomics, ranks)
     # SGD-degenerated first RAdam step: p -= lr * step_size * m, m = (1 - beta1) * g / world -- the parameters moved by the mean gradient
@@ -167,10 +180,13 @@ from transfusion_amd.runner.config import load_fusion_config
 from transfusion_amd.runner.trainer import FusionTrainStep, OrderedRangeReducer
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 single = os.environ.get("TF_TREE_SINGLE") == "1"
-if not single:
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+rehearse = os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"          # ONE rank over RCCL with a phantom peer (trainer._phantom_peers)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+if rehearse:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+elif not single:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 if int(os.environ.get("TF_TEST_WGRAD_DELAY_US", "0")):
     from transfusion_amd import ops
     ops.debug_delay_wgrad(int(os.environ["TF_TEST_WGRAD_DELAY_US"]))
@@ -197,7 +213,7 @@ feats = [torch.randn(B, l["C"], l["H"], l["W"], generator=g) for l in levels]
 lens = [9, 3, 11, 6]
 lang = [torch.randn(n, d, generator=g) for n in lens]
 cots = [torch.randn(B, l["C"], l["H"], l["W"], generator=g) for l in levels]
-mine = list(range(B)) if single else [2 * rank, 2 * rank + 1]
+mine = list(range(B)) if single or rehearse else [2 * rank, 2 * rank + 1]
 def loss_fn(m, idx):
     out = m({{"image": [f[idx].to(dev) for f in feats], "language_f": [lang[i].to(dev) for i in idx]}})
     return sum((out["features"][str(i)].float() * cots[i][idx].to(dev)).sum() for i in range(2))
@@ -207,7 +223,7 @@ for step in range(3):
     tr.step([mine], loss_fn)
     torch.cuda.synchronize()
     hist.append(dict(before=before.cpu(), grad=tr.flat.grad.cpu().clone(), param=tr.flat.flat.cpu().clone()))
-if not single and not os.environ.get("TF_TEST_BREAK_EDGE"):      # (with an edge removed the ranks may well disagree: that IS the finding)
+if not single and not rehearse and not os.environ.get("TF_TEST_BREAK_EDGE"):      # (with an edge removed the ranks may well disagree: that IS the finding)
     chk = tr.flat.flat.double().sum().reshape(1).cpu()
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -216,7 +232,8 @@ grouped = int(getattr(model.cross_fusion_encoders[0], "_last_desc").groups)
 if rank == 0:
     extra = dict(grouped=grouped) if single else dict(grouped=grouped, agreed=tr.layerwise.agreed, collectives=tr.layerwise.collectives, nunits=len(tr.layerwise.units),
                                           keys=[u["key"] for u in tr.layerwise.units], order=tr.layerwise.order,
-                                          ranges=[(u["lo"], u["hi"]) for u in tr.layerwise.units])
+                                          ranges=[(u["lo"], u["hi"]) for u in tr.layerwise.units], backend=dist.get_backend(),
+                                          own_comm=tr.bucket_comm is not None)
     torch.save(dict(hist=hist, **extra), {out!r})
 if not single:
     dist.barrier()
@@ -339,3 +356,93 @@ def test_two_ranks_one_gpu_ordered_reducer_on_the_real_wrapper(tmp_path, delay_u
     _check_tree(two, one, grouped=False)
     keys = [two["keys"][u] for u in two["order"]]
     assert keys[0].startswith("tokens_to_features.1") and keys[-1].startswith("patches_to_token.0"), keys     # backward order: level 1 first
+
+
+# ---- the N > 1 step against the REAL backend, on one GPU: a one-rank RCCL process group with a phantom peer ----
+def _run_one(tmp_path, template, tag, env_extra, **fmt):
+    out = str(tmp_path / f"{tag}.pt")
+    script = tmp_path / f"{tag}.py"
+    script.write_text(template.format(root=ROOT, out=out, **fmt))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TF_REHEARSE")}
+    env.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update({k: v for k, v in env_extra.items() if v != ""})
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return torch.load(out)
+
+
+def _rehearsal_env(comm, delay_us, break_edge="", hw_queues=""):
+    return dict(TF_REHEARSE_COLLECTIVES="1", TF_REHEARSE_PHANTOM_PEERS="1", TF_COMM=comm, TF_TEST_WGRAD_DELAY_US=str(delay_us),
+                TF_TEST_BREAK_EDGE=break_edge, GPU_MAX_HW_QUEUES=hw_queues)
+
+
+def _tree_rehearsal_error(got, one, steps=slice(0, None)):
+    """the phantom peer doubles every reduced range: the rehearsal's gradients must be exactly twice the single process's"""
+    return max(((st2["grad"] - 2 * st1["grad"]).norm() / (2 * st1["grad"]).norm()).item() for st2, st1 in zip(got["hist"][steps], one["hist"][steps]))
+
+
+@pytest.mark.parametrize("comm", ["torch", "rccl"])
+def test_rccl_rehearsal_of_the_ordered_reducer_with_a_phantom_peer(tmp_path, comm):
+    """What the two-rank runs above cannot show: they share one GPU and therefore go over gloo, whose CUDA all-reduce stages through the
+    host and synchronises far more than RCCL does.  Here the N > 1 step runs against the real backend -- a ONE-rank "nccl" process group
+    (TF_REHEARSE_COLLECTIVES=1), through torch's process group and through the library's own communicator (tf_allreduce_bucket) --
+    with asynchronous collectives on the communication stream, every weight gradient 3 ms late, and a phantom peer that doubles each
+    range right behind its collective (TF_REHEARSE_PHANTOM_PEERS=1): a gradient written after its range was reduced misses the factor."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    one = _run_one(tmp_path, _TREE_WORKER, "ref", dict(TF_TREE_SINGLE="1"), levels=_LEVELS_EQUAL)
+    got = _run_one(tmp_path, _TREE_WORKER, "reh", _rehearsal_env(comm, 3000), levels=_LEVELS_EQUAL)
+    assert got["backend"] == "nccl" and got["own_comm"] == (comm == "rccl")
+    assert got["agreed"] is True and got["nunits"] == 8 and got["collectives"] == 1 + 2 * 8, (got["nunits"], got["collectives"])
+    assert _tree_rehearsal_error(got, one) < 5e-3, _tree_rehearsal_error(got, one)
+
+
+@pytest.mark.parametrize("comm", ["torch", "rccl"])
+def test_rccl_rehearsal_of_the_layerwise_reducer_with_a_phantom_peer(tmp_path, comm):
+    """The bare encoder's reducer (bench.py's path) the same way: one all-reduce per layer behind the communication stream, over RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    got = _run_one(tmp_path, _WORKER, "lw", _rehearsal_env(comm, 3000), acc=1)
+    assert got["backend"] == "nccl" and got["own_comm"] == (comm == "rccl") and got["collectives"] == 3
+    ref = _encoder_reference_grad(got["before"])
+    err = ((got["grad"] - 2 * ref).norm() / (2 * ref).norm()).item()
+    assert err < 2e-3, err
+
+
+def test_the_rccl_rehearsal_sees_a_missing_edge(tmp_path):
+    """Negative control of the two rehearsals: with the side-stream edge of a reducer removed the delayed weight gradients land after the
+    phantom peer's factor, and the run must come out WRONG (under some stream -> hardware-queue mapping; the intact reducer must then be
+    right under the same one)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    one = _run_one(tmp_path, _TREE_WORKER, "ref", dict(TF_TREE_SINGLE="1"), levels=_LEVELS_EQUAL)
+    seen = {}
+    for q in ("", "16", "8", "2"):
+        bad = _run_one(tmp_path, _TREE_WORKER, f"bad{q}", _rehearsal_env("torch", 3000, "side", q), levels=_LEVELS_EQUAL)
+        worst = _tree_rehearsal_error(bad, one, slice(1, None))         # (step 1 reduces everything after the backward: no unit events)
+        seen[q or "default"] = round(worst, 6)
+        if worst > 5e-2:
+            ok = _run_one(tmp_path, _TREE_WORKER, f"ok{q}", _rehearsal_env("torch", 3000, "", q), levels=_LEVELS_EQUAL)
+            assert _tree_rehearsal_error(ok, one) < 5e-3
+            return
+    pytest.fail(f"no hardware-queue mapping exposed the removed edge: {seen}")
+
+
+def test_bench_rehearses_the_rccl_path_on_one_gpu():
+    """TF_REHEARSE_COLLECTIVES=1 python bench.py: the headline workload with the process group, the layer-wise all-reduces, the rank
+    check, the bandwidth probe and the library's own communicator live on ONE GPU -- what the driver's N > 1 runs execute, minus peers."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TF_REHEARSE_COLLECTIVES="1", TF_BENCH_WATCHDOG_S="250", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for comm in ("torch", "rccl"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-census", "--no-legs", "--comm", comm],
+                           env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert res["n_gpus"] == 1 and res["value"] > 0 and "rehearsal" in res
+        ar = res["allreduce"]
+        assert ar["backend"] == "nccl" and ar["group_world"] == 1 and ar["collectives_per_step"] == 4 and ar["bytes"] > 7e7
+        assert ar["rccl"].get("matches_process_group") is True and ar["rccl"]["world"] == 1, ar["rccl"]
+        assert res["rank_sync"]["identical_on_ranks"] == 1

@@ -20,6 +20,30 @@ import torch.distributed as dist
 from torch import nn
 
 
+def _live_world(group=None):
+    """(world size, whether the collectives are issued).  They are issued whenever more than one rank takes part -- and, for a REHEARSAL
+    of the RCCL path on one GPU, also in a one-rank process group when TF_REHEARSE_COLLECTIVES=1: every all-reduce, event and stream of the
+    N > 1 step then runs against the real backend (bench.py's rehearsal entry; tests/test_gpu_ddp.py), only without peers."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, False
+    world = dist.get_world_size(group)
+    return world, world > 1 or os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"
+
+
+def _phantom_peers(g, handle=None):
+    """Rehearsal only (TF_REHEARSE_PHANTOM_PEERS=k, with TF_REHEARSE_COLLECTIVES=1): a one-rank sum all-reduce leaves the buffer as it
+    was, so a collective that ran BEFORE its gradients were written (a missing event edge) would go unnoticed.  With k phantom peers the
+    reduced range is multiplied by 1 + k right behind the collective, on the collective's stream -- as if k peers had contributed the same
+    gradient: whatever is written into the range after the collective misses the factor, and tests/test_gpu_ddp.py sees it."""
+    k = int(os.environ.get("TF_REHEARSE_PHANTOM_PEERS", "0"))
+    if not k or os.environ.get("TF_REHEARSE_COLLECTIVES") != "1":
+        return handle
+    if handle is not None:
+        handle.wait()                       # (RCCL: the CURRENT stream waits for the collective; the host does not)
+    g.mul_(float(1 + k))
+    return None
+
+
 class FlatParams:
     """Re-homes a module's trainable parameters (and their gradients) as views into two flat fp32 buffers."""
 
@@ -62,23 +86,24 @@ class DataParallelReducer:
         self.grad = flat_grad
         self.group = group
         self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm: the C ABI's tf_allreduce_bucket instead of torch's
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world, self.live = _live_world(group)
         n = flat_grad.numel()
         per = max(1, int(bucket_mb * (1 << 20) // 4))
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
         self.bytes_per_step = n * 4
 
     def all_reduce(self, async_op: bool = False):
-        if self.world == 1:
+        if not self.live:
             return []
         handles = []
         if self.bucket_comm is not None:              # stream-ordered: nothing to wait for on the host
             for s, e in self.buckets:
                 self.bucket_comm.all_reduce_(self.grad[s:e])
+                _phantom_peers(self.grad[s:e])
             return handles
         for s, e in self.buckets:
-            h = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-            if async_op:
+            h = _phantom_peers(self.grad[s:e], dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+            if async_op and h is not None:
                 handles.append(h)
         return handles
 
@@ -93,7 +118,7 @@ class LayerwiseReducer:
     def __init__(self, flat: FlatParams, group=None, bucket_comm=None):
         self.flat, self.group = flat, group
         self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm or None (torch.distributed's process group)
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world, self.live = _live_world(group)
         self.bytes_per_step = flat.grad.numel() * 4
         self.handles = []
         self.comm = None
@@ -128,13 +153,14 @@ class LayerwiseReducer:
         self.collectives = 0          # all-reduces issued so far (every rank must issue the same number: tests assert it)
 
     joins_overlap = True      # finish() joins the encoder runtime's side stream: the per-layer backward calls need not
+    _debug_break_edge = None  # tests only ("side" / "main"): drop one event edge, the negative control of tests/test_gpu_ddp.py's RCCL rehearsal
 
     def hook(self, module, layer):
         """Called right after layer `layer`'s backward has been ENQUEUED.  Its weight gradients are produced partly on the
         chain's stream and partly on the runtime's side stream, which the per-layer calls do not join (a join stalls the chain
         until that layer's last wgrad has finished: -2.5 % on one GPU).  The collective therefore runs behind a communication
         stream that waits for an event on each of the two."""
-        if self.world == 1 or not self.active:
+        if not self.live or not self.active:
             return
         from transfusion_amd import ops
         lo, hi = self.ranges[layer]
@@ -147,13 +173,18 @@ class LayerwiseReducer:
             return
         if self.comm is None:
             self.comm = torch.cuda.Stream(device=g.device)
-        self.comm.wait_event(main.record_event())
-        self.comm.wait_event(side.record_event())
-        if self.bucket_comm is not None:
-            self.bucket_comm.all_reduce_(g[lo:hi], stream=self.comm)         # tf_allreduce_bucket, enqueued on the communication stream
-            return
+        if self._debug_break_edge != "main":
+            self.comm.wait_event(main.record_event())
+        if self._debug_break_edge != "side":
+            self.comm.wait_event(side.record_event())
         with torch.cuda.stream(self.comm):
-            self.handles.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.bucket_comm is not None:
+                self.bucket_comm.all_reduce_(g[lo:hi], stream=self.comm)     # tf_allreduce_bucket, enqueued on the communication stream
+                _phantom_peers(g[lo:hi])
+                return
+            h = _phantom_peers(g[lo:hi], dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if h is not None:
+                self.handles.append(h)
 
     def finish(self):
         from transfusion_amd import ops
@@ -187,7 +218,7 @@ class OrderedRangeReducer:
 
     def __init__(self, flat: FlatParams, module: nn.Module, group=None, bucket_comm=None):
         self.flat, self.group, self.bucket_comm = flat, group, bucket_comm
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world, self.live = _live_world(group)
         self.bytes_per_step = flat.grad.numel() * 4
         total = flat.grad.numel()
         slice_of = {n: (off, num) for n, _, off, num in flat.slices}
@@ -285,7 +316,7 @@ class OrderedRangeReducer:
         return hook
 
     def _complete(self, u):
-        if self.world == 1 or not self.active or self._ready[u]:
+        if not self.live or not self.active or self._ready[u]:
             return
         self._ready[u] = True
         self._seen.append(u)
@@ -318,18 +349,21 @@ class OrderedRangeReducer:
             self.comm = torch.cuda.Stream(device=g.device)
         for ev in unit.pop("events", []):
             self.comm.wait_event(ev)
-        if self.bucket_comm is not None:
-            self.bucket_comm.all_reduce_(g, stream=self.comm)
-            return
         with torch.cuda.stream(self.comm):
-            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.bucket_comm is not None:
+                self.bucket_comm.all_reduce_(g, stream=self.comm)
+                _phantom_peers(g)
+                return
+            h = _phantom_peers(g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if h is not None:
+                self.handles.append(h)
 
     def finish(self):
         g = self.flat.grad
         if g.is_cuda:
             from transfusion_amd import ops
             ops.join_overlap(g.device)
-        if self.world > 1:
+        if self.live:
             if self.order is None:
                 # first step: everything at once, then agree on the order (identical on every rank, or no overlap at all)
                 if g.is_cuda:                # ... behind every stream a unit's gradients came from (level streams and their side streams)
@@ -342,6 +376,7 @@ class OrderedRangeReducer:
                     self.bucket_comm.all_reduce_(g)
                 else:
                     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                _phantom_peers(g)
                 mine = self._seen + [u for u in range(len(self.units)) if u not in self._seen]
                 orders = [None] * self.world
                 dist.all_gather_object(orders, mine, group=self.group)
@@ -356,6 +391,7 @@ class OrderedRangeReducer:
                         self.bucket_comm.all_reduce_(g)
                     else:
                         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                    _phantom_peers(g)
                 else:
                     for u in self.order[self._next:]:
                         if g.is_cuda:
@@ -390,20 +426,21 @@ class FusionTrainStep:
             if hasattr(m, "accumulate_into_grad"):
                 m.accumulate_into_grad = True
         self.bucket_comm = None
-        if comm == "rccl" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if comm == "rccl" and _live_world()[1]:
             if not self.flat.grad.is_cuda:
                 raise ValueError("comm='rccl' needs the parameters on a GPU")
             from transfusion_amd.comm import BucketComm
             self.bucket_comm = BucketComm.from_process_group(self.flat.grad.device)
         self.reducer = DataParallelReducer(self.flat.grad, bucket_mb, bucket_comm=self.bucket_comm)
         self.world = self.reducer.world
+        live = self.reducer.live                  # collectives are issued (world > 1, or a one-rank rehearsal: _live_world)
         self.layerwise = None
         encoders = [m for m in module.modules() if hasattr(m, "layer_grad_hook")]
         force = os.environ.get("TF_FORCE_LAYERWISE") == "1"      # measurement hook: the per-layer call path on one GPU (no-op reduce)
-        if overlap and (self.world > 1 or force) and len(encoders) == 1 and encoders[0] is module:
+        if overlap and (live or force) and len(encoders) == 1 and encoders[0] is module:
             self.layerwise = LayerwiseReducer(self.flat, bucket_comm=self.bucket_comm)
             module.layer_grad_hook = self.layerwise.hook
-        elif overlap and (self.world > 1 or force):
+        elif overlap and (live or force):
             # any other module tree (the 4-level wrapper, encoder + heads, ...): units fired in a learnt, rank-agreed order
             self.layerwise = OrderedRangeReducer(self.flat, module, bucket_comm=self.bucket_comm)
         if lr_scale is None:
@@ -439,7 +476,7 @@ class FusionTrainStep:
         # reducer their post-accumulate hooks are what reports a range complete, so there autograd keeps accumulating)
         for m in module.modules():
             if hasattr(m, "accumulate_linear_grad"):
-                m.accumulate_linear_grad = self.world == 1
+                m.accumulate_linear_grad = not live
         self._all_params = [p for _, p, _, _ in self.flat.slices]
         self._shadow_owners = [m for m in module.modules() if hasattr(m, "mark_weights_updated")]
 
