@@ -23,8 +23,9 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 7
+#define TF_ABI_VERSION 8
 #define TF_MAX_LAYERS 16
+#define TF_MAX_GROUPS 8     /* ragged groups (ABI v8): at most this many row ranges of unequal size in one grouped launch */
 
 enum TfEpilogue {
   TF_EPI_NONE = 0,            // C = acc
@@ -67,6 +68,10 @@ typedef struct TfGemmArgs {
   // fp32-accuracy mode, epilogues NONE / BIAS (ABI v7): c_is_f32 != 0 -> C is an fp32 [M, ldc] tensor written directly (C_lo unused):
   // the tokens K1 hands the encoder and the gradient K9 hands back are fp32 tensors, not plane pairs
   int c_is_f32;
+  // RAGGED groups (ABI v8; the reference's real FPN geometry gives level 0 four times the tokens of levels 1 - 3,
+  // cross_fusion_config_sym_ego_res50.yml:8-17): group_rows[0] > 0 -> range g holds group_rows[g] rows (groups <= TF_MAX_GROUPS, the
+  // counts add up to M) instead of M / groups; all zero = equal ranges.  Tiles never straddle two ranges either way.
+  int group_rows[TF_MAX_GROUPS];
 } TfGemmArgs;
 
 /* row-wise fp8 (e4m3) quantisation: dst[r][c] = fp8(src[r][c] / scale[r]), scale[r] = max|src[r][:]| / 448 (1 for an all-zero row);
@@ -87,6 +92,7 @@ typedef struct TfWgradArgs {
   // grouped launch (see TfGemmArgs.groups): `groups` equal row ranges of dY / X, range g accumulates into the dW / db that start
   // g * dw_gstride BYTES after dW / db; m_chunk counts rows inside a group
   int groups; long long dw_gstride;
+  int group_rows[TF_MAX_GROUPS];          // ragged row ranges (see TfGemmArgs.group_rows; tf_gemm_wgrad_multi only), all zero = equal
 } TfWgradArgs;
 /* Several weight gradients as ONE launch (tf_gemm_wgrad_multi): a layer's four linears (torch18_adapters.py:683-685,608,111: in-proj,
  * out-proj, linear1, linear2) are ready together at the end of the layer's backward and fill the chip together at two row chunks per
@@ -170,6 +176,10 @@ typedef struct TfLnArgs {
   // parameter groups (see TfGemmArgs.groups): pgroups equal ranges of the `rows`, range g normalised with the gamma / beta that start
   // g * p_gstride BYTES after gamma / beta (dgamma / dbeta likewise)
   int pgroups; long long p_gstride;
+  int group_rows[TF_MAX_GROUPS];          // ragged parameter groups (see TfGemmArgs.group_rows): rows of range g, all zero = equal ranges
+  // x-side row of EVERY row given explicitly (ragged visual rows of a packed batch: row r of the output is token r of the concatenated
+  // visual tokens, x_row_map[r] its packed row); overrides rows_per_group / x_group_stride / x_group_row0 on the x side.  null: unused
+  const int* x_row_map;
 } TfLnArgs;
 
 typedef struct TfAssembleArgs {
@@ -193,6 +203,11 @@ typedef struct TfAssembleArgs {
   // parameter groups (see TfGemmArgs.groups): sample b belongs to group b / (B / pgroups); group g adds the kind embeddings that start
   // g * p_gstride BYTES after kind_v / kind_l (dkind_v / dkind_l likewise); with a row_map the rows must be group-major
   int pgroups; long long p_gstride;
+  // ragged groups (ABI v8, packed batches only): the samples of group g carry group_nv[g] <= Nv visual tokens -- vis / dvis are then the
+  // CONCATENATION [sum_g (B / pgroups) group_nv[g], d] (group-major, sample, token), positions >= group_nv[g] of the dense index space
+  // (b * (Nv + Nl) + s) do not exist -- and group g owns group_rows[g] of the packed rows (backward: whose kind-embedding gradients
+  // a workgroup accumulates).  group_nv[0] == 0: every sample has Nv visual tokens, equal ranges.
+  int group_nv[TF_MAX_GROUPS]; int group_rows[TF_MAX_GROUPS];
 } TfAssembleArgs;
 
 // rowsum(dO . O) per (b, head, s)
@@ -510,6 +525,14 @@ typedef struct TfEncoderDesc {
                                  * (tf_encoder_plan_ex sizes it).  pe / pe_lang are shared by the groups; attn_block_bits must be null;
                                  * with packed_rows every group must drop the same tokens (same lang_pad_mask rows).  0 / 1: one encoder. */
   long long param_gstride;
+  int group_nv[TF_MAX_GROUPS];  /* RAGGED groups (ABI v8): group_nv[0] > 0 -> the samples of group g carry group_nv[g] visual tokens (Nv is the
+                                 * LARGEST of them and shapes the dense index space b * (Nv + Nl) + s, the attention grid, the dropout
+                                 * bitmasks).  The reference's real FPN geometry: 28 x 28 tokens on level 0, 14 x 14 on levels 1 - 3
+                                 * (cross_fusion_config_sym_ego_res50.yml:8-17) -- with this all four levels are ONE launch sequence.
+                                 * Needs packed_rows > 0 = sum_g (B / groups) group_nv[g] + the un-masked language tokens of all groups
+                                 * (every group drops the same tokens).  vis / vis_out / d_vis_out / d_vis are then the CONCATENATION
+                                 * [sum_g (B / groups) group_nv[g], d], group-major; pe is read by its first group_nv[g] rows (the tables
+                                 * of the levels must agree on their common prefix: the sin1d tables do).  All zero: every group has Nv. */
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);   /* precision 0 */

@@ -46,7 +46,7 @@ def test_library_holds_the_expected_kernels(table):
     assert len(table) > 150
     for must in ("gemm_nt_big_kernel<1, 9, false, false, 2>", "wgrad_tn2_kernel<false, 3>", "attn_fwd_kernel<192, false>",
                  "attn_bwd_dkv16_kernel<192, false, 64, true, 2>", "attn_bwd_dq_ds_kernel<192>", "attn_delta_kernel", "row_map_kernel",
-                 "ln_bwd_kernel<2, 8, false>", "radam_kernel", "wgrad_multi_kernel<false, 3, 1>", "wgrad_multi_kernel<true, 3, 1>",
+                 "ln_bwd_kernel<2, 8, false, false>", "radam_kernel", "wgrad_multi_kernel<false, 3, 1>", "wgrad_multi_kernel<true, 3, 1>",
                  "attn_bwd_dkv_pair_kernel<192, false>", "attn_bwd_dkv_pair_kernel<192, true>"):
         assert must in table, must
     # every kernel was compiled for wave64 workgroups of at most 1024 threads and declares its registers
@@ -100,5 +100,5 @@ def test_occupancy_assumptions(table):
     assert alloc("wgrad_multi_kernel<false, 3, 1>") <= 256           # two 4-wave workgroups per CU
     assert alloc("wgrad_multi_kernel<true, 3, 1>") <= 256
     assert alloc("attn_bwd_dkv_pair_kernel<192, false>") <= 256      # the wave pair of a SIMD
-    assert alloc("ln_bwd_kernel<2, 8, false>") <= 128                # four waves per SIMD at d <= 1024
+    assert alloc("ln_bwd_kernel<2, 8, false, false>") <= 128                # four waves per SIMD at d <= 1024
     assert alloc("gemm_nt_big_kernel<1, 9, false, false, 1>") <= 256 # the two-workgroups-per-CU form

@@ -73,7 +73,7 @@ def test_layerwise_reducer_drives_the_own_communicator(monkeypatch):
         comm = None
         if with_comm:
             comm = BucketComm(1, 0, BucketComm.new_unique_id(), dev)
-            tr.layerwise.world = 2                       # take the exchange branch (the optimiser's 1 / world stays 1)
+            tr.layerwise.live = True                     # take the exchange branch (the optimiser's 1 / world stays 1)
             tr.layerwise.bucket_comm = comm
 
         def loss_fn(m, batch):

@@ -750,3 +750,70 @@ def test_backward_through_repacked_weight_shadows_raises(dev):
     y2.float().sum().backward()                        # the current graph is fine
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         y1.float().sum().backward()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protected", [True, False])
+def test_linear_input_from_another_stream_survives_until_its_weight_gradient_ran(dev, protected, monkeypatch):
+    """The root cause of round 4's one-off 0.37 two-rank gradient mismatch, as a unit test.  ``ops.linear`` SAVES its input for the weight
+    gradient, and when that input is already bf16 / contiguous / unpadded it saves the caller's own tensor -- which may have been
+    allocated on another stream (the grouped encoder's output on the main stream, handed to a level's back-projection on a level
+    stream).  Autograd replays the node on the level stream and drops the saved tensor as soon as the backward is ENQUEUED; the caching
+    allocator then recycles the block for the next same-sized allocation on its home stream, whose kernel may run before the weight
+    gradient has read it.  Here the weight gradient sits behind a 3-ms spin (ops.debug_delay_wgrad) and a main-stream node of the same
+    graph, which runs right after the linear node's backward, asks the allocator for blocks of the input's size until it is handed the
+    input's own block, and scribbles over it.  With ``record_stream`` (ops._LinearFn.forward) the allocator never hands that block out
+    while the level stream still owes the weight gradient; ``protected=False`` is the negative control (record_stream disabled): the
+    block IS handed out and the weight gradient comes out wrong."""
+    from transfusion_amd import ops
+    M, K, N = 4096, 512, 256
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(M, K, generator=g).to(dev)
+    w0 = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    cot = torch.randn(M, N, generator=g).to(dev)
+    ref = cot.to(torch.bfloat16).float().t() @ x0.to(torch.bfloat16).float()          # dW = dY^T X on the bf16-rounded operands
+    target = {"ptr": 0, "hit": False}
+
+    class Scribbler(torch.autograd.Function):              # identity; its backward runs on the main stream, after the linear node's
+        @staticmethod
+        def forward(ctx, t):
+            return t * 1.0
+
+        @staticmethod
+        def backward(ctx, grad):
+            held = []
+            for _ in range(512):                           # the allocator serves cached free blocks before it asks the driver for memory
+                j = torch.empty(M, K, dtype=torch.bfloat16, device=grad.device)
+                held.append(j)
+                if j.data_ptr() == target["ptr"]:
+                    j.fill_(7.0)
+                    target["hit"] = True
+                    break
+            return grad
+
+    if not protected:
+        monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None)
+    w = torch.nn.Parameter(w0.clone())
+    main, st = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    xb = x0.to(torch.bfloat16).requires_grad_(True)
+    mid = xb * 1.0                                         # an intermediate allocated on main: the tensor ops.linear will save
+    target["ptr"] = mid.data_ptr()
+    probe = Scribbler.apply(mid)                           # created BEFORE the linear node: its backward runs after it
+    st.wait_stream(main)
+    with torch.cuda.stream(st):
+        y = ops.linear(mid, w)
+    main.wait_stream(st)
+    loss = (y.float() * cot).sum() + probe.float().sum()
+    del mid, probe, y                                      # only the graph holds the intermediate now
+    prev = ops.debug_delay_wgrad(3000)
+    try:
+        loss.backward()
+    finally:
+        ops.debug_delay_wgrad(prev)
+        monkeypatch.undo()
+    torch.cuda.synchronize()
+    err = ((w.grad.float() - ref).norm() / ref.norm()).item()
+    if protected:
+        assert not target["hit"] and err < 1e-2, (target["hit"], err)
+    else:
+        assert target["hit"] and err > 5e-2, (target["hit"], err)

@@ -426,11 +426,12 @@ def test_three_levels_in_one_forward_against_oracle(monkeypatch, precision, stre
     assert rel(lang_dev.grad.cpu()[valid], lang_ref.grad[valid]) < gtol          # sum over the three levels (valid rows; padded rows get none)
 
 
-@pytest.mark.parametrize("precision,packed", [(16, True), (16, False), (32, True)])
-def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, packed):
+@pytest.mark.parametrize("precision,packed,ragged", [(16, True, True), (16, True, False), (16, False, False), (32, True, True)])
+def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, packed, ragged, monkeypatch):
     """The reference's level loop over four levels with its real token geometry (Nv = 4N, N, N, N; one shared, padded narration input)
     against the REFERENCE-generated fixture, through the path the training step takes: parameters in FusionTrainStep's flat layout, so
-    that levels 1 - 3 run as ONE grouped encoder call and level 0 beside them on its own stream.  Every level's fused map, the gradient
+    that all four levels run as ONE RAGGED grouped encoder call (packed rows; TfEncoderDesc.group_nv) -- or, with dense rows or
+    TF_RAGGED_GROUPS=0, levels 1 - 3 as one grouped call and level 0 beside them on its own stream.  Every level's fused map, the gradient
     of every feature map, of the shared narration tokens (summed over the levels) and of EVERY parameter; bf16 and fp32-accuracy mode,
     packed and dense rows."""
     if not torch.cuda.is_available():
@@ -440,6 +441,7 @@ def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, pac
     from transfusion_amd.runner.config import load_fusion_config
     from transfusion_amd.runner.trainer import FusionTrainStep
     dev = torch.device("cuda:0")
+    monkeypatch.setenv("TF_RAGGED_GROUPS", "1" if ragged else "0")
     name = "mlevel_4n_n_n_n"
     cfg = MLEVEL_CASES[name]
     g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
@@ -488,9 +490,14 @@ def test_multi_level_fixture_through_the_grouped_path(golden_dir, precision, pac
 
     tr.step([None], loss_fn)
     torch.cuda.synchronize()
-    # the path under test: levels 1 - 3 as one grouped call, level 0 beside it
-    assert int(model.cross_fusion_encoders[1]._last_desc.groups) == 3 and int(model.cross_fusion_encoders[0]._last_desc.groups) in (0, 1)
-    assert (int(model.cross_fusion_encoders[1]._last_desc.packed_rows) > 0) == packed
+    # the path under test: all four levels as one ragged call, or levels 1 - 3 as one grouped call with level 0 beside it
+    if ragged:
+        desc = model.cross_fusion_encoders[0]._last_desc
+        assert int(desc.groups) == 4 and list(desc.group_nv)[:4] == [l["H"] // l["p"] * (l["W"] // l["p"]) for l in lv] and int(desc.packed_rows) > 0
+        assert len(set(list(desc.group_nv)[:4])) > 1
+    else:
+        assert int(model.cross_fusion_encoders[1]._last_desc.groups) == 3 and int(model.cross_fusion_encoders[0]._last_desc.groups) in (0, 1)
+        assert (int(model.cross_fusion_encoders[1]._last_desc.packed_rows) > 0) == packed
     ftol, gtol = (1e-2, 3e-2) if precision == 16 else (1e-3, 1e-3)
     for i in range(n):
         pre = f"l{i}/"
@@ -600,7 +607,7 @@ def test_wrapper_switches_against_reference_fixtures(golden_dir, name, precision
     assert float(torch.from_numpy(g["grad_lang"])[~valid].abs().max()) == 0.0 and float(lang.grad.cpu()[~valid].abs().max()) == 0.0
 
 
-def _level_stream_step(dev, delay_us):
+def _level_stream_step(dev, delay_us, path="streams"):
     """One FusionTrainStep.step of a two-level wrapper whose levels run on their own streams (unequal token grids: the level loop) with
     FROZEN inputs: feature maps and narration tokens need no gradient, so the last backward node on each level stream is K1's weight
     gradient, written straight into the flat gradient buffer.  -> (parameters before, after, parameter ranges by name); with
@@ -640,12 +647,13 @@ def _level_stream_step(dev, delay_us):
         torch.cuda.synchronize()
     finally:
         ops.debug_delay_wgrad(prev)
-    assert model._last_path == "streams"
+    assert model._last_path == path
     ranges = {n: (off, off + num) for n, _, off, num in tr.flat.slices}
     return before.cpu(), tr.flat.flat.cpu().clone(), ranges
 
 
-def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen():
+@pytest.mark.parametrize("ragged", [False, True])
+def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen(ragged, monkeypatch):
     """One of the edges audited for round 4's intermittent two-rank mismatch: at world 1 the encoders and K1 / K9 add
     their weight gradients straight into ``.grad`` on the LEVEL stream and hand autograd None; with frozen feature maps nothing
     downstream of a level's K1 needs a gradient, so no tensor ever flows from the level stream back to the main stream.  What still
@@ -655,8 +663,10 @@ def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     dev = torch.device("cuda:0")
-    b0, plain, ranges = _level_stream_step(dev, 0)
-    b1, late, _ = _level_stream_step(dev, 3000)
+    # ragged=False: the level loop on level streams; True: the two levels as one ragged grouped call, K1 / K9 beside it on level streams
+    monkeypatch.setenv("TF_RAGGED_GROUPS", "1" if ragged else "0")
+    b0, plain, ranges = _level_stream_step(dev, 0, "grouped" if ragged else "streams")
+    b1, late, _ = _level_stream_step(dev, 3000, "grouped" if ragged else "streams")
     assert torch.equal(b0, b1)
     m0, m1 = plain - b0, late - b0
     for key in ("cross_fusion_encoders.0.t_encoder.layers.0.linear1.weight", "cross_fusion_encoders.1.t_encoder.layers.1.self_attn.in_proj_weight",
@@ -666,7 +676,7 @@ def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen():
         assert ((m1[lo:hi] - m0[lo:hi]).norm() / m0[lo:hi].norm()).item() < 2e-2, (key, "the optimiser ran before this gradient was written")
 
 
-def test_capturing_level_streams_with_side_streams_raises_instead_of_crashing():
+def test_capturing_level_streams_with_side_streams_raises_instead_of_crashing(monkeypatch):
     """ROCm 7.2's hipStreamEndCapture segfaults on a capture that holds level-stream forks WITH a side-stream fork inside each (round 3).
     The product refuses such a capture before it launches anything (CrossFusionBoxWrapper._refuse_nested_fork_capture): a user who wraps
     a step in torch.cuda.graph with the default settings gets a ValueError that names the ways out, not a core dump."""
@@ -674,6 +684,7 @@ def test_capturing_level_streams_with_side_streams_raises_instead_of_crashing():
         pytest.skip("needs an MI355X")
     from transfusion_amd import ops
     dev = torch.device("cuda:0")
+    monkeypatch.setenv("TF_RAGGED_GROUPS", "0")        # the level loop on level streams (packed rows would group the two levels raggedly)
     model, tr = _level_stream_step(dev, None)
     assert ops.wgrad_overlap_enabled()
     g = torch.Generator().manual_seed(77)

@@ -18,6 +18,8 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(42)
 ps, chans = [4, 4, 2, 1], [256, 512, 1024, 2048]
 grids = [28, 14, 14, 14] if os.environ.get("REAL") == "1" else [14, 14, 14, 14]        # REAL=1: the reference's FPN geometry (bench leg wrapper_b4_real)
+if os.environ.get("GRIDS"):                          # e.g. GRIDS=19,19,19,19: four equal levels with about the real geometry's total token count
+    grids = [int(x) for x in os.environ["GRIDS"].split(",")]
 shapes = [(g * p, g * p) for g, p in zip(grids, ps)]
 fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
 fusion.update({"fpn_features": [0, 1, 2, 3], "replace_fpn_features": True})       # run.narr_fusion.* keys of the experiment YAML
@@ -89,6 +91,21 @@ print(f"host enqueue {t_host:.2f} ms/step")
 print(f"wrapper fwd+bwd, B={B}, 4 levels x 4 layers: {ms:.2f} ms/step ({B / ms * 1e3:.1f} samples/s), loss {float(loss):.4f}")
 if os.environ.get("GRAPH") == "1":
     sys.exit(0)                                     # (the launch tracer sees launches, a replay makes none)
+if os.environ.get("PROFILE") == "1":
+    # where the HOST time of a step goes: cProfile over 10 steps (the backward runs on the autograd engine's thread, which the profiler
+    # does not see: it shows as the wall time of loss.backward() on this thread), sorted by own time and by cumulative time
+    import cProfile, pstats, gc
+    gc.collect(); gc.freeze()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    for key in ("tottime", "cumulative"):
+        print(f"---- host profile, 10 steps, by {key} ----")
+        pstats.Stats(pr).strip_dirs().sort_stats(key).print_stats(int(os.environ.get("TOP", 45)))
+    sys.exit(0)
 lib = Lb.load()
 Lb.check(lib.tf_trace_start(), "trace")
 for _ in range(2):

@@ -24,24 +24,51 @@ namespace {
 constexpr int BN = 128;
 int num_cus();
 // row tiles of a launch: TfGemmArgs.groups independent row ranges of M / groups rows each (tiles never straddle two groups)
-inline long row_tiles(int M, int G, int BM) { const int g = G > 1 ? G : 1; return (long)g * ((M / g + BM - 1) / BM); }
-inline long row_tiles(const TfGemmArgs* a, int BM) { return row_tiles(a->M, a->groups, BM); }
+// gr: ragged row ranges (TfGemmArgs.group_rows) or null / [0] == 0 for equal ones
+inline long row_tiles(int M, int G, int BM, const int* gr = nullptr) {
+  const int g = G > 1 ? G : 1;
+  if (g > 1 && gr != nullptr && gr[0] > 0) {
+    long t = 0;
+    for (int i = 0; i < g; ++i) t += (gr[i] + BM - 1) / BM;
+    return t;
+  }
+  return (long)g * ((M / g + BM - 1) / BM);
+}
+inline long row_tiles(const TfGemmArgs* a, int BM) { return row_tiles(a->M, a->groups, BM, a->group_rows); }
 // Device side of the grouping: logical tile -> (group, tile inside the group); the local copy of the arguments is narrowed to the
 // group -- rows [m_lo, M) of the global row space, the group's weight / bias / scale tensors -- so that every later bound and clamp of
 // the kernel (which all read g.M) holds unchanged.  Returns the tile index inside the group.
 __device__ __forceinline__ int enter_group(TfGemmArgs& g, int logical, int BM, int tiles_n, int& m_lo) {
   m_lo = 0;
   if (g.groups <= 1) return logical;
-  const int Mg = g.M / g.groups, tiles_g = ((Mg + BM - 1) / BM) * tiles_n;
-  const int grp = logical / tiles_g;
+  int grp, Mg, inside;
+  if (g.group_rows[0] > 0) {                      // ragged ranges: walk the (at most TF_MAX_GROUPS) tile counts; constant indices, scalar work
+    int t = logical, lo = 0, left = logical;
+    grp = 0; Mg = g.group_rows[0];
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+      const int tg = ((g.group_rows[i] + BM - 1) / BM) * tiles_n;
+      if (!found && i < g.groups) {
+        if (t < tg || i == g.groups - 1) { found = true; grp = i; Mg = g.group_rows[i]; m_lo = lo; left = t; }
+        t -= tg; lo += g.group_rows[i];
+      }
+    }
+    inside = left;
+  } else {
+    Mg = g.M / g.groups;
+    const int tiles_g = ((Mg + BM - 1) / BM) * tiles_n;
+    grp = logical / tiles_g;
+    m_lo = grp * Mg;
+    inside = logical - grp * tiles_g;
+  }
   const long long off = (long long)grp * g.w_gstride;
-  m_lo = grp * Mg;
   g.M = m_lo + Mg;
   g.W = (const unsigned char*)g.W + off;
   if (g.W_lo != nullptr) g.W_lo = (const unsigned char*)g.W_lo + off;
   if (g.bias != nullptr) g.bias = (const float*)((const unsigned char*)g.bias + off);
   if (g.scale_w != nullptr) g.scale_w = (const float*)((const unsigned char*)g.scale_w + off);
-  return logical - grp * tiles_g;
+  return inside;
 }
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per 128-row x 64-deep operand tile (wgrad; the W operand at BK = 64)
 constexpr int CT_STRIDE = 272;                    // C-tile row stride in LDS (256 B + 16 B pad)
@@ -1129,14 +1156,14 @@ int num_cus();
 // the taller tile.  64- and 96-row tiles (MI = 2, 3) exist for SMALL row counts -- the reference's own per-GPU batch of 4 - 5 samples is
 // ~2,000 - 3,500 token rows, where a 128-row tiling of an N = 768 GEMM is ~100 - 170 tiles for 512 slots.
 int plan_cus();
-int pick_mi(int M, int N, int G = 1) {
+int pick_mi(int M, int N, int G = 1, const int* gr = nullptr) {
   const int slots = 2 * plan_cus();
   const int tn = (N + BN - 1) / BN;
   static const int env_lo = TF_ENV_INT("TF_GEMM_MI_MIN", 2);       // experiment switch
   // half-filled chips: the time is one tile's, so the shortest tile that still leaves every CU at most one workgroup wins
   int best = 6; double best_cost = -1.0;
   for (int mi = 6; mi >= (env_lo < 2 ? 2 : env_lo); --mi) {
-    const long tiles = row_tiles(M, G, 32 * mi) * tn;
+    const long tiles = row_tiles(M, G, 32 * mi, gr) * tn;
     const long rounds = (tiles + slots - 1) / slots;
     // two workgroups share a CU: a round in which at most half the slots are taken runs each workgroup alone on its CU (~1.6x as fast)
     const double share = (tiles - (rounds - 1) * slots) * 2 <= slots ? 0.62 : 1.0;
@@ -1238,13 +1265,13 @@ int num_cus() {
 // large tile: 160 .. 288 rows (MF = 5 .. 9), one workgroup per CU: minimise rounds x (height + the per-tile fixed cost, ~3 row
 // blocks' worth: fill, the C-tile burst).  The row count is whatever the batch's real tokens add up to (packed batches), so
 // the height that makes the tile grid an exact number of rounds changes from step to step; fp8 / fp32-accuracy operands keep 8 / 9.
-int pick_mf(int M, int N, int mf_lo = 5, int G = 1) {
+int pick_mf(int M, int N, int mf_lo = 5, int G = 1, const int* gr = nullptr) {
   const int tn = (N + BIG_BN - 1) / BIG_BN, slots = plan_cus();
   static const int env_lo = TF_ENV_INT("TF_GEMM_MF_MIN", 0);      // experiment switch
   if (env_lo > mf_lo) mf_lo = env_lo > 9 ? 9 : env_lo;
   int best = 9; long best_cost = -1;
   for (int mf = 9; mf >= mf_lo; --mf) {                 // ties go to the taller tile (fewer W re-stagings)
-    const long tiles = row_tiles(M, G, 32 * mf) * tn;
+    const long tiles = row_tiles(M, G, 32 * mf, gr) * tn;
     const long cost = ((tiles + slots - 1) / slots) * (mf + 3);
     if (best_cost < 0 || cost < best_cost) { best = mf; best_cost = cost; }
   }
@@ -1277,7 +1304,8 @@ extern "C" void tf_set_gemm_concurrency(int n) { g_gemm_concurrency.store(n < 1 
 
 extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   if (a->M <= 0 || a->N <= 0) return 0;
-  if (a->groups > 1 && (a->M % a->groups) != 0) return -7;          // equal row ranges
+  if (a->groups > 1 && a->group_rows[0] > 0) { if (!tf_ragged_ok(a->group_rows, a->groups, a->M)) return -7; }   // ragged row ranges
+  else if (a->groups > 1 && (a->M % a->groups) != 0) return -7;     // equal row ranges
   if (a->K <= 0 || a->K % 64 != 0 || a->N % 8 != 0) return -2;
   if ((a->lda % 8) || (a->ldw % 8) || (a->ldc % 8)) return -3;
   static const int big = TF_ENV_INT("TF_GEMM_BIG", 1);
@@ -1305,9 +1333,9 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
   static const int split_mf_lo = TF_ENV_INT("TF_GEMM_SPLIT_MF_MIN", 5);     // experiment switch (8: the two heights the mode had before)
   bool use_big = big && a->M >= 1024 && a->N >= 256;
   if (use_big) {
-    const int mfp = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups);
+    const int mfp = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups, a->group_rows);
     const long tb = row_tiles(a, 32 * mfp) * ((a->N + BIG_BN - 1) / BIG_BN);
-    const int mi = split ? 4 : pick_mi(a->M, a->N, a->groups);            // (the fp32-accuracy mode has one tile height of this kernel)
+    const int mi = split ? 4 : pick_mi(a->M, a->N, a->groups, a->group_rows);            // (the fp32-accuracy mode has one tile height of this kernel)
     const long ts = row_tiles(a, 32 * mi) * ((a->N + BN - 1) / BN);
     const int pc = plan_cus();
     const double t_big = (double)((tb + pc - 1) / pc) * (13.3 + 0.0264 * a->K) * (mfp / 9.0);
@@ -1335,7 +1363,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     }
   }
   if (use_big) {
-    const int mf = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups);
+    const int mf = pick_mf(a->M, a->N, split ? split_mf_lo : 5, a->groups, a->group_rows);
     char nm[56];
     snprintf(nm, sizeof(nm), split ? "gemm_nt_big_kernel<%d, %d, x3>" : "gemm_nt_big_kernel<%d, %d>", a->epilogue, mf);
     TfTraceScope tr(nm, stream, fl);
@@ -1348,7 +1376,7 @@ extern "C" int tf_launch_gemm_nt(const TfGemmArgs* a, hipStream_t stream) {
     TfTraceScope tr(nm, stream, fl);
     return launch_gemm_mi<4, 64, true>(a, stream);
   }
-  const int mi_sel = pick_mi(a->M, a->N, a->groups);
+  const int mi_sel = pick_mi(a->M, a->N, a->groups, a->group_rows);
   // at most about one workgroup per CU: the 4-slot ring form (see the kernel's header).  TF_GEMM_RING = percent of the CU count up
   // to which a grid takes it (0 = never).
   static const int ring_pct = TF_ENV_INT("TF_GEMM_RING", 100);
@@ -1406,7 +1434,7 @@ extern "C" int tf_launch_wgrad_tn(const TfWgradArgs* a_in, hipStream_t stream) {
   TfWgradArgs a = *a_in;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
   const int ngroups = a.groups > 1 ? a.groups : 1;
-  if (a.M % ngroups) return -7;
+  if (a.M % ngroups || a.group_rows[0] > 0) return -7;            // (ragged row ranges: tf_launch_wgrad_multi only)
   const int M_all = a.M;
   a.M = M_all / ngroups;                      // the sizing below is per group; the kernels get the full extent back
   if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8) || a.zeros == nullptr) return -2;

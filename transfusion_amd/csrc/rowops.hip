@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.rows) return;
-  const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
+  const int xr = a.x_row_map != nullptr ? a.x_row_map[row] : map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
   const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
-  // parameter groups (TfLnArgs.pgroups): equal row ranges, each with its own gamma / beta, p_gstride bytes apart
-  const long long poff = a.pgroups > 1 ? (long long)(row / (a.rows / a.pgroups)) * a.p_gstride : 0;
+  // parameter groups (TfLnArgs.pgroups): equal (or ragged: group_rows) row ranges, each with its own gamma / beta, p_gstride bytes apart
+  const int pgrp = a.pgroups > 1 ? (a.group_rows[0] > 0 ? tf_range_of_row(a.group_rows, a.pgroups, row).g : row / (a.rows / a.pgroups)) : 0;
+  const long long poff = (long long)pgrp * a.p_gstride;
   const float* gamma = (const float*)((const unsigned char*)a.gamma + poff);
   const float* beta = (const float*)((const unsigned char*)a.beta + poff);
   float v[MAXC][8];
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // LNB_WAVES waves per workgroup, one row per wave per pass: the kernel is a dependent load -> reduce -> store chain per
 // row, so its HBM rate is set by rows in flight (4-wave blocks at the 512-block cap ran 2 waves per SIMD: 3.2 TB/s)
-template <int MAXC, int LNB_WAVES, bool SPLIT>
+// RAGGED: ragged parameter groups (TfLnArgs.group_rows) and / or an explicit x-side row map (x_row_map) -- its own instantiation, so that
+// the form every other launch takes keeps its 126 registers (4 waves per SIMD at d <= 1024; the tables cost ~8 registers' worth of
+// scalar spills)
+template <int MAXC, int LNB_WAVES, bool SPLIT, bool RAGGED = false>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a) {
   const unsigned drop_key = tf_salted(a.drop_key);       // the step clock (tf_common.h); (a copy of the whole struct cost 10 registers)
   __shared__ float red[LNB_WAVES][64 * MAXC * 8];
@@ -126,11 +130,18 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
 
   // parameter groups (blockIdx.y): a block's column partials belong to ONE group's dgamma / dbeta
-  const int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g;
+  int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g;
+  if constexpr (RAGGED) {
+    if (a.pgroups > 1 && a.group_rows[0] > 0) {                        // ragged ranges (TfLnArgs.group_rows)
+      const TfRange rg = tf_range_of_group(a.group_rows, (int)blockIdx.y);
+      rows_g = rg.n; row_lo = rg.lo;
+    }
+  }
   const long long poff = (long long)blockIdx.y * a.p_gstride;
   const float* gamma_g = (const float*)((const unsigned char*)a.gamma + poff);
   for (int row = row_lo + blockIdx.x * LNB_WAVES + wave; row < row_lo + rows_g; row += gridDim.x * LNB_WAVES) {
-    const int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
+    int xr = map_row_x(row, a.rows_per_group, a.x_group_stride, a.x_group_row0);
+    if constexpr (RAGGED) { if (a.x_row_map != nullptr) xr = a.x_row_map[row]; }
     const int yr = map_row(row, a.rows_per_group, a.y_group_stride);
     const float mean = a.mean[row], rstd = a.rstd[row];
     float xh[MAXC][8], g[MAXC][8];
@@ -206,6 +217,19 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 // ------------------------------------------------------------------------------------------------
 // Token assemble (K2): out[b, s] = s < Nv ? dropout(vis[b,s] + pe[s] + kind_v) : lang[b,s-Nv] + kind_l
 // ------------------------------------------------------------------------------------------------
+// row of visual token s of sample b inside vis / dvis: [B, Nv, d], or (ragged groups, TfAssembleArgs.group_nv) the concatenation
+// [sum_g (B / pgroups) group_nv[g], d] -- group-major, then sample, then token
+__device__ __forceinline__ int vis_row_of(const TfAssembleArgs& a, int grp, int b, int s) {
+  if (a.group_nv[0] <= 0) return b * a.Nv + s;
+  const int Bg = a.B / (a.pgroups > 1 ? a.pgroups : 1);
+  int before = 0, nv = a.group_nv[0];
+#pragma unroll
+  for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+    if (i < grp) before += a.group_nv[i];
+    if (i == grp) nv = a.group_nv[i];
+  }
+  return before * Bg + (b - grp * Bg) * nv + s;
+}
 __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs a_in) {
   TfAssembleArgs a = a_in;
   a.drop_key = tf_salted(a.drop_key);
@@ -223,9 +247,11 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
   }
   const int b = dense / S, s = dense - b * S;
   // parameter groups (TfAssembleArgs.pgroups): sample b belongs to group b / (B / pgroups); its kind embeddings sit p_gstride bytes apart
-  const long long poff = a.pgroups > 1 ? (long long)(b / (a.B / a.pgroups)) * a.p_gstride : 0;
+  const int grp = a.pgroups > 1 ? b / (a.B / a.pgroups) : 0;
+  const long long poff = (long long)grp * a.p_gstride;
   const float* kind_v = (const float*)((const unsigned char*)a.kind_v + poff);
   const float* kind_l = (const float*)((const unsigned char*)a.kind_l + poff);
+  const int vrow = vis_row_of(a, grp, b, s);                           // (used for s < Nv only)
   u16* out = (u16*)a.out + (size_t)row * a.ld_out;
   for (int c = lane * 8; c < a.ld_out; c += 512) {
     if (c >= a.d) {
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(const TfAssembleArgs 
     float v[8], k[8];
     if (s < a.Nv) {
       float pe[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      load8_any(a.vis, (size_t)(b * a.Nv + s) * a.ld_vis + c, a.vis_is_f32, v);
+      load8_any(a.vis, (size_t)vrow * a.ld_vis + c, a.vis_is_f32, v);
       if (a.pe != nullptr) load8_f32(a.pe + (size_t)s * a.d + c, pe);
       load8_f32(kind_v + c, k);
       const unsigned km = a.drop_thr ? tf_keep8((unsigned)row * (unsigned)a.ld_out + (unsigned)c, a.drop_key, a.drop_thr) : 0xffu;
@@ -271,7 +297,11 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kv[i][e] = 0.f; kl[i][e] = 0.f; }
   const int nrows_all = a.row_map != nullptr ? a.rows : a.B * S;
-  const int nrows_g = a.pgroups > 1 ? nrows_all / a.pgroups : nrows_all, row_lo = (int)blockIdx.y * nrows_g;
+  int nrows_g = a.pgroups > 1 ? nrows_all / a.pgroups : nrows_all, row_lo = (int)blockIdx.y * nrows_g;
+  if (a.pgroups > 1 && a.group_rows[0] > 0) {                          // ragged groups: the packed rows group blockIdx.y owns
+    const TfRange rg = tf_range_of_group(a.group_rows, (int)blockIdx.y);
+    nrows_g = rg.n; row_lo = rg.lo;
+  }
   const long long poff = (long long)blockIdx.y * a.p_gstride;
   for (int row = row_lo + blockIdx.x * 4 + wave; row < row_lo + nrows_g; row += gridDim.x * 4) {
     const int dense = a.row_map != nullptr ? a.row_map[row] : row;
@@ -291,7 +321,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) kv[i][e] += g[e];
-        if (a.dvis != nullptr) store8_any(a.dvis, (size_t)(b * a.Nv + s) * a.ld_dvis + c, a.dvis_is_f32, g);
+        if (a.dvis != nullptr) store8_any(a.dvis, (size_t)vis_row_of(a, (int)blockIdx.y, b, s) * a.ld_dvis + c, a.dvis_is_f32, g);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) kl[i][e] += g[e];
@@ -323,7 +353,9 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TfAssembleArgs 
 // kernel 0.8 TB/s).  The element-wise path serves odd head widths (hd = 18) and the fp32 bias copies.
 // tile0[i]: first block of tensor i in the 1-D grid (tile0[n] = grid size), gx[i]: its tiles per tile row -- every block is a real
 // tile (a 3-D grid over the LARGEST tensor's extents launched 10 368 blocks for a d = 768 layer, 1 236 of them with work)
-struct PackBatch { TfPackArgs a[8]; int tile0[9]; int gx[8]; };
+// groups > 1 (blockIdx.y): the same tensors of `groups` parameter sets, src_gstride / dst_gstride BYTES apart (the encoders of a grouped
+// call: one launch re-packs a layer of ALL of them)
+struct PackBatch { TfPackArgs a[8]; int tile0[9]; int gx[8]; long long src_gstride, dst_gstride; };
 __device__ __forceinline__ int pack_src_index(int p, int g, int gp, int n_src) {      // padded index -> source index or -1
   const int q = gp >= (1 << 28) ? 0 : p / gp, e = p - q * gp;
   const int s = q * g + e;
@@ -334,7 +366,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackBatch pb) {
   int z = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i) z = (int)blockIdx.x >= pb.tile0[i] ? i : z;      // (tile0 of unused slots = grid size)
-  const TfPackArgs& a = pb.a[z];
+  TfPackArgs a = pb.a[z];
+  if (blockIdx.y > 0) {
+    a.src = (const float*)((const unsigned char*)a.src + (long long)blockIdx.y * pb.src_gstride);
+    if (a.dst != nullptr) a.dst = (unsigned char*)a.dst + (long long)blockIdx.y * pb.dst_gstride;
+    if (a.dst_t != nullptr) a.dst_t = (unsigned char*)a.dst_t + (long long)blockIdx.y * pb.dst_gstride;
+  }
   const int local = (int)blockIdx.x - pb.tile0[z];
   const int r0 = (local / pb.gx[z]) * 64, c0 = (local % pb.gx[z]) * 64;
   if (r0 >= a.rows_p || c0 >= a.cols_p) return;        // block-uniform
@@ -463,11 +500,28 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
 // call -- but every access stays inside the `expected`-row tensors.
 __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
                                                        int* __restrict__ start_of, int* __restrict__ dense_of, int* __restrict__ packed_of_lang,
-                                                       int expected, int* __restrict__ err, int groups) {
+                                                       int expected, int* __restrict__ err, int groups, const TfGroupTab gnv,
+                                                       int* __restrict__ vis_rows) {
   extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position) | total
   int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int S = Nv + Nl;
+  // ragged groups (TfEncoderDesc.group_nv): the samples of group g carry nvs[g] <= Nv visual tokens (dense positions nvs[g] .. Nv - 1 of
+  // such a sample do not exist); vfirst[g] = first row of group g inside the concatenated visual tokens
+  __shared__ int nvs[TF_MAX_GROUPS], vfirst[TF_MAX_GROUPS + 1];
+  const bool ragged = gnv.v[0] > 0;
+  if (threadIdx.x == 0) {
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+      nvs[i] = ragged ? gnv.v[i] : Nv;
+      vfirst[i] = run;
+      run += (i < groups ? nvs[i] : 0) * (B / groups);
+    }
+    vfirst[TF_MAX_GROUPS] = run;
+  }
+  __syncthreads();
+  auto nv_of = [&](int b) { return nvs[b / (B / groups)]; };
   // fast path: a lane reads 8 mask bytes with one load (a row of 512 tokens = one load per lane: the byte-per-lane loop below made 8
   // dependent trips per sample and pass, 23 us for 32 samples)
   const bool wide = lm != nullptr && (Nl & 7) == 0 && (((size_t)lm) & 7) == 0;
@@ -493,7 +547,7 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
         c += __popcll(__ballot(ok));
       }
     }
-    if (lane == 0) cnt[b] = Nv + c;
+    if (lane == 0) cnt[b] = nv_of(b) + c;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {             // position of sample b in the longest-first order (stable)
@@ -510,9 +564,11 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
     int run = 0;
     bool bad = false;
     const int Bg = B / groups;
+    // every group owns expected / groups rows -- ragged: Bg * nvs[g] visual rows + an equal share of the language rows
+    const int lang_share = (expected - vfirst[TF_MAX_GROUPS]) / groups;
     for (int p = 0; p < B; ++p) {
       const int c = start[p + 1];
-      if (groups > 1 && p % Bg == 0 && run != (p / Bg) * (expected / groups)) bad = true;      // every group owns expected / groups rows
+      if (groups > 1 && p % Bg == 0 && run != vfirst[p / Bg] + (p / Bg) * lang_share) bad = true;
       start[p] = run; cu[p] = min(run, expected); run += c;
     }
     start[B] = run; cu[B] = min(run, expected);
@@ -523,9 +579,14 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
   for (int i = total + (int)threadIdx.x; i < expected; i += blockDim.x) dense_of[i] = -1;       // rows no token maps to
   for (int b = wave; b < B; b += nw) {
     const int base = start[pos_of[b]];
-    if (lane == 0) start_of[b] = max(0, min(base, expected - Nv));
-    for (int i = lane; i < Nv; i += 64) dense_of[base + i] = b * S + i;
-    int run = base + Nv;
+    const int nvb = nv_of(b);
+    if (lane == 0) start_of[b] = max(0, min(base, expected - nvb));
+    for (int i = lane; i < nvb; i += 64) dense_of[base + i] = b * S + i;
+    if (vis_rows != nullptr) {                                     // token i of sample b inside the concatenated visual tokens -> its packed row
+      const int g = b / (B / groups), v0 = vfirst[g] + (b - g * (B / groups)) * nvb;
+      for (int i = lane; i < nvb; i += 64) vis_rows[v0 + i] = min(base + i, expected - 1);
+    }
+    int run = base + nvb;
     if (wide) {
       for (int j0 = 0; j0 < Nl; j0 += 512) {
         const int j8 = j0 + lane * 8;
@@ -1189,6 +1250,7 @@ __global__ void lm_pool_affine_kernel(const float* __restrict__ scratch, float* 
 extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->ldy % 8)) return -2;
+  if (a->pgroups > 1 && a->group_rows[0] > 0 && !tf_ragged_ok(a->group_rows, a->pgroups, a->rows)) return -2;
   const dim3 grid((a->rows + 3) / 4);
   const int width = max(a->d, a->y_is_f32 ? a->d : a->ldy);      // columns a lane set must cover (payload + zeroed pad)
   if (width > 64 * MAXC_MAX * 8) return -2;
@@ -1211,13 +1273,20 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   constexpr int nw = 8;        // waves per workgroup (16 measured slower: 39.9 vs 38.3 us; its instantiations spilled and are gone)
   static const int env_g = TF_ENV_INT("TF_LNB_GRID", 512);     // experiment switch
   const int pg = a->pgroups > 1 ? a->pgroups : 1;
-  if (a->rows % pg) return -2;
-  const dim3 grid(grid_for(a->rows / pg, nw, max(1, env_g / pg)), pg);       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
+  int rows_g = a->rows / pg;                            // rows of the LARGEST parameter group (sizes grid.x; a block walks its own group's rows)
+  if (pg > 1 && a->group_rows[0] > 0) {
+    if (!tf_ragged_ok(a->group_rows, pg, a->rows)) return -2;
+    for (int g = 0; g < pg; ++g) rows_g = max(rows_g, a->group_rows[g]);
+  } else if (a->rows % pg) return -2;
+  const dim3 grid(grid_for(rows_g, nw, max(1, env_g / pg)), pg);       // every block ends with 2*d atomics onto the SAME addresses: keep blocks few (the cap);
                                                        // small row counts get one row per wave (2,083 rows: 261 blocks instead of 131, 17 -> 13 us)
   const bool split = a->x_lo != nullptr || a->dx_lo != nullptr || a->dy_lo != nullptr || a->dx_drop_lo != nullptr || a->dres_lo != nullptr;
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
-#define TF_LNB(C, W) do { if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \
+  const bool ragged = (pg > 1 && a->group_rows[0] > 0) || a->x_row_map != nullptr;
+#define TF_LNB(C, W) do { if (split && ragged) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true, true>), grid, block, 0, st, *a); \
+                          else if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \
+                          else if (ragged) hipLaunchKernelGGL((ln_bwd_kernel<C, W, false, true>), grid, block, 0, st, *a); \
                           else hipLaunchKernelGGL((ln_bwd_kernel<C, W, false>), grid, block, 0, st, *a); } while (0)
   if (width <= 512) TF_LNB(1, 8);
   else if (width <= 1024) TF_LNB(2, 8);
@@ -1230,6 +1299,10 @@ extern "C" int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t st) {
   if (rows <= 0) return 0;
   if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if ((a->d % 8) || (a->ld_out % 8) || (a->ld_vis % 8) || (a->ld_lang % 8)) return -2;
+  if (a->group_nv[0] > 0) {                             // ragged groups: packed batches only
+    if (a->row_map == nullptr || a->pgroups < 2 || a->pgroups > TF_MAX_GROUPS || a->B % a->pgroups) return -2;
+    for (int g = 0; g < a->pgroups; ++g) if (a->group_nv[g] <= 0 || a->group_nv[g] > a->Nv) return -2;
+  }
   TfTraceScope tr("assemble_fwd_kernel", st);
   hipLaunchKernelGGL(assemble_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
@@ -1240,18 +1313,25 @@ extern "C" int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t st) {
   if (rows > a->B * (a->Nv + a->Nl)) return -2;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ld_dout % 8)) return -2;
   const int pg = a->pgroups > 1 ? a->pgroups : 1;
-  if (rows % pg || a->B % pg) return -2;
-  const dim3 grid(grid_for(rows / pg, 4, max(1, 512 / pg)), pg);             // (small row counts: one row per wave)
+  if (a->B % pg) return -2;
+  int rows_g = rows / pg;
+  if (a->group_nv[0] > 0) {                             // ragged groups: packed batches only, both tables or none
+    if (a->row_map == nullptr || pg < 2 || !tf_ragged_ok(a->group_rows, pg, rows)) return -2;
+    for (int g = 0; g < pg; ++g) { if (a->group_nv[g] <= 0 || a->group_nv[g] > a->Nv) return -2; rows_g = max(rows_g, a->group_rows[g]); }
+  } else if (rows % pg || a->group_rows[0] > 0) return -2;
+  const dim3 grid(grid_for(rows_g, 4, max(1, 512 / pg)), pg);             // (small row counts: one row per wave)
   TfTraceScope tr("assemble_bwd_kernel", st, 0.0, 0.0);
   if (a->d <= 512) hipLaunchKernelGGL(assemble_bwd_kernel<1>, grid, dim3(256), 0, st, *a);
   else if (a->d <= 1024) hipLaunchKernelGGL(assemble_bwd_kernel<2>, grid, dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(assemble_bwd_kernel<4>, grid, dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
-extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) {
+extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) { return tf_launch_pack_batch_groups(a, n, 1, 0, 0, st); }
+extern "C" int tf_launch_pack_batch_groups(const TfPackArgs* a, int n, int groups, long long src_gstride, long long dst_gstride, hipStream_t st) {
   if (n <= 0) return 0;
-  if (n > 8) return -2;
+  if (n > 8 || groups < 1 || groups > 65535) return -2;
   PackBatch pb;
+  pb.src_gstride = src_gstride; pb.dst_gstride = dst_gstride;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     if (a[i].rg <= 0 || a[i].cg <= 0 || a[i].rgp < a[i].rg || a[i].cgp < a[i].cg || a[i].rows_p <= 0 || a[i].cols_p <= 0) return -2;
@@ -1263,7 +1343,7 @@ extern "C" int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t st) 
   for (int i = n; i < 8; ++i) { pb.a[i] = a[0]; pb.gx[i] = 1; pb.tile0[i] = total; }
   pb.tile0[8] = total;
   TfTraceScope tr("pack_kernel", st);
-  hipLaunchKernelGGL(pack_kernel, dim3(total), dim3(256), 0, st, pb);
+  hipLaunchKernelGGL(pack_kernel, dim3(total, groups), dim3(256), 0, st, pb);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_pack(const TfPackArgs* a, hipStream_t st) {
@@ -1278,13 +1358,24 @@ extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang,
-                                 int expected, int* err, int groups, hipStream_t st) {
+                                 int expected, int* err, int groups, const int* group_nv, int* vis_rows, hipStream_t st) {
   if (groups < 1 || B % groups) return -2;
   if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || start_of == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
+  TfGroupTab gnv{};
+  if (group_nv != nullptr && group_nv[0] > 0) {                  // ragged groups: 0 < group_nv[g] <= Nv for every group
+    if (groups > TF_MAX_GROUPS || vis_rows == nullptr) return -2;
+    for (int g = 0; g < groups; ++g) {
+      if (group_nv[g] <= 0 || group_nv[g] > Nv) return -2;
+      gnv.v[g] = group_nv[g];
+    }
+  } else {
+    vis_rows = nullptr;
+  }
   const size_t lds = (size_t)(3 * B + 1) * sizeof(int);
   if (lds > 60000) return -2;          // the per-sample tables live in LDS
   TfTraceScope tr("row_map_kernel", st);
-  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err, groups);
+  hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err, groups, gnv,
+                     vis_rows);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {

@@ -67,18 +67,43 @@ struct Dims {
   int Md;           // B * S: token rows of the dense layout.  M = rows that take part: Md, or TfEncoderDesc.packed_rows (packed batches)
   int split;        // fp32-accuracy mode: every bf16 tensor of the workspace and of the weight shadows is a hi + lo plane pair
   int G;            // TfEncoderDesc.groups: G encoders' samples (B / G each) in one batch, each with its own parameters
+  // ragged groups (TfEncoderDesc.group_nv): visual tokens per sample of group g, the group's rows inside the concatenated visual tokens
+  // (B / G * nv[g]) and its packed rows (those + an equal share of the un-masked language tokens); vis_total = all visual rows
+  bool ragged;
+  int nv[TF_MAX_GROUPS], vrows[TF_MAX_GROUPS], grows[TF_MAX_GROUPS], vis_total;
 };
-bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0, int packed_rows = 0, int groups = 1) {
+bool make_dims(int B, int Nv, int Nl, int d, int H, int L, int ff, Dims* o, int split = 0, int packed_rows = 0, int groups = 1,
+               const int* group_nv = nullptr) {
   o->split = split ? 1 : 0;
   o->G = groups > 1 ? groups : 1;
-  if (B % o->G != 0 || packed_rows % o->G != 0) return false;       // equal groups (packed: every group drops the same tokens)
+  o->ragged = o->G > 1 && group_nv != nullptr && group_nv[0] > 0;
+  if (B <= 0 || B % o->G != 0) return false;
+  if (!o->ragged && packed_rows % o->G != 0) return false;          // equal groups (packed: every group drops the same tokens)
   if (B <= 0 || Nv < 0 || Nl < 0 || Nv + Nl <= 0 || d <= 0 || H <= 0 || L <= 0 || L > TF_MAX_LAYERS || ff <= 0) return false;
   if (d % H != 0 || d % 8 != 0) return false;
   o->B = B; o->Nv = Nv; o->Nl = Nl; o->d = d; o->H = H; o->L = L; o->ff = ff;
   o->S = Nv + Nl; o->Md = B * o->S; o->M = o->Md;
+  o->vis_total = B * Nv;
+  for (int g = 0; g < TF_MAX_GROUPS; ++g) { o->nv[g] = g < o->G ? Nv : 0; o->vrows[g] = g < o->G ? B / o->G * Nv : 0; o->grows[g] = 0; }
+  if (o->ragged) {
+    if (o->G > TF_MAX_GROUPS) return false;
+    o->vis_total = 0;
+    int nv_max = 0;
+    for (int g = 0; g < o->G; ++g) {
+      if (group_nv[g] <= 0 || group_nv[g] > Nv) return false;
+      o->nv[g] = group_nv[g]; o->vrows[g] = B / o->G * group_nv[g]; o->vis_total += o->vrows[g];
+      nv_max = group_nv[g] > nv_max ? group_nv[g] : nv_max;
+    }
+    if (nv_max != Nv) return false;                    // Nv is the LARGEST group's token count
+  }
   if (packed_rows != 0) {                              // packed batches: every visual row and the un-masked language tokens
-    if (packed_rows < B * Nv || packed_rows > o->Md || packed_rows <= 0) return false;
+    if (packed_rows < o->vis_total || packed_rows > o->Md || packed_rows <= 0) return false;
     o->M = packed_rows;
+    if (o->ragged) {                                   // every group drops the same language tokens: an equal share each
+      const int lang = packed_rows - o->vis_total;
+      if (lang % o->G != 0) return false;
+      for (int g = 0; g < o->G; ++g) o->grows[g] = o->vrows[g] + lang / o->G;
+    }
   }
   o->hd = d / H;
   o->hdp = (int)up(o->hd, 32);
@@ -124,6 +149,7 @@ struct AOff {   // byte offsets inside work
   size_t dsw;                                     // dS tiles of the attention backward (TfAttnArgs.ds_work)
   size_t a8, sa8;                                 // fp8 copy of the current GEMM input [M, max(dp, ffp)] bytes + per-token scales
   size_t bskip;                                   // block-sparse tile maps of attn_block_bits: skip_q | skip_k, ceil(S/128) u64 words each
+  size_t visrows;                                 // ragged groups: packed row of every token of the concatenated visual tokens (int32, <= B * Nv)
   size_t total;
 };
 AOff make_aoff(const Dims& D) {
@@ -137,6 +163,7 @@ AOff make_aoff(const Dims& D) {
   a.perr = take(256);
   a.bskip = take((size_t)2 * ((D.S + 127) / 128) * 8);
   a.cu = take((size_t)(D.B + 1) * 4); a.starts = take((size_t)D.B * 4); a.dense_of = take((size_t)D.Md * 4); a.pol = take((size_t)D.B * (D.Nl > 0 ? D.Nl : 1) * 4);
+  a.visrows = take((size_t)D.B * (D.Nv > 0 ? D.Nv : 1) * 4);
   a.keymask = take((size_t)D.Md);
   a.x0 = o; a.x_stride = plane(md) * (size_t)(1 + D.split); o += a.x_stride * (D.L + 1);
   a.layer0 = o;
@@ -188,11 +215,16 @@ struct Ctx {
   unsigned char* WB(int l) const { return wp + (size_t)l * W.stride; }
   long long wg() const { return (long long)(W.stride * (size_t)D.L); }        // bytes between the shadow blocks of two groups
   long long pg() const { return D.G > 1 ? e->param_gstride : 0; }             // bytes between the parameters (and gradients) of two groups
+  // ragged groups: the groups' packed row counts / visual row counts into a launch's group_rows (left all zero otherwise: equal ranges)
+  void rows_into(int (&dst)[TF_MAX_GROUPS]) const { if (D.ragged) for (int g = 0; g < TF_MAX_GROUPS; ++g) dst[g] = D.grows[g]; }
+  void vrows_into(int (&dst)[TF_MAX_GROUPS]) const { if (D.ragged) for (int g = 0; g < TF_MAX_GROUPS; ++g) dst[g] = D.vrows[g]; }
+  const int* vis_rows() const { return D.ragged ? (const int*)(wk + A.visrows) : nullptr; }   // concatenated visual token -> packed row
 };
 bool make_ctx(const TfEncoderDesc* e, hipStream_t st, Ctx* c) {
   if (e == nullptr || e->wpack == nullptr || e->work == nullptr) return false;
-  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision, e->packed_rows, e->groups)) return false;
+  if (!make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &c->D, e->precision, e->packed_rows, e->groups, e->group_nv)) return false;
   if (c->D.G > 1 && (e->param_gstride <= 0 || (e->param_gstride & 15) != 0 || e->attn_block_bits != nullptr)) return false;
+  if (c->D.ragged && e->packed_rows <= 0) return false;               // ragged groups exist on packed rows only
   if (e->precision != 0 && e->precision != 1) return false;
   if (e->precision && e->fp8_proj) return false;      // fp8 operands have no lo plane
   if (e->act != 0 && e->act != 1) return false;
@@ -219,6 +251,7 @@ int gemm(const Ctx& c, Buf A, Buf W, Buf C, const float* bias, Buf R, Buf C2, in
   g.A_lo = A.lo; g.W_lo = W.lo; g.C_lo = (void*)C.lo; g.R_lo = R.lo; g.C2_lo = (void*)C2.lo;
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
   g.groups = c.D.G; g.w_gstride = c.wg();            // (every W / bias of the runtime lives in a layer's shadow block)
+  c.rows_into(g.group_rows);
   return tf_launch_gemm_nt(&g, c.st);
 }
 // forward projection with fp8 operands: quantise the bf16 activation per token, then the fp8 large-tile GEMM
@@ -232,6 +265,7 @@ int gemm_fp8(const Ctx& c, const void* A, int lda, int K, const void* W8, const 
   g.M = c.D.M; g.N = N; g.K = K; g.epilogue = epi; g.drop_thr = dr.thr; g.drop_key = dr.key; g.drop_scale = dr.scale; g.act = c.e->act;
   g.fp8 = 1; g.scale_a = sa; g.scale_w = sw;
   g.groups = c.D.G; g.w_gstride = c.wg();
+  c.rows_into(g.group_rows);
   return tf_launch_gemm_nt(&g, c.st);
 }
 // Side stream of one tf_encoder_bwd call: the weight gradients.  A layer's four weight-gradient products read tensors the chain has
@@ -291,6 +325,7 @@ TfWgradArgs wjob(const Ctx& c, Buf dY, int N, Buf X, int K, float* dW, int lddw,
   w.dY_lo = dY.lo; w.X_lo = X.lo;
   w.M = c.D.M; w.N = N; w.K = K; w.rg = rg; w.rgp = rgp; w.n_src = n_src; w.cg = cg; w.cgp = cgp; w.k_src = k_src; w.m_chunk = 0;
   w.groups = c.D.G; w.dw_gstride = c.pg();
+  c.rows_into(w.group_rows);
   return w;
 }
 // the products `mask` selects out of jobs[0..3] (W_W2, W_W1, W_WO, W_WI) as one launch on the side stream (or on the chain without one)
@@ -548,19 +583,12 @@ void tf_trace_mark_side(hipStream_t side) {
   g_trace_sides.push_back(side);
 }
 namespace {
-int pack_layer_group(const Ctx& c, int l, int grp, hipStream_t st);
+// bf16 shadows of layer l, for ALL groups of a grouped call in one launch (blockIdx.y = group: the same tensors, param_gstride bytes
+// further in the parameters, wg() bytes further in wpack)
 int pack_layer(const Ctx& c, int l, hipStream_t st) {
-  for (int grp = 0; grp < c.D.G; ++grp) { const int rc = pack_layer_group(c, l, grp, st); if (rc != 0) return rc; }
-  return 0;
-}
-int pack_layer_group(const Ctx& c, int l, int grp, hipStream_t st) {
   const Dims& D = c.D;
-  unsigned char* w = c.WB(l) + (size_t)grp * c.wg();
-  TfLayerParams p = c.e->p[l];
-  if (grp > 0) {                                                   // group grp's parameters: the same tensors, param_gstride bytes further
-    float** f = (float**)&p;
-    for (size_t i = 0; i < sizeof(TfLayerParams) / sizeof(float*); ++i) f[i] = (float*)((unsigned char*)f[i] + (size_t)grp * c.pg());
-  }
+  unsigned char* w = c.WB(l);
+  const TfLayerParams p = c.e->p[l];
   for (int residual = 0; residual <= D.split; ++residual) {      // split mode: a second launch writes the lo planes, bf16(w - bf16(w))
     TfPackArgs batch[8];
     int nb = 0;
@@ -582,14 +610,15 @@ int pack_layer_group(const Ctx& c, int l, int grp, hipStream_t st) {
     pack(p.out_b, 1, D.d, w + c.W.bo, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
     pack(p.b1, 1, D.ff, w + c.W.b1, D.ffp, nullptr, 0, 1, D.ffp, BIG, BIG, BIG, BIG, 1);
     pack(p.b2, 1, D.d, w + c.W.b2, D.dp, nullptr, 0, 1, D.dp, BIG, BIG, BIG, BIG, 1);
-    const int rc = tf_launch_pack_batch(batch, nb, st);
+    const int rc = tf_launch_pack_batch_groups(batch, nb, D.G, c.pg(), c.wg(), st);
     if (rc != 0) return rc;
   }
   int rc = 0;
-  if (c.e->fp8_proj) {                 // fp8 shadows of the forward projections, one scale per output channel
-    rc = tf_launch_quant_rows_fp8(w + c.W.win, D.dp, w + c.W.win8, D.dp, (float*)(w + c.W.s_in), D.nqkv, D.dp, st);
-    if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w1, D.dp, w + c.W.w18, D.dp, (float*)(w + c.W.s_w1), D.ffp, D.dp, st);
-    if (rc == 0) rc = tf_launch_quant_rows_fp8(w + c.W.w2, D.ffp, w + c.W.w28, D.ffp, (float*)(w + c.W.s_w2), D.dp, D.ffp, st);
+  for (int grp = 0; grp < D.G && c.e->fp8_proj && rc == 0; ++grp) {   // fp8 shadows of the forward projections, one scale per output channel
+    unsigned char* wg = w + (size_t)grp * c.wg();
+    rc = tf_launch_quant_rows_fp8(wg + c.W.win, D.dp, wg + c.W.win8, D.dp, (float*)(wg + c.W.s_in), D.nqkv, D.dp, st);
+    if (rc == 0) rc = tf_launch_quant_rows_fp8(wg + c.W.w1, D.dp, wg + c.W.w18, D.dp, (float*)(wg + c.W.s_w1), D.ffp, D.dp, st);
+    if (rc == 0) rc = tf_launch_quant_rows_fp8(wg + c.W.w2, D.ffp, wg + c.W.w28, D.ffp, (float*)(wg + c.W.s_w2), D.dp, D.ffp, st);
   }
   return rc;
 }
@@ -598,6 +627,20 @@ void ln_rows(const Ctx& c, TfLnArgs& n, Buf x, const float* gamma, float* mean, 
   n.x = x.p; n.x_lo = x.lo; n.ldx = x.ld; n.gamma = gamma; n.mean = mean; n.rstd = rstd;
   n.rows = c.D.M; n.d = c.D.d; n.rows_per_group = c.D.M; n.x_group_stride = c.D.M; n.y_group_stride = c.D.M; n.eps = 1e-5f;
   n.pgroups = c.D.G; n.p_gstride = c.pg();
+  c.rows_into(n.group_rows);
+}
+// final LayerNorm / copy over the visual rows: with ragged groups the output rows are the concatenated visual tokens, found through the
+// row map of this forward (the x side), in ragged parameter groups
+void ln_vis_rows(const Ctx& c, TfLnArgs& n) {
+  const Dims& D = c.D;
+  n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
+  n.x_group_row0 = c.starts();
+  n.pgroups = D.G; n.p_gstride = c.pg();
+  if (D.ragged) {
+    n.rows = D.vis_total; n.rows_per_group = D.vis_total; n.y_group_stride = D.vis_total; n.x_group_row0 = nullptr;
+    n.x_row_map = c.vis_rows();
+    c.vrows_into(n.group_rows);
+  }
 }
 }  // namespace
 extern "C" {
@@ -605,7 +648,7 @@ extern "C" {
 int tf_encoder_plan_ex(const TfEncoderDesc* e, TfEncoderPlan* out) {
   Dims D;
   if (e == nullptr || out == nullptr || (e->precision != 0 && e->precision != 1) ||
-      !make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &D, e->precision, 0, e->groups)) return fail(-1, "tf_encoder_plan_ex");
+      !make_dims(e->B, e->Nv, e->Nl, e->d, e->H, e->L, e->ff, &D, e->precision, 0, e->groups, e->group_nv)) return fail(-1, "tf_encoder_plan_ex");
   const WOff W = make_woff(D); const AOff A = make_aoff(D);
   out->hd = D.hd; out->hdp = D.hdp; out->dp = D.dp; out->ffp = D.ffp; out->ldq = D.ldq; out->S = D.S; out->M = D.M;
   out->wpack_bytes = W.stride * (size_t)D.L * (size_t)D.G; out->work_bytes = A.total;       // one shadow block per group, back to back
@@ -655,7 +698,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
     TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
-                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, c.st), "row_map");
+                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, D.ragged ? D.nv : nullptr, (int*)(c.wk + c.A.visrows), c.st), "row_map");
     km = nullptr;
   } else {
     TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
@@ -668,6 +711,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.B = D.B; a.Nv = D.Nv; a.Nl = D.Nl; a.d = D.d;
     a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
     a.pgroups = D.G; a.p_gstride = c.pg();
+    if (D.ragged) { for (int g = 0; g < TF_MAX_GROUPS; ++g) a.group_nv[g] = D.nv[g]; c.rows_into(a.group_rows); }
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);
     a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale;
     TF_TRY(tf_launch_assemble_fwd(&a, c.st), "assemble_fwd");
@@ -730,14 +774,14 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     if (e->final_norm) {
       TfLnArgs n{};
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.y = e->vis_out; n.ldy = D.d; n.y_is_f32 = e->vis_out_is_f32; n.gamma = e->fn_w; n.beta = e->fn_b;
-      n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf); n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv;
-      n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f; n.x_group_row0 = c.starts();
-      n.pgroups = D.G; n.p_gstride = c.pg();
+      n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
+      ln_vis_rows(c, n);
       TF_TRY(tf_launch_ln_fwd(&n, c.st), "final_ln_fwd");
     } else {
       TfCopyRowsArgs r{};
       r.src = xl.p; r.src_lo = xl.lo; r.src_is_f32 = 0; r.ld_src = D.dp; r.src_rpg = D.Nv; r.src_gstride = D.S; r.src_group_row0 = c.starts();
       r.dst = e->vis_out; r.dst_is_f32 = e->vis_out_is_f32; r.ld_dst = D.d; r.dst_rpg = D.Nv; r.dst_gstride = D.Nv; r.rows = D.B * D.Nv; r.cols = D.d;
+      if (D.ragged) { r.src_row_map = c.vis_rows(); r.rows = D.vis_total; r.dst_rpg = D.vis_total; r.dst_gstride = D.vis_total; }
       TF_TRY(tf_launch_copy_rows(&r, c.st), "vis_copy");
     }
   }
@@ -783,17 +827,16 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
       TfLnArgs n{};
       const Buf xl = c.act_d(c.X(D.L));
       n.x = xl.p; n.x_lo = xl.lo; n.ldx = D.dp; n.gamma = e->fn_w; n.mean = (float*)(c.wk + c.A.meanf); n.rstd = (float*)(c.wk + c.A.rstdf);
-      n.rows = D.B * D.Nv; n.d = D.d; n.rows_per_group = D.Nv; n.x_group_stride = D.S; n.y_group_stride = D.Nv; n.eps = 1e-5f;
-      n.x_group_row0 = c.starts();
+      ln_vis_rows(c, n);
       n.dy = e->d_vis_out; n.lddy = D.d; n.dy_is_f32 = e->d_vis_out_is_f32; n.dx = (void*)dxa.p; n.dx_lo = (void*)dxa.lo; n.lddx = D.dp;
       n.dgamma = e->g_fn_w; n.dbeta = e->g_fn_b;
-      n.pgroups = D.G; n.p_gstride = c.pg();
       TF_TRY(tf_launch_ln_bwd(&n, c.st), "final_ln_bwd");
     } else {
       TfCopyRowsArgs r{};
       r.src = e->d_vis_out; r.src_is_f32 = e->d_vis_out_is_f32; r.ld_src = D.d; r.src_rpg = D.Nv; r.src_gstride = D.Nv;
       r.dst = (void*)dxa.p; r.dst_lo = (void*)dxa.lo; r.dst_is_f32 = 0; r.ld_dst = D.dp; r.dst_rpg = D.Nv; r.dst_gstride = D.S; r.rows = D.B * D.Nv; r.cols = D.d;
       r.dst_group_row0 = c.starts();
+      if (D.ragged) { r.dst_row_map = c.vis_rows(); r.rows = D.vis_total; r.src_rpg = D.vis_total; r.src_gstride = D.vis_total; }
       TF_TRY(tf_launch_copy_rows(&r, c.st), "dvis_copy");
     }
   }
@@ -884,6 +927,7 @@ int tf_encoder_bwd(const TfEncoderDesc* e, tf_stream_t s) {
     a.dkind_v = e->g_kind_v; a.dkind_l = e->g_kind_l;
     a.pgroups = D.G; a.p_gstride = c.pg();
     a.row_map = c.dense_of(); a.rows = c.packed() ? D.M : 0;
+    if (D.ragged) { for (int g = 0; g < TF_MAX_GROUPS; ++g) a.group_nv[g] = D.nv[g]; c.rows_into(a.group_rows); }
     if (c.packed() && e->d_lang != nullptr)          // rows of masked language tokens are not visited: their gradient is zero
       TF_TRY((int)hipMemsetAsync(e->d_lang, 0, (size_t)D.B * D.Nl * D.d * (e->d_lang_is_f32 ? 4 : 2), c.st), "d_lang zero fill");
     const Drop dr = drop_for(e, e->p_patch, SITE_PATCH);

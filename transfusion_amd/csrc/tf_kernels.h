@@ -22,11 +22,15 @@ int tf_launch_assemble_fwd(const TfAssembleArgs* a, hipStream_t stream);
 int tf_launch_assemble_bwd(const TfAssembleArgs* a, hipStream_t stream);
 int tf_launch_pack(const TfPackArgs* a, hipStream_t stream);
 int tf_launch_pack_batch(const TfPackArgs* a, int n, hipStream_t stream);   // n <= 8 tensors, one launch
+// ... of `groups` parameter sets whose tensors sit src_gstride (sources) / dst_gstride (shadows) BYTES apart
+int tf_launch_pack_batch_groups(const TfPackArgs* a, int n, int groups, long long src_gstride, long long dst_gstride, hipStream_t stream);
 int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t stream);
 // packed batches: cu [B+1] (by position, longest sample first), start_of [B] (by sample), dense_of [B*S], packed_of_lang [B*Nl] from the
 // language padding mask; err[0] = the mask's row total when != expected
+// ragged groups: group_nv [TF_MAX_GROUPS] host ints (visual tokens per sample of group g; null / [0] == 0: Nv everywhere) and vis_rows
+// [sum_g (B / groups) group_nv[g]] (packed row of every token of the concatenated visual tokens; null unless ragged)
 int tf_launch_row_map(const uint8_t* lang_pad_mask, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang, int expected,
-                      int* err, int groups, hipStream_t stream);
+                      int* err, int groups, const int* group_nv, int* vis_rows, hipStream_t stream);
 int tf_launch_key_mask(const uint8_t* lang_pad_mask, uint8_t* key_mask, int B, int Nv, int Nl, hipStream_t stream);
 int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t stream);
 int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t stream);
@@ -57,6 +61,42 @@ int tf_launch_split_planes(const TfPlanesArgs* a, hipStream_t st);
 #endif
 
 #ifdef __cplusplus
+// ---- ragged row ranges (TfGemmArgs.group_rows and its siblings) ----
+// The TF_MAX_GROUPS counts are kernel-argument words; every loop below is fully unrolled over CONSTANT indices, so they stay scalar
+// registers (a dynamic index would send the array through scratch memory).
+struct TfGroupTab { int v[TF_MAX_GROUPS]; };
+struct TfRange { int g, lo, n; };                                     // range index, its first row, its row count
+__device__ __forceinline__ TfRange tf_range_of_row(const int (&gr)[TF_MAX_GROUPS], int G, int r) {
+  TfRange t{0, 0, gr[0]};
+  int start = 0;
+#pragma unroll
+  for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+    if (i < G && r >= start) { t.g = i; t.lo = start; t.n = gr[i]; }
+    start += gr[i];
+  }
+  return t;
+}
+__device__ __forceinline__ TfRange tf_range_of_group(const int (&gr)[TF_MAX_GROUPS], int g) {
+  TfRange t{g, 0, 0};
+  int start = 0;
+#pragma unroll
+  for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+    if (i == g) { t.lo = start; t.n = gr[i]; }
+    start += gr[i];
+  }
+  return t;
+}
+// host: are these ragged counts well-formed (G of them, all positive, adding up to M)?
+inline bool tf_ragged_ok(const int (&gr)[TF_MAX_GROUPS], int G, int M) {
+  if (G < 1 || G > TF_MAX_GROUPS) return false;
+  long long sum = 0;
+  for (int i = 0; i < TF_MAX_GROUPS; ++i) {
+    if (i < G ? gr[i] <= 0 : gr[i] != 0) return false;
+    sum += gr[i];
+  }
+  return sum == M;
+}
+
 // Experiment switches (TF_* environment variables read by the launch planners) exist in EXPERIMENTS builds only (-DTF_EXPERIMENTS:
 // `python -m transfusion_amd.build --exp`, tools/build_variant.sh -> build/variants/, selected with TFUSION_LIB).  In the shipped
 // library the macros are their defaults: no environment variable can change what it computes, and the names are not even in the binary.

@@ -280,20 +280,23 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) continue;
     if (a.dY == nullptr || a.X == nullptr || a.dW == nullptr) return -1;
     const int G = a.groups > 1 ? a.groups : 1;
-    if (a.M % G) return -7;
+    const bool ragged = G > 1 && a.group_rows[0] > 0;              // TfWgradArgs.group_rows: range g holds group_rows[g] rows
+    if (ragged ? !tf_ragged_ok(a.group_rows, G, a.M) : (a.M % G) != 0) return -7;
     if ((a.N % 8) || (a.K % 8) || (a.ldy % 8) || (a.ldx % 8)) return -2;
     if (a.rgp < a.rg || a.cgp < a.cg || a.rg <= 0 || a.cg <= 0) return -3;
     const bool sp = a.dY_lo != nullptr;
     if (sp && a.X_lo == nullptr) return -6;
     if (any && sp != split) return -8;                        // one arithmetic mode per launch
     split = sp; any = true;
-    const int Mg = a.M / G;
+    size_t row0 = 0;
     for (int g = 0; g < G; ++g) {
       if (n >= WG_MAX) return -9;
+      const int Mg = ragged ? a.group_rows[g] : a.M / G;
       WgProb& p = m.p[n++];
-      p.dY = (const unsigned char*)a.dY + (size_t)g * Mg * a.ldy * 2; p.X = (const unsigned char*)a.X + (size_t)g * Mg * a.ldx * 2;
-      p.dY_lo = sp ? (const unsigned char*)a.dY_lo + (size_t)g * Mg * a.ldy * 2 : nullptr;
-      p.X_lo = sp ? (const unsigned char*)a.X_lo + (size_t)g * Mg * a.ldx * 2 : nullptr;
+      p.dY = (const unsigned char*)a.dY + row0 * a.ldy * 2; p.X = (const unsigned char*)a.X + row0 * a.ldx * 2;
+      p.dY_lo = sp ? (const unsigned char*)a.dY_lo + row0 * a.ldy * 2 : nullptr;
+      p.X_lo = sp ? (const unsigned char*)a.X_lo + row0 * a.ldx * 2 : nullptr;
+      row0 += (size_t)Mg;
       p.dW = (float*)((unsigned char*)a.dW + (long long)g * a.dw_gstride);
       p.db = a.db != nullptr ? (float*)((unsigned char*)a.db + (long long)g * a.dw_gstride) : nullptr;
       p.ldy = a.ldy; p.ldx = a.ldx; p.lddw = a.lddw; p.M = Mg; p.N = a.N; p.K = a.K;

@@ -54,7 +54,7 @@ def k9_supported(mods, d):
 
 class _LevelsK1Fn(torch.autograd.Function):
     """feats[g] [B, C_g, H_g, W_g] -> tokens [G * B, Nv, d] bf16, group-major (what the grouped encoder call takes): per level an im2col
-    gather and a GEMM that writes straight into its slice of the stacked output."""
+    gather and a GEMM that writes straight into its slice of the stacked output.  Levels of unequal token counts: [sum_g B nv_g, d]."""
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
@@ -64,8 +64,12 @@ class _LevelsK1Fn(torch.autograd.Function):
         main = torch.cuda.current_stream(feats[0].device)
         B = feats[0].shape[0]
         d = weights[0].shape[0]
-        Nv = (feats[0].shape[2] // mods[0].patch_h) * (feats[0].shape[3] // mods[0].patch_w)
-        out = torch.empty(G * B * Nv, d, dtype=torch.bfloat16, device=feats[0].device)
+        # tokens per level; levels of unequal token counts (RAGGED groups, TfEncoderDesc.group_nv) give the concatenation [sum_g B nv_g, d]
+        nvs = [(f.shape[2] // m.patch_h) * (f.shape[3] // m.patch_w) for m, f in zip(mods, feats)]
+        offs = [0]
+        for n in nvs:
+            offs.append(offs[-1] + B * n)
+        out = torch.empty(offs[-1], d, dtype=torch.bfloat16, device=feats[0].device)
         saved, meta = [], []
         for g, (m, f, w) in enumerate(zip(mods, feats, weights)):
             Bc, Cc, H, W = f.shape
@@ -73,24 +77,24 @@ class _LevelsK1Fn(torch.autograd.Function):
             wsh, wsh_t = ops._weight_shadows(w, d, K, d)
             with _on(streams, main, g):
                 f = f.contiguous()
-                rows = torch.empty(Bc * Nv, K, dtype=torch.bfloat16, device=f.device)
+                rows = torch.empty(Bc * nvs[g], K, dtype=torch.bfloat16, device=f.device)
                 L.call("tf_patchify_fwd", ops._patch_args(f, rows, Bc, Cc, H, W, m.patch_h, m.patch_w), ops._stream())
-                ops.gemm(rows, wsh, out[g * B * Nv:(g + 1) * B * Nv], d, K, L.TF_EPI_NONE)
+                ops.gemm(rows, wsh, out[offs[g]:offs[g + 1]], d, K, L.TF_EPI_NONE)
             saved += [rows, wsh_t]
             meta.append((tuple(f.shape), f.dtype, m.patch_h, m.patch_w, K))
         _join(streams, main, G)
         ctx.save_for_backward(*saved)
-        ctx.cfg = (mods, streams, accumulate, meta, B, Nv, d)
+        ctx.cfg = (mods, streams, accumulate, meta, B, offs, d)
         ctx.into = [(w.grad if (accumulate and w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == torch.float32) else None)
                     for w in weights]
-        return out.view(G * B, Nv, d)
+        return out.view(G * B, nvs[0], d) if len(set(nvs)) == 1 else out
 
     @staticmethod
     def backward(ctx, gy):
-        mods, streams, accumulate, meta, B, Nv, d = ctx.cfg
+        mods, streams, accumulate, meta, B, offs, d = ctx.cfg
         G = len(mods)
         saved = ctx.saved_tensors
-        gy = gy.reshape(G * B * Nv, d)
+        gy = gy.reshape(offs[-1], d)
         if gy.dtype != torch.bfloat16 or not gy.is_contiguous():
             gy = gy.contiguous().to(torch.bfloat16)
         main = torch.cuda.current_stream(gy.device)
@@ -98,7 +102,7 @@ class _LevelsK1Fn(torch.autograd.Function):
         for g, m in enumerate(mods):
             rows, wsh_t = saved[2 * g], saved[2 * g + 1]
             shape, dtype, ph, pw, K = meta[g]
-            gyg = gy[g * B * Nv:(g + 1) * B * Nv]
+            gyg = gy[offs[g]:offs[g + 1]]
             with _on(streams, main, g):
                 gw = ctx.into[g]
                 if gw is None:
@@ -110,7 +114,7 @@ class _LevelsK1Fn(torch.autograd.Function):
                     dws.append(None)
                 ops.wgrad(gyg, d, rows, K, gw.view(d, K), None)
                 if ctx.needs_input_grad[1 + g]:
-                    dx = torch.empty(B * Nv, K, dtype=torch.bfloat16, device=gy.device)
+                    dx = torch.empty(offs[g + 1] - offs[g], K, dtype=torch.bfloat16, device=gy.device)
                     ops.gemm(gyg, wsh_t, dx, K, d, L.TF_EPI_NONE)
                     df = torch.empty(shape, dtype=dtype, device=gy.device)
                     L.call("tf_patchify_bwd", ops._patch_args(df, dx, shape[0], shape[1], shape[2], shape[3], ph, pw), ops._stream(), ops._is_f32(df))
@@ -133,9 +137,16 @@ class _LevelsK9Fn(torch.autograd.Function):
         weights, biases = params[:G], params[G:]
         dev = fused.device
         main = torch.cuda.current_stream(dev)
-        B = fused.shape[0] // G
-        Nv, d = fused.shape[1], fused.shape[2]
-        x = fused.reshape(G * B * Nv, d)
+        d = fused.shape[-1]
+        # tokens per level from the maps to rebuild; fused is [G * B, Nv, d] or (levels of unequal token counts) [sum_g B nv_g, d]
+        nvs = [(m.init_h // m.patch_h) * (m.init_w // m.patch_w) for m in mods]
+        x = fused.reshape(-1, d)
+        if x.shape[0] % sum(nvs):
+            raise RuntimeError(f"regroup_patches: {x.shape[0]} tokens do not tile the levels' maps ({nvs} tokens per sample)")
+        B = x.shape[0] // sum(nvs)
+        offs = [0]
+        for n in nvs:
+            offs.append(offs[-1] + B * n)
         if x.dtype != torch.bfloat16 or not x.is_contiguous():
             x = x.contiguous().to(torch.bfloat16)
         outs, saved, meta = [], [], []
@@ -143,12 +154,13 @@ class _LevelsK9Fn(torch.autograd.Function):
             N = w.shape[0]
             Cc = N // (m.patch_h * m.patch_w)
             H, W = m.init_h, m.init_w
-            if (H // m.patch_h) * (W // m.patch_w) != Nv:
-                raise RuntimeError(f"regroup_patches: {Nv} tokens do not tile a {H}x{W} map with {m.patch_h}x{m.patch_w} patches")
+            Nv = nvs[g]
+            if fused.dim() == 3 and fused.shape[1] != Nv:
+                raise RuntimeError(f"regroup_patches: {fused.shape[1]} tokens do not tile a {H}x{W} map with {m.patch_h}x{m.patch_w} patches")
             wsh, wsh_t = ops._weight_shadows(w, N, d, N)
             p = float(m.backproj_dropout) if training else 0.0
             drop = ops.drop_params(p, ops.next_seed() if p > 0 else 0, 7)
-            xg = x[g * B * Nv:(g + 1) * B * Nv]
+            xg = x[offs[g]:offs[g + 1]]
             with _on(streams, main, g):
                 if drop[0]:
                     xd = torch.empty_like(xg)
@@ -167,19 +179,19 @@ class _LevelsK9Fn(torch.autograd.Function):
             meta.append((N, Cc, H, W, m.patch_h, m.patch_w, drop))
         _join(streams, main, G)
         ctx.save_for_backward(*saved)
-        ctx.cfg = (mods, streams, meta, B, Nv, d, fused.dtype)
+        ctx.cfg = (mods, streams, meta, B, offs, d, fused.dtype, tuple(fused.shape))
         ok = lambda t: t is not None and t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32
         ctx.into = [((w.grad, b.grad) if (accumulate and ok(w) and ok(b)) else None) for w, b in zip(weights, biases)]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
-        mods, streams, meta, B, Nv, d, xdtype = ctx.cfg
+        mods, streams, meta, B, offs, d, xdtype, xshape = ctx.cfg
         G = len(mods)
         saved = ctx.saved_tensors
         dev = saved[0].device
         main = torch.cuda.current_stream(dev)
-        dx = torch.empty(G * B * Nv, d, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
+        dx = torch.empty(offs[-1], d, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
         dws, dbs = [], []
         for g, m in enumerate(mods):
             xd, wsh_t = saved[2 * g], saved[2 * g + 1]
@@ -189,7 +201,7 @@ class _LevelsK9Fn(torch.autograd.Function):
                 if go is None:
                     go = torch.zeros(B, Cc, H, W, dtype=torch.float32, device=dev)
                 go = go.contiguous()
-                drows = torch.empty(B * Nv, N, dtype=torch.bfloat16, device=dev)
+                drows = torch.empty(offs[g + 1] - offs[g], N, dtype=torch.bfloat16, device=dev)
                 L.call("tf_regroup_bwd", ops._patch_args(go, drows, B, Cc, H, W, ph, pw), ops._stream())
                 into = ctx.into[g]
                 if into is None:
@@ -206,14 +218,14 @@ class _LevelsK9Fn(torch.autograd.Function):
                     dbs.append(None)
                 ops.wgrad(drows, N, xd, d, gw.view(N, d), gb)
                 if dx is not None:
-                    dxg = dx[g * B * Nv:(g + 1) * B * Nv]
+                    dxg = dx[offs[g]:offs[g + 1]]
                     ops.gemm(drows, wsh_t, dxg, d, N, L.TF_EPI_NONE)
                     if drop[0]:
                         L.check(L.load().tf_dropout_apply(L.ptr(dxg), L.ptr(dxg), dxg.numel(), drop[1], drop[0], drop[2], ops._stream()), "tf_dropout_apply")
         _join(streams, main, G)
         gx = None
         if dx is not None:
-            gx = dx.view(G * B, Nv, d)
+            gx = dx.view(xshape)
             if xdtype != torch.bfloat16:
                 gx = gx.to(xdtype)
         return (None, gx) + tuple(dws) + tuple(dbs)

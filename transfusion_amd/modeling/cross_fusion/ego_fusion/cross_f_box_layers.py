@@ -89,10 +89,10 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, mod, need_grad, x, lang, pad_mask, *params):
         # need_grad comes from the caller: inside Function.forward grad mode is always off
         desc, keep = mod._make_desc(x, lang, pad_mask)
-        B, Nv, d = x.shape
-        Nl = lang.shape[1]
+        B, Nl, d = lang.shape
         out_dtype = x.dtype
-        vis_out = torch.empty(B, Nv, d, dtype=out_dtype, device=x.device)
+        # (ragged groups: x and the visual outputs are the concatenation [sum_g B_g nv_g, d] of the groups' tokens)
+        vis_out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         lang_out = torch.empty(B, Nl, d, dtype=out_dtype, device=x.device)
         desc.vis_out, desc.vis_out_is_f32 = L.ptr(vis_out), ops._is_f32(vis_out)
         desc.lang_out, desc.lang_out_is_f32 = L.ptr(lang_out), ops._is_f32(lang_out)
@@ -110,6 +110,7 @@ class _EncoderFn(torch.autograd.Function):
         # per-call tensors the descriptor points at live on ctx (the workspace item may be recycled by a later forward)
         ctx.held = (keep["inputs"], keep.get("mask"), keep.get("block_bits"))
         ctx.io = (x.dtype, lang.dtype, x.requires_grad, lang.requires_grad)
+        ctx.x_shape = tuple(x.shape)
         ctx.nparams = len(params)
         if not need_grad:
             mod._release(keep)           # no graph: the saved activations are not needed
@@ -131,7 +132,7 @@ class _EncoderFn(torch.autograd.Function):
             return (None,) * (5 + ctx.nparams)
         desc.d_vis_out, desc.d_vis_out_is_f32 = L.ptr(g_vis), 0 if g_vis is None else ops._is_f32(g_vis)
         desc.d_lang_out, desc.d_lang_out_is_f32 = L.ptr(g_lang), 0 if g_lang is None else ops._is_f32(g_lang)
-        d_vis = torch.empty(B, Nv, d, dtype=x_dtype, device=dev) if x_rg else None
+        d_vis = torch.empty(ctx.x_shape, dtype=x_dtype, device=dev) if x_rg else None
         d_lang = torch.empty(B, Nl, d, dtype=lang_dtype, device=dev) if lang_rg else None
         desc.d_vis, desc.d_vis_is_f32 = L.ptr(d_vis), 0 if d_vis is None else ops._is_f32(d_vis)
         desc.d_lang, desc.d_lang_is_f32 = L.ptr(d_lang), 0 if d_lang is None else ops._is_f32(d_lang)
@@ -297,6 +298,7 @@ class CrossTransformerModuleBox(nn.Module):
         self._grad_ptr_cache = None           # the same for the .grad tensors of the direct-accumulation path: _bind_grads
         self._group_mods = None               # set for the duration of a forward_grouped call: [self, the other encoders of the group]
         self._group_stride = None
+        self._group_nv = None                 # ... and, for RAGGED groups, the visual tokens per sample of every group
         self._wpack = None
         self._wpack_versions = None
         self._work_pool = {}
@@ -357,8 +359,15 @@ class CrossTransformerModuleBox(nn.Module):
 
     def _make_desc(self, x, lang, pad_mask):
         ops._require_cuda(x, lang, pad_mask, self.image_kind_embedding)
-        B, Nv, d = x.shape
-        Nl = lang.shape[1]
+        gnv = self._group_nv                 # ragged groups (forward_grouped): visual tokens per sample of every group, or None
+        if gnv is not None:
+            B, Nl, d = lang.shape
+            Nv = max(gnv)
+            if x.dim() != 2 or x.shape[1] != d or B % len(gnv) or x.shape[0] != (B // len(gnv)) * sum(gnv):
+                raise RuntimeError(f"ragged groups {gnv}: visual tokens {tuple(x.shape)} are not the concatenation of {B // len(gnv)} samples per group")
+        else:
+            B, Nv, d = x.shape
+            Nl = lang.shape[1]
         if d != self.token_dim or lang.shape[2] != d or lang.shape[0] != B:
             raise RuntimeError(f"token shapes {tuple(x.shape)} / {tuple(lang.shape)} do not match input_f_size={self.token_dim}")
         params = self._param_list()
@@ -387,12 +396,17 @@ class CrossTransformerModuleBox(nn.Module):
         e.packed_rows = 0                   # the plan is the dense one (an upper bound for every packed layout of this shape)
         if self._group_mods:
             e.groups, e.param_gstride = len(self._group_mods), int(self._group_stride)
+        if gnv is not None:
+            if len(gnv) != e.groups or e.groups > L.CONSTS["TF_MAX_GROUPS"]:
+                raise ValueError(f"ragged groups {gnv}: {e.groups} encoders in the call (at most {L.CONSTS['TF_MAX_GROUPS']})")
+            for i, n in enumerate(gnv):
+                e.group_nv[i] = int(n)
         plan = L.TfEncoderPlan()
         L.check(lib.tf_encoder_plan_ex(C.addressof(e), C.addressof(plan)), "tf_encoder_plan_ex")
         if self._wpack is None or self._wpack.numel() != plan.wpack_bytes or self._wpack.device != x.device:
             self._wpack = torch.zeros(plan.wpack_bytes, dtype=torch.uint8, device=x.device)
             self._wpack_versions = None
-        keep = self._get_work((B, Nv, Nl, self.precision), plan, x.device)
+        keep = self._get_work((B, Nv, Nl, self.precision) + (() if gnv is None else (tuple(gnv),)), plan, x.device)
         keep["busy"] = True
         e.training = 1 if self.training else 0
         e.final_norm = 1 if self.final_norm == "ln" else 0
@@ -407,6 +421,8 @@ class CrossTransformerModuleBox(nn.Module):
         # positional tables: the sin1d BUFFERS are read by the assemble kernel; learned / zero tables are Parameters (utils.py:181-184)
         # whose gradient autograd needs, so forward() has already added those with a torch op and they are not passed here
         pe = self.pos_embedding_layer.pos_embedding
+        if gnv is not None:                  # the LONGEST table of the group (group_stride checked that the others are its prefixes)
+            pe = self._group_mods[max(range(len(gnv)), key=lambda i: gnv[i])].pos_embedding_layer.pos_embedding
         if not isinstance(pe, nn.Parameter):
             e.pe = self._table(pe, Nv, d, "pos_embedding")
         lpe = None if not self.lang_pos_embedding else self.lang_pos_embedding.pos_embedding
@@ -438,9 +454,12 @@ class CrossTransformerModuleBox(nn.Module):
             e.lang_pad_mask = m8.data_ptr()
             pr = int(self._packed_rows)
             if pr:
-                if not (B * Nv <= pr <= B * (Nv + Nl)):
-                    raise ValueError(f"lang_valid_rows: {pr - B * Nv} un-masked language tokens do not fit a [{B}, {Nl}] mask")
+                nvis = x.shape[0] if gnv is not None else B * Nv
+                if not (nvis <= pr <= nvis + B * Nl):
+                    raise ValueError(f"lang_valid_rows: {pr - nvis} un-masked language tokens do not fit a [{B}, {Nl}] mask")
                 e.packed_rows = pr
+        if gnv is not None and not e.packed_rows:
+            raise L.TfError("ragged groups run on packed token rows: pass lang_valid_rows (and a padding mask) to forward_grouped")
         return e, keep
 
     @staticmethod
@@ -539,11 +558,14 @@ class CrossTransformerModuleBox(nn.Module):
             language_tokens = self.lang_pos_embedding(language_tokens)
         self._packed_rows = 0
         if lang_valid_rows is not None and language_tokens_att_maks is not None and self.pack_tokens:
-            self._packed_rows = x.shape[0] * x.shape[1] + int(lang_valid_rows)
+            nvis = x.shape[0] if self._group_nv is not None else x.shape[0] * x.shape[1]
+            self._packed_rows = nvis + int(lang_valid_rows)
         elif language_tokens_att_maks is not None and self.pack_tokens and self.training:
             _warn_dense_rows_once()
         self._block_bits = None
         if vis_tokens_mask is not None:
+            if self._group_nv is not None:
+                raise L.TfError("a visual token mask and ragged groups exclude each other")
             self._block_bits = self._pack_block_bits(vis_tokens_mask, x.shape[1], language_tokens.shape[1], x.device)
         params = self._param_list()
         need_grad = torch.is_grad_enabled() and (x.requires_grad or language_tokens.requires_grad or any(p.requires_grad for p in params))
@@ -554,14 +576,16 @@ class CrossTransformerModuleBox(nn.Module):
     _GROUP_CFG = ("num_layers", "num_heads", "token_dim", "dim_feedforward", "token_dropout", "patch_dropout", "activ_f", "final_norm",
                   "precision", "fp8_projections", "training", "accumulate_into_grad", "pack_tokens")
 
-    def group_stride(self, mods):
-        """Byte stride between the parameters of consecutive encoders of ``mods`` (``mods[0] is self``) if they can run as one grouped
+    def group_stride(self, mods, ragged=False):
+        """``ragged``: the encoders may differ in their number of visual tokens (TfEncoderDesc.group_nv): their positional tables then
+        need not have one shape, but every table must be a PREFIX of the longest one (the kernel reads one table by row).
+        Byte stride between the parameters of consecutive encoders of ``mods`` (``mods[0] is self``) if they can run as one grouped
         call, else None: identical configuration, gradients accumulated in place, per-layer gradient hooks on all members or on none, fixed positional tables
         with equal contents, and every parameter AND every gradient tensor of encoder g exactly g * stride bytes after encoder 0's --
         what FusionTrainStep's flat buffers give.  Cached on the tensors' addresses."""
         if len(mods) < 2 or mods[0] is not self:
             return None
-        key = tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr()) for m in mods for p in m._param_list())
+        key = tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr()) for m in mods for p in m._param_list()) + (bool(ragged),)
         cached = getattr(self, "_group_check", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -587,27 +611,44 @@ class CrossTransformerModuleBox(nn.Module):
         if stride is not None:
             pe0 = self.pos_embedding_layer.pos_embedding
             ok = not isinstance(pe0, nn.Parameter) and not self.lang_pos_embedding
-            ok = ok and all(not m.lang_pos_embedding and not isinstance(m.pos_embedding_layer.pos_embedding, nn.Parameter)
-                            and m.pos_embedding_layer.pos_embedding.shape == pe0.shape
-                            and (m.pos_embedding_layer.pos_embedding is pe0 or torch.equal(m.pos_embedding_layer.pos_embedding, pe0)) for m in mods[1:])
+            ok = ok and all(not m.lang_pos_embedding and not isinstance(m.pos_embedding_layer.pos_embedding, nn.Parameter) for m in mods[1:])
+            if ok and ragged:
+                tables = [m.pos_embedding_layer.pos_embedding for m in mods]
+                longest = max(tables, key=lambda t: t.shape[1])
+                ok = all(t.dim() == 3 and t.shape[0] == longest.shape[0] and t.shape[2] == longest.shape[2]
+                         and (t is longest or torch.equal(t, longest[:, :t.shape[1]])) for t in tables)
+            elif ok:
+                ok = all(m.pos_embedding_layer.pos_embedding.shape == pe0.shape
+                         and (m.pos_embedding_layer.pos_embedding is pe0 or torch.equal(m.pos_embedding_layer.pos_embedding, pe0)) for m in mods[1:])
             if not ok:
                 stride = None
         self._group_check = (key, stride)
         return stride
 
-    def forward_grouped(self, mods, x, language_tokens, language_tokens_att_maks, lang_valid_rows=None):
+    def forward_grouped(self, mods, x, language_tokens, language_tokens_att_maks, lang_valid_rows=None, group_nv=None):
         """``x`` [G * B, Nv, d]: the visual tokens of the G encoders ``mods`` (``mods[0] is self``), group-major; ``language_tokens`` /
         mask [G * B, Nl, ...] likewise (the wrapper repeats the shared narration tokens).  One runtime call for all G encoders, each
         row range against its own parameters (TfEncoderDesc.groups).  ``lang_valid_rows`` counts the un-masked tokens of ALL groups.
-        Returns what ``forward`` returns, for the stacked batch.  Check ``group_stride(mods)`` first."""
-        stride = self.group_stride(mods)
+        Returns what ``forward`` returns, for the stacked batch.  Check ``group_stride(mods)`` first.
+        ``group_nv`` (RAGGED groups, TfEncoderDesc.group_nv): the encoders differ in their visual token count -- ``group_nv[g]`` per sample
+        of group g, the reference's real FPN geometry (28 x 28 tokens on level 0, 14 x 14 on levels 1 - 3).  ``x`` is then the
+        CONCATENATION [sum_g B * group_nv[g], d] of the groups' tokens and so is the first return value; needs ``lang_valid_rows`` and a
+        mask (ragged groups exist on packed rows); check ``group_stride(mods, ragged=True)`` first."""
+        ragged = group_nv is not None and len(set(group_nv)) > 1
+        stride = self.group_stride(mods, ragged=ragged)
         if stride is None:
             raise L.TfError("these encoders cannot run as one grouped call (CrossTransformerModuleBox.group_stride)")
+        if ragged and (lang_valid_rows is None or language_tokens_att_maks is None or not self.pack_tokens):
+            raise L.TfError("ragged groups run on packed token rows: lang_valid_rows, a padding mask and pack_tokens are required")
+        if group_nv is not None and not ragged:                      # equal counts after all: the plain grouped call on [G B, Nv, d]
+            x = x.reshape(language_tokens.shape[0], group_nv[0], x.shape[-1])
         self._group_mods, self._group_stride = list(mods), stride
+        self._group_nv = [int(n) for n in group_nv] if ragged else None
         try:
             return self.forward(x, language_tokens, language_tokens_att_maks, None, lang_valid_rows)
         finally:
             self._group_mods = None
+            self._group_nv = None
 
     def _pack_block_bits(self, vis_tokens_mask, Nv, Nl, device):
         """vis_tokens_mask [Nv,Nv] (nonzero = blocked, reference utils.py:14-30) -> the [S, ceil(S/64)] u64 block-bit matrix of

@@ -15,6 +15,7 @@ import os
 import torch
 from torch import nn
 
+from transfusion_amd import _lib as L
 from transfusion_amd import ops
 from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
 from transfusion_amd.modeling.cross_fusion.ego_fusion.lm_layers import get_lm_layer
@@ -292,13 +293,20 @@ class CrossFusionBoxWrapper(nn.Module):
         if any(f.shape[0] != B for f in feats):
             return None
         n_tok = [(f.shape[2] // self.patches_to_token[i].patch_h) * (f.shape[3] // self.patches_to_token[i].patch_w) for i, f in enumerate(feats)]
-        # the largest class of levels with one token count whose encoders sit at a common stride (ties: the first)
-        members = None
-        for cnt in sorted(set(n_tok), key=lambda c: -n_tok.count(c)):
-            idx = [i for i in range(nlev) if n_tok[i] == cnt]
-            if len(idx) >= 2 and encs[idx[0]].group_stride([encs[i] for i in idx]) is not None:
-                members = idx
-                break
+        # ALL levels as one RAGGED grouped call (TfEncoderDesc.group_nv) when they differ in their token counts and the rows are packed
+        # (the batch's un-masked token count is known): the reference's real geometry, 4N / N / N / N tokens.  TF_RAGGED_GROUPS=0: off
+        members, ragged = None, False
+        if (len(set(n_tok)) > 1 and n_valid is not None and getattr(encs[0], "pack_tokens", False) and pad_mask is not None
+                and nlev <= L.CONSTS["TF_MAX_GROUPS"] and os.environ.get("TF_RAGGED_GROUPS", "1") != "0"
+                and encs[0].group_stride(encs, ragged=True) is not None):
+            members, ragged = list(range(nlev)), True
+        # otherwise the largest class of levels with one token count whose encoders sit at a common stride (ties: the first)
+        if members is None:
+            for cnt in sorted(set(n_tok), key=lambda c: -n_tok.count(c)):
+                idx = [i for i in range(nlev) if n_tok[i] == cnt]
+                if len(idx) >= 2 and encs[idx[0]].group_stride([encs[i] for i in idx]) is not None:
+                    members = idx
+                    break
         if members is None:
             return None
         others = [i for i in range(nlev) if i not in members]
@@ -331,6 +339,9 @@ class CrossFusionBoxWrapper(nn.Module):
             for i, a in zip(levels, args):
                 st = self._level_streams[i]
                 st.wait_stream(main)
+                # `a` was allocated on main and is about to be read (and possibly SAVED for the backward) on the level stream: tell the
+                # allocator, or the block is recycled the moment the last reference drops -- see ops._LinearFn.forward
+                a.record_stream(st)
                 with torch.cuda.stream(st):
                     r = fn(i, a)
                 r.record_stream(main)
@@ -366,14 +377,22 @@ class CrossFusionBoxWrapper(nn.Module):
             x = level_ops.levels_patch_embed(p2t, gfeats, sts)
         else:
             toks = per_level(lambda i, feat: self.patches_to_token[i](feat), members, gfeats)
-            x = torch.cat(toks, dim=0)                             # [G * B, Nv, d], group-major
+            x = torch.cat([t.reshape(-1, t.shape[-1]) for t in toks], dim=0) if ragged else torch.cat(toks, dim=0)   # [G * B, Nv, d], group-major
         lang_g, pad_g = language_f.repeat(G, 1, 1), pad_mask.repeat(G, 1)
         kw = {}
         if n_valid is not None and getattr(lead, "pack_tokens", False):
             kw["lang_valid_rows"] = G * n_valid
+        if ragged:
+            kw["group_nv"] = [n_tok[i] for i in members]
         fused, fused_l, _, _ = lead.forward_grouped([encs[i] for i in members], x, lang_g, pad_g, **kw)
         if fused_ops and level_ops.k9_supported(t2f, self.token_dim):
             gouts = level_ops.levels_back_project(t2f, fused, sts)
+        elif ragged:                                               # fused: the concatenation [sum_g B nv_g, d]
+            offs = [0]
+            for i in members:
+                offs.append(offs[-1] + B * n_tok[i])
+            gouts = per_level(lambda i, f: self.tokens_to_features[i](f), members,
+                              [fused[offs[k]:offs[k + 1]].view(B, n_tok[i], fused.shape[-1]) for k, i in enumerate(members)])
         else:
             gouts = per_level(lambda i, f: self.tokens_to_features[i](f), members, [fused[k * B:(k + 1) * B] for k in range(G)])
         for k, (i, fl) in enumerate(zip(members, fused_l.chunk(G, dim=0))):

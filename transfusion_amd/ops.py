@@ -692,6 +692,13 @@ class _LinearFn(torch.autograd.Function):
             xd = torch.empty_like(xb)
             L.check(L.load().tf_dropout_apply(L.ptr(xb), L.ptr(xd), xb.numel(), drop[1], drop[0], drop[2], _stream()), "tf_dropout_apply")
             xb = xd
+        # xb is SAVED for the backward's weight gradient, and it may be the caller's own tensor (bf16, contiguous, no pad): one that was
+        # allocated on ANOTHER stream -- the grouped encoder's output (main) handed to a level's back-projection (level stream).  Autograd
+        # replays this node on the stream it ran on and drops the saved tensor as soon as its backward has been ENQUEUED; the allocator
+        # would then hand the block to the next allocation on its home stream while the weight gradient has not read it yet (round 4's
+        # one-off 0.37 gradient mismatch; DESIGN.md "Round 5").  record_stream defers the reuse behind this stream's work.
+        if xb.is_cuda:
+            xb.record_stream(torch.cuda.current_stream(xb.device))
         y = torch.zeros(M, Np, dtype=torch.bfloat16, device=x2d.device) if Np != N else torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
         bf = None if bias is None else bias.detach().float().contiguous()
         if bf is not None and N8 != N:
