@@ -791,29 +791,36 @@ def test_linear_input_from_another_stream_survives_until_its_weight_gradient_ran
                     break
             return grad
 
+    def scenario(st):
+        target["ptr"], target["hit"] = 0, False
+        w = torch.nn.Parameter(w0.clone())
+        main = torch.cuda.current_stream(dev)
+        xb = x0.to(torch.bfloat16).requires_grad_(True)
+        mid = xb * 1.0                                         # an intermediate allocated on main: the tensor ops.linear will save
+        target["ptr"] = mid.data_ptr()
+        probe = Scribbler.apply(mid)                           # created BEFORE the linear node: its backward runs after it
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            y = ops.linear(mid, w)
+        main.wait_stream(st)
+        loss = (y.float() * cot).sum() + probe.float().sum()
+        del mid, probe, y                                      # only the graph holds the intermediate now
+        prev = ops.debug_delay_wgrad(3000)
+        try:
+            loss.backward()
+        finally:
+            ops.debug_delay_wgrad(prev)
+        torch.cuda.synchronize()
+        return target["hit"], ((w.grad.float() - ref).norm() / ref.norm()).item()
+
     if not protected:
         monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None)
-    w = torch.nn.Parameter(w0.clone())
-    main, st = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
-    xb = x0.to(torch.bfloat16).requires_grad_(True)
-    mid = xb * 1.0                                         # an intermediate allocated on main: the tensor ops.linear will save
-    target["ptr"] = mid.data_ptr()
-    probe = Scribbler.apply(mid)                           # created BEFORE the linear node: its backward runs after it
-    st.wait_stream(main)
-    with torch.cuda.stream(st):
-        y = ops.linear(mid, w)
-    main.wait_stream(st)
-    loss = (y.float() * cot).sum() + probe.float().sum()
-    del mid, probe, y                                      # only the graph holds the intermediate now
-    prev = ops.debug_delay_wgrad(3000)
-    try:
-        loss.backward()
-    finally:
-        ops.debug_delay_wgrad(prev)
-        monkeypatch.undo()
-    torch.cuda.synchronize()
-    err = ((w.grad.float() - ref).norm() / ref.norm()).item()
+    # Several level streams: two streams that the runtime maps onto ONE hardware queue run in submission order, and the scribble then
+    # waits behind the spin by accident (the mapping depends on how many streams the process has created).  With the
+    # fix every stream must be right; the control needs one stream on a queue of its own.
+    seen = [scenario(torch.cuda.Stream(device=dev)) for _ in range(8)]
+    monkeypatch.undo()
     if protected:
-        assert not target["hit"] and err < 1e-2, (target["hit"], err)
+        assert all(not hit and err < 1e-2 for hit, err in seen), seen
     else:
-        assert target["hit"] and err > 5e-2, (target["hit"], err)
+        assert any(hit and err > 5e-2 for hit, err in seen), seen
