@@ -30,9 +30,14 @@ def _join(streams, main, n):
             main.wait_stream(st)
 
 
+def _up64(n):
+    return (n + 63) // 64 * 64
+
+
 def k1_supported(mods, feats, d):
-    """K and d multiples of 64 (no padded copies), bf16 arithmetic, 4-D feature maps that tile into patches."""
-    if d % 64:
+    """K a multiple of 64, d of 8 (d = 712, the Ego4D v1 width, costs one padded copy of the token gradients in the backward), bf16
+    arithmetic, 4-D feature maps that tile into patches."""
+    if d % 8:
         return False
     for m, f in zip(mods, feats):
         if getattr(m, "precision", "bf16") != "bf16" or f.dim() != 4 or not f.is_cuda:
@@ -43,7 +48,7 @@ def k1_supported(mods, feats, d):
 
 
 def k9_supported(mods, d):
-    if d % 64:
+    if d % 8:              # (d % 64 != 0: the tokens are copied into rows padded to 64 in front of the GEMM, as ops.linear does)
         return False
     for m in mods:
         n = m.linear.weight.shape[0]
@@ -74,7 +79,7 @@ class _LevelsK1Fn(torch.autograd.Function):
         for g, (m, f, w) in enumerate(zip(mods, feats, weights)):
             Bc, Cc, H, W = f.shape
             K = Cc * m.patch_h * m.patch_w
-            wsh, wsh_t = ops._weight_shadows(w, d, K, d)
+            wsh, wsh_t = ops._weight_shadows(w, d, K, _up64(d))
             with _on(streams, main, g):
                 f = f.contiguous()
                 rows = torch.empty(Bc * nvs[g], K, dtype=torch.bfloat16, device=f.device)
@@ -115,7 +120,7 @@ class _LevelsK1Fn(torch.autograd.Function):
                 ops.wgrad(gyg, d, rows, K, gw.view(d, K), None)
                 if ctx.needs_input_grad[1 + g]:
                     dx = torch.empty(offs[g + 1] - offs[g], K, dtype=torch.bfloat16, device=gy.device)
-                    ops.gemm(gyg, wsh_t, dx, K, d, L.TF_EPI_NONE)
+                    ops.gemm(ops.to_bf16_padded(gyg, _up64(d)), wsh_t, dx, K, _up64(d), L.TF_EPI_NONE)   # (a copy only when d % 64 != 0)
                     df = torch.empty(shape, dtype=dtype, device=gy.device)
                     L.call("tf_patchify_bwd", ops._patch_args(df, dx, shape[0], shape[1], shape[2], shape[3], ph, pw), ops._stream(), ops._is_f32(df))
                     if streams is not None:
@@ -157,7 +162,8 @@ class _LevelsK9Fn(torch.autograd.Function):
             Nv = nvs[g]
             if fused.dim() == 3 and fused.shape[1] != Nv:
                 raise RuntimeError(f"regroup_patches: {fused.shape[1]} tokens do not tile a {H}x{W} map with {m.patch_h}x{m.patch_w} patches")
-            wsh, wsh_t = ops._weight_shadows(w, N, d, N)
+            dp = _up64(d)
+            wsh, wsh_t = ops._weight_shadows(w, N, dp, N)
             p = float(m.backproj_dropout) if training else 0.0
             drop = ops.drop_params(p, ops.next_seed() if p > 0 else 0, 7)
             xg = x[offs[g]:offs[g + 1]]
@@ -167,8 +173,9 @@ class _LevelsK9Fn(torch.autograd.Function):
                     L.check(L.load().tf_dropout_apply(L.ptr(xg), L.ptr(xd), xg.numel(), drop[1], drop[0], drop[2], ops._stream()), "tf_dropout_apply")
                 else:
                     xd = xg
+                xd = ops.to_bf16_padded(xd, dp)                    # (a copy only when d % 64 != 0; the dropout mask is indexed on the unpadded rows)
                 y = torch.empty(B * Nv, N, dtype=torch.bfloat16, device=dev)
-                ops.gemm(xd, wsh, y, N, d, L.TF_EPI_BIAS, bias=b)
+                ops.gemm(xd, wsh, y, N, dp, L.TF_EPI_BIAS, bias=b)
                 o = torch.empty(B, Cc, H, W, dtype=torch.float32, device=dev)
                 L.call("tf_regroup_fwd", ops._patch_args(o, y, B, Cc, H, W, m.patch_h, m.patch_w), ops._stream(), 1)
                 if streams is not None:
@@ -216,7 +223,7 @@ class _LevelsK9Fn(torch.autograd.Function):
                     gw, gb = into
                     dws.append(None)
                     dbs.append(None)
-                ops.wgrad(drows, N, xd, d, gw.view(N, d), gb)
+                ops.wgrad(drows, N, xd, xd.shape[1], gw.view(N, d), gb)      # (xd is padded to 64 columns: k_src = d masks the pad)
                 if dx is not None:
                     dxg = dx[offs[g]:offs[g + 1]]
                     ops.gemm(drows, wsh_t, dxg, d, N, L.TF_EPI_NONE)
