@@ -503,20 +503,42 @@ def probe_under_timer(result, probe, rank, timeout_s=None):
     RCCL communicator exercised with its peers (a second communicator next to the process group's): its bootstrap has never run on a
     multi-GPU node, and a communicator that never forms cannot be cancelled -- so if the probe is not back in time, the line measured so
     far is printed WITHOUT it (rank 0) and the process leaves with exit code 0: the benchmark result never depends on the probe."""
-    import threading
     line = dict(result)
     line["allreduce"] = dict(result.get("allreduce", {}), rccl={"error": "probe did not return in time"})
+    out = _under_timer(line, probe, rank, float(timeout_s if timeout_s is not None else os.environ.get("TF_RCCL_PROBE_TIMEOUT_S", "90")))
+    result.setdefault("allreduce", {}).update(out)
+
+
+def _under_timer(line_if_late, fn, rank, timeout_s):
+    """``fn()`` under a timer on EVERY rank: if it is not back in time, rank 0 prints ``line_if_late`` and every rank leaves with exit
+    code 0 (a collective that never completes cannot be cancelled, and the measured line must not depend on an extra)."""
+    import threading
 
     def bail():
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line_if_late), flush=True)
         os._exit(0)
-    timer = threading.Timer(float(timeout_s if timeout_s is not None else os.environ.get("TF_RCCL_PROBE_TIMEOUT_S", "90")), bail)
+    timer = threading.Timer(timeout_s, bail)
     timer.daemon = True
     timer.start()
-    out = probe()
-    timer.cancel()
-    result.setdefault("allreduce", {}).update(out)
+    try:
+        return fn()
+    finally:
+        timer.cancel()
+
+
+def extra_under_timer(result, key, fn, rank, timeout_s):
+    """An EXTRA measurement of the N > 1 line (``result[key] = fn()``), under the same rule as the probe: a failure is reported in the
+    entry, a hang costs the entry, never the line."""
+    line = dict(result)
+    line[key] = {"error": "did not return in time"}
+
+    def guarded():
+        try:
+            return fn()
+        except BaseException as e:                   # noqa: BLE001 -- reported on the line (SystemExit of a non-finite loss included)
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+    result[key] = _under_timer(line, guarded, rank, timeout_s)
 
 
 def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
@@ -984,6 +1006,13 @@ def main():
             strong = run_leg("strong", device, rank, comm, batch=per, steps=16, warmup=4)
             result["strong"] = {"global_batch": per * world, "samples_s": strong["samples_s"], "ms_per_step": strong["ms_per_step"],
                                 "batch_per_gpu": per}
+        if live and os.environ.get("TF_WRAPPER_DP_LEG", "1") != "0":
+            # the reference's REAL module under data parallelism, at its own per-GPU batch and FPN geometry: the four-level wrapper as one
+            # ragged grouped call, gradients exchanged unit by unit behind the backward (OrderedRangeReducer over the process group).
+            # An extra of the N > 1 line: under a timer, reported or dropped, never fatal
+            faulthandler.cancel_dump_traceback_later()
+            extra_under_timer(result, "wrapper_b4_real_dp", lambda: run_wrapper_leg(device, rank, comm, batch=4, real=True, steps=8, warmup=3), rank,
+                              float(os.environ.get("TF_WRAPPER_DP_TIMEOUT_S", "150")))
         if legs:
             result["legs"] = legs
             if "fp32" in legs:            # BASELINE configs[2] (Ego4Dv2, run.precision: 32) names fp32: that leg's figure at top level too

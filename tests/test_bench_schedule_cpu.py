@@ -114,3 +114,26 @@ def test_a_probe_that_never_returns_cannot_take_the_bench_line_with_it(tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["allreduce"]["rccl"] == {"world": 8, "calls": 11} and line["allreduce"]["backend"] == "nccl"
+
+
+def test_an_extra_leg_that_hangs_or_raises_cannot_take_the_bench_line_with_it(tmp_path):
+    """bench.extra_under_timer (the real module under data parallelism as an extra of the N > 1 line): a hang costs the entry -- the line
+    is printed without it, exit code 0 --, an exception becomes the entry's error text, a result is merged under its key."""
+    import json
+    import subprocess
+    script = tmp_path / "extra.py"
+    script.write_text(
+        "import importlib.util, json, os, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "res = {'metric': 'm', 'value': 2.0}\n"
+        "def boom():\n"
+        "    raise SystemExit('non-finite loss')\n"
+        "fn = {'hang': lambda: time.sleep(3600), 'raise': boom, 'ok': lambda: {'ms_per_step': 5.5}}[sys.argv[1]]\n"
+        "b.extra_under_timer(res, 'wrapper_b4_real_dp', fn, 0, 1.0 if sys.argv[1] == 'hang' else 30.0)\n"
+        "print(json.dumps(res))\n")
+    want = {"hang": lambda e: "did not return" in e["error"], "raise": lambda e: "non-finite" in e["error"], "ok": lambda e: e == {"ms_per_step": 5.5}}
+    for mode, check in want.items():
+        r = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (mode, r.stderr[-2000:])
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["value"] == 2.0 and check(line["wrapper_b4_real_dp"]), (mode, line)

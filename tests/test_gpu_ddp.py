@@ -151,6 +151,9 @@ def test_bench_two_ranks_on_one_gpu_does_not_hang(tmp_path):
     assert res["rank_sync"]["identical_on_ranks"] == 2                      # the self-check runs by default at N > 1
     # strong scaling next to the weak number: the reference divides the GLOBAL batch of 32 by the device count (run_experiment.py:373)
     assert res["strong"]["global_batch"] == 32 and res["strong"]["batch_per_gpu"] == 16 and res["strong"]["samples_s"] > 0
+    # ... and the reference's real module (four-level wrapper, real FPN geometry, batch 4 per rank) under the ordered range reducer
+    w = res["wrapper_b4_real_dp"]
+    assert "error" not in w and w["ms_per_step"] > 0 and w["reducer"] == "OrderedRangeReducer" and w["batch_per_gpu"] == 4, w
 
 
 def test_bench_bare_gpus_2_starts_its_own_ranks(tmp_path):
@@ -437,8 +440,8 @@ def test_bench_rehearses_the_rccl_path_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TF_REHEARSE_COLLECTIVES="1", TF_BENCH_WATCHDOG_S="250", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for comm in ("torch", "rccl"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-census", "--no-legs", "--comm", comm],
-                           env=env, capture_output=True, text=True, timeout=280)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-census", "--legs", "b4", "--comm", comm,
+                            "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
         res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert res["n_gpus"] == 1 and res["value"] > 0 and "rehearsal" in res
@@ -446,3 +449,5 @@ def test_bench_rehearses_the_rccl_path_on_one_gpu():
         assert ar["backend"] == "nccl" and ar["group_world"] == 1 and ar["collectives_per_step"] == 4 and ar["bytes"] > 7e7
         assert ar["rccl"].get("matches_process_group") is True and ar["rccl"]["world"] == 1, ar["rccl"]
         assert res["rank_sync"]["identical_on_ranks"] == 1
+        w = res["wrapper_b4_real_dp"]                            # the real module's data-parallel step over RCCL (one rank)
+        assert "error" not in w and w["ms_per_step"] > 0 and w["reducer"] == "OrderedRangeReducer", w
