@@ -13,7 +13,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def _encoders(dev, G, d, H, layers, p_tok, p_patch):
+def _encoders(dev, G, d, H, layers, p_tok, p_patch, final_norm="ln"):
     from transfusion_amd.modeling.cross_fusion.ego_fusion.cross_f_box_layers import CrossTransformerModuleBox
     from transfusion_amd.modeling.cross_fusion.utils import PositionalEmbeddingLayer
     mods = []
@@ -22,7 +22,7 @@ def _encoders(dev, G, d, H, layers, p_tok, p_patch):
         pe = PositionalEmbeddingLayer("sin1d", 256, d)
         m = CrossTransformerModuleBox(no_patches=256, pos_embedding_layer=pe, lang_pos_embedding=None, num_layers=layers, patch_dropout=p_patch,
                                       num_heads=H, fforward_multiplier=2, token_dropout=p_tok, back_to_img_fn="regroup", activ_f="gelu",
-                                      final_norm="ln", input_f_size=d)
+                                      final_norm=final_norm, input_f_size=d)
         # LayerNorm weights / kind embeddings away from their defaults, so that a group reading ANOTHER group's vector shows
         with torch.no_grad():
             for q in m.parameters():
@@ -119,6 +119,7 @@ def test_group_stride_refuses_what_cannot_be_grouped():
     ([9, 36], 3, 24, 192, 4, 1, "bf16"),                # the LARGEST group need not come first
     ([196, 49], 4, 128, 768, 4, 2, "bf16"),             # d = 768: the large-tile kernels walk the ragged ranges
     ([64, 16, 16], 2, 40, 64, 2, 2, "fp32"),            # fp32-accuracy mode
+    ([25, 64, 9], 2, 40, 64, 2, 1, "bf16-nonorm"),      # final_norm: false -- the visual rows leave / enter through plain copies
 ])
 def test_ragged_grouped_call_equals_separate_calls(nvs, B, Nl, d, H, layers, precision):
     """TfEncoderDesc.group_nv: encoders that differ in their visual token count as ONE grouped call on packed rows -- visual tokens,
@@ -129,7 +130,9 @@ def test_ragged_grouped_call_equals_separate_calls(nvs, B, Nl, d, H, layers, pre
     from transfusion_amd.runner.trainer import FusionTrainStep
     dev = torch.device("cuda:0")
     G = len(nvs)
-    mods = _encoders(dev, G, d, H, layers, 0.0, 0.0)              # dropout off: element indices (hence masks) differ between the two paths
+    final_norm = False if precision.endswith("-nonorm") else "ln"
+    precision = precision.split("-")[0]
+    mods = _encoders(dev, G, d, H, layers, 0.0, 0.0, final_norm)  # dropout off: element indices (hence masks) differ between the two paths
     for m in mods:
         m.precision = precision
     tr = FusionTrainStep(mods, lr=0.0, weight_decay=0.0, grad_clip=None)
