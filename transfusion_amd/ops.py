@@ -81,10 +81,12 @@ def from_padded(x2d: torch.Tensor, cols: int, dtype) -> torch.Tensor:
     return out
 
 
-def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG, into=None):
+def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, want_t: bool = True, rg=BIG, rgp=BIG, cg=BIG, cgp=BIG, into=None,
+                residual: bool = False):
     """fp32 [N,K] parameter -> bf16 shadow [rows_p, ld] and transpose [cols_p, ld_t]; rows / columns may be regrouped (source index
     (p // gp) * g + p % gp, valid iff p % gp < g): heads of width hd padded to hdp.  ``into``: (dst, dst_t) of an earlier call with
-    the same geometry, re-packed in place (their pad columns are still the zeros they were created with)."""
+    the same geometry, re-packed in place (their pad columns are still the zeros they were created with).  ``residual``: the lo plane of
+    the fp32-accuracy mode, bf16(w - bf16(w)), formed by the kernel (TfPackArgs.residual)."""
     N, K = w.shape
     w = w.detach().contiguous().float()
     if into is not None and into[0].shape == (rows_p, ld) and (not want_t or (into[1] is not None and into[1].shape == (cols_p, ld_t))):
@@ -97,7 +99,7 @@ def pack_weight(w: torch.Tensor, rows_p: int, cols_p: int, ld: int, ld_t: int, w
         dst = torch.zeros(rows_p, ld, dtype=torch.bfloat16, device=w.device)
         dst_t = torch.zeros(cols_p, ld_t, dtype=torch.bfloat16, device=w.device) if want_t else None
     a = L.TfPackArgs(src=L.ptr(w), rows=N, cols=K, dst=L.ptr(dst), ld_dst=ld, dst_t=L.ptr(dst_t), ld_dst_t=ld_t,
-                     rows_p=rows_p, cols_p=cols_p, rg=rg, rgp=rgp, cg=cg, cgp=cgp, dst_is_f32=0)
+                     rows_p=rows_p, cols_p=cols_p, rg=rg, rgp=rgp, cg=cg, cgp=cgp, dst_is_f32=0, residual=1 if residual else 0)
     L.call("tf_pack_weight", a, _stream())
     return dst, dst_t
 
@@ -478,14 +480,13 @@ def _weight_shadows(weight, N8, Kp, Np, planes=False, sources=None):
     # same owners, new version (the optimiser stepped): re-pack into the entry's tensors instead of zero-filling two fresh ones per
     # weight and step.  (A forward whose backward is still pending must not be followed by an optimiser step and another forward of the
     # same weight before that backward runs: pack_weight bumps the shadows' autograd version, so that backward RAISES.)
-    reuse = hit[2][:2] if (hit is not None and not planes and all(r() is o for r, o in zip(hit[0], owners))
-                          and hit[2][0].device == w2.device) else None
-    wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np, into=reuse)
+    reuse = hit[2] if (hit is not None and all(r() is o for r, o in zip(hit[0], owners)) and hit[2][0].device == w2.device) else None
+    wsh, wsh_t = pack_weight(w2, N8, Kp, Kp, Np, into=reuse[:2] if reuse else None)
     out = (wsh, wsh_t)
     if planes:
-        wf = w2.detach().float()
-        lo = wf - wf.to(torch.bfloat16).float()                    # exact in fp32; the pack kernel rounds to nearest even as torch does
-        out = out + pack_weight(lo, N8, Kp, Kp, Np)
+        # the lo planes, bf16(w - bf16(w)), by the same kernel (round 5; before: three elementwise torch passes over the weight and four
+        # zero-filled shadows per weight and optimiser step -- the K1 / K9 weights of the wrapper are 4 - 8 M elements each)
+        out = out + pack_weight(w2, N8, Kp, Kp, Np, into=reuse[2:4] if (reuse and len(reuse) == 4) else None, residual=True)
     if not cacheable:
         return out
     if len(_shadow_cache) > 256:                                   # drop entries whose parameter is gone
