@@ -702,3 +702,50 @@ def test_capturing_level_streams_with_side_streams_raises_instead_of_crashing(mo
     out2 = model({"image": feats, "language_f": lang})                  # the refusal left the runtime usable
     torch.cuda.synchronize()
     assert torch.isfinite(out2["features"]["1"].float()).all()
+
+
+def test_ragged_and_split_paths_train_alike(monkeypatch):
+    """Dropout ON (the fixtures run without): 60 optimiser steps of a two-level wrapper with unequal token grids on a fixed batch, once
+    through the ragged grouped call and once through the level loop.  The dropout masks of the two paths differ (they are functions of
+    the packed row index), so the trajectories are compared, not the steps: both losses must fall by the same factor within a few per
+    cent, nothing may turn non-finite, and no packed-row error may be pending."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from transfusion_amd.modeling.model_factory import get_fusion_model
+    from transfusion_amd.runner.config import load_fusion_config
+    from transfusion_amd.runner.trainer import FusionTrainStep
+    dev = torch.device("cuda:0")
+    d, h, L, B = 64, 4, 2, 4
+    levels = [dict(C=16, H=24, W=24, p=2), dict(C=4, H=24, W=24, p=4)]            # 144 and 36 visual tokens; C p^2 = 64 on both
+    final = {}
+    for ragged in (True, False):
+        monkeypatch.setenv("TF_RAGGED_GROUPS", "1" if ragged else "0")
+        fusion = load_fusion_config(os.path.join(ROOT, "transfusion_amd", "runner", "configs", "cross_fusion_config_sym_ego_res50.yml"))
+        fusion.update({"fpn_features": [0, 1], "replace_fpn_features": True, "patch_h": [l["p"] for l in levels], "patch_w": [l["p"] for l in levels],
+                       "backproj_dropout": 0.1})
+        fusion["args"].update({"num_layers": [L] * 2, "num_heads": h, "patch_dropout": 0.1, "token_dropout": 0.1, "input_f_size": d})
+        run_cfg = {"experiment": "egonao", "narr_fusion": fusion, "criterion": {"lm": 0}, "precision": 16,
+                   "narration_embeds": {"use": True, "args": {"text_pooling": "slowfast", "strategy": "current", "out_mlp": 0, "size": d,
+                                                             "out_dropout": 0.0, "out_tanh": False, "train_ep": 0}}}
+        torch.manual_seed(5)
+        model = get_fusion_model(StubDetector([(l["H"], l["W"]) for l in levels], [l["C"] for l in levels]), {}, run_cfg, None).to(dev).train()
+        tr = FusionTrainStep(model, lr=2e-3, weight_decay=0.0, grad_clip=1.0)
+        g = torch.Generator().manual_seed(77)
+        feats = [torch.randn(B, l["C"], l["H"], l["W"], generator=g).to(dev) for l in levels]
+        lang = [torch.randn(n, d, generator=g).to(dev) for n in [9, 3, 11, 6]]
+        want = [0.3 * torch.randn(B, l["C"], l["H"], l["W"], generator=g).to(dev) for l in levels]
+
+        def loss_fn(m, _):
+            out = m({"image": feats, "language_f": lang})
+            return sum((out["features"][str(i)].float() - want[i]).square().mean() for i in range(2))
+        losses = [float(tr.step([None], loss_fn).item()) for _ in range(60)]
+        torch.cuda.synchronize()
+        tr.check_errors(sync=True)
+        assert model._last_path == ("grouped" if ragged else "streams")
+        assert int(model.cross_fusion_encoders[0]._last_desc.groups) == (2 if ragged else 0) or not ragged
+        assert all(np.isfinite(losses)) and bool(torch.isfinite(tr.flat.flat).all())
+        first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
+        assert last < 0.8 * first, (ragged, first, last)
+        final[ragged] = (first, last)
+    assert abs(final[True][0] - final[False][0]) < 0.05 * final[False][0], final          # same start (dropout noise aside)
+    assert abs(final[True][1] - final[False][1]) < 0.08 * final[False][1], final          # same place after 60 steps
