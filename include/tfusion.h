@@ -145,6 +145,8 @@ typedef struct TfAttnArgs {
   //   block_skip_q [ceil(S/128)] u64: bit t of word qb = every query of block qb has all 64 keys of tile t blocked (forward, dQ);
   //   block_skip_k [ceil(S/128)] u64: bit j of word kb = every key of block kb is blocked for all 32 queries of tile j (dK / dV).
   // (S <= 4096 / 2048 respectively; beyond that the words are zero)
+  // Both must be null when block_bits is null (tf_attn_fwd / tf_attn_bwd return -9 otherwise).  tf_attn_block_skip never marks EVERY tile
+  // of a query block: a block whose rows attend nothing keeps tile 0, so its rows come out as with element-wise masking, bit for bit.
   const void* block_skip_q; const void* block_skip_k;
 } TfAttnArgs;
 /* the two maps above from block_bits [S, ceil(S/64)] u64: skip_q and skip_k each ceil(S/128) u64 words (device memory) */

@@ -94,3 +94,29 @@ def test_layerwise_reducer_drives_the_own_communicator(monkeypatch):
     got, stats, tr = run(True)
     assert stats["calls"] == 3 * L and stats["elems"] == 3 * tr.flat.grad.numel()     # every layer range, every step, nothing twice
     assert torch.equal(got, ref)
+
+
+def test_close_leaves_no_communicator_thread_behind():
+    """BucketComm.close() = ncclCommDestroy: the communicator's proxy / progress threads are joined.  (Round 5's GPU abort came from a
+    native thread; the RCCL threads of this file's in-process communicators were the one native-thread source besides the HSA runtime.
+    They were not the cause -- DESIGN.md "Round 6" -- and this file now runs at the END of the GPU suite, but the property is cheap to
+    hold: after a first create / close has started whatever the library keeps for the process, a second one changes nothing.)"""
+    import os
+    from transfusion_amd.comm import BucketComm
+    dev = torch.device("cuda", 0)
+    threads = lambda: len(os.listdir("/proc/self/task"))
+
+    def cycle():
+        comm = BucketComm(1, 0, BucketComm.new_unique_id(), dev)
+        g = torch.ones(4096, device=dev)
+        comm.all_reduce_(g)
+        torch.cuda.synchronize()
+        during = threads()
+        comm.close()
+        return during
+
+    cycle()                          # whatever the library starts once per process exists now
+    before = threads()
+    during = cycle()
+    after = threads()
+    assert after <= before, (before, during, after)

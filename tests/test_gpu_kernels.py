@@ -43,16 +43,17 @@ def gelu_grad(x):
                                    # small row counts (the reference's per-GPU batch of 4): 64- and 96-row tiles of the 128-wide kernel
                                    (2070, 768, 128), (2833, 1536, 64), (3011, 768, 192),
                                    (2083, 768, 1536), (2083, 1536, 768), (1200, 2304, 768), (700, 768, 2304)])    # one workgroup per CU or fewer: the ring form of the 128-wide kernel
-def test_gemm_epilogues(dev, M, N, K):
+def test_gemm_epilogues(dev, guard, M, N, K):
+    """(operands and outputs end at unmapped pages: ``guard``, tests/guard_alloc.py)"""
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)
-    A = bf(torch.randn(M, K, generator=g)).to(dev)
-    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    R = bf(torch.randn(M, N, generator=g)).to(dev)
+    A = guard(bf(torch.randn(M, K, generator=g)))
+    W = guard(bf(torch.randn(N, K, generator=g) / math.sqrt(K)))
+    bias = guard(torch.randn(N, generator=g))
+    R = guard(bf(torch.randn(M, N, generator=g)))
     ref = A.float() @ W.float().t()
     # EPI_NONE / BIAS
-    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    C = guard(torch.zeros(M, N, dtype=torch.bfloat16))
     ops.gemm(A, W, C, N, K, L.TF_EPI_NONE)
     assert rel(C, ref) < 4e-3            # bf16 output rounding only (fp32 accumulate)
     ops.gemm(A, W, C, N, K, L.TF_EPI_BIAS, bias=bias)
@@ -61,8 +62,8 @@ def test_gemm_epilogues(dev, M, N, K):
     ops.gemm(A, W, C, N, K, L.TF_EPI_ADD, R=R)
     assert rel(C, bf(ref).float() + R.float()) < 4e-3
     # BIAS_GELU_DROP without and with dropout
-    U = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    H = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    U = guard(torch.zeros(M, N, dtype=torch.bfloat16))
+    H = guard(torch.zeros(M, N, dtype=torch.bfloat16))
     ops.gemm(A, W, U, N, K, L.TF_EPI_BIAS_GELU_DROP, bias=bias, C2=H)
     assert rel(U, ref + bias) < 4e-3
     assert rel(H, gelu(U.float())) < 4e-3
@@ -84,16 +85,16 @@ def test_gemm_epilogues(dev, M, N, K):
 @pytest.mark.parametrize("M,N,K,grouped", [(200, 136, 72, False), (708 * 2, 768, 768, False), (1000, 384, 128, True),
                                            # one ragged 32-row step, tile tails in both directions, the benchmark's largest launch
                                            (33, 8, 8, False), (5000, 520, 264, False), (22656, 2304, 768, False)])
-def test_wgrad(dev, M, N, K, grouped):
+def test_wgrad(dev, guard, M, N, K, grouped):
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(7)
-    dY = bf(torch.randn(M, N, generator=g)).to(dev)
-    X = bf(torch.randn(M, K, generator=g)).to(dev)
+    dY = guard(bf(torch.randn(M, N, generator=g)))
+    X = guard(bf(torch.randn(M, K, generator=g)))
     ref = dY.float().t() @ X.float()
     refb = dY.float().sum(0)
     if not grouped:
-        dW = torch.zeros(N, K, device=dev)
-        db = torch.zeros(N, device=dev)
+        dW = guard(torch.zeros(N, K))
+        db = guard(torch.zeros(N))
         ops.wgrad(dY, N, X, K, dW, db)
         assert rel(dW, ref) < 1e-4          # fp32 accumulation of exact bf16 products, atomics order only
         assert rel(db, refb) < 1e-4
@@ -104,8 +105,8 @@ def test_wgrad(dev, M, N, K, grouped):
         # padded row groups of 32 holding 18 valid rows each (head_dim 18 -> 32): N = 12 * 32
         rg, rgp = 18, 32
         n_src = (N // rgp) * rg
-        dW = torch.zeros(n_src, K, device=dev)
-        db = torch.zeros(n_src, device=dev)
+        dW = guard(torch.zeros(n_src, K))
+        db = guard(torch.zeros(n_src))
         ops.wgrad(dY, N, X, K, dW, db, rg=rg, rgp=rgp, n_src=n_src)
         idx = torch.tensor([i for i in range(N) if i % rgp < rg])
         assert rel(dW, ref[idx]) < 1e-4
@@ -135,9 +136,11 @@ def _attn_ref(qkv, B, S, H, hd, hdp, key_mask, keep=None, p=0.0):
                                       (3, 1, 2, 64), (2, 64, 1, 96), (1, 65, 2, 128), (2, 128, 3, 40), (1, 129, 8, 8), (1, 257, 4, 178),
                                       (2, 200, 1, 160), (1, 321, 2, 256), (5, 33, 4, 32)])
 @pytest.mark.parametrize("ds", [False, True])
-def test_attention_fwd_bwd(dev, B, S, H, hd, ds):
+def test_attention_fwd_bwd(dev, guard, B, S, H, hd, ds):
     """``ds``: with TfAttnArgs.ds_work the backward is delta -> dK / dV (+ dS tiles) -> dQ = dS . K (S and dP computed once; head dims
-    <= 192), without it the dQ kernel recomputes them."""
+    <= 192), without it the dQ kernel recomputes them.  Every operand sits flush against unmapped pages (``guard``, tests/guard_alloc.py):
+    a kernel that reads or writes past a tensor's end faults here, in this test, every time -- [False-2-64-1-96] is the shape whose
+    keep-bit image was over-read by attn_bwd_dkv16_kernel until round 6."""
     from transfusion_amd import _lib as L, ops
     hdp = (hd + 31) // 32 * 32
     g = torch.Generator().manual_seed(S + hd)
@@ -145,17 +148,17 @@ def test_attention_fwd_bwd(dev, B, S, H, hd, ds):
     qkv = torch.zeros(B * S, ldq)
     view = qkv[:, : 3 * H * hdp].view(B * S, 3, H, hdp)
     view[..., :hd] = torch.randn(B * S, 3, H, hd, generator=g)
-    qkv = bf(qkv).to(dev)
+    qkv = guard(bf(qkv))
     key_mask = torch.zeros(B, S, dtype=torch.uint8)
     key_mask[0, S - S // 3:] = 1
-    key_mask = key_mask.to(dev)
+    key_mask = guard(key_mask)
     ldo = (H * hdp + 63) // 64 * 64
-    out = torch.zeros(B * S, ldo, dtype=torch.bfloat16, device=dev)
-    lse = torch.empty(B * H * S, device=dev)
+    out = guard(torch.zeros(B * S, ldo, dtype=torch.bfloat16))
+    lse = guard(torch.zeros(B * H * S))
     for p in (0.0, 0.15):
         seed, site = 99, 17
         drop = ops.drop_params(p, seed, site)
-        bits = ops.attn_dropmask(B, H, S, p, seed, site, dev) if p > 0 else None
+        bits = guard(ops.attn_dropmask(B, H, S, p, seed, site, dev)) if p > 0 else None
         a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=L.ptr(key_mask),
                          B=B, S=S, H=H, HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2],
                          drop_bits=L.ptr(bits))
@@ -179,11 +182,11 @@ def test_attention_fwd_bwd(dev, B, S, H, hd, ds):
         # ---- backward ----
         do = torch.zeros(B * S, ldo)
         do[:, : H * hdp].view(B * S, H, hdp)[..., :hd] = torch.randn(B * S, H, hd, generator=g)
-        do = bf(do).to(dev)
-        dqkv = torch.zeros(B * S, ldq, dtype=torch.bfloat16, device=dev)
-        delta = torch.empty(B * H * S, device=dev)
+        do = guard(bf(do))
+        dqkv = guard(torch.zeros(B * S, ldq, dtype=torch.bfloat16))
+        delta = guard(torch.zeros(B * H * S))
         a.dout, a.ld_dout, a.dqkv, a.ld_dqkv, a.delta = L.ptr(do), ldo, L.ptr(dqkv), ldq, L.ptr(delta)
-        dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
+        dsw = guard(torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16)) if ds else None
         a.ds_work = L.ptr(dsw)                 # NaN-filled: tiles the dK / dV kernel does not write must not reach a stored dQ row
         L.call("tf_attn_bwd", a, ops._stream())
         xr = qkv[:, : 3 * H * hdp].double().cpu().view(B, S, 3, H, hdp)[..., :hd].clone().requires_grad_(True)
@@ -209,7 +212,7 @@ def test_attention_fwd_bwd(dev, B, S, H, hd, ds):
 @pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("lens,H,hd", [([150, 1, 64, 129], 2, 64), ([708, 324, 500], 4, 192), ([33, 70], 4, 18), ([0, 200, 17], 1, 128),
                                        ([130, 260], 1, 224)])
-def test_attention_packed_rows(dev, lens, H, hd, ds):
+def test_attention_packed_rows(dev, guard, lens, H, hd, ds):
     """TfAttnArgs.cu_rows: sample b owns rows cu[b] .. cu[b+1]-1 of the token-major tensors (ragged batch, no key mask); lse / delta /
     the dropout rows keep their dense [B, H, S] indexing.  Every sample against fp64 attention on its own rows, with dropout."""
     from transfusion_amd import _lib as L, ops
@@ -220,18 +223,18 @@ def test_attention_packed_rows(dev, lens, H, hd, ds):
     ldq, ldo = (3 * H * hdp + 63) // 64 * 64, (H * hdp + 63) // 64 * 64
     qkv = torch.zeros(M + 5, ldq)                            # a few spare rows behind the last sample
     qkv[:M, : 3 * H * hdp].view(M, 3, H, hdp)[..., :hd] = torch.randn(M, 3, H, hd, generator=g)
-    qkv = bf(qkv).to(dev)
+    qkv = guard(bf(qkv))
     do = torch.zeros(M + 5, ldo)
     do[:M, : H * hdp].view(M, H, hdp)[..., :hd] = torch.randn(M, H, hd, generator=g)
-    do = bf(do).to(dev)
-    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).to(dev)
-    out = torch.zeros(M + 5, ldo, dtype=torch.bfloat16, device=dev)
-    dqkv = torch.zeros(M + 5, ldq, dtype=torch.bfloat16, device=dev)
-    lse, delta = torch.zeros(B * H * S, device=dev), torch.zeros(B * H * S, device=dev)
+    do = guard(bf(do))
+    cu = guard(torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32))
+    out = guard(torch.zeros(M + 5, ldo, dtype=torch.bfloat16))
+    dqkv = guard(torch.zeros(M + 5, ldq, dtype=torch.bfloat16))
+    lse, delta = guard(torch.zeros(B * H * S)), guard(torch.zeros(B * H * S))
     p, seed, site = 0.15, 7, 21
     drop = ops.drop_params(p, seed, site)
-    bits = ops.attn_dropmask(B, H, S, p, seed, site, dev)
-    dsw = torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16, device=dev) if ds else None
+    bits = guard(ops.attn_dropmask(B, H, S, p, seed, site, dev))
+    dsw = guard(torch.full((L.load().tf_attn_ds_bytes(B, H, S) // 2,), float("nan"), dtype=torch.bfloat16)) if ds else None
     a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hdp,
                      scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=L.ptr(bits),
                      dout=L.ptr(do), ld_dout=ldo, dqkv=L.ptr(dqkv), ld_dqkv=ldq, delta=L.ptr(delta), cu_rows=L.ptr(cu), ds_work=L.ptr(dsw))

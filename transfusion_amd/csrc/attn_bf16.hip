@@ -764,8 +764,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const TfAttnArgs a) {
   // (threads 0..31) and the keep-bit word of (row q0 + (lane & 31), this wave's 32 keys).  Loaded inside the loop body
   // they sat between the two barriers with their global latency fully exposed, once per tile.
   const int dw_ld = 2 * ((S + 63) / 64);
-  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
-  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  // (a wave whose 32 keys all lie past S -- S mod 128 in 1 .. 64 -- has no word of its own in a row of dw_ld words: it reads the row's
+  // last word and never uses it.  Unclamped, the last row of the last (batch, head) read 4 - 8 bytes past the end of drop_bits)
+  const int wsel = min(key0 >> 5, dw_ld - 1);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + wsel;
+  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + wsel : nullptr;
   float lse_n = 1.0e30f, del_n = 0.f;
   unsigned dw_n = 0xffffffffu, bw_n = 0u;
   // (RAW loaded values are carried, from clamped addresses; the row-validity selects happen when they are stored to
@@ -959,8 +962,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv16_kernel(const TfAttnArgs
 
   const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sb + QT - 1) / QT;
   const int dw_ld = 2 * ((S + 63) / 64);
-  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + (key0 >> 5);
-  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  // (waves whose 16 keys all lie past S read the row's last word and never use it: see attn_bwd_dkv_kernel.  This unclamped index was
+  // the round-5 abort of test_attention_fwd_bwd[False-2-64-1-96]: DESIGN.md, "Round 6")
+  const int wsel = min(key0 >> 5, dw_ld - 1);
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * S * dw_ld + wsel;
+  const unsigned* bbits = BLK ? (const unsigned*)a.block_bits + wsel : nullptr;
   float lse_n = 1.0e30f, del_n = 0.f;
   unsigned dw_n = 0xffffffffu, bw_n = 0u;
   // (RAW loaded values are carried; the row-validity selects happen when they are stored)
@@ -1582,7 +1588,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
   // their dS is exactly 0 -- the dK / dV kernel writes zeros or nothing there).  t = the tile in hand, tn = the next one.
   const int nts = __builtin_amdgcn_readfirstlane(ntiles);
   unsigned long long act = nts >= 64 ? ~0ull : ((1ull << nts) - 1ull);
-  const bool listed = a.block_skip_q != nullptr && nts <= 64;
+  // (gated on the block-bit matrix like the forward and the dK / dV pair kernel: a skip map in a TfAttnArgs WITHOUT block_bits -- a struct
+  // reused across calls -- must not drop tiles; check() rejects that pairing before any launch)
+  const bool listed = a.block_bits != nullptr && a.block_skip_q != nullptr && nts <= 64;
   if (listed) {
     const unsigned long long sk = ((const unsigned long long*)a.block_skip_q)[qblk];
     act &= ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sk >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sk));
@@ -1670,7 +1678,9 @@ __global__ __launch_bounds__(256) void attn_block_skip_kernel(const unsigned lon
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) skip_q[blk] = word;
+    // never every tile of a query block: a block whose rows attend nothing (softmax over the empty set) keeps tile 0, so the kernels
+    // walk the same code as with element-wise masking and produce the same (undefined-in-the-reference, NaN there) rows bit for bit
+    if (threadIdx.x == 0) skip_q[blk] = (SW <= 64 && word == (SW == 64 ? ~0ull : (1ull << SW) - 1ull)) ? (word & ~1ull) : word;
   } else {
     // bit j: the (up to) 128 keys of this block -- words 2 blk, 2 blk + 1 -- blocked for all 32 query rows of tile j
     if (nqt <= 64) {
@@ -1849,6 +1859,7 @@ int check(const TfAttnArgs* a) {
   if (a->drop_thr && a->drop_bits == nullptr) return -6;
   if (a->q != nullptr && (a->Sq <= 0 || (a->ld_q % 8) || a->block_bits != nullptr)) return -7;   // cross attention: own query rows, no block mask
   if (a->cu_rows != nullptr && (a->key_mask != nullptr || a->q != nullptr)) return -8;           // packed batches hold real tokens only
+  if ((a->block_skip_q != nullptr || a->block_skip_k != nullptr) && a->block_bits == nullptr) return -9;   // tile maps belong to a block mask
   return 0;
 }
 

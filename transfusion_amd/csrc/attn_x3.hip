@@ -436,8 +436,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
 
   const int ntiles = ((logical % nkb) * 128 >= valid_key_limit(a.key_mask, b, Sb, lane)) ? 0 : (Sqb + 31) / 32;
   const int dw_ld = 2 * ((S + 63) / 64);
-  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + (key0 >> 5);
-  const unsigned* bbits = blk ? (const unsigned*)a.block_bits + (key0 >> 5) : nullptr;
+  const int wsel = min(key0 >> 5, dw_ld - 1);      // (waves whose keys all lie past S: the row's last word, never used -- attn_bf16.hip)
+  const unsigned* dbits = (const unsigned*)a.drop_bits + (size_t)bh * Sq * dw_ld + wsel;
+  const unsigned* bbits = blk ? (const unsigned*)a.block_bits + wsel : nullptr;
   // the per-row scalars of a query block (LSE, delta, keep / block bit words) are fetched ONE BLOCK AHEAD into four registers: read
   // in place they were a dependent global load between the two barriers of every block
   auto row_scalars = [&](int q0, float& r_lse, float& r_del, unsigned& r_dw, unsigned& r_bw) {

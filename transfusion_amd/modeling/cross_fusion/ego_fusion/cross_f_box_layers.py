@@ -373,12 +373,14 @@ class CrossTransformerModuleBox(nn.Module):
         params = self._param_list()
         # the parameters' addresses as one key: the dtype / layout checks and the 50-odd ctypes field stores below are redone only when a
         # tensor has moved (host time counts: at the reference's per-GPU batch the step is bound by how fast the host enqueues it)
+        # (the cheap dtype / contiguity check runs on EVERY call, outside the cache: an address can survive a `.data` reassignment or a
+        # `.to(dtype)` round trip through the caching allocator, and the kernels read these pointers as contiguous fp32 unchecked)
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise L.TfError("parameters must be contiguous fp32 (bf16 shadows are derived inside the runtime)")
         pkey = tuple(p.data_ptr() for p in params)
         pc = self._param_ptr_cache
         if pc is None or pc[0] != pkey:
-            for p in params:
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise L.TfError("parameters must be contiguous fp32 (bf16 shadows are derived inside the runtime)")
             blk = (L.TfLayerParams * L.TF_MAX_LAYERS)()
             for j in range(self.num_layers):
                 for k, (field, _) in enumerate(_LAYER_FIELDS):
@@ -482,6 +484,8 @@ class CrossTransformerModuleBox(nn.Module):
             for p in params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
+                elif p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.numel() != p.numel():
+                    raise L.TfError("direct accumulation needs contiguous fp32 .grad tensors of the parameters' sizes")
                 grads.append(p.grad)
             gkey = tuple(g.data_ptr() for g in grads)
             gc = self._grad_ptr_cache

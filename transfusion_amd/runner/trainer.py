@@ -20,23 +20,35 @@ import torch.distributed as dist
 from torch import nn
 
 
+def _rehearsal_switches(world: int):
+    """(collectives issued in a one-rank group?, phantom peers).  The two TEST-ONLY environment switches of the one-GPU rehearsal, read
+    ONCE -- when a reducer is constructed -- and kept as attributes (like ``_debug_break_edge``): the step's hot path reads no environment,
+    and a variable leaked into a real job's environment cannot scale gradients: phantom peers are refused when there are real ones."""
+    rehearse = os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"
+    k = int(os.environ.get("TF_REHEARSE_PHANTOM_PEERS", "0")) if rehearse else 0
+    if k and world > 1:
+        raise RuntimeError("TF_REHEARSE_PHANTOM_PEERS is a one-rank rehearsal switch: refused with %d real ranks" % world)
+    return rehearse, k
+
+
 def _live_world(group=None):
     """(world size, whether the collectives are issued).  They are issued whenever more than one rank takes part -- and, for a REHEARSAL
     of the RCCL path on one GPU, also in a one-rank process group when TF_REHEARSE_COLLECTIVES=1: every all-reduce, event and stream of the
-    N > 1 step then runs against the real backend (bench.py's rehearsal entry; tests/test_gpu_ddp.py), only without peers."""
+    N > 1 step then runs against the real backend (bench.py's rehearsal entry; tests/test_gpu_ddp.py), only without peers.  Called at
+    construction time only (see _rehearsal_switches)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1, False
     world = dist.get_world_size(group)
-    return world, world > 1 or os.environ.get("TF_REHEARSE_COLLECTIVES") == "1"
+    return world, world > 1 or _rehearsal_switches(world)[0]
 
 
-def _phantom_peers(g, handle=None):
-    """Rehearsal only (TF_REHEARSE_PHANTOM_PEERS=k, with TF_REHEARSE_COLLECTIVES=1): a one-rank sum all-reduce leaves the buffer as it
-    was, so a collective that ran BEFORE its gradients were written (a missing event edge) would go unnoticed.  With k phantom peers the
-    reduced range is multiplied by 1 + k right behind the collective, on the collective's stream -- as if k peers had contributed the same
-    gradient: whatever is written into the range after the collective misses the factor, and tests/test_gpu_ddp.py sees it."""
-    k = int(os.environ.get("TF_REHEARSE_PHANTOM_PEERS", "0"))
-    if not k or os.environ.get("TF_REHEARSE_COLLECTIVES") != "1":
+def _phantom_peers(k, g, handle=None):
+    """Rehearsal only (k = the reducer's ``_phantom_k``: TF_REHEARSE_PHANTOM_PEERS with TF_REHEARSE_COLLECTIVES=1, resolved when the
+    reducer was built): a one-rank sum all-reduce leaves the buffer as it was, so a collective that ran BEFORE its gradients were written
+    (a missing event edge) would go unnoticed.  With k phantom peers the reduced range is multiplied by 1 + k right behind the collective,
+    on the collective's stream -- as if k peers had contributed the same gradient: whatever is written into the range after the collective
+    misses the factor, and tests/test_gpu_ddp.py sees it."""
+    if not k:
         return handle
     if handle is not None:
         handle.wait()                       # (RCCL: the CURRENT stream waits for the collective; the host does not)
@@ -87,6 +99,7 @@ class DataParallelReducer:
         self.group = group
         self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm: the C ABI's tf_allreduce_bucket instead of torch's
         self.world, self.live = _live_world(group)
+        self._phantom_k = _rehearsal_switches(self.world)[1]      # test-only, resolved once
         n = flat_grad.numel()
         per = max(1, int(bucket_mb * (1 << 20) // 4))
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
@@ -99,10 +112,10 @@ class DataParallelReducer:
         if self.bucket_comm is not None:              # stream-ordered: nothing to wait for on the host
             for s, e in self.buckets:
                 self.bucket_comm.all_reduce_(self.grad[s:e])
-                _phantom_peers(self.grad[s:e])
+                _phantom_peers(self._phantom_k, self.grad[s:e])
             return handles
         for s, e in self.buckets:
-            h = _phantom_peers(self.grad[s:e], dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+            h = _phantom_peers(self._phantom_k, self.grad[s:e], dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
             if async_op and h is not None:
                 handles.append(h)
         return handles
@@ -119,6 +132,7 @@ class LayerwiseReducer:
         self.flat, self.group = flat, group
         self.bucket_comm = bucket_comm          # transfusion_amd.comm.BucketComm or None (torch.distributed's process group)
         self.world, self.live = _live_world(group)
+        self._phantom_k = _rehearsal_switches(self.world)[1]      # test-only, resolved once
         self.bytes_per_step = flat.grad.numel() * 4
         self.handles = []
         self.comm = None
@@ -180,9 +194,9 @@ class LayerwiseReducer:
         with torch.cuda.stream(self.comm):
             if self.bucket_comm is not None:
                 self.bucket_comm.all_reduce_(g[lo:hi], stream=self.comm)     # tf_allreduce_bucket, enqueued on the communication stream
-                _phantom_peers(g[lo:hi])
+                _phantom_peers(self._phantom_k, g[lo:hi])
                 return
-            h = _phantom_peers(g[lo:hi], dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            h = _phantom_peers(self._phantom_k, g[lo:hi], dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             if h is not None:
                 self.handles.append(h)
 
@@ -219,6 +233,7 @@ class OrderedRangeReducer:
     def __init__(self, flat: FlatParams, module: nn.Module, group=None, bucket_comm=None):
         self.flat, self.group, self.bucket_comm = flat, group, bucket_comm
         self.world, self.live = _live_world(group)
+        self._phantom_k = _rehearsal_switches(self.world)[1]      # test-only, resolved once
         self.bytes_per_step = flat.grad.numel() * 4
         total = flat.grad.numel()
         slice_of = {n: (off, num) for n, _, off, num in flat.slices}
@@ -352,9 +367,9 @@ class OrderedRangeReducer:
         with torch.cuda.stream(self.comm):
             if self.bucket_comm is not None:
                 self.bucket_comm.all_reduce_(g, stream=self.comm)
-                _phantom_peers(g)
+                _phantom_peers(self._phantom_k, g)
                 return
-            h = _phantom_peers(g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            h = _phantom_peers(self._phantom_k, g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             if h is not None:
                 self.handles.append(h)
 
@@ -376,7 +391,7 @@ class OrderedRangeReducer:
                     self.bucket_comm.all_reduce_(g)
                 else:
                     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                _phantom_peers(g)
+                _phantom_peers(self._phantom_k, g)
                 mine = self._seen + [u for u in range(len(self.units)) if u not in self._seen]
                 orders = [None] * self.world
                 dist.all_gather_object(orders, mine, group=self.group)
@@ -391,7 +406,7 @@ class OrderedRangeReducer:
                         self.bucket_comm.all_reduce_(g)
                     else:
                         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                    _phantom_peers(g)
+                    _phantom_peers(self._phantom_k, g)
                 else:
                     for u in self.order[self._next:]:
                         if g.is_cuda:
