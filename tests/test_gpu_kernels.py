@@ -266,7 +266,7 @@ def test_attention_packed_rows(dev, guard, lens, H, hd, ds):
         r0 += n
 
 
-def test_attention_online_softmax_rescale(dev):
+def test_attention_online_softmax_rescale(dev, guard):
     """Forces the running-max update late in the key loop (a spike in the LAST key tile), which bounded
     random data never exercises."""
     from transfusion_amd import _lib as L, ops
@@ -276,9 +276,9 @@ def test_attention_online_softmax_rescale(dev):
     k = torch.randn(S, hd, generator=g)
     v = torch.randn(S, hd, generator=g)
     k[S - 3] = 6.0 * q[10]          # a huge score for query 10 in the last tile
-    qkv = bf(torch.cat([q, k, v], dim=1)).to(dev)
-    out = torch.zeros(S, hd, dtype=torch.bfloat16, device=dev)
-    lse = torch.empty(S, device=dev)
+    qkv = guard(bf(torch.cat([q, k, v], dim=1)))
+    out = guard(torch.zeros(S, hd, dtype=torch.bfloat16))
+    lse = guard(torch.zeros(S))
     a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=3 * hd, out=L.ptr(out), ld_out=hd, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hd,
                      scale=1 / math.sqrt(hd), drop_thr=0, drop_key=0, drop_scale=1.0)
     L.call("tf_attn_fwd", a, ops._stream())
@@ -289,18 +289,18 @@ def test_attention_online_softmax_rescale(dev):
 
 @pytest.mark.parametrize("rows,d,ld", [(37, 64, 64), (500, 768, 768), (64, 72, 128), (10, 712, 768),
                                        (1, 8, 8), (22656, 768, 768), (300, 1024, 1024), (129, 896, 896), (77, 1536, 1536)])
-def test_layernorm_fwd_bwd(dev, rows, d, ld):
+def test_layernorm_fwd_bwd(dev, guard, rows, d, ld):
     from transfusion_amd import _lib as L, ops
     from oracle import fusion_oracle as O
     g = torch.Generator().manual_seed(rows)
     x = torch.zeros(rows, ld)
     x[:, :d] = torch.randn(rows, d, generator=g) * 2 + 0.5
-    xb = bf(x).to(dev)
-    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
-    beta = (0.1 * torch.randn(d, generator=g)).to(dev)
-    y = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=dev)
-    mean = torch.empty(rows, device=dev)
-    rstd = torch.empty(rows, device=dev)
+    xb = guard(bf(x))
+    gamma = guard(1 + 0.1 * torch.randn(d, generator=g))
+    beta = guard(0.1 * torch.randn(d, generator=g))
+    y = guard(torch.full((rows, ld), 7.0, dtype=torch.bfloat16))
+    mean = guard(torch.zeros(rows))
+    rstd = guard(torch.zeros(rows))
     a = L.TfLnArgs(x=L.ptr(xb), ldx=ld, y=L.ptr(y), ldy=ld, y_is_f32=0, gamma=L.ptr(gamma), beta=L.ptr(beta), mean=L.ptr(mean),
                    rstd=L.ptr(rstd), rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=1e-5)
     L.call("tf_layernorm_fwd", a, ops._stream())
@@ -310,10 +310,10 @@ def test_layernorm_fwd_bwd(dev, rows, d, ld):
     assert rel(y[:, :d], yr.detach()) < 4e-3
     if ld > d:
         assert y[:, d:].float().abs().max().item() == 0.0
-    dy = bf(torch.randn(rows, ld, generator=g)).to(dev)
-    dx = torch.empty(rows, ld, dtype=torch.bfloat16, device=dev)
-    dg = torch.zeros(d, device=dev)
-    db = torch.zeros(d, device=dev)
+    dy = guard(bf(torch.randn(rows, ld, generator=g)))
+    dx = guard(torch.zeros(rows, ld, dtype=torch.bfloat16))
+    dg = guard(torch.zeros(d))
+    db = guard(torch.zeros(d))
     a.dy, a.lddy, a.dy_is_f32, a.dx, a.lddx, a.dgamma, a.dbeta = L.ptr(dy), ld, 0, L.ptr(dx), ld, L.ptr(dg), L.ptr(db)
     L.call("tf_layernorm_bwd", a, ops._stream())
     yr.backward(dy.float().cpu()[:, :d])
@@ -445,7 +445,7 @@ def _pack_bits(m):
 
 
 @pytest.mark.parametrize("B,S,H,hd,p", [(2, 150, 2, 64, 0.0), (1, 333, 3, 18, 0.15)])
-def test_attention_block_mask(dev, B, S, H, hd, p):
+def test_attention_block_mask(dev, guard, B, S, H, hd, p):
     """Boolean attn_mask (TfAttnArgs.block_bits, the reference's local_k visual mask mechanism): random blocked pairs on the
     first two thirds of the sequence (every query keeps its own key), together with key padding and dropout."""
     from transfusion_amd import _lib as L, ops
@@ -454,26 +454,26 @@ def test_attention_block_mask(dev, B, S, H, hd, p):
     ldq = (3 * H * hdp + 63) // 64 * 64
     qkv = torch.zeros(B * S, ldq)
     qkv[:, : 3 * H * hdp].view(B * S, 3, H, hdp)[..., :hd] = torch.randn(B * S, 3, H, hd, generator=g)
-    qkv = bf(qkv).to(dev)
+    qkv = guard(bf(qkv))
     nv = 2 * S // 3
     blk = torch.zeros(S, S, dtype=torch.bool)
     blk[:nv, :nv] = torch.rand(nv, nv, generator=g) < 0.6
     blk[torch.arange(S), torch.arange(S)] = False
-    bits = _pack_bits(blk).to(dev)
+    bits = guard(_pack_bits(blk))
     key_mask = torch.zeros(B, S, dtype=torch.uint8)
     key_mask[0, S - S // 5:] = 1
-    key_mask = key_mask.to(dev)
+    key_mask = guard(key_mask)
     ldo = (H * hdp + 63) // 64 * 64
-    out = torch.zeros(B * S, ldo, dtype=torch.bfloat16, device=dev)
-    lse = torch.empty(B * H * S, device=dev)
+    out = guard(torch.zeros(B * S, ldo, dtype=torch.bfloat16))
+    lse = guard(torch.zeros(B * H * S))
     seed, site = 5, 9
     drop = ops.drop_params(p, seed, site)
-    dbits = ops.attn_dropmask(B, H, S, p, seed, site, dev) if p > 0 else None
+    dbits = guard(ops.attn_dropmask(B, H, S, p, seed, site, dev)) if p > 0 else None
     do = torch.zeros(B * S, ldo)
     do[:, : H * hdp].view(B * S, H, hdp)[..., :hd] = torch.randn(B * S, H, hd, generator=g)
-    do = bf(do).to(dev)
-    dqkv = torch.zeros(B * S, ldq, dtype=torch.bfloat16, device=dev)
-    delta = torch.empty(B * H * S, device=dev)
+    do = guard(bf(do))
+    dqkv = guard(torch.zeros(B * S, ldq, dtype=torch.bfloat16))
+    delta = guard(torch.zeros(B * H * S))
     a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=L.ptr(key_mask), B=B, S=S, H=H,
                      HDP=hdp, scale=1 / math.sqrt(hd), drop_thr=drop[0], drop_key=drop[1], drop_scale=drop[2], drop_bits=L.ptr(dbits),
                      block_bits=L.ptr(bits), dout=L.ptr(do), ld_dout=ldo, dqkv=L.ptr(dqkv), ld_dqkv=ldq, delta=L.ptr(delta))
@@ -508,7 +508,7 @@ def _local_block(gh, gw, k, Nl):
 
 
 @pytest.mark.parametrize("gh,gw,k,Nl,hd,packed", [(28, 28, 2, 100, 64, False), (28, 28, 4, 512, 192, True), (14, 14, 1, 70, 32, False), (40, 45, 1, 30, 64, False)])
-def test_attention_block_sparse_tiles(dev, gh, gw, k, Nl, hd, packed):
+def test_attention_block_sparse_tiles(dev, guard, gh, gw, k, Nl, hd, packed):
     """TfAttnArgs.block_skip_q / block_skip_k (the local_k mask as block-sparse tiles): the maps tf_attn_block_skip derives
     from the bit matrix are exactly the tiles a torch reduction of the mask finds fully blocked, a local mask on a 28 x 28 grid leaves a
     visual query block with less than half of its visual key tiles, and forward and backward with the maps give the SAME BITS as
@@ -519,10 +519,10 @@ def test_attention_block_sparse_tiles(dev, gh, gw, k, Nl, hd, packed):
     B, H = 2, 2
     Nv, S = gh * gw, gh * gw + Nl
     blk = _local_block(gh, gw, k, Nl)
-    bits = _pack_bits(blk).to(dev)
+    bits = guard(_pack_bits(blk))
     nb, SW, nqt = (S + 127) // 128, (S + 63) // 64, (S + 31) // 32
-    skq = torch.full((nb,), -1, dtype=torch.int64, device=dev)
-    skk = torch.full((nb,), -1, dtype=torch.int64, device=dev)
+    skq = guard(torch.full((nb,), -1, dtype=torch.int64))
+    skk = guard(torch.full((nb,), -1, dtype=torch.int64))
     L.check(lib.tf_attn_block_skip(L.ptr(bits), S, L.ptr(skq), L.ptr(skk), ops._stream()), "tf_attn_block_skip")
     # the maps against a torch reduction of the mask (keys / rows past S count as blocked for the tile test only when the WHOLE word is:
     # the bit matrix pads with zeros, so a ragged last tile is never skippable)
@@ -559,18 +559,18 @@ def test_attention_block_sparse_tiles(dev, gh, gw, k, Nl, hd, packed):
     rows = sum(lens) if packed else B * S
     qkv = torch.zeros(rows, ldq)
     qkv[:, : 3 * H * hdp].view(rows, 3, H, hdp)[..., :hd] = torch.randn(rows, 3, H, hd, generator=g)
-    qkv = bf(qkv).to(dev)
+    qkv = guard(bf(qkv))
     do = torch.zeros(rows, ldo)
     do[:, : H * hdp].view(rows, H, hdp)[..., :hd] = torch.randn(rows, H, hd, generator=g)
-    do = bf(do).to(dev)
-    cu = torch.tensor([0, lens[0], lens[0] + lens[1]], dtype=torch.int32, device=dev) if packed else None
-    dsw = torch.empty(lib.tf_attn_ds_bytes(B, H, S), dtype=torch.uint8, device=dev)
+    do = guard(bf(do))
+    cu = guard(torch.tensor([0, lens[0], lens[0] + lens[1]], dtype=torch.int32)) if packed else None
+    dsw = guard(torch.zeros(lib.tf_attn_ds_bytes(B, H, S), dtype=torch.uint8))
     res = {}
     for use in (False, True):
-        out = torch.zeros(rows, ldo, dtype=torch.bfloat16, device=dev)
-        lse = torch.zeros(B * H * S, device=dev)
-        dqkv = torch.zeros(rows, ldq, dtype=torch.bfloat16, device=dev)
-        delta = torch.empty(B * H * S, device=dev)
+        out = guard(torch.zeros(rows, ldo, dtype=torch.bfloat16))
+        lse = guard(torch.zeros(B * H * S))
+        dqkv = guard(torch.zeros(rows, ldq, dtype=torch.bfloat16))
+        delta = guard(torch.zeros(B * H * S))
         dsw.fill_(0x7F)                                         # bf16 NaN patterns: a dS tile that is read without having been written shows
         a = L.TfAttnArgs(qkv=L.ptr(qkv), ld_qkv=ldq, out=L.ptr(out), ld_out=ldo, lse=L.ptr(lse), key_mask=0, B=B, S=S, H=H, HDP=hdp,
                          scale=1 / math.sqrt(hd), drop_thr=0, drop_key=0, drop_scale=1.0, block_bits=L.ptr(bits), dout=L.ptr(do), ld_dout=ldo,
@@ -675,16 +675,16 @@ def test_sumsq_never_reads_a_stale_partial(dev):
 
 @pytest.mark.parametrize("G,Mg,N,K", [(4, 2083, 768, 768), (4, 2083, 2304, 768), (4, 2832, 768, 1536), (3, 300, 264, 128), (4, 5000, 1536, 768),
                                       (2, 8300, 768, 768)])     # 128-wide (ring and two-slot), large-tile and two-per-CU forms
-def test_gemm_grouped_rows(dev, G, Mg, N, K):
+def test_gemm_grouped_rows(dev, guard, G, Mg, N, K):
     """TfGemmArgs.groups: G equal row ranges, each against its own weight / bias (w_gstride apart) -- the wrapper's FPN levels as one
     launch.  Must equal G separate launches bit for bit (same tiles, same arithmetic), ragged last row tile of every group included."""
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(G * Mg + N)
-    x = bf(torch.randn(G * Mg, K, generator=g)).to(dev)
-    r = bf(torch.randn(G * Mg, N, generator=g)).to(dev)
+    x = guard(bf(torch.randn(G * Mg, K, generator=g)))
+    r = guard(bf(torch.randn(G * Mg, N, generator=g)))
     # one buffer holds [W_g | bias_g] blocks at a constant byte stride, as the encoder runtime's per-level shadow blocks do
     blk = (N * K * 2 + N * 4 + 255) // 256 * 256
-    store = torch.zeros(G * blk, dtype=torch.uint8, device=dev)
+    store = guard(torch.zeros((G - 1) * blk + N * K * 2 + N * 4, dtype=torch.uint8))    # ends with the last group's bias: no slack behind it
     Ws, bs = [], []
     for k in range(G):
         w = store[k * blk: k * blk + N * K * 2].view(torch.bfloat16).view(N, K)
@@ -695,7 +695,7 @@ def test_gemm_grouped_rows(dev, G, Mg, N, K):
         bs.append(b)
     drop = ops.drop_params(0.15, 5, 2)
     for epi, kw in ((L.TF_EPI_BIAS, {}), (L.TF_EPI_BIAS_DROP_RES, {"R": r, "drop": drop}), (L.TF_EPI_ADD, {"R": r})):
-        out_g = torch.zeros(G * Mg, N, dtype=torch.bfloat16, device=dev)
+        out_g = guard(torch.zeros(G * Mg, N, dtype=torch.bfloat16))
         has_b = epi != L.TF_EPI_ADD
         ops.gemm(x, Ws[0], out_g, N, K, epi, bias=bs[0] if has_b else None, groups=G, w_gstride=blk, **kw)
         out_s = torch.zeros_like(out_g)
@@ -715,16 +715,16 @@ def test_gemm_grouped_rows(dev, G, Mg, N, K):
 
 
 @pytest.mark.parametrize("G,Mg,N,K,chunk", [(4, 2083, 768, 768, 0), (4, 2832, 2304, 768, 704), (3, 300, 264, 136, 0), (2, 8300, 768, 1536, 2080)])
-def test_wgrad_grouped_rows(dev, G, Mg, N, K, chunk):
+def test_wgrad_grouped_rows(dev, guard, G, Mg, N, K, chunk):
     """TfWgradArgs.groups: range g of the rows accumulates dY_g^T X_g into ITS dW / db (dw_gstride apart); both kernels (caller-sized
     256x128 and self-sized 128x128), ragged group heights."""
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(G * Mg + K)
-    dy = bf(torch.randn(G * Mg, N, generator=g) * 0.1).to(dev)
-    x = bf(torch.randn(G * Mg, K, generator=g)).to(dev)
+    dy = guard(bf(torch.randn(G * Mg, N, generator=g) * 0.1))
+    x = guard(bf(torch.randn(G * Mg, K, generator=g)))
     blk = N * K + N + 13                                     # floats per group: [dW | db | slack], an odd stride on purpose
     blk = (blk + 3) // 4 * 4
-    store = torch.zeros(G * blk, dtype=torch.float32, device=dev)
+    store = guard(torch.zeros(G * blk, dtype=torch.float32))
     dW0 = store[: N * K].view(N, K)
     db0 = store[N * K: N * K + N]
     ops.wgrad(dy, N, x, K, dW0, db0, m_chunk=chunk, groups=G, dw_gstride=blk * 4)

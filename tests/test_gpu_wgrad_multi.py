@@ -23,14 +23,16 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def _problem(g, M, N, K, dev, scale=1.0):
-    dY = bf(torch.randn(M, N, generator=g) * scale).to(dev)
-    X = bf(torch.randn(M, K, generator=g)).to(dev)
+def _problem(g, M, N, K, dev, scale=1.0, guard=None):
+    """guard: the conftest fixture -- operands flush against unmapped pages (tests/guard_alloc.py)"""
+    put = guard if guard is not None else (lambda t: t.to(dev))
+    dY = put(bf(torch.randn(M, N, generator=g) * scale))
+    X = put(bf(torch.randn(M, K, generator=g)))
     return dY, X, dY.double().cpu().t() @ X.double().cpu(), dY.double().cpu().sum(0)
 
 
 @pytest.mark.parametrize("blocks", [0, -1, 1, 40, 97, 512])
-def test_layer_shaped_problems(dev, blocks):
+def test_layer_shaped_problems(dev, guard, blocks):
     """four problems with a layer's operand relations (shared rows, different N / K, one without a bias) at a small width"""
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(11 + abs(blocks))
@@ -38,9 +40,9 @@ def test_layer_shaped_problems(dev, blocks):
     shapes = [(3 * d, d, True), (d, d, True), (2 * d, d, False), (d, 2 * d, True)]
     probs, outs, keep = [], [], []
     for N, K, bias in shapes:
-        dY, X, ref, refb = _problem(g, M, N, K, dev, 0.1)
-        dW = torch.zeros(N, K, device=dev)
-        db = torch.zeros(N, device=dev) if bias else None
+        dY, X, ref, refb = _problem(g, M, N, K, dev, 0.1, guard)
+        dW = guard(torch.zeros(N, K))
+        db = guard(torch.zeros(N)) if bias else None
         probs.append(ops.wgrad_args(dY, N, X, K, dW, db))
         outs.append((dW, db, ref, refb))
         keep += [dY, X]
