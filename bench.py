@@ -58,39 +58,19 @@ def make_batch(B, device, rank, d=D, nv=NV, nl=NL, variant=0, padded=True):
     if not padded:
         lens = torch.full((B,), nl)                     # the no-padding variant
     pad = torch.arange(nl).view(1, -1) >= lens.view(-1, 1)                                # True = ignore
-    valid = (~pad).unsqueeze(-1).float()                                                  # batch constants of the synthetic loss
-    km = torch.tensor(1.0 / (float(valid.sum()) * d))
-    return x.to(device), lang.to(device), pad.to(device), valid.to(device), km.to(device), lens.tolist()
+    valid = (~pad).float().contiguous()                                                   # [B, nl] row weights of the synthetic loss (0 / 1)
+    km = 1.0 / (float(valid.sum()) * d)                                                   # ... and its normaliser (a host float)
+    return x.to(device), lang.to(device), pad.to(device), valid.to(device), km, lens.tolist()
 
 
-def _sumsq(t):
-    """sum(t^2) of a contiguous fp32 CUDA tensor through the library's own tf_sumsq (the optimiser's norm kernel): the timed region
-    holds no vendor-library kernel, the harness's loss included (torch.dot is rocBLAS)."""
+def _masked_square_loss(vis, lo, valid, km):
+    """mean(vis^2) + mean(lang[valid]^2) through the library's own loss kernels (tf_sq_loss_fwd / _bwd: two launches
+    forward, two backward, deterministic sums): the timed region holds no framework elementwise kernel and no vendor-library kernel,
+    the harness's loss included (round 5: ~1.5 % of the step's kernel time were at::native mul / fill kernels of this function)."""
     from transfusion_amd import ops
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        t = t.float().contiguous()
-    out = torch.zeros(1, dtype=torch.float32, device=t.device)
-    ops.sumsq(t, out)
-    return out[0]
-
-
-class _MaskedSquareLoss(torch.autograd.Function):
-    """mean(vis^2) + mean(lang[valid]^2) with a hand-written backward: 3 elementwise passes and 2 dot products per step
-    instead of autograd's ~10 (the harness's own loss was ~1 GB/step of fp32 traffic next to the block it is timing); the mask
-    in float form and 1 / (valid count * d) come with the batch."""
-
-    @staticmethod
-    def forward(ctx, vis, lo, valid, km):
-        m = lo * valid
-        kv = 1.0 / vis.numel()
-        ctx.save_for_backward(vis, m, km)
-        ctx.kv = kv
-        return _sumsq(vis) * kv + _sumsq(m) * km
-
-    @staticmethod
-    def backward(ctx, g):
-        vis, m, km = ctx.saved_tensors
-        return vis * (g * (2.0 * ctx.kv)), m * (g * (2.0 * km)), None, None      # valid is 0/1: d/dlo = 2 km lo valid^2 = 2 km m
+    vis = vis if (vis.dtype == torch.float32 and vis.is_contiguous()) else vis.float().contiguous()
+    lo = lo if (lo.dtype == torch.float32 and lo.is_contiguous()) else lo.float().contiguous()
+    return ops.sq_loss([(vis, None, 1.0 / vis.numel()), (lo, valid, km)])
 
 
 ZERO_IN_OPT = os.environ.get("TF_ZERO_IN_OPT", "0") == "1"      # A/B switch: the gradient zero fill rides in the optimiser pass (measured neutral)
@@ -107,22 +87,15 @@ def loss_fn(module, batch):
     """mean(vis^2) + mean(lang[valid]^2)."""
     x, lang, pad, valid, km = batch[:5]
     vis, lo, _, _ = module(x, lang, pad, lang_valid_rows=_valid_rows(batch))
-    return _MaskedSquareLoss.apply(vis, lo, valid, km)
+    return _masked_square_loss(vis, lo, valid, km)
 
 
-class _SquareMean(torch.autograd.Function):
-    """mean(f^2) of a feature map with a hand-written backward (one dot product forward, one scaled copy backward): the harness's own
-    loss should not be a visible part of the step it times."""
-
-    @staticmethod
-    def forward(ctx, f):
-        ctx.save_for_backward(f)
-        return _sumsq(f) / f.numel() if f.dtype == torch.float32 else f.reshape(-1).float().pow(2).mean()
-
-    @staticmethod
-    def backward(ctx, g):
-        (f,) = ctx.saved_tensors
-        return f * (g * (2.0 / f.numel())).to(f.dtype)
+def _square_mean(f):
+    """mean(f^2) of a feature map (the wrapper legs' loss), on the library's loss kernels when the map is fp32."""
+    from transfusion_amd import ops
+    if f.dtype == torch.float32 and f.is_contiguous() and f.shape[-1] % 4 == 0 and f.data_ptr() % 16 == 0:
+        return ops.sq_loss([(f, None, 1.0 / f.numel())])
+    return f.reshape(-1).float().pow(2).mean()
 
 
 class _EncoderWithHeads(torch.nn.Module):
@@ -154,7 +127,7 @@ def make_heads_batch(B, device, rank, variant, rois_per_image=512, repr_size=102
 def loss_fn_heads(module, batch):
     x, lang, pad, valid, km = batch[:5]
     vis, lo, _, _ = module(x, lang, pad, lang_valid_rows=_valid_rows(batch))
-    loss = _MaskedSquareLoss.apply(vis, lo, valid, km)
+    loss = _masked_square_loss(vis, lo, valid, km)
     feats, noun, verb, ttc, reg = batch[6]
     out = module.heads(feats)
     l = module.crit(out, noun, verb, ttc, reg)
@@ -541,6 +514,40 @@ def extra_under_timer(result, key, fn, rank, timeout_s):
     result[key] = _under_timer(line, guarded, rank, timeout_s)
 
 
+def live_sections(result, *, world, rank, checksum, busbw, strong=None, wrapper_dp=None, probe=None, log_fn=None):
+    """Everything the N > 1 line carries beyond the headline, in the ONE order every rank walks it (each part holds collectives: a rank
+    that skipped one, or took them in another order, would hang the others):
+      1. ``rank_sync``     -- the data-parallel invariant: after any number of steps every rank holds bit-identical parameters
+                              (``checksum()``: a one-element float64 tensor on the collectives' device; MIN and MAX over ranks must agree);
+      2. ``allreduce``     -- ``busbw()``: the gradient exchange alone, algorithm and bus bandwidth, + the backend and the group size;
+      3. ``strong``        -- ``strong()``: the reference's own batch arithmetic, the GLOBAL batch of 32 divided by the device count
+                              (run_experiment.py:373-374), world > 1 only;
+      4. ``wrapper_b4_real_dp`` -- ``wrapper_dp()``: the reference's real module under the ordered range reducer, an EXTRA under a timer;
+      5. ``allreduce.rccl`` -- ``probe()``: the library's own communicator with its peers, LAST and under a timer.
+    main() passes the real measurements; tests/test_bench_schedule_cpu.py drives the same function with eight gloo ranks and stand-ins
+    that issue real collectives (no 8-GPU node has been available to any round: this is the part of the N = 8 line that can be
+    rehearsed without one)."""
+    if os.environ.get("TF_CHECK_SYNC", "1") != "0":
+        mine = checksum().reshape(1)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert lo.item() == hi.item(), (lo.item(), hi.item())
+        result["rank_sync"] = {"parameter_checksum": lo.item(), "identical_on_ranks": world}
+        if rank == 0 and log_fn is not None:
+            log_fn(f"  parameter checksum identical on {world} ranks: {lo.item():.6f}")
+    result["allreduce"] = busbw()                                 # every rank takes part; rank 0 prints
+    result["allreduce"].update({"backend": dist.get_backend(), "group_world": dist.get_world_size()})
+    if world > 1 and strong is not None:
+        s = strong()
+        result["strong"] = {"global_batch": s["batch_per_gpu"] * world, "samples_s": s["samples_s"], "ms_per_step": s["ms_per_step"],
+                            "batch_per_gpu": s["batch_per_gpu"]}
+    if wrapper_dp is not None and os.environ.get("TF_WRAPPER_DP_LEG", "1") != "0":
+        extra_under_timer(result, "wrapper_b4_real_dp", wrapper_dp, rank, float(os.environ.get("TF_WRAPPER_DP_TIMEOUT_S", "150")))
+    if probe is not None and os.environ.get("TF_RCCL_PROBE", "1") != "0":
+        probe_under_timer(result, probe, rank)
+
+
 def run_leg(name, device, rank, comm, *, precision="bf16", batch=32, d=D, h=H, layers=L, nv=NV, nl=NL, fp8=False, pack=True, padded=True,
             steps=8, warmup=3, grad_clip=1.0):
     """One more BASELINE configuration in the same process, after the headline: its own encoder, trainer and batches, `warmup` untimed +
@@ -676,7 +683,11 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
 
         def wloss(m, _):
             out = m({"image": feats, "language_f": lang})
-            return sum(_SquareMean.apply(f) for f in out["features"].values())
+            fs = [f for f in out["features"].values()]
+            if all(f.dtype == torch.float32 and f.is_contiguous() and f.shape[-1] % 4 == 0 and f.data_ptr() % 16 == 0 for f in fs):
+                from transfusion_amd import ops
+                return ops.sq_loss([(f, None, 1.0 / f.numel()) for f in fs])        # one scalar, len(fs) launches each way
+            return sum(_square_mean(f) for f in fs)
 
         last = {}
         for _ in range(warmup):
@@ -775,7 +786,7 @@ def main():
                     help="bf16: the headline (BASELINE configs[1]); fp32: the fp32-accuracy mode of configs[2] (run.precision: 32)")
     ap.add_argument("--no-overlap", action="store_true", help="reduce gradients after the backward instead of layer by layer")
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations that follow the headline leg")
-    ap.add_argument("--legs", default="fp32,stress,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_real_v1,wrapper_b4_real_v2,wrapper_b4_dp,b16,v1_d712,v2_d896_fp32,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
+    ap.add_argument("--legs", default="fp32,stress,fp8,b4,b4_dense,wrapper_b4,wrapper_b4_real,wrapper_b4_real_v1,wrapper_b4_real_v2,wrapper_b4_dp,b16,v1_d712,v2_d896_fp32,dense_rows,no_padding", help="comma-separated subset of the legs to run (N = 1)")
     ap.add_argument("--dense-rows", action="store_true",
                     help="carry the masked (padding) language tokens through every kernel as dead rows instead of dropping them "
                          "(CrossTransformerModuleBox.pack_tokens = False); same results on every real token, A/B switch")
@@ -866,16 +877,6 @@ def main():
 
     elapsed, rows = run_schedule(step, comm, rank, args.warmup, args.steps, 0 if args.no_census else args.trace_steps, traced_kernels)
     final_loss = float(last["loss"].item())
-    if live and os.environ.get("TF_CHECK_SYNC", "1") != "0":
-        # data-parallel invariant: after any number of steps every rank holds bit-identical parameters
-        mine = trainer.flat.flat.double().sum().reshape(1)
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert lo.item() == hi.item(), (lo.item(), hi.item())
-        rank_sync = {"parameter_checksum": lo.item(), "identical_on_ranks": world}
-        if rank == 0:
-            log(f"  parameter checksum identical on {world} ranks: {lo.item():.6f}; overlap={'on' if trainer.layerwise is not None else 'off'}")
     if not math.isfinite(final_loss):
         raise SystemExit(f"non-finite loss {final_loss}")
 
@@ -920,9 +921,6 @@ def main():
         result["block_mfma_util_dense_credit"] = round(train_flops_step / (ms * 1e-3) / 1e12 / peak, 4)
         result["peak_tflops_used"] = round(peak, 1)
         result["peak_fp32_mfma_tflops"] = 157.3
-    if live:
-        result["allreduce"] = allreduce_busbw(trainer, comm)          # every rank takes part; rank 0 prints
-        result["allreduce"].update({"backend": dist.get_backend(), "group_world": dist.get_world_size()})
     if rank == 0 and rows is not None:
         # in-situ kernel table: the traced steps ran AFTER the timed region (two event records per launch would perturb it)
         total = sum(r["us_per_step"] for r in rows)
@@ -966,8 +964,6 @@ def main():
         if args.isolated_census:
             census = kernel_census(args.batch, device)
             result["kernels_isolated"] = [{k: c[k] for k in ("kernel", "us", "launches_per_step", "us_per_step", "tflops", "gbs")} for c in census]
-    if live and os.environ.get("TF_CHECK_SYNC", "1") != "0":
-        result["rank_sync"] = rank_sync
     # ---- the other BASELINE configurations, in the same run (every rank takes part: each step holds the gradient collectives) ----
     if not args.no_legs and not args.with_heads and args.precision == "bf16" and args.batch == 32:
         legs = {}
@@ -1000,32 +996,47 @@ def main():
                 if name not in specs:
                     raise SystemExit(f"--legs: unknown leg {name!r} (known: {', '.join(specs)}, wrapper_b4, wrapper_b4_real, wrapper_b4_real_v1, wrapper_b4_real_v2, wrapper_b4_dp)")
                 legs[name if name not in legs else f"{name}#{len(legs)}"] = run_leg(name, device, rank, comm, **specs[name])
-        else:
-            # strong scaling (run_experiment.py:373-374: the GLOBAL batch is divided by the device count): global batch 32
-            per = max(1, 32 // world)
-            strong = run_leg("strong", device, rank, comm, batch=per, steps=16, warmup=4)
-            result["strong"] = {"global_batch": per * world, "samples_s": strong["samples_s"], "ms_per_step": strong["ms_per_step"],
-                                "batch_per_gpu": per}
-        if live and os.environ.get("TF_WRAPPER_DP_LEG", "1") != "0":
-            # the reference's REAL module under data parallelism, at its own per-GPU batch and FPN geometry: the four-level wrapper as one
-            # ragged grouped call, gradients exchanged unit by unit behind the backward (OrderedRangeReducer over the process group).
-            # An extra of the N > 1 line: under a timer, reported or dropped, never fatal
-            faulthandler.cancel_dump_traceback_later()
-            extra_under_timer(result, "wrapper_b4_real_dp", lambda: run_wrapper_leg(device, rank, comm, batch=4, real=True, steps=8, warmup=3), rank,
-                              float(os.environ.get("TF_WRAPPER_DP_TIMEOUT_S", "150")))
         if legs:
             result["legs"] = legs
             if "fp32" in legs:            # BASELINE configs[2] (Ego4Dv2, run.precision: 32) names fp32: that leg's figure at top level too
                 result["value_fp32"] = legs["fp32"]["samples_s"]
                 result["ms_per_step_fp32"] = legs["fp32"]["ms_per_step"]
+            if "no_padding" in legs:      # SURVEY.md 8(d)'s other variant: 196 + 512 REAL tokens per sample (nothing to drop)
+                result["value_no_padding"] = legs["no_padding"]["samples_s"]
+                result["ms_per_step_no_padding"] = legs["no_padding"]["ms_per_step"]
+            if "fp8" in legs:             # BASELINE configs[4]: fp8 projections
+                result["value_fp8"] = legs["fp8"]["samples_s"]
+                result["ms_per_step_fp8"] = legs["fp8"]["ms_per_step"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     faulthandler.cancel_dump_traceback_later()
-    if live and os.environ.get("TF_RCCL_PROBE", "1") != "0":
-        probe_under_timer(result, lambda: rccl_probe(trainer, comm, device, rank), rank)
+    if live:
+        # the sections of the N > 1 line (live_sections: one order on every rank).  strong scaling and the real module under data
+        # parallelism are legs: only with the default headline (no --no-legs / --with-heads / fp32 / another batch)
+        with_legs = not args.no_legs and not args.with_heads and args.precision == "bf16" and args.batch == 32
+        per = max(1, 32 // world)
+
+        def strong_leg():
+            out = run_leg("strong", device, rank, comm, batch=per, steps=16, warmup=4)
+            return dict(out, batch_per_gpu=per)
+        live_sections(result, world=world, rank=rank, log_fn=log,
+                      checksum=lambda: trainer.flat.flat.double().sum(),
+                      busbw=lambda: allreduce_busbw(trainer, comm),
+                      strong=strong_leg if with_legs else None,
+                      # the reference's REAL module under data parallelism, at its own per-GPU batch and FPN geometry: the four-level wrapper
+                      # as one ragged grouped call, gradients exchanged unit by unit behind the backward (OrderedRangeReducer)
+                      wrapper_dp=(lambda: run_wrapper_leg(device, rank, comm, batch=4, real=True, steps=8, warmup=3)) if with_legs else None,
+                      probe=lambda: rccl_probe(trainer, comm, device, rank))
     if rehearse:
         result["rehearsal"] = "one-rank process group: the N > 1 code path against the real backend, without peers"
     if rank == 0:
+        # the three figures that must be quoted TOGETHER (never the first alone): the headline drops masked tokens (random right padding,
+        # mean valid tokens beside it), no_padding runs 708 real tokens per sample, fp32 is the B = 32 Ego4Dv2 config's own precision
+        def _f(k, unit="samples/s"):
+            return f"{result[k]:.0f} {unit}" if isinstance(result.get(k), (int, float)) else "n/a"
+        log(f"[bench] SUMMARY bf16 padded+packed {result['value']:.0f} samples/s ({result['ms_per_step']} ms, mean valid tokens "
+            f"{result.get('mean_valid_tokens')}) | no_padding {_f('value_no_padding')} | fp32 {_f('value_fp32')} | fp8 {_f('value_fp8')} | "
+            f"block_mfma_util {result.get('block_mfma_util')} (executed work) | roofline.frac {result.get('roofline', {}).get('frac')}")
         print(json.dumps(result), flush=True)
     if live:
         dist.barrier()

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 8
+#define TF_ABI_VERSION 9
 #define TF_MAX_LAYERS 16
 #define TF_MAX_GROUPS 8     /* ragged groups (ABI v8): at most this many row ranges of unequal size in one grouped launch */
 
@@ -418,6 +418,21 @@ const uint32_t* tf_clock_ptr(void);
 int tf_clock_advance(uint32_t by, tf_stream_t s);
 int tf_clock_set(uint32_t value, tf_stream_t s);
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
+/* ABI v9.  One term of the synthetic training loss of the benchmark (mean(vis^2) + mean(lang[valid]^2); the reference
+ * has no counterpart -- its losses sit behind the detector, losses.py:98-135) and its gradient, so that a timed step holds no
+ * framework elementwise kernel.  x: contiguous fp32 [rows, d], d % 4 == 0, 16-B aligned; row_w: optional [rows] weights (the 0 / 1
+ * valid-token mask).  fwd: out[0] = (accumulate ? out[0] : 0) + scale * sum_r row_w[r]^2 |x[r, :]|^2 -- block partials summed in index
+ * order by the last block to arrive, like tf_sumsq: the same bits on every run and rank.  bwd: dx[r, :] = g[0] * 2 * scale *
+ * row_w[r]^2 * x[r, :] (g: optional device scalar, the upstream gradient; null = 1). */
+typedef struct TfSqLossArgs {
+  const float* x; long long rows; int d;
+  const float* row_w;
+  float scale;
+  float* out; int accumulate;         /* forward */
+  const float* g; float* dx;          /* backward */
+} TfSqLossArgs;
+int tf_sq_loss_fwd(const TfSqLossArgs* a, tf_stream_t s);
+int tf_sq_loss_bwd(const TfSqLossArgs* a, tf_stream_t s);
 int tf_heads_loss_fwd(const TfHeadsLossArgs* a, tf_stream_t s);
 int tf_heads_loss_bwd(const TfHeadsLossArgs* a, tf_stream_t s);
 /* dy == null: y[r] = softplus(x[r, col]) (F.softplus defaults, roi_wrappers.py:229); dy != null: dx[r, col] += dy[r] * sigmoid(x[r, col]).

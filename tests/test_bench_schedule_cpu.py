@@ -137,3 +137,110 @@ def test_an_extra_leg_that_hangs_or_raises_cannot_take_the_bench_line_with_it(tm
         assert r.returncode == 0, (mode, r.stderr[-2000:])
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["value"] == 2.0 and check(line["wrapper_b4_real_dp"]), (mode, line)
+
+
+def _live_sections_worker(rank, world, port, out, bench_path, skew):
+    import importlib.util
+    import json
+    import time
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench_under_test", bench_path)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seq = []                                             # the collectives this rank issued, in order
+    real_ar, real_bar = dist.all_reduce, dist.barrier
+
+    def ar(t, *a, **k):
+        seq.append(("all_reduce", int(t.numel()), str(k.get("op", a[0] if a else "SUM"))))
+        return real_ar(t, *a, **k)
+
+    def bar(*a, **k):
+        seq.append(("barrier",))
+        return real_bar(*a, **k)
+    b.dist.all_reduce, b.dist.barrier = ar, bar
+    if skew:
+        time.sleep(0.05 * ((rank * 5) % world))          # ranks arrive at every section at different times
+
+    def busbw():                                         # stand-in for allreduce_busbw: the same shape of work -- barrier, collectives, barrier, max
+        g = torch.ones(1000)
+        dist.barrier()
+        for _ in range(3):
+            dist.all_reduce(g)
+        dist.barrier()
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return dict(bytes=4000, collectives_per_step=4, ms=1.0, algbw_gbs=4.0, busbw_gbs=round(4.0 * 2 * (world - 1) / world, 2))
+
+    def leg(ms):
+        def run():                                       # a leg = warm-up, barrier, timed steps with gradient collectives, barrier, max over ranks
+            g = torch.ones(64)
+            dist.barrier()
+            for _ in range(2):
+                dist.all_reduce(g)
+            dist.barrier()
+            t = torch.tensor([ms * (1 + 0.01 * rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return {"samples_s": round(4 * world / (float(t) * 1e-3), 1), "ms_per_step": round(float(t), 3), "batch_per_gpu": 32 // world,
+                    "reducer": "OrderedRangeReducer"}
+        return run
+
+    result = {"metric": "m", "value": 1.0, "n_gpus": world}
+    b.live_sections(result, world=world, rank=rank, checksum=lambda: torch.tensor(42.5, dtype=torch.float64), busbw=busbw,
+                    strong=leg(1.5), wrapper_dp=leg(5.0), probe=lambda: {"rccl": {"world": world, "calls": 1, "matches_process_group": True}})
+    seqs = [None] * world
+    dist.all_gather_object(seqs, seq)
+    if rank == 0:
+        json.dump({"result": result, "seqs": seqs}, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_the_n8_line_carries_its_sections_and_every_rank_walks_them_alike(tmp_path, skew):
+    """bench.live_sections with EIGHT gloo ranks (what `python bench.py --gpus 8` runs after the headline): rank 0's line carries
+    ``rank_sync`` (identical on 8 ranks), ``allreduce.busbw_gbs`` + backend + group size, ``strong`` (global batch 32 = 4 per rank,
+    run_experiment.py:373-374), ``wrapper_b4_real_dp`` and ``allreduce.rccl``; all eight ranks issue the SAME sequence of collectives,
+    also when they reach the sections at different times.  The measurements are stand-ins (no GPU here) that issue real collectives in the
+    shape the real ones do; the order, the keys and the timers are the product code."""
+    import json
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "n8.json")
+    from test_ddp_cpu import _free_port
+    mp.spawn(_live_sections_worker, args=(8, _free_port(), out, os.path.join(ROOT, "bench.py"), skew), nprocs=8, join=True)
+    got = json.load(open(out))
+    r = got["result"]
+    assert r["rank_sync"] == {"parameter_checksum": 42.5, "identical_on_ranks": 8}
+    assert r["allreduce"]["busbw_gbs"] == 7.0 and r["allreduce"]["backend"] == "gloo" and r["allreduce"]["group_world"] == 8
+    assert r["allreduce"]["rccl"] == {"world": 8, "calls": 1, "matches_process_group": True}
+    assert r["strong"]["global_batch"] == 32 and r["strong"]["batch_per_gpu"] == 4 and r["strong"]["samples_s"] > 0
+    assert "error" not in r["wrapper_b4_real_dp"] and r["wrapper_b4_real_dp"]["reducer"] == "OrderedRangeReducer"
+    assert all(s == got["seqs"][0] for s in got["seqs"]) and len(got["seqs"][0]) > 10
+
+
+def _mismatch_worker(rank, world, port, bench_path):
+    import importlib.util
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench_under_test", bench_path)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    try:
+        b.live_sections({}, world=world, rank=rank, checksum=lambda: torch.tensor(1.0 + (rank == 2), dtype=torch.float64),
+                        busbw=lambda: {})
+    except AssertionError:
+        dist.destroy_process_group()
+        return
+    raise SystemExit("ranks with different parameters passed the check")
+
+
+def test_ranks_that_drifted_apart_fail_the_line_on_every_rank():
+    import torch.multiprocessing as mp
+    from test_ddp_cpu import _free_port
+    mp.spawn(_mismatch_worker, args=(4, _free_port(), os.path.join(ROOT, "bench.py")), nprocs=4, join=True)

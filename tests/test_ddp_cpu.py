@@ -357,6 +357,98 @@ def test_gloo_world2_ordered_range_reducer_on_a_module_tree(tmp_path, accumulate
             torch.testing.assert_close(st["param"][off:off + k], want, rtol=1e-4, atol=1e-5)
 
 
+class FlippableWrapper(StubWrapper):
+    """StubWrapper whose two levels can be evaluated in either order: autograd replays independent branches latest-created first, so
+    ``flip`` reverses the order in which this rank's units COMPLETE in the backward -- the ranks of a real job see such differences
+    through timing (level streams, side streams); here they are made deterministic."""
+    flip = False
+
+    def forward(self, xs):
+        outs = {}
+        for i in ((1, 0) if self.flip else (0, 1)):
+            outs[i] = self.tokens_to_features[i](self.cross_fusion_encoders[i](self.patches_to_token[i](xs[i])))
+        return self.head(torch.cat([outs[0], outs[1]], dim=-1))
+
+
+def _uneven_worker(rank, world, port, out, mode):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transfusion_amd.runner import trainer as T
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real(t, *a, **k)
+
+    T.dist.all_reduce = counting
+    torch.manual_seed(11)
+    n = 2 * world
+    data = [torch.randn(n, 4), torch.randn(n, 5)]
+    model = FlippableWrapper()
+    odd = rank % 2 == 1
+    model.flip = odd and mode == "first_step"
+    tr = T.FusionTrainStep(model, lr=0.05, weight_decay=0.0, grad_clip=None, optimizer_cls=_PlainSGD)
+    mine = [d[rank::world] for d in data]
+    steps, local_orders = [], []
+    for it in range(3):
+        if mode == "later_steps" and it >= 1:
+            model.flip = odd                                   # the order was agreed on in step 1; from step 2 on the odd ranks complete differently
+        before = tr.flat.flat.clone()
+        n0 = len(calls)
+        tr.step([[mine[0], mine[1]]], lambda m, b: m(b).pow(2).sum())
+        steps.append({"before": before, "grad": tr.flat.grad.clone(), "param": tr.flat.flat.clone(), "calls": calls[n0:]})
+    counts, agreed = [None] * world, [None] * world
+    dist.all_gather_object(counts, calls)
+    dist.all_gather_object(agreed, bool(tr.layerwise.agreed))
+    if rank == 0:
+        torch.save({"steps": steps, "counts": counts, "agreed": agreed, "slices": [(n_, o, k) for n_, _, o, k in tr.flat.slices],
+                    "units": [(u["key"], u["lo"], u["hi"]) for u in tr.layerwise.units], "order": tr.layerwise.order}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["first_step", "later_steps"])
+def test_gloo_world4_ordered_range_reducer_with_uneven_completion_order(tmp_path, mode):
+    """FOUR ranks whose units complete in DIFFERENT orders (what the one-rank RCCL rehearsal on the GPU box cannot show: it has no peer
+    to disagree with).  ``first_step``: the odd ranks see another order already in the learning step -- the all-gather of the orders
+    must find the disagreement on EVERY rank and the reducer must never overlap (one collective over the whole buffer per step);
+    ``later_steps``: the order is agreed on in step 1 and the odd ranks complete differently afterwards -- every rank must still issue
+    the collectives in the agreed order (a unit that completes early waits for its turn).  Either way: identical collective sequences
+    on all four ranks (anything else is a hang on real hardware) and gradients / parameters equal to one process over all samples."""
+    out = str(tmp_path / f"uneven_{mode}.pt")
+    world = 4
+    mp.spawn(_uneven_worker, args=(world, _free_port(), out, mode), nprocs=world, join=True)
+    got = torch.load(out)
+    assert all(c == got["counts"][0] for c in got["counts"]), got["counts"]                # the SAME sequence of collective sizes everywhere
+    total = got["steps"][0]["grad"].numel()
+    sizes = {i: hi - lo for i, (_, lo, hi) in enumerate(got["units"])}
+    if mode == "first_step":
+        assert got["agreed"] == [False] * world                                           # every rank knows, none overlaps
+        for st in got["steps"]:
+            assert st["calls"] == [total]
+    else:
+        assert got["agreed"] == [True] * world
+        assert got["steps"][0]["calls"] == [total]
+        for st in got["steps"][1:]:
+            assert st["calls"] == [sizes[u] for u in got["order"]]                        # the agreed order, whatever completed first locally
+    torch.manual_seed(11)
+    n = 2 * world
+    data = [torch.randn(n, 4), torch.randn(n, 5)]
+    for st in got["steps"]:
+        ref = StubWrapper()
+        named = dict(ref.named_parameters())
+        for nme, off, k in got["slices"]:
+            named[nme].data.copy_(st["before"][off:off + k].view_as(named[nme]))
+            named[nme].grad = torch.zeros_like(named[nme])
+        ref(data).pow(2).sum().backward()
+        for nme, off, k in got["slices"]:
+            torch.testing.assert_close(st["grad"][off:off + k], named[nme].grad.reshape(-1), rtol=1e-4, atol=1e-5)
+            want = named[nme].data.reshape(-1) - 0.05 * named[nme].grad.reshape(-1) / world
+            torch.testing.assert_close(st["param"][off:off + k], want, rtol=1e-4, atol=1e-5)
+
+
 def test_lr_scale_builds_contiguous_ranges_with_their_own_rate():
     """FusionTrainStep(lr_scale=...): the reference's parameter groups (lr / div_rate, lr / ttc_rate) as ranges of the flat buffer."""
     import torch

@@ -828,3 +828,28 @@ def test_linear_input_from_another_stream_survives_until_its_weight_gradient_ran
     elif not any(hit and err > 5e-2 for hit, err in seen):
         # (none of the eight streams got a hardware queue of its own: the control is void on this box, the product is not at fault)
         pytest.skip(f"the control did not reproduce the hazard on this box: {seen}")
+
+
+def test_sq_loss_kernels(dev, guard):
+    """tf_sq_loss_fwd / tf_sq_loss_bwd (ABI v9: the benchmark's synthetic loss, SURVEY.md 8d, as library kernels): value and gradient
+    against fp64 torch, with and without row weights, accumulation across terms, the same bits on a second call (deterministic sum), an
+    upstream gradient that is not 1."""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(11)
+    vis = torch.randn(7, 196, 72, generator=g)
+    lo = torch.randn(7, 130, 72, generator=g)
+    valid = (torch.rand(7, 130, generator=g) < 0.6).float()
+    v, l, w = guard(vis).requires_grad_(True), guard(lo).requires_grad_(True), guard(valid)
+    kv, km = 1.0 / vis.numel(), 1.0 / (float(valid.sum()) * 72)
+    loss = ops.sq_loss([(v, None, kv), (l, w, km)])
+    (loss * 3.0).backward()
+    vr, lr = vis.double().requires_grad_(True), lo.double().requires_grad_(True)
+    ref = (vr ** 2).sum() * kv + ((lr * valid.double().unsqueeze(-1)) ** 2).sum() * km
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel(v.grad, vr.grad) < 1e-6 and rel(l.grad, lr.grad) < 1e-6
+    assert float(l.grad.cpu()[valid == 0].abs().max()) == 0.0
+    again = ops.sq_loss([(v.detach(), None, kv), (l.detach(), w, km)])
+    assert float(again) == float(loss)                                   # no float atomics: the same bits
+    big = guard(torch.randn(22656, 768, generator=g))                     # the benchmark's size: many blocks, the 8-deep body and its tail
+    assert abs(float(ops.sq_loss([(big, None, 1.0)])) - float((big.double() ** 2).sum())) < 1e-5 * float((big.double() ** 2).sum())

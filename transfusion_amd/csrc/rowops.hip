@@ -751,7 +751,11 @@ constexpr int SUMSQ_MAX_BLOCKS = 512, SUMSQ_SLOTS = 16;
 __device__ float g_sumsq_part[SUMSQ_SLOTS][SUMSQ_MAX_BLOCKS];
 __device__ unsigned g_sumsq_ticket[SUMSQ_SLOTS];
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out, int slot) {
+// MASK: element i is weighted by row_w[i / d] (tf_sq_loss_fwd: the synthetic loss's valid-token mask; d % 4 == 0, so a 16-B lane
+// stays inside one row).  out[0] = (accumulate ? out[0] : 0) + scale * sum.
+template <bool MASK>
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out, int slot, const float* __restrict__ row_w,
+                                                    int d4, float scale, int accumulate) {
   float s = 0.f;
   const long long n4 = n >> 2;                               // 16-B lanes over the aligned body, scalar tail
   const f32x4* x4 = (const f32x4*)x;
@@ -761,17 +765,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (; i + 7 * stride < n4; i += 8 * stride) {
     f32x4 v[8];
+    float w[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
+    for (int u = 0; u < 8; ++u) { v[u] = x4[i + u * stride]; w[u] = MASK ? row_w[(i + u * stride) / d4] : 1.f; }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+    for (int u = 0; u < 8; ++u) {
+      const float q = v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+      acc[u] += MASK ? q * (w[u] * w[u]) : q;
+    }
   }
   for (; i < n4; i += stride) {
     const f32x4 v = x4[i];
-    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    const float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    if (MASK) { const float w = row_w[i / d4]; s += q * (w * w); }
+    else s += q;
   }
   s += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+  if (!MASK)       // (masked form: n is rows * d with d % 4 == 0 -- no scalar tail)
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
   __shared__ float part[4];
   __shared__ int is_last;
   s = wave_sum(s);
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) t += __hip_atomic_load(&g_sumsq_part[slot][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = wave_sum(t);
     if (threadIdx.x == 0) {
-      out[0] += t;                                           // single writer; launches that share `out` are stream-ordered
+      out[0] = (accumulate ? out[0] : 0.f) + scale * t;      // single writer; launches that share `out` are stream-ordered
       __hip_atomic_store(&g_sumsq_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1452,7 +1463,41 @@ extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStrea
   TfTraceScope tr("sumsq_kernel", st);
   static std::atomic<unsigned> next_slot{0};
   const int slot = (int)(next_slot.fetch_add(1u) % SUMSQ_SLOTS);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS)), dim3(256), 0, st, x, n, out, slot);
+  hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS)), dim3(256), 0, st, x, n, out, slot, (const float*)nullptr, 1, 1.0f, 1);
+  return (int)hipGetLastError();
+}
+// The synthetic training loss of SURVEY.md 8(d) -- mean(vis^2) + mean(lang[valid]^2) -- as library kernels, so that a benchmark step holds
+// no framework elementwise kernel: fwd: out[0] (+)= scale * sum_r row_w[r]^2 |x[r, :]|^2 (deterministic: tf_sumsq's last-arriver sum);
+// bwd: dx[r, :] = g[0] * 2 * scale * row_w[r]^2 * x[r, :].
+__global__ __launch_bounds__(256) void sq_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ row_w, int d4, long long n4,
+                                                          float scale2, const float* __restrict__ g, float* __restrict__ dx) {
+  const float gs = (g != nullptr ? g[0] : 1.f) * scale2;
+  const f32x4* x4 = (const f32x4*)x;
+  f32x4* y4 = (f32x4*)dx;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float w = gs;
+    if (row_w != nullptr) { const float rw = row_w[i / d4]; w *= rw * rw; }
+    const f32x4 v = x4[i];
+    y4[i] = f32x4{v[0] * w, v[1] * w, v[2] * w, v[3] * w};
+  }
+}
+extern "C" int tf_launch_sq_loss(const TfSqLossArgs* a, int backward, hipStream_t st) {
+  if (a->rows <= 0 || a->d <= 0) return 0;
+  if (a->x == nullptr || (a->d % 4) || ((size_t)a->x & 15)) return -2;
+  const long long n = a->rows * (long long)a->d;
+  if (!backward) {
+    if (a->out == nullptr) return -2;
+    TfTraceScope tr("sq_loss_fwd_kernel", st, 0.0, 4.0 * n);
+    static std::atomic<unsigned> next_slot{8};
+    const int slot = (int)(next_slot.fetch_add(1u) % SUMSQ_SLOTS);
+    const dim3 grid(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS));
+    if (a->row_w != nullptr) hipLaunchKernelGGL(sumsq_kernel<true>, grid, dim3(256), 0, st, a->x, n, a->out, slot, a->row_w, a->d / 4, a->scale, a->accumulate);
+    else hipLaunchKernelGGL(sumsq_kernel<false>, grid, dim3(256), 0, st, a->x, n, a->out, slot, (const float*)nullptr, 1, a->scale, a->accumulate);
+  } else {
+    if (a->dx == nullptr || ((size_t)a->dx & 15)) return -2;
+    TfTraceScope tr("sq_loss_bwd_kernel", st, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(sq_loss_bwd_kernel, dim3(grid_for(n / 4, 256 * 4, 2048)), dim3(256), 0, st, a->x, a->row_w, a->d / 4, n / 4, 2.0f * a->scale, a->g, a->dx);
+  }
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {

@@ -230,6 +230,59 @@ def sumsq(x: torch.Tensor, out: torch.Tensor):
     L.check(L.load().tf_sumsq(L.ptr(x), x.numel(), L.ptr(out), _stream()), "tf_sumsq")
 
 
+class _SqLossFn(torch.autograd.Function):
+    """sum_t scale_t * sum_r row_w_t[r]^2 |x_t[r, :]|^2 over the given terms (tf_sq_loss_fwd / tf_sq_loss_bwd): the benchmark's synthetic loss
+     without a framework elementwise kernel in the step.  Every term: a contiguous fp32 CUDA tensor [..., d] (d % 4 == 0), an
+    optional fp32 row-weight tensor with one entry per row, a float weight."""
+
+    @staticmethod
+    def forward(ctx, n_terms, *flat):
+        xs, ws, scales = flat[:n_terms], flat[n_terms:2 * n_terms], flat[2 * n_terms:]
+        out = torch.empty(1, dtype=torch.float32, device=xs[0].device)
+        lib = L.load()
+        args = []
+        for i, (x, w, sc) in enumerate(zip(xs, ws, scales)):
+            _require_cuda(x)
+            if x.dtype != torch.float32 or not x.is_contiguous() or (w is not None and (w.dtype != torch.float32 or not w.is_contiguous())):
+                raise L.TfError("tf_sq_loss needs contiguous fp32 tensors")
+            d = x.shape[-1]
+            rows = x.numel() // d
+            if w is not None and w.numel() != rows:
+                raise L.TfError(f"tf_sq_loss: {w.numel()} row weights for {rows} rows")
+            a = L.TfSqLossArgs(x=L.ptr(x), rows=rows, d=d, row_w=L.ptr(w), scale=float(sc), out=L.ptr(out), accumulate=1 if i else 0)
+            L.check(lib.tf_sq_loss_fwd(C.byref(a), C.c_void_p(_stream())), "tf_sq_loss_fwd")
+            args.append(a)
+        ctx.save_for_backward(*xs, *[w for w in ws if w is not None])
+        ctx.has_w = [w is not None for w in ws]
+        ctx.scales = [float(sc) for sc in scales]
+        ctx.n_terms = n_terms
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = list(ctx.saved_tensors)
+        xs, rest = saved[:ctx.n_terms], saved[ctx.n_terms:]
+        lib = L.load()
+        g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
+        grads = []
+        for x, has_w, sc in zip(xs, ctx.has_w, ctx.scales):
+            w = rest.pop(0) if has_w else None
+            dx = torch.empty_like(x)
+            d = x.shape[-1]
+            a = L.TfSqLossArgs(x=L.ptr(x), rows=x.numel() // d, d=d, row_w=L.ptr(w), scale=sc, g=L.ptr(g), dx=L.ptr(dx))
+            L.check(lib.tf_sq_loss_bwd(C.byref(a), C.c_void_p(_stream())), "tf_sq_loss_bwd")
+            grads.append(dx)
+        return (None, *grads, *([None] * (2 * ctx.n_terms)))
+
+
+def sq_loss(terms):
+    """terms: [(x, row_w or None, scale), ...] -> the scalar sum of scale * sum_r row_w[r]^2 |x[r]|^2 (differentiable w.r.t. every x)."""
+    xs = [t[0] for t in terms]
+    ws = [t[1] for t in terms]
+    scales = [float(t[2]) for t in terms]
+    return _SqLossFn.apply(len(terms), *xs, *ws, *scales)
+
+
 def set_gemm_concurrency(n: int):
     """Planning hint for the GEMM tile choice: ``n`` launch sequences share the chip (tf_set_gemm_concurrency)."""
     L.load().tf_set_gemm_concurrency(int(n))
