@@ -341,13 +341,18 @@ def test_pack_and_patch_permutations(dev):
     assert torch.equal(img.cpu(), expect)
 
 
-@pytest.mark.parametrize("B,C,H,W,p", [(2, 256, 56, 56, 4), (3, 40, 15, 17, 2), (2, 2048, 14, 14, 1), (1, 12, 7, 300, 3), (2, 520, 29, 28, 2)])
-def test_patch_permutations_tiled_kernels(dev, B, C, H, W, p):
+@pytest.mark.parametrize("B,C,H,W,p", [(2, 256, 56, 56, 4), (3, 40, 15, 17, 2), (2, 2048, 14, 14, 1), (1, 12, 7, 300, 3), (2, 520, 29, 28, 2),
+                                       # the reference's FPN levels at batch 4 (plane-tile kernels: 7 of 28 patch rows / whole planes per workgroup)
+                                       (4, 256, 112, 112, 4), (4, 512, 56, 56, 4), (4, 1024, 28, 28, 2), (4, 2048, 14, 14, 1),
+                                       # plane-tile plan edges: one patch row per workgroup, odd patch-row counts, 16 / 64 channels exactly
+                                       (1, 8, 4, 2000, 4), (2, 16, 6, 10, 2), (1, 64, 3, 4, 1), (3, 128, 10, 6, 1), (2, 32, 18, 22, 2)])
+def test_patch_permutations_tiled_kernels(dev, guard, B, C, H, W, p):
     """K1 / K9 permutations at the wrapper's level shapes and at ragged ones (channel tails, maps that are not a multiple of the patch,
-    several channel chunks per patch row): im2col rows and the fold must be EXACT permutations of the bf16-rounded input."""
+    several channel chunks per patch row): im2col rows and the fold must be EXACT permutations of the bf16-rounded input.  (The feature
+    map ends at unmapped pages: ``guard``.)"""
     from transfusion_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + C + H + W + p)
-    feat = torch.randn(B, C, H, W, generator=g).to(dev)
+    feat = guard(torch.randn(B, C, H, W, generator=g))
     Hp, Wp = H // p, W // p
     rows = ops.patchify(feat, p, p)
     x = feat.cpu()[:, :, : Hp * p, : Wp * p].reshape(B, C, Hp, p, Wp, p).permute(0, 2, 4, 1, 3, 5).reshape(B, -1, C * p * p)

@@ -644,13 +644,22 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const u16* __restric
 
 // Attention-probability dropout as a bitmask: bits[row][w] bit k = keep(element row*S + 32*w + k), row = (b*H+h)*S + q.
 // Generated once per layer and forward; read by attn_fwd / attn_bwd_dq / attn_bwd_dkv (2 VALU ops per element there).
+// cu != null (packed batches, TfAttnArgs.cu_rows): row (b, h, q) exists only for q < len_b = cu[b + 1] - cu[b] and attends keys < len_b;
+// words outside are never read by the attention kernels (they stop at the sample's last 64-key tile, whose surplus keys have P = 0),
+// so they are not generated: at the benchmark's padding ~46 % of the 17-hash words.  The index space stays the dense one -- the words
+// that are written hold the same bits as without the row table.
 __global__ __launch_bounds__(256) void attn_dropmask_kernel(unsigned* __restrict__ bits, long long nrows, int S, int SW32, unsigned key_in,
-                                                            unsigned thr16) {
+                                                            unsigned thr16, const int* __restrict__ cu, int H) {
   const unsigned key = tf_salted(key_in);
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= nrows * SW32) return;
   // (the grid is checked against 2^32 elements by the launcher, so the row / word split fits 32-bit arithmetic)
   const unsigned row = (unsigned)t / (unsigned)SW32, w = (unsigned)t - row * (unsigned)SW32;
+  if (cu != nullptr) {
+    const unsigned bh = row / (unsigned)S, q = row - bh * (unsigned)S, b = bh / (unsigned)H;
+    const int len = cu[b + 1] - cu[b];
+    if ((int)q >= len || (int)(w >> 1) * 64 >= len) return;          // (whole 64-key tiles: the kernels read 64-bit words)
+  }
   const unsigned base = row * (unsigned)S + w * 32u;
   // Branch-free: the word's 32 elements span 16 or (odd base) 17 index PAIRS; hash all 17, lay their keep bits out as a
   // 34-bit stream and shift by the base's parity.  x >= thr16  <=>  carry out of x + (65536 - thr16).
@@ -915,6 +924,146 @@ static int patch_chunk(const TfPatchArgs* a) {
   if (cc < 8) return 0;
   const int cpad = (a->C + 7) / 8 * 8;
   return cc < cpad ? cc : cpad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 gather / K9 scatter on PLANE TILES (round 6).  The kernels above spend their time on index arithmetic (four 64-bit divisions per
+// element in col2im_kernel: 96 us for the 77 MB of the reference's largest FPN level, 0.8 TB/s) and on 4 - 16-byte pieces.  Here one
+// workgroup owns (sample b, CC channels, HPn patch rows): on the image side that is CC contiguous runs of RL = HPn * P * W elements
+// (whole image rows of whole patch rows: 16-byte accesses, no division at all -- the channel is the outer, uniform loop); on the token
+// side every token of the tile receives / supplies ONE contiguous segment of CC * P * P elements (>= 128 bytes), 16 bytes per thread;
+// the permutation between the two is LDS addressing (bf16 tile [cc][row][x]), with the (cc, i, j) split of a 16-byte piece resolved at
+// compile time per patch size P.  Conditions (else the kernels above): square patches of 1, 2 or 4, H = Hp P and W = Wp P exactly,
+// C % CC == 0, no lo plane, 16-byte aligned tensors.
+// ------------------------------------------------------------------------------------------------
+struct PatchPlan { int CC, HPn, RL, G, ok; };
+constexpr int PLANE_TILE = 16384;                      // elements per workgroup (32 KiB of bf16)
+static PatchPlan patch_plan(const TfPatchArgs* a) {
+  PatchPlan p{0, 0, 0, 0, 0};
+  const int P = a->ph;
+  if (a->cols_lo != nullptr || a->ph != a->pw || (P != 1 && P != 2 && P != 4)) return p;
+  const int Hp = a->H / P, Wp = a->W / P, pp = P * P;
+  if (Hp <= 0 || Wp <= 0 || Hp * P != a->H || Wp * P != a->W || (a->ld_cols % 8) || a->ld_cols < a->C * pp) return p;
+  if (((size_t)a->feat & 15) || ((size_t)a->cols & 15)) return p;
+  int CC = 64 / pp;                                     // a token's segment = 64 elements = 128 bytes = 8 threads
+  if (CC < 1 || a->C % CC) return p;
+  int HPn = 0;
+  for (int h = 1; h <= Hp; ++h)
+    if (Hp % h == 0 && (long long)CC * h * P * a->W <= PLANE_TILE && ((h * P * a->W) % 4) == 0) HPn = h;
+  if (HPn == 0 || ((a->H * a->W) % 4) != 0) return p;
+  p.CC = CC; p.HPn = HPn; p.RL = HPn * P * a->W; p.G = CC * pp / 8; p.ok = 1;
+  return p;
+}
+// element index inside the LDS tile of piece u (0 .. NPIECE - 1) of the 16-byte group g of a token at (hp_l, wp); a piece is 8 / NPIECE
+// consecutive x of one (channel, patch row)
+template <int P> struct PatchPiece;
+template <> struct PatchPiece<4> { static constexpr int N = 2;      // 16 elements per channel: group g = channel g >> 1, rows 2 (g & 1), + 1
+  __device__ static int at(int g, int u, int RL, int W, int hp_l, int wp) { return (g >> 1) * RL + (hp_l * 4 + 2 * (g & 1) + u) * W + wp * 4; } };
+template <> struct PatchPiece<2> { static constexpr int N = 4;      // 4 elements per channel: group g = channels 2g, 2g + 1, two rows each
+  __device__ static int at(int g, int u, int RL, int W, int hp_l, int wp) { return (2 * g + (u >> 1)) * RL + (hp_l * 2 + (u & 1)) * W + wp * 2; } };
+template <> struct PatchPiece<1> { static constexpr int N = 8;      // 1 element per channel: group g = channels 8g .. 8g + 7
+  __device__ static int at(int g, int u, int RL, int W, int hp_l, int wp) { return (8 * g + u) * RL + hp_l * W + wp; } };
+
+template <int P, bool F32>       // image (fp32 / bf16) -> token rows (bf16): K1 forward, K9 backward
+__global__ __launch_bounds__(256) void patch_gather_kernel(const TfPatchArgs a, const PatchPlan pl) {
+  __shared__ __attribute__((aligned(16))) u16 tile[PLANE_TILE];
+  const int tid = threadIdx.x, Hp = a.H / P, Wp = a.W / P, nhr = Hp / pl.HPn, nch = a.C / pl.CC;
+  int blk = blockIdx.x;
+  const int hr = blk % nhr; blk /= nhr;
+  const int ch = blk % nch, b = blk / nch;
+  const int c0 = ch * pl.CC, hp0 = hr * pl.HPn, RL = pl.RL;
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t src0 = ((size_t)b * a.C + c0) * plane + (size_t)hp0 * P * a.W;
+  for (int cc = 0; cc < pl.CC; ++cc) {                   // CC contiguous runs of RL elements
+    for (int off = tid * 4; off < RL; off += 1024) {
+      u32x2 w;
+      if (F32) {
+        const f32x4 v = *(const f32x4*)((const float*)a.feat + src0 + cc * plane + off);
+        w[0] = pack2bf(v[0], v[1]); w[1] = pack2bf(v[2], v[3]);
+      } else {
+        w = *(const u32x2*)((const u16*)a.feat + src0 + cc * plane + off);
+      }
+      *(u32x2*)(tile + cc * RL + off) = w;
+    }
+  }
+  __syncthreads();
+  const int G = pl.G, ntask = pl.HPn * Wp * G, pp = P * P;
+  u16* __restrict__ cols = (u16*)a.cols;
+  for (int t = tid; t < ntask; t += 256) {
+    const int tok = t / G, g = t - tok * G;              // (G is a small power of two)
+    const int hp_l = tok / Wp, wp = tok - hp_l * Wp;
+    u16 v[8];
+    constexpr int NP = PatchPiece<P>::N, PE = 8 / NP;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {                       // (RL, W and wp * P are multiples of PE: the pieces are naturally aligned)
+      const int at = PatchPiece<P>::at(g, u, RL, a.W, hp_l, wp);
+      if constexpr (PE == 4) { const u32x2 q = *(const u32x2*)(tile + at); v[4 * u] = (u16)q[0]; v[4 * u + 1] = (u16)(q[0] >> 16); v[4 * u + 2] = (u16)q[1]; v[4 * u + 3] = (u16)(q[1] >> 16); }
+      else if constexpr (PE == 2) { const unsigned q = *(const unsigned*)(tile + at); v[2 * u] = (u16)q; v[2 * u + 1] = (u16)(q >> 16); }
+      else v[u] = tile[at];
+    }
+    u32x4 w;
+    w[0] = v[0] | ((unsigned)v[1] << 16); w[1] = v[2] | ((unsigned)v[3] << 16);
+    w[2] = v[4] | ((unsigned)v[5] << 16); w[3] = v[6] | ((unsigned)v[7] << 16);
+    *(u32x4*)(cols + ((size_t)(b * Hp + hp0 + hp_l) * Wp + wp) * a.ld_cols + (size_t)c0 * pp + 8 * g) = w;
+  }
+  const int Kc = a.C * pp;
+  if (ch == 0 && a.ld_cols > Kc) {                       // the rows' zero padding, once per token
+    const int padw = a.ld_cols - Kc, ntok = pl.HPn * Wp;
+    for (int idx = tid; idx < ntok * padw; idx += 256) {
+      const int tok = idx / padw, q = idx - tok * padw;
+      cols[((size_t)(b * Hp + hp0) * Wp + tok) * a.ld_cols + Kc + q] = 0;
+    }
+  }
+}
+template <int P, bool F32>       // token rows (bf16) -> image (fp32 / bf16): K9 forward (F.fold), K1 backward
+__global__ __launch_bounds__(256) void patch_scatter_kernel(const TfPatchArgs a, const PatchPlan pl) {
+  __shared__ __attribute__((aligned(16))) u16 tile[PLANE_TILE];
+  const int tid = threadIdx.x, Hp = a.H / P, Wp = a.W / P, nhr = Hp / pl.HPn, nch = a.C / pl.CC;
+  int blk = blockIdx.x;
+  const int hr = blk % nhr; blk /= nhr;
+  const int ch = blk % nch, b = blk / nch;
+  const int c0 = ch * pl.CC, hp0 = hr * pl.HPn, RL = pl.RL;
+  const int G = pl.G, ntask = pl.HPn * Wp * G, pp = P * P;
+  const u16* __restrict__ cols = (const u16*)a.cols;
+  for (int t = tid; t < ntask; t += 256) {
+    const int tok = t / G, g = t - tok * G;
+    const int hp_l = tok / Wp, wp = tok - hp_l * Wp;
+    const u32x4 w = *(const u32x4*)(cols + ((size_t)(b * Hp + hp0 + hp_l) * Wp + wp) * a.ld_cols + (size_t)c0 * pp + 8 * g);
+    const u16 v[8] = {(u16)w[0], (u16)(w[0] >> 16), (u16)w[1], (u16)(w[1] >> 16), (u16)w[2], (u16)(w[2] >> 16), (u16)w[3], (u16)(w[3] >> 16)};
+    constexpr int NP = PatchPiece<P>::N, PE = 8 / NP;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int at = PatchPiece<P>::at(g, u, RL, a.W, hp_l, wp);
+      if constexpr (PE == 4) *(u32x2*)(tile + at) = u32x2{(unsigned)v[4 * u] | ((unsigned)v[4 * u + 1] << 16), (unsigned)v[4 * u + 2] | ((unsigned)v[4 * u + 3] << 16)};
+      else if constexpr (PE == 2) *(unsigned*)(tile + at) = (unsigned)v[2 * u] | ((unsigned)v[2 * u + 1] << 16);
+      else tile[at] = v[u];
+    }
+  }
+  __syncthreads();
+  const size_t plane = (size_t)a.H * a.W;
+  const size_t dst0 = ((size_t)b * a.C + c0) * plane + (size_t)hp0 * P * a.W;
+  for (int cc = 0; cc < pl.CC; ++cc) {
+    for (int off = tid * 4; off < RL; off += 1024) {
+      const u32x2 w = *(const u32x2*)(tile + cc * RL + off);
+      if (F32) {
+        *(f32x4*)((float*)a.feat + dst0 + cc * plane + off) =
+            f32x4{bf2f((u16)w[0]), bf2f((u16)(w[0] >> 16)), bf2f((u16)w[1]), bf2f((u16)(w[1] >> 16))};
+      } else {
+        *(u32x2*)((u16*)a.feat + dst0 + cc * plane + off) = w;
+      }
+    }
+  }
+}
+template <bool GATHER>
+static int launch_patch_planes(const TfPatchArgs* a, const PatchPlan& pl, bool f32, hipStream_t st) {
+  const dim3 grid((unsigned)((long long)a->B * (a->C / pl.CC) * ((a->H / a->ph) / pl.HPn)));
+#define TF_PP(P) do { if (GATHER) { if (f32) hipLaunchKernelGGL((patch_gather_kernel<P, true>), grid, dim3(256), 0, st, *a, pl); \
+                                    else hipLaunchKernelGGL((patch_gather_kernel<P, false>), grid, dim3(256), 0, st, *a, pl); } \
+                      else { if (f32) hipLaunchKernelGGL((patch_scatter_kernel<P, true>), grid, dim3(256), 0, st, *a, pl); \
+                             else hipLaunchKernelGGL((patch_scatter_kernel<P, false>), grid, dim3(256), 0, st, *a, pl); } } while (0)
+  if (a->ph == 4) TF_PP(4); else if (a->ph == 2) TF_PP(2); else TF_PP(1);
+#undef TF_PP
+  return (int)hipGetLastError();
 }
 
 // fp32 [rows, cols] -> hi + lo bf16 operand planes [rows, ld_dst] (zero-padded), optional input dropout first, optional fp32 copy of the
@@ -1406,6 +1555,18 @@ extern "C" int tf_launch_dropout_apply(const void* x, void* y, long long n, unsi
 extern "C" int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t st) {
   return tf_launch_attn_dropmask_rows(bits, (long long)B * H * S, S, key, thr, st);
 }
+// packed batches: only the rows and key tiles the samples have (cu: TfAttnArgs.cu_rows, device, B + 1 entries, ready on `st`)
+extern "C" int tf_launch_attn_dropmask_packed(void* bits, int B, int H, int S, const int* cu, unsigned key, unsigned thr, hipStream_t st) {
+  if (cu == nullptr) return tf_launch_attn_dropmask(bits, B, H, S, key, thr, st);
+  const int SW32 = 2 * ((S + 63) / 64);
+  const long long nrows = (long long)B * H * S;
+  if (nrows <= 0) return 0;
+  if (nrows * S >= (1ll << 32)) return -5;
+  const long long n = nrows * SW32;
+  TfTraceScope tr("attn_dropmask_kernel", st);
+  hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)bits, nrows, S, SW32, key, thr, cu, H);
+  return (int)hipGetLastError();
+}
 // nrows query rows (batch x head x query) of S key bits each; element index = row * S + key
 extern "C" int tf_launch_attn_dropmask_rows(void* bits, long long nrows, int S, unsigned key, unsigned thr, hipStream_t st) {
   const int SW32 = 2 * ((S + 63) / 64);
@@ -1413,7 +1574,7 @@ extern "C" int tf_launch_attn_dropmask_rows(void* bits, long long nrows, int S, 
   if (nrows * S >= (1ll << 32)) return -5;
   const long long n = nrows * SW32;
   TfTraceScope tr("attn_dropmask_kernel", st);
-  hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)bits, nrows, S, SW32, key, thr);
+  hipLaunchKernelGGL(attn_dropmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)bits, nrows, S, SW32, key, thr, (const int*)nullptr, 1);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t st) {
@@ -1504,6 +1665,14 @@ extern "C" int tf_launch_im2col(const TfPatchArgs* a, hipStream_t st) {
   const long long total = (long long)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols;
   if (total <= 0) return 0;
   static const int tiled = TF_ENV_INT("TF_PATCH_TILED", 1);
+  {
+    const PatchPlan pl = patch_plan(a);
+    if (pl.ok) {
+      const double bytes = (double)a->B * a->C * a->H * a->W * (a->feat_is_f32 ? 4.0 : 2.0) + (double)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols * 2.0;
+      TfTraceScope tr("patch_gather_kernel", st, 0.0, bytes);
+      return launch_patch_planes<true>(a, pl, a->feat_is_f32 != 0, st);
+    }
+  }
   const int cc = (tiled && a->cols_lo == nullptr) ? patch_chunk(a) : 0;      // (the plane-pair form: element-per-thread kernel)
   if (cc > 0) {
     const int nch = (a->C + cc - 1) / cc;
@@ -1531,6 +1700,14 @@ extern "C" int tf_launch_split_planes(const TfPlanesArgs* a, hipStream_t st) {
 extern "C" int tf_launch_col2im(const TfPatchArgs* a, int out_is_f32, hipStream_t st) {
   const long long total = (long long)a->B * a->C * a->H * a->W;
   if (total <= 0) return 0;
+  {
+    const PatchPlan pl = patch_plan(a);
+    if (pl.ok) {
+      const double bytes = (double)total * (out_is_f32 ? 4.0 : 2.0) + (double)a->B * (a->H / a->ph) * (a->W / a->pw) * a->ld_cols * 2.0;
+      TfTraceScope tr("patch_scatter_kernel", st, 0.0, bytes);
+      return launch_patch_planes<false>(a, pl, out_is_f32 != 0, st);
+    }
+  }
   TfTraceScope tr("col2im_kernel", st);
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, st, *a, out_is_f32);
   return (int)hipGetLastError();

@@ -686,6 +686,17 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
   bool side_work[TF_MAX_LAYERS] = {};
   if (side != nullptr && e->overlap->pending != 0u) TF_TRY(tf_overlap_join(e->overlap, s), "fwd join");   // events are about to be reused
+  // the row map (packed batches) comes BEFORE the fork: the side stream's attention dropout masks are generated for the rows and key
+  // tiles the samples really have (tf_launch_attn_dropmask_packed reads cu), so they wait for it through the fork event
+  uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
+  if (c.packed()) {
+    // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
+    TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
+                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, D.ragged ? D.nv : nullptr, (int*)(c.wk + c.A.visrows), c.st), "row_map");
+    km = nullptr;
+  } else {
+    TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
+  }
   if (side != nullptr) {
     TF_TRY((int)hipEventRecord(ev[0], c.st), "fwd fork");        // earlier work on the chain may still use these buffers
     TF_TRY((int)hipStreamWaitEvent(side, ev[0], 0), "fwd fork");
@@ -696,7 +707,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
     for (int l = 0; l < c.D.L; ++l) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       if (e->repack && l >= 1) { TF_TRY(pack_layer(c, l, side), "pack layer"); side_work[l] = true; }
-      if (dr.thr) { TF_TRY(tf_launch_attn_dropmask(c.LB(l) + c.A.dbits, c.D.B, c.D.H, c.D.S, dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
+      if (dr.thr) { TF_TRY(tf_launch_attn_dropmask_packed(c.LB(l) + c.A.dbits, c.D.B, c.D.H, c.D.S, c.cu(), dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
       if (side_work[l]) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
     }
   } else if (e->repack) {
@@ -704,15 +715,6 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   }
   if (e->attn_block_bits != nullptr)              // the block mask's skippable tiles, once per forward (the backward reads them too)
     TF_TRY(tf_launch_attn_block_skip(e->attn_block_bits, D.S, c.wk + c.A.bskip, c.wk + c.A.bskip + (size_t)((D.S + 127) / 128) * 8, c.st), "block_skip");
-  uint8_t* km = (uint8_t*)(c.wk + c.A.keymask);
-  if (c.packed()) {
-    // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
-    TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
-                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, D.ragged ? D.nv : nullptr, (int*)(c.wk + c.A.visrows), c.st), "row_map");
-    km = nullptr;
-  } else {
-    TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");
-  }
   {
     TfAssembleArgs a{};
     const Buf x0 = c.act_d(c.X(0));
@@ -748,7 +750,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       a.drop_thr = dr.thr; a.drop_key = dr.key; a.drop_scale = dr.scale; a.drop_bits = b + c.A.dbits; a.block_bits = e->attn_block_bits;
       if (e->attn_block_bits != nullptr) { a.block_skip_q = c.wk + c.A.bskip; a.block_skip_k = c.wk + c.A.bskip + (size_t)((D.S + 127) / 128) * 8; }
-      if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask(b + c.A.dbits, D.B, D.H, D.S, dr.key, dr.thr, c.st), "attn_dropmask");
+      if (dr.thr && side == nullptr) TF_TRY(tf_launch_attn_dropmask_packed(b + c.A.dbits, D.B, D.H, D.S, c.cu(), dr.key, dr.thr, c.st), "attn_dropmask");
       if (dr.thr && side != nullptr && l == 0) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(0)], 0), "mask wait");
       TF_TRY(tf_launch_attn_fwd(&a, c.st), "attn_fwd");
     }

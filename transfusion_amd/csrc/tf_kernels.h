@@ -34,6 +34,7 @@ int tf_launch_row_map(const uint8_t* lang_pad_mask, int B, int Nv, int Nl, int* 
 int tf_launch_key_mask(const uint8_t* lang_pad_mask, uint8_t* key_mask, int B, int Nv, int Nl, hipStream_t stream);
 int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t stream);
 int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t stream);
+int tf_launch_attn_dropmask_packed(void* bits, int B, int H, int S, const int* cu, unsigned key, unsigned thr, hipStream_t stream);
 int tf_launch_attn_block_skip(const void* block_bits, int S, void* skip_q, void* skip_k, hipStream_t stream);
 int tf_launch_attn_dropmask_rows(void* bits, long long nrows, int S, unsigned key, unsigned thr, hipStream_t stream);
 int tf_launch_dropout_mask(uint8_t* out, long long n, unsigned key, unsigned thr, hipStream_t stream);

@@ -9,10 +9,15 @@ Here a level costs its two or three kernel launches.  Numerically these are the 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import ops
+
+
+_K9_WGRAD_SIDE = os.environ.get("TF_K9_WGRAD_SIDE", "1") != "0"     # A/B switch of the host mirror (see _LevelsK9Fn.backward)
 
 
 def _on(streams, main, i):
@@ -104,20 +109,29 @@ class _LevelsK1Fn(torch.autograd.Function):
             gy = gy.contiguous().to(torch.bfloat16)
         main = torch.cuda.current_stream(gy.device)
         dfeats, dws = [], []
+        # The levels' weight gradients as ONE launch (tf_gemm_wgrad_multi), on the main stream, FIRST: their operands -- the upstream
+        # gradient and the im2col rows saved by the forward -- exist when this node starts, and the launch runs beside the levels' dgrad
+        # GEMMs and folds (with level streams it is issued behind their fork, below).  (Round 5: one tf_gemm_wgrad per level -- 8 launches of 25 - 98 row steps per wrapper step for K1 + K9, each
+        # ending in its own atomic flush: 556 us of kernel time at 133 TFLOP/s.  Together the levels' 432 output tiles fill the chip at
+        # ONE row chunk each.)
+        probs = []
+        for g, m in enumerate(mods):
+            rows = saved[2 * g]
+            K = meta[g][4]
+            gw = ctx.into[g]
+            if gw is None:
+                gw = torch.zeros(d, K, dtype=torch.float32, device=gy.device)
+                dws.append(gw.view(m.weight.shape))
+            else:
+                dws.append(None)
+            probs.append(ops.wgrad_args(gy[offs[g]:offs[g + 1]], d, rows, K, gw.view(d, K), None))
+        if streams is None:
+            ops.wgrad_multi(probs, 0)
         for g, m in enumerate(mods):
             rows, wsh_t = saved[2 * g], saved[2 * g + 1]
             shape, dtype, ph, pw, K = meta[g]
             gyg = gy[offs[g]:offs[g + 1]]
             with _on(streams, main, g):
-                gw = ctx.into[g]
-                if gw is None:
-                    gw = torch.zeros(d, K, dtype=torch.float32, device=gy.device)
-                    if streams is not None:
-                        gw.record_stream(main)
-                    dws.append(gw.view(m.weight.shape))
-                else:
-                    dws.append(None)
-                ops.wgrad(gyg, d, rows, K, gw.view(d, K), None)
                 if ctx.needs_input_grad[1 + g]:
                     dx = torch.empty(offs[g + 1] - offs[g], K, dtype=torch.bfloat16, device=gy.device)
                     ops.gemm(ops.to_bf16_padded(gyg, _up64(d)), wsh_t, dx, K, _up64(d), L.TF_EPI_NONE)   # (a copy only when d % 64 != 0)
@@ -128,6 +142,8 @@ class _LevelsK1Fn(torch.autograd.Function):
                     dfeats.append(df)
                 else:
                     dfeats.append(None)
+        if streams is not None:
+            ops.wgrad_multi(probs, 0)          # (after the level streams were forked: they wait for what main held THEN, not for this launch)
         _join(streams, main, G)
         return (None,) + tuple(dfeats) + tuple(dws)
 
@@ -199,7 +215,7 @@ class _LevelsK9Fn(torch.autograd.Function):
         dev = saved[0].device
         main = torch.cuda.current_stream(dev)
         dx = torch.empty(offs[-1], d, dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
-        dws, dbs = [], []
+        dws, dbs, all_drows = [], [], []
         for g, m in enumerate(mods):
             xd, wsh_t = saved[2 * g], saved[2 * g + 1]
             N, Cc, H, W, ph, pw, drop = meta[g]
@@ -210,26 +226,46 @@ class _LevelsK9Fn(torch.autograd.Function):
                 go = go.contiguous()
                 drows = torch.empty(offs[g + 1] - offs[g], N, dtype=torch.bfloat16, device=dev)
                 L.call("tf_regroup_bwd", ops._patch_args(go, drows, B, Cc, H, W, ph, pw), ops._stream())
-                into = ctx.into[g]
-                if into is None:
-                    gw = torch.zeros(N, d, dtype=torch.float32, device=dev)
-                    gb = torch.zeros(N, dtype=torch.float32, device=dev)
-                    if streams is not None:
-                        gw.record_stream(main)
-                        gb.record_stream(main)
-                    dws.append(gw)
-                    dbs.append(gb)
-                else:
-                    gw, gb = into
-                    dws.append(None)
-                    dbs.append(None)
-                ops.wgrad(drows, N, xd, xd.shape[1], gw.view(N, d), gb)      # (xd is padded to 64 columns: k_src = d masks the pad)
+                if streams is not None:
+                    drows.record_stream(main)                              # read by the merged weight-gradient launch on the main stream
+                all_drows.append(drows)
                 if dx is not None:
                     dxg = dx[offs[g]:offs[g + 1]]
                     ops.gemm(drows, wsh_t, dxg, d, N, L.TF_EPI_NONE)
                     if drop[0]:
                         L.check(L.load().tf_dropout_apply(L.ptr(dxg), L.ptr(dxg), dxg.numel(), drop[1], drop[0], drop[2], ops._stream()), "tf_dropout_apply")
         _join(streams, main, G)
+        # the levels' weight and bias gradients as ONE launch on the main stream, behind the gathers that produce their dY operands
+        # (see _LevelsK1Fn.backward)
+        probs = []
+        for g, m in enumerate(mods):
+            xd = saved[2 * g]
+            N = meta[g][0]
+            into = ctx.into[g]
+            if into is None:
+                gw = torch.zeros(N, d, dtype=torch.float32, device=dev)
+                gb = torch.zeros(N, dtype=torch.float32, device=dev)
+                dws.append(gw)
+                dbs.append(gb)
+            else:
+                gw, gb = into
+                dws.append(None)
+                dbs.append(None)
+            probs.append(ops.wgrad_args(all_drows[g], N, xd, xd.shape[1], gw.view(N, d), gb))      # (xd is padded to 64 columns: k_src = d masks the pad)
+        # Under direct accumulation (FusionTrainStep: nothing is handed back to autograd) the launch goes to the encoders' weight-gradient
+        # side stream: this node is the FIRST of the backward, so on the main stream the launch (~100 us) would stand in front of the whole
+        # encoder backward; on the side stream it runs beside its first kernels, and the optimiser waits for it (ops.note_grad_writer).
+        side = ops.side_stream(dev) if (all(i is not None for i in ctx.into) and _K9_WGRAD_SIDE) else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.wgrad_multi(probs, -1)
+                ops.note_grad_writer(dev)
+            for g in range(G):
+                all_drows[g].record_stream(side)                          # (freed when this node returns: the allocator must know the reader)
+                saved[2 * g].record_stream(side)
+        else:
+            ops.wgrad_multi(probs, 0)
         gx = None
         if dx is not None:
             gx = dx.view(xshape)
