@@ -32,6 +32,13 @@
 #undef TF_DKV16_QT
 #endif
 
+// output-row stores of the forward, the dK / dV pair kernel and the dQ kernel.  TF_NT_ATTN (experiments builds): nontemporal
+#if defined(TF_EXPERIMENTS) && defined(TF_NT_ATTN)
+#define TF_ST_ROW(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define TF_ST_ROW(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace {
 
 // ================================================================================================
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
         u32x2 v;
         v[0] = pack2bf(o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv);
         v[1] = pack2bf(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
-        *(u32x2*)(orow + d * 32 + 8 * g4 + 4 * h) = v;
+        TF_ST_ROW((u32x2*)(orow + d * 32 + 8 * g4 + 4 * h), v);
       }
     if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
   }
@@ -1500,7 +1507,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pair_kernel(const TfAttnA
       const unsigned rlo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(odd ? lo0 : lo1), 0x401F);      // lane ^ 16
       const unsigned rhi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(odd ? hi0 : hi1), 0x401F);
       const u32x4 v = odd ? u32x4{rlo, rhi, lo1, hi1} : u32x4{lo0, hi0, rlo, rhi};
-      if (ok) *(u32x4*)(row + (2 * m + (odd ? 1 : 0)) * 16 + 4 * (g & 2)) = v;
+      if (ok) TF_ST_ROW((u32x4*)(row + (2 * m + (odd ? 1 : 0)) * 16 + 4 * (g & 2)), v);
     }
   }
 }
@@ -1651,7 +1658,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
         u32x2 v;
         v[0] = pack2bf(dq[j][d][0] * a.scale, dq[j][d][1] * a.scale);
         v[1] = pack2bf(dq[j][d][2] * a.scale, dq[j][d][3] * a.scale);
-        *(u32x2*)(orow + d * 16 + 4 * g) = v;
+        TF_ST_ROW((u32x2*)(orow + d * 16 + 4 * g), v);
       }
     }
   }

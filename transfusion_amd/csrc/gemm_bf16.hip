@@ -99,29 +99,48 @@ __device__ __forceinline__ void act_loop8(int act, F&& body) {      // body(e, r
 }
 #define TF_ACT(tag, u, h, dh) act_parts<decltype(tag)::value>(u, h, dh)
 
+// 16-byte store of an output chunk; NT: nontemporal (a streaming store: the launch's output burst does not displace what the NEXT kernel
+// is about to read from the L2 / the memory-side cache).  Which epilogues store that way: TF_NT_MASK, bit EPI for C, bit 8 + EPI for C2
+// (measured per epilogue in the step: DESIGN.md "Round 6"; experiments builds may override the mask).
+#ifndef TF_EXPERIMENTS
+#undef TF_NT_MASK
+#endif
+#ifndef TF_NT_MASK
+// shipped: the FFN-up outputs (G: read again only by the backward; H) and the residual-add dgrads (EPI_ADD).  Same-box A/B of the step,
+// three runs each (gpurun_out/r6_nt_ab3.txt): none 4.181 ms; G 4.162; G + H 4.159; ADD 4.162; every epilogue 4.152; BIAS (QKV, read at
+// once by the attention), BIAS_DROP_RES (read at once by LayerNorm), NONE, MUL: within +-0.1 % of none.  The same hint on the LayerNorm
+// outputs cost +1.2 %, on the attention outputs +4.6 %: what the next kernel reads at once should stay cached.
+#define TF_NT_MASK 0x4050
+#endif
+template <bool NT> __device__ __forceinline__ void st_c16(void* p, u32x4 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, (u32x4*)p);
+  else *(u32x4*)p = v;
+}
 // elementwise epilogue of one 16-B chunk (8 consecutive columns of one output row) -- shared by both GEMM kernels
 // rpre: the chunk of R already in registers (the large-tile kernel fetches every R chunk of its tile before the C tile goes
 // through LDS, so the HBM latency is paid once per tile instead of once per chunk), or null = load it here
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __restrict__ C, u32x4 v, int gm, int gn,
                                                     const u32x4* rpre = nullptr) {
+  constexpr bool NTC = ((TF_NT_MASK >> EPI) & 1) != 0;
+  [[maybe_unused]] constexpr bool NTC2 = ((TF_NT_MASK >> (8 + EPI)) & 1) != 0;
   [[maybe_unused]] auto load_r = [&]() -> u32x4 {
     return rpre != nullptr ? *rpre : *(const u32x4*)((const u16*)g.R + (size_t)gm * g.ldr + gn);
   };
   if constexpr (EPI == TF_EPI_BIAS || EPI == TF_EPI_NONE) {
-    *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;
+    st_c16<NTC>(C + (size_t)gm * g.ldc + gn, v);
   } else {
     float f[8];
     unpack8(v, f);
     if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) {
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = v;       // pre-activation U (saved for backward)
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, v);       // pre-activation U (saved for backward)
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
       act_loop8(g.act, [&](int e, auto relu) {
         float hh, dh;
         TF_ACT(relu, f[e], hh, dh);
         f[e] = ((km >> e) & 1u) ? hh * g.drop_scale : 0.f;
       });
-      *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
+      st_c16<NTC2>((u16*)g.C2 + (size_t)gm * g.ldc2 + gn, pack8(f));
     } else if constexpr (EPI == TF_EPI_BIAS_GELU_DROP_G) {
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc2 + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
       float gd[8];
@@ -132,27 +151,27 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
         gd[e] = keep * dh;                                           // d dropout(act(u)) / du
         f[e] = keep * hh;
       });
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(gd);
-      *(u32x4*)((u16*)g.C2 + (size_t)gm * g.ldc2 + gn) = pack8(f);
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, pack8(gd));
+      st_c16<NTC2>((u16*)g.C2 + (size_t)gm * g.ldc2 + gn, pack8(f));
     } else if constexpr (EPI == TF_EPI_MUL) {
       float r[8];
       unpack8(load_r(), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] *= r[e];
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, pack8(f));
     } else if constexpr (EPI == TF_EPI_BIAS_DROP_RES) {
       float r[8];
       unpack8(load_r(), r);
       const unsigned km = g.drop_thr ? tf_keep8((unsigned)gm * (unsigned)g.ldc + (unsigned)gn, g.drop_key, g.drop_thr) : 0xffu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = r[e] + (((km >> e) & 1u) ? f[e] * g.drop_scale : 0.f);
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, pack8(f));
     } else if constexpr (EPI == TF_EPI_ADD) {
       float r[8];
       unpack8(load_r(), r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] += r[e];
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, pack8(f));
     } else if constexpr (EPI == TF_EPI_DGELU_DROP) {
       // dU = dH . mask/(1-p) . gelu'(U); R = U, dropout index space = that of H (ldr == ld of H)
       float u[8];
@@ -163,7 +182,7 @@ __device__ __forceinline__ void gemm_epilogue_chunk(const TfGemmArgs& g, u16* __
         TF_ACT(relu, u[e], hh, dh);
         f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
       });
-      *(u32x4*)(C + (size_t)gm * g.ldc + gn) = pack8(f);
+      st_c16<NTC>(C + (size_t)gm * g.ldc + gn, pack8(f));
     }
   }
 }

@@ -44,7 +44,13 @@ template <bool SPLIT> __device__ __forceinline__ void ld8s(const void* hi, const
 }
 template <bool SPLIT> __device__ __forceinline__ void st8s(void* hi, void* lo, size_t off, const float (&f)[8]) {
   if constexpr (SPLIT) store8_split(hi, lo, off, f);
-  else *(u32x4*)((u16*)hi + off) = pack8(f);
+  else {
+#if defined(TF_EXPERIMENTS) && defined(TF_NT_ROW)
+    __builtin_nontemporal_store(pack8(f), (u32x4*)((u16*)hi + off));
+#else
+    *(u32x4*)((u16*)hi + off) = pack8(f);
+#endif
+  }
 }
 template <bool SPLIT> __device__ __forceinline__ void zero8s(void* hi, void* lo, size_t off) {
   *(u32x4*)((u16*)hi + off) = u32x4{0, 0, 0, 0};

@@ -57,7 +57,11 @@ template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_imp
 // (a __device__ function: the LDS-DMA builtin inside a lambda of a kernel TEMPLATE can make hipcc's host pass drop the instantiation
 // silently -- the library then fails to load with an undefined __device_stub__; it did when a fourth template parameter was tried)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, int voff, int soff) {
+#if defined(TF_EXPERIMENTS) && defined(TF_WGM_AUX)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TF_LDS_PTR(lds_dst), 16, voff, soff, 0, TF_WGM_AUX);      // cache-policy experiment (bit 1: nt)
+#else
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, TF_LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+#endif
 }
 // INTL: 0 = the step's transfers in front of its MFMAs (the form of wgrad_tn2_kernel), 1 = one transfer after every second MFMA
 template <bool SPLIT, int NS, int INTL>
