@@ -829,7 +829,11 @@ def test_linear_input_from_another_stream_survives_until_its_weight_gradient_ran
     seen = [scenario(torch.cuda.Stream(device=dev)) for _ in range(8)]
     monkeypatch.undo()
     if protected:
-        assert all(not hit and err < 1e-2 for hit, err in seen), seen
+        # the property: the weight gradient is computed from the intact input.  (Round 6: "the block is never handed out" was asserted
+        # too, and failed on a box with a slow host -- the scribbler's 512 allocations took longer than the 3-ms spin, the recorded stream's
+        # work was DONE, and the allocator rightly recycled the block: hits with an error of 6e-7.  A hit is harmless exactly when the
+        # gradient is right, which is what is asserted.)
+        assert all(err < 1e-2 for _, err in seen), seen
     elif not any(hit and err > 5e-2 for hit, err in seen):
         # (none of the eight streams got a hardware queue of its own: the control is void on this box, the product is not at fault)
         pytest.skip(f"the control did not reproduce the hazard on this box: {seen}")
