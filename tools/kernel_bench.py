@@ -117,6 +117,28 @@ if which in ("wgradm",):
     for blocks in (144, 288, 432):
         timeit(f"merged {{in,out}} blocks={blocks}", lambda: ops.wgrad_multi(half[0], blocks), fl2[0])
         timeit(f"merged {{w1,w2}} blocks={blocks}", lambda: ops.wgrad_multi(half[1], blocks), fl2[1])
+if which in ("wgradp",):
+    # every product of a layer's weight-gradient launch ALONE, at the chunking the merged launch gives it (three row chunks), then the merged
+    # launch: the dispatch order tools/wgrad_product_pmc.sh reads its per-product FETCH_SIZE / WRITE_SIZE from
+    Mp = int(os.environ.get("KB_ROWS", "16672"))
+    x, o, x1, hh = rnd(Mp, D), rnd(Mp, D), rnd(Mp, D), rnd(Mp, ff)
+    dqkv, dy1, dy2, du = rnd(Mp, 3 * D), rnd(Mp, D), rnd(Mp, D), rnd(Mp, ff)
+    pairs = [("in_proj  dW[2304, 768]", dqkv, x), ("out_proj dW[768, 768]", dy1, o), ("linear1  dW[1536, 768]", du, x1), ("linear2  dW[768, 1536]", dy2, hh)]
+    for nm, a, b in pairs + [("merged layer", None, None)]:
+        if a is not None:
+            w, v = torch.zeros(a.shape[1], b.shape[1], device=dev), torch.zeros(a.shape[1], device=dev)
+            probs = [ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v)]
+            tiles = ((a.shape[1] + 255) // 256) * ((b.shape[1] + 127) // 128)
+            fl, by = 2.0 * Mp * a.shape[1] * b.shape[1], (Mp * a.shape[1] + Mp * b.shape[1]) * 2.0 + a.shape[1] * b.shape[1] * 4.0
+        else:
+            ws = [torch.zeros(a.shape[1], b.shape[1], device=dev) for _, a, b in pairs]
+            vs = [torch.zeros(a.shape[1], device=dev) for _, a, _ in pairs]
+            probs = [ops.wgrad_args(a, a.shape[1], b, b.shape[1], w, v) for (_, a, b), w, v in zip(pairs, ws, vs)]
+            tiles = 144
+            fl = sum(2.0 * Mp * a.shape[1] * b.shape[1] for _, a, b in pairs)
+            by = sum((Mp * a.shape[1] + Mp * b.shape[1]) * 2.0 + a.shape[1] * b.shape[1] * 4.0 for _, a, b in pairs)
+        print(f"# {nm}: {tiles} tiles x 3 chunks, algorithmic {by / 1e6:.1f} MB", flush=True)
+        timeit(nm, lambda: ops.wgrad_multi(probs, 3 * tiles), fl)
 if which in ("gemm", "all"):
     X, Xf = rnd(M, D), rnd(M, ff)
     Wq, Wo, W1, W2 = rnd(3 * D, D) * 0.03, rnd(D, D) * 0.03, rnd(ff, D) * 0.03, rnd(D, ff) * 0.03
