@@ -27,8 +27,13 @@ M._EncoderFn.backward = staticmethod(timed("_EncoderFn.backward", M._EncoderFn.b
 M._EncoderFn.forward = staticmethod(timed("_EncoderFn.forward", M._EncoderFn.forward))
 enc._bind_grads = timed("_bind_grads", enc._bind_grads)
 enc._make_desc = timed("_make_desc", enc._make_desc)
-b._MaskedSquareLoss.backward = staticmethod(timed("loss.backward fn", b._MaskedSquareLoss.backward))
-b._MaskedSquareLoss.forward = staticmethod(timed("loss.forward fn", b._MaskedSquareLoss.forward))
+from transfusion_amd import ops as _ops
+_ops._SqLossFn.backward = staticmethod(timed("loss.backward fn", _ops._SqLossFn.backward))
+_ops._SqLossFn.forward = staticmethod(timed("loss.forward fn", _ops._SqLossFn.forward))
+b.loss_fn = timed("loss_fn (module forward + loss)", b.loss_fn)
+tr.zero_grad = timed("zero_grad", tr.zero_grad)
+tr.mark_parameters_updated = timed("mark_parameters_updated", tr.mark_parameters_updated)
+tr.check_errors = timed("check_errors", tr.check_errors)
 orig_bw = torch.Tensor.backward
 torch.Tensor.backward = timed("Tensor.backward()", orig_bw)
 tr.opt.step = timed("opt.step", tr.opt.step)
