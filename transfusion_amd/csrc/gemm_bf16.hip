@@ -116,6 +116,24 @@ template <bool NT> __device__ __forceinline__ void st_c16(void* p, u32x4 v) {
   if constexpr (NT) __builtin_nontemporal_store(v, (u32x4*)p);
   else *(u32x4*)p = v;
 }
+// the fp32-accuracy mode's plane-pair store with the same hint (TF_NT_MASK3: bit EPI for C, bit 8 + EPI for C2)
+#ifndef TF_EXPERIMENTS
+#undef TF_NT_MASK3
+#endif
+#ifndef TF_NT_MASK3
+#define TF_NT_MASK3 0x4050      // as TF_NT_MASK (the fp32 leg: 9.98 -> 9.91 ms, two runs each, gpurun_out/r6_nt3.txt: inside the noise, same policy)
+#endif
+template <bool NT> __device__ __forceinline__ void store8_split_nt(void* hi, void* lo, size_t off, const float (&f)[8]) {
+  if constexpr (!NT) { store8_split(hi, lo, off, f); return; }
+  if (lo != nullptr) {
+    u32x4 h, l;
+    split8(f, h, l);
+    __builtin_nontemporal_store(h, (u32x4*)((u16*)hi + off));
+    __builtin_nontemporal_store(l, (u32x4*)((u16*)lo + off));
+  } else {
+    __builtin_nontemporal_store(pack8(f), (u32x4*)((u16*)hi + off));
+  }
+}
 // elementwise epilogue of one 16-B chunk (8 consecutive columns of one output row) -- shared by both GEMM kernels
 // rpre: the chunk of R already in registers (the large-tile kernel fetches every R chunk of its tile before the C tile goes
 // through LDS, so the HBM latency is paid once per tile instead of once per chunk), or null = load it here
@@ -210,9 +228,10 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
       gd[e] = keep * dh;
       hv[e] = keep * hh;
     });
-    if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) store8_split(g.C, g.C_lo, oc, f);      // pre-activation U
-    else store8_split(g.C, g.C_lo, oc, gd);                                             // G = d h / d u
-    store8_split(g.C2, g.C2_lo, (size_t)gm * g.ldc2 + gn, hv);
+    constexpr bool NT3 = ((TF_NT_MASK3 >> EPI) & 1) != 0, NT3B = ((TF_NT_MASK3 >> (8 + EPI)) & 1) != 0;
+    if constexpr (EPI == TF_EPI_BIAS_GELU_DROP) store8_split_nt<NT3>(g.C, g.C_lo, oc, f);      // pre-activation U
+    else store8_split_nt<NT3>(g.C, g.C_lo, oc, gd);                                             // G = d h / d u
+    store8_split_nt<NT3B>(g.C2, g.C2_lo, (size_t)gm * g.ldc2 + gn, hv);
   } else {
     float r[8];
     if (rhi != nullptr) join8(*rhi, *rlo, r);
@@ -235,7 +254,7 @@ __device__ __forceinline__ void gemm_epilogue_chunk_f32(const TfGemmArgs& g, flo
         f[e] = ((km >> e) & 1u) ? f[e] * g.drop_scale * dh : 0.f;
       });
     }
-    store8_split(g.C, g.C_lo, oc, f);
+    store8_split_nt<((TF_NT_MASK3 >> EPI) & 1) != 0>(g.C, g.C_lo, oc, f);
   }
 }
 
