@@ -70,6 +70,9 @@ def pytest_collection_modifyitems(session, config, items):
 # is preceded by the test that launched the kernel; (iii) every GPU test ends with a device synchronise: an asynchronous
 # error surfaces in ITS OWN test, not in the next test's first sync.
 # ------------------------------------------------------------------------------------------------------------------------
+_LEAK_ENV = ("TF_REHEARSE_COLLECTIVES", "TF_REHEARSE_PHANTOM_PEERS", "TF_TEST_WGRAD_DELAY_US", "TF_TEST_BREAK_EDGE", "TF_FORCE_LAYERWISE")
+
+
 @pytest.fixture(autouse=True)
 def _gpu_fault_attribution(request):
     if request.node.get_closest_marker("gpu") is None:
@@ -80,6 +83,7 @@ def _gpu_fault_attribution(request):
             os.write(2, f"[gpu-test] {request.node.nodeid}\n".encode())
         except OSError:
             pass
+    env_before = {k: os.environ.get(k) for k in _LEAK_ENV}
     yield
     import torch
     if torch.cuda.is_available():
@@ -87,6 +91,20 @@ def _gpu_fault_attribution(request):
             torch.cuda.synchronize()
         except Exception as e:       # noqa: BLE001
             pytest.fail(f"device error surfaced at the end of {request.node.nodeid}: {e}")
+        # test-only hooks must not outlive their test: the weight-gradient delay probe (a process-wide word inside the library) and the
+        # rehearsal switches of the reducers (environment; the worker scripts get them through their own environment, never this process's)
+        ops = sys.modules.get("transfusion_amd.ops")
+        if ops is not None and getattr(ops, "_debug_wgrad_delay_us", 0):
+            ops.debug_delay_wgrad(0)
+            pytest.fail(f"{request.node.nodeid} left ops.debug_delay_wgrad set")
+    leaked = [k for k in _LEAK_ENV if os.environ.get(k) != env_before[k]]
+    if leaked:
+        for k in leaked:
+            if env_before[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = env_before[k]
+        pytest.fail(f"{request.node.nodeid} changed {leaked} in the test process's environment")
 
 
 # ------------------------------------------------------------------------------------------------------------------------
