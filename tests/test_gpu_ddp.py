@@ -260,7 +260,9 @@ def _run_tree(tmp_path, levels, tag, delay_us=0, break_edge=None, single=True, h
     procs = []
     # (hw_queues -> GPU_MAX_HW_QUEUES: ROCm multiplexes streams onto a few hardware queues -- 4 by default -- and two streams that share
     # one run in submission order, which can HIDE a missing event edge from the probe: see test_the_delay_probe_sees_a_missing_edge)
-    extra = {"TF_TEST_WGRAD_DELAY_US": str(delay_us)}
+    # (the delayed runs keep the fused K1 / K9 nodes on the LEVEL streams, round 5's default, so that both stream layouts stay under the
+    # two-rank tests; the undelayed runs take round 6's default, the main stream)
+    extra = {"TF_TEST_WGRAD_DELAY_US": str(delay_us), "TF_K_LEVEL_STREAMS": "1" if delay_us else "0"}
     if hw_queues:
         extra["GPU_MAX_HW_QUEUES"] = hw_queues
     for rank in range(2):

@@ -665,6 +665,7 @@ def test_optimizer_waits_for_level_streams_whose_inputs_are_frozen(ragged, monke
     dev = torch.device("cuda:0")
     # ragged=False: the level loop on level streams; True: the two levels as one ragged grouped call, K1 / K9 beside it on level streams
     monkeypatch.setenv("TF_RAGGED_GROUPS", "1" if ragged else "0")
+    monkeypatch.setenv("TF_K_LEVEL_STREAMS", "1")        # (round 6's default puts the fused K1 / K9 nodes on the main stream: this test is about the level streams)
     b0, plain, ranges = _level_stream_step(dev, 0, "grouped" if ragged else "streams")
     b1, late, _ = _level_stream_step(dev, 3000, "grouped" if ragged else "streams")
     assert torch.equal(b0, b1)

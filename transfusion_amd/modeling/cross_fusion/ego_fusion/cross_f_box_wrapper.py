@@ -372,7 +372,12 @@ class CrossFusionBoxWrapper(nn.Module):
                 fused_ls[i].record_stream(main)
             else:
                 outs[i], fused_ls[i] = whole_level()
-        sts = [self._level_streams[i] for i in members] if use_streams else None
+        # The fused K1 / K9 nodes of the group's members run on the MAIN stream by default (TF_K_LEVEL_STREAMS=1: on the level streams, as
+        # in rounds 3 - 5).  Side by side the levels' gathers and GEMMs did overlap on the device, but every stream region costs the host
+        # ~50 us (wait_stream, the stream context, record_stream) and the legs follow the host's enqueue time: same box, three runs each,
+        # on / off: wrapper_b4 4.94 / 4.72 ms, wrapper_b4_real 5.58 / 5.53 ms (gpurun_out/r6_levelstreams.txt) -- since round 6 the
+        # permutations are 6x shorter and the levels' weight gradients one launch, so there is less to overlap
+        sts = [self._level_streams[i] for i in members] if (use_streams and os.environ.get("TF_K_LEVEL_STREAMS", "0") != "0") else None
         if k1_fused:
             x = level_ops.levels_patch_embed(p2t, gfeats, sts)
         else:
