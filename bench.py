@@ -93,7 +93,7 @@ def loss_fn(module, batch):
 def _square_mean(f):
     """mean(f^2) of a feature map (the wrapper legs' loss), on the library's loss kernels when the map is fp32."""
     from transfusion_amd import ops
-    if f.dtype == torch.float32 and f.is_contiguous() and f.shape[-1] % 4 == 0 and f.data_ptr() % 16 == 0:
+    if f.dtype == torch.float32 and f.is_contiguous() and f.numel() % 4 == 0 and f.data_ptr() % 16 == 0:
         return ops.sq_loss([(f, None, 1.0 / f.numel())])
     return f.reshape(-1).float().pow(2).mean()
 
@@ -684,7 +684,7 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
         def wloss(m, _):
             out = m({"image": feats, "language_f": lang})
             fs = [f for f in out["features"].values()]
-            if all(f.dtype == torch.float32 and f.is_contiguous() and f.shape[-1] % 4 == 0 and f.data_ptr() % 16 == 0 for f in fs):
+            if all(f.dtype == torch.float32 and f.is_contiguous() and f.numel() % 4 == 0 and f.data_ptr() % 16 == 0 for f in fs):
                 from transfusion_amd import ops
                 return ops.sq_loss([(f, None, 1.0 / f.numel()) for f in fs])        # one scalar, len(fs) launches each way
             return sum(_square_mean(f) for f in fs)

@@ -860,5 +860,9 @@ def test_sq_loss_kernels(dev, guard):
     assert float(l.grad.cpu()[valid == 0].abs().max()) == 0.0
     again = ops.sq_loss([(v.detach(), None, kv), (l.detach(), w, km)])
     assert float(again) == float(loss)                                   # no float atomics: the same bits
+    fmap = guard(torch.randn(3, 5, 14, 14, generator=g)).requires_grad_(True)      # a feature map whose last dimension is not a multiple of 4
+    lf = ops.sq_loss([(fmap, None, 0.5)])
+    lf.backward()
+    assert abs(float(lf) - 0.5 * float((fmap.detach().double() ** 2).sum())) < 1e-5 * float(lf) and rel(fmap.grad, fmap.detach()) < 1e-6
     big = guard(torch.randn(22656, 768, generator=g))                     # the benchmark's size: many blocks, the 8-deep body and its tail
     assert abs(float(ops.sq_loss([(big, None, 1.0)])) - float((big.double() ** 2).sum())) < 1e-5 * float((big.double() ** 2).sum())

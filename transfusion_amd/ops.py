@@ -25,7 +25,20 @@ def _require_cuda(*ts):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Stream object through
+    _get_device_index / _lazy_init / is_available -- ~10 us a call, ~100 calls per wrapper step across the forward and the autograd
+    thread: ~1 ms of the 3.5 ms the host needs to enqueue that step.  The two C entry points below return the same handle in < 1 us.)"""
+    return _raw_stream(_cur_device())
+
+
+try:
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:               # (a torch build without the private entry points: the public, slower spelling)
+    def _raw_stream(_idx):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _cur_device():
+        return 0
 
 
 def _is_f32(t) -> int:
@@ -230,6 +243,20 @@ def sumsq(x: torch.Tensor, out: torch.Tensor):
     L.check(L.load().tf_sumsq(L.ptr(x), x.numel(), L.ptr(out), _stream()), "tf_sumsq")
 
 
+def _sq_rows(x, w):
+    """(rows, d) of a term of tf_sq_loss: with row weights the tensor's own [..., d] rows (d % 4 == 0); without, the row structure means
+    nothing to the kernels and any tensor whose element count is a multiple of 4 goes as [numel / 4, 4] (a 14 x 14 feature map)."""
+    if w is None:
+        if x.numel() % 4:
+            raise L.TfError("tf_sq_loss: the element count must be a multiple of 4")
+        return x.numel() // 4, 4
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if d % 4 or w.numel() != rows:
+        raise L.TfError(f"tf_sq_loss: {w.numel()} row weights for {rows} rows of {d} (d % 4 must be 0)")
+    return rows, d
+
+
 class _SqLossFn(torch.autograd.Function):
     """sum_t scale_t * sum_r row_w_t[r]^2 |x_t[r, :]|^2 over the given terms (tf_sq_loss_fwd / tf_sq_loss_bwd): the benchmark's synthetic loss
      without a framework elementwise kernel in the step.  Every term: a contiguous fp32 CUDA tensor [..., d] (d % 4 == 0), an
@@ -245,10 +272,7 @@ class _SqLossFn(torch.autograd.Function):
             _require_cuda(x)
             if x.dtype != torch.float32 or not x.is_contiguous() or (w is not None and (w.dtype != torch.float32 or not w.is_contiguous())):
                 raise L.TfError("tf_sq_loss needs contiguous fp32 tensors")
-            d = x.shape[-1]
-            rows = x.numel() // d
-            if w is not None and w.numel() != rows:
-                raise L.TfError(f"tf_sq_loss: {w.numel()} row weights for {rows} rows")
+            rows, d = _sq_rows(x, w)
             a = L.TfSqLossArgs(x=L.ptr(x), rows=rows, d=d, row_w=L.ptr(w), scale=float(sc), out=L.ptr(out), accumulate=1 if i else 0)
             L.check(lib.tf_sq_loss_fwd(C.byref(a), C.c_void_p(_stream())), "tf_sq_loss_fwd")
             args.append(a)
@@ -268,8 +292,8 @@ class _SqLossFn(torch.autograd.Function):
         for x, has_w, sc in zip(xs, ctx.has_w, ctx.scales):
             w = rest.pop(0) if has_w else None
             dx = torch.empty_like(x)
-            d = x.shape[-1]
-            a = L.TfSqLossArgs(x=L.ptr(x), rows=x.numel() // d, d=d, row_w=L.ptr(w), scale=sc, g=L.ptr(g), dx=L.ptr(dx))
+            rows, d = _sq_rows(x, w)
+            a = L.TfSqLossArgs(x=L.ptr(x), rows=rows, d=d, row_w=L.ptr(w), scale=sc, g=L.ptr(g), dx=L.ptr(dx))
             L.check(lib.tf_sq_loss_bwd(C.byref(a), C.c_void_p(_stream())), "tf_sq_loss_bwd")
             grads.append(dx)
         return (None, *grads, *([None] * (2 * ctx.n_terms)))
@@ -292,8 +316,8 @@ _overlap_cache = {}      # (device index, stream handle) -> TfOverlap: every str
 
 
 def _overlap_key(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return idx, torch.cuda.current_stream(idx).cuda_stream
+    idx = device.index if device.index is not None else _cur_device()
+    return idx, _raw_stream(idx)
 
 
 def overlap_handle(device):
