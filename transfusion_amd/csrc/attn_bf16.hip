@@ -25,6 +25,18 @@
 // Ablation / variant macros (TF_ABL_FWD, TF_FWD_PRIO, TF_FWD_NO_DMA, TF_ABL_PAIR, TF_DKV16_QT) act in experiments builds only
 // (-DTF_EXPERIMENTS: tools/build_variant.sh); without it they are forced off -- no flag changes what the shipped library computes.
 #ifndef TF_EXPERIMENTS
+#undef TF_FWD_WIDE_STORE
+#endif
+#ifndef TF_FWD_WIDE_STORE
+#define TF_FWD_WIDE_STORE 1      // 16-byte output stores of the forward after a half-wave swap (round 6: 65.0 -> 61.2 us at the benchmark's packed rows)
+#endif
+#ifndef TF_EXPERIMENTS
+#undef TF_DQ_WIDE_STORE
+#endif
+#ifndef TF_DQ_WIDE_STORE
+#define TF_DQ_WIDE_STORE 1       // the same for attn_bwd_dq_ds_kernel's dQ rows, across 16-lane groups (round 6: 38.8 -> 34.9 us)
+#endif
+#ifndef TF_EXPERIMENTS
 #undef TF_ABL_FWD
 #undef TF_FWD_PRIO
 #undef TF_FWD_NO_DMA
@@ -274,6 +286,30 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
+#if TF_FWD_WIDE_STORE
+  // A lane holds 4 consecutive columns of every 8-column group, its partner (lane ^ 32, the same query) the other 4: as they stand
+  // that is 24 8-byte stores per lane at head dim 192, each instruction writing 16 bytes of 32 rows.  The halves swap one group per pair
+  // (v_permlane32_swap_b32: lanes 32-63 of the first register <-> lanes 0-31 of the second): the low half keeps the pair's even group,
+  // the high half the odd one, whole -- 12 16-byte stores per lane.  (All 64 lanes take part in the swaps; rows past the end only skip
+  // their stores.)
+  {
+    u16* orow = (u16*)a.out + (qrow0 + min(qrow, Sqb - 1)) * a.ld_out + (size_t)head * HDP;
+#pragma unroll
+    for (int d = 0; d < G::DBLK; ++d)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int ge = 2 * pr, go = 2 * pr + 1;
+        unsigned e0 = pack2bf(o[d][4 * ge] * inv, o[d][4 * ge + 1] * inv), e1 = pack2bf(o[d][4 * ge + 2] * inv, o[d][4 * ge + 3] * inv);
+        unsigned o0 = pack2bf(o[d][4 * go] * inv, o[d][4 * go + 1] * inv), o1 = pack2bf(o[d][4 * go + 2] * inv, o[d][4 * go + 3] * inv);
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+        // low half: (own even group, partner's even group); high half: (partner's odd group, own odd group) -- column order in both
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        if (qrow < Sqb) TF_ST_ROW((u32x4*)(orow + d * 32 + 8 * (2 * pr + h)), v);
+      }
+    if (qrow < Sqb && h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
+  }
+#else
   if (qrow < Sqb) {
     u16* orow = (u16*)a.out + (qrow0 + qrow) * a.ld_out + (size_t)head * HDP;
 #pragma unroll
@@ -287,6 +323,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
       }
     if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
   }
+#endif
 }
 
 // ================================================================================================
@@ -1648,6 +1685,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
     }
     t = tn;
   }
+#if TF_DQ_WIDE_STORE
+  // lane group g holds quarter g (4 columns) of every 16-column block: neighbouring groups swap one block per PAIR of blocks
+  // (v_permlane16_swap_b32: odd rows of the first register <-> even rows of the second), so that even groups keep block 2m, odd groups
+  // block 2m + 1, two adjacent quarters each: 16-byte stores, half as many
+  static_assert(DB % 2 == 0, "blocks are exchanged in pairs");
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qrow = qblk * 128 + wave * 32 + 16 * j + n;
+    u16* orow = (u16*)a.dqkv + (sr.row0 + min(qrow, Sb - 1)) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+#pragma unroll
+    for (int m = 0; m < DB / 2; ++m) {
+      const unsigned e0 = pack2bf(dq[j][2 * m][0] * a.scale, dq[j][2 * m][1] * a.scale), e1 = pack2bf(dq[j][2 * m][2] * a.scale, dq[j][2 * m][3] * a.scale);
+      const unsigned o0 = pack2bf(dq[j][2 * m + 1][0] * a.scale, dq[j][2 * m + 1][1] * a.scale), o1 = pack2bf(dq[j][2 * m + 1][2] * a.scale, dq[j][2 * m + 1][3] * a.scale);
+      const u32x2 s0 = __builtin_amdgcn_permlane16_swap(e0, o0, false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane16_swap(e1, o1, false, false);
+      const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+      if (qrow < Sb) TF_ST_ROW((u32x4*)(orow + (2 * m + (g & 1)) * 16 + 8 * (g >> 1)), v);
+    }
+  }
+#else
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int qrow = qblk * 128 + wave * 32 + 16 * j + n;
@@ -1662,6 +1719,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(const TfAttnArgs
       }
     }
   }
+#endif
 }
 
 // ================================================================================================
