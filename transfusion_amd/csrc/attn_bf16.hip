@@ -32,6 +32,10 @@
 #endif
 #ifndef TF_EXPERIMENTS
 #undef TF_DQ_WIDE_STORE
+#undef TF_FWD_SKIP_IDLE
+#endif
+#ifndef TF_FWD_SKIP_IDLE
+#define TF_FWD_SKIP_IDLE 1       // forward: waves that own no query of the sample skip their matrix / softmax work (round 6: 60.3 -> 57.2 us packed)
 #endif
 #ifndef TF_DQ_WIDE_STORE
 #define TF_DQ_WIDE_STORE 1       // the same for attn_bwd_dq_ds_kernel's dQ rows, across 16-lane groups (round 6: 38.8 -> 34.9 us)
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = a.scale * LOG2E;
   const int qrow = q0 + (lane & 31);
+  const bool wave_live = TF_FWD_SKIP_IDLE ? (__builtin_amdgcn_readfirstlane(q0) < Sqb) : true;       // wave-uniform
   const int SW = (S + 63) / 64;
   const unsigned long long* drow = a.drop_thr ? (const unsigned long long*)a.drop_bits + ((size_t)bh * Sq + min(qrow, Sqb - 1)) * SW : nullptr;
   const unsigned long long* brow = BLK ? (const unsigned long long*)a.block_bits + (size_t)min(qrow, Sqb - 1) * SW : nullptr;
@@ -175,6 +180,11 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
     const bool masked_tile = vall != ~0ull || (BLK && __any(blk != 0ull));
     const unsigned long long vbits = (vall & ~blk) >> (4 * h);
 
+    unsigned pk[2][8];
+    // A wave whose 32 queries all lie past the sample's end (packed batches: the last query block of most samples holds a few rows --
+    // three of its four waves own none) takes part in the tile transfers and the barriers only: its matrix and vector slots go to the
+    // wave of the co-resident workgroup on the same SIMD (TF_FWD_SKIP_IDLE=0: experiments builds keep them computing on clamped rows)
+    if (wave_live) {
     // ---- St[key][q] = K . Q^T ----  (two accumulator chains interleaved, fragment reads PF ahead: attn_common.h)
     f32x16 st[2];
 #pragma unroll
@@ -199,7 +209,6 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
         st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fr[i]), qf[i >> 1], st[i & 1], 0, 0, 0);
       });
     }
-    unsigned pk[2][8];
     // ---- online softmax (log2 domain; raw scores stay unscaled, the scale rides in the FMA) ----
 #ifdef TF_FWD_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -249,12 +258,13 @@ __global__ __launch_bounds__(256, (HDP <= 192 ? 2 : 1)) void attn_fwd_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; r += 2) pk[kb][r >> 1] = cvt_pk_bf16(st[kb][r], st[kb][r + 1]);
 #endif
+    }   // wave_live
 #ifndef TF_FWD_NO_DMA
     dma_wait_barrier();                    // V(t) landed and visible; every wave has finished S(t)
     if (tn >= 0) { fetch_words(tn); dma.issue(krs, (unsigned)tn * tile_bytes, kt); }     // K(next) travels under PV(t)
 #endif
     // ---- O^T[d][q] += V^T . Pt ----  (transposed V fragments PF ahead of their MFMA)
-    {
+    if (wave_live) {
       constexpr int NF = 4 * G::DBLK, PF = 2;
       u64 fa[NF], fb[NF];
       bf16x8 pf[4];
