@@ -52,6 +52,34 @@ __device__ __forceinline__ void store4_split(u16* hi, u16* lo, float a, float b,
   *(u32x2*)hi = h;
   *(u32x2*)lo = l;
 }
+// The rows of a set of 32 x 32 accumulator tiles (lane = row, lane half h owns 4 of every 8 columns) as hi + lo planes.  Stored as they
+// stand that is two 8-byte stores per group and lane; here the halves swap one group per pair (v_permlane32_swap_b32: see
+// attn_fwd_kernel's epilogue, attn_bf16.hip) and store 16 bytes per plane.  Every lane takes part in the swaps; `pred` guards the stores
+// (rows past the sample's end), so the row pointers must be computed from a clamped row.
+template <int DBLK>
+__device__ __forceinline__ void store_acc_rows_split(u16* row_h, u16* row_l, const f32x16 (&acc)[DBLK], float scale, int h, bool pred) {
+#pragma unroll
+  for (int d = 0; d < DBLK; ++d)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      unsigned wh[2][2], wl[2][2];                                  // [even / odd group][word]: hi and lo plane words
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int g4 = 2 * pr + q;
+        const float a = acc[d][4 * g4] * scale, b = acc[d][4 * g4 + 1] * scale, c = acc[d][4 * g4 + 2] * scale, e = acc[d][4 * g4 + 3] * scale;
+        wh[q][0] = pack2bf(a, b); wh[q][1] = pack2bf(c, e);
+        wl[q][0] = pack2bf(a - bf2f((u16)(wh[q][0] & 0xffffu)), b - bf2f((u16)(wh[q][0] >> 16)));
+        wl[q][1] = pack2bf(c - bf2f((u16)(wh[q][1] & 0xffffu)), e - bf2f((u16)(wh[q][1] >> 16)));
+      }
+      const u32x2 h0 = __builtin_amdgcn_permlane32_swap(wh[0][0], wh[1][0], false, false), h1 = __builtin_amdgcn_permlane32_swap(wh[0][1], wh[1][1], false, false);
+      const u32x2 l0 = __builtin_amdgcn_permlane32_swap(wl[0][0], wl[1][0], false, false), l1 = __builtin_amdgcn_permlane32_swap(wl[0][1], wl[1][1], false, false);
+      if (pred) {
+        const int c0 = d * 32 + 8 * (2 * pr + h);
+        *(u32x4*)(row_h + c0) = u32x4{h0[0], h1[0], h0[1], h1[1]};
+        *(u32x4*)(row_l + c0) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+      }
+    }
+}
 // one 64- or 32-row tile of both planes: global -> registers -> LDS (256 threads)
 template <int ROWS, int HDP>
 __device__ __forceinline__ void stage_pair(cu16p hi, cu16p lo, size_t ld, int row0, int row_max, bool zero_fill, unsigned char* lds_hi,
@@ -210,18 +238,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_x3_kernel(const TfAttnArgs a)
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (a.drop_thr ? a.drop_scale : 1.0f) / l_tot;
-  if (qrow < Sqb) {
-    const size_t off = (qrow0 + qrow) * a.ld_out + (size_t)head * HDP;
-    u16* orow_h = (u16*)a.out + off;
-    u16* orow_l = (u16*)a.out_lo + off;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = d * 32 + 8 * g4 + 4 * h;
-        store4_split(orow_h + c, orow_l + c, o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv, o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
-      }
-    if (h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
+  {
+    const size_t off = (qrow0 + min(qrow, Sqb - 1)) * a.ld_out + (size_t)head * HDP;
+    store_acc_rows_split<G::DBLK>((u16*)a.out + off, (u16*)a.out_lo + off, o, inv, h, qrow < Sqb);
+    if (qrow < Sqb && h == 0 && a.lse != nullptr) a.lse[(size_t)bh * Sq + qrow] = m_run + log2f(l_tot);
   }
 }
 
@@ -339,17 +359,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const TfAttnArgs
       }
     }
   }
-  if (qrow < Sqb) {
-    const size_t off = cross ? (qrow0 + qrow) * a.ld_dq + (size_t)head * HDP : (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
-    u16* r_h = (cross ? (u16*)a.dq : (u16*)a.dqkv) + off;
-    u16* r_l = (cross ? (u16*)a.dq_lo : (u16*)a.dqkv_lo) + off;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = d * 32 + 8 * g4 + 4 * h;
-        store4_split(r_h + c, r_l + c, dq[d][4 * g4] * a.scale, dq[d][4 * g4 + 1] * a.scale, dq[d][4 * g4 + 2] * a.scale, dq[d][4 * g4 + 3] * a.scale);
-      }
+  {
+    const size_t qc = (size_t)min(qrow, Sqb - 1);
+    const size_t off = cross ? (qrow0 + qc) * a.ld_dq + (size_t)head * HDP : (sr.row0 + qc) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+    store_acc_rows_split<G::DBLK>((cross ? (u16*)a.dq : (u16*)a.dqkv) + off, (cross ? (u16*)a.dq_lo : (u16*)a.dqkv_lo) + off, dq, a.scale, h, qrow < Sqb);
   }
 }
 
@@ -573,18 +586,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const TfAttnArg
     }
   }
   if constexpr (DEFER) { if (ds_h != nullptr && ntiles > 0) flush_pending(ntiles - 1); }
-  if (key < Sb) {
-    const size_t off = (sr.row0 + key) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
-    u16* r_h = (u16*)a.dqkv + off;
-    u16* r_l = (u16*)a.dqkv_lo + off;
-    const float osc = WHICH == 0 ? 1.0f : a.scale;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = d * 32 + 8 * g4 + 4 * h;
-        store4_split(r_h + c, r_l + c, acc[d][4 * g4] * osc, acc[d][4 * g4 + 1] * osc, acc[d][4 * g4 + 2] * osc, acc[d][4 * g4 + 3] * osc);
-      }
+  {
+    const size_t off = (sr.row0 + min(key, Sb - 1)) * a.ld_dqkv + (size_t)((WHICH == 0 ? 2 : 1) * a.H + head) * HDP;
+    store_acc_rows_split<G::DBLK>((u16*)a.dqkv + off, (u16*)a.dqkv_lo + off, acc, WHICH == 0 ? 1.0f : a.scale, h, key < Sb);
   }
 }
 
@@ -646,17 +650,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dv_pd_x3_kernel(const TfAttnA
     }
   }
   const int key = key0 + (lane & 31);
-  if (key < Sb) {
-    const size_t off = (sr.row0 + key) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
-    u16* o_h = (u16*)a.dqkv + off;
-    u16* o_l = (u16*)a.dqkv_lo + off;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = d * 32 + 8 * g4 + 4 * h;
-        store4_split(o_h + c, o_l + c, acc[d][4 * g4], acc[d][4 * g4 + 1], acc[d][4 * g4 + 2], acc[d][4 * g4 + 3]);
-      }
+  {
+    const size_t off = (sr.row0 + min(key, Sb - 1)) * a.ld_dqkv + (size_t)(2 * a.H + head) * HDP;
+    store_acc_rows_split<G::DBLK>((u16*)a.dqkv + off, (u16*)a.dqkv_lo + off, acc, 1.0f, h, key < Sb);
   }
 }
 
@@ -769,17 +765,9 @@ __global__ __launch_bounds__(256, (KT == 32 && HDP <= 192) ? 2 : 1) void attn_bw
     }
   }
   const int qrow = qblk * 128 + wave * 32 + (lane & 31);
-  if (qrow < Sb) {
-    const size_t off = (sr.row0 + qrow) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
-    u16* r_h = (u16*)a.dqkv + off;
-    u16* r_l = (u16*)a.dqkv_lo + off;
-#pragma unroll
-    for (int d = 0; d < G::DBLK; ++d)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = d * 32 + 8 * g4 + 4 * h;
-        store4_split(r_h + c, r_l + c, dq[d][4 * g4] * a.scale, dq[d][4 * g4 + 1] * a.scale, dq[d][4 * g4 + 2] * a.scale, dq[d][4 * g4 + 3] * a.scale);
-      }
+  {
+    const size_t off = (sr.row0 + min(qrow, Sb - 1)) * a.ld_dqkv + (size_t)(0 * a.H + head) * HDP;
+    store_acc_rows_split<G::DBLK>((u16*)a.dqkv + off, (u16*)a.dqkv_lo + off, dq, a.scale, h, qrow < Sb);
   }
 }
 
