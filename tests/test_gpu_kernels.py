@@ -321,6 +321,56 @@ def test_layernorm_fwd_bwd(dev, guard, rows, d, ld):
     assert rel(dg, gr.grad) < 1e-3 and rel(db, br.grad) < 1e-3
 
 
+@pytest.mark.parametrize("rows,d,ld,groups", [(2 * 4500, 768, 768, 2), (16640, 768, 768, 1), (3 * 333, 712, 768, 3), (130, 72, 128, 1),
+                                              (2 * 257, 1024, 1024, 2)])
+def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld, groups):
+    """The per-layer form of the LayerNorm backward (ln_bwd2_kernel, both of its shipped configurations: >= 8192 rows per group and
+    fewer): dx, the dropout-masked copy dx_drop = dx * keep / (1 - p) with the mask tf_dropout_mask replays, zeroed pad columns, and
+    dgamma / dbeta per parameter group (equal row ranges, parameters p_gstride bytes apart) -- against fp64 torch, operands at guard pages."""
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + d)
+    rg = rows // groups
+    x = torch.zeros(rows, ld)
+    x[:, :d] = torch.randn(rows, d, generator=g) * 1.5 - 0.3
+    xb = guard(bf(x))
+    dy = guard(bf(torch.randn(rows, ld, generator=g)))
+    gstride = ((d + 63) // 64) * 64                         # floats between the groups' parameter vectors
+    gamma = guard((1 + 0.1 * torch.randn(groups, gstride, generator=g)).contiguous())
+    xd = xb.double().cpu()[:, :d]
+    mean = xd.mean(1)
+    rstd = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+    mean_d, rstd_d = guard(mean.float()), guard(rstd.float())
+    dx = guard(torch.full((rows, ld), 3.0, dtype=torch.bfloat16))
+    dxd = guard(torch.full((rows, ld), 3.0, dtype=torch.bfloat16))
+    dg = guard(torch.zeros(groups, gstride))
+    db = guard(torch.zeros(groups, gstride))
+    p, seed, site = 0.15, 11, 5
+    thr, key, scale = ops.drop_params(p, seed, site)
+    a = L.TfLnArgs(x=L.ptr(xb), ldx=ld, gamma=L.ptr(gamma), mean=L.ptr(mean_d), rstd=L.ptr(rstd_d), rows=rows, d=d, rows_per_group=rows,
+                   x_group_stride=rows, y_group_stride=rows, eps=1e-5, dy=L.ptr(dy), lddy=ld, dy_is_f32=0, dx=L.ptr(dx), lddx=ld,
+                   dx_drop=L.ptr(dxd), lddxd=ld, drop_thr=thr, drop_key=key, drop_scale=scale, drop_ld=ld, dgamma=L.ptr(dg), dbeta=L.ptr(db),
+                   pgroups=groups, p_gstride=gstride * 4)
+    L.call("tf_layernorm_bwd", a, ops._stream())
+    torch.cuda.synchronize()
+    gam = gamma.double().cpu()[:, :d].repeat_interleave(rg, 0)
+    dyd = dy.double().cpu()[:, :d]
+    xh = (xd - mean[:, None]) * rstd[:, None]
+    gg = dyd * gam
+    ref = rstd[:, None] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    assert rel(dx[:, :d], ref) < 6e-3
+    keep = ops.dropout_mask(rows * ld, p, seed, site, dev).view(rows, ld)[:, :d].cpu()
+    got = dxd.float().cpu()[:, :d]
+    assert (got[~keep.bool()] == 0).all() and 0.1 < 1.0 - keep.float().mean().item() < 0.2
+    assert rel(got, ref * keep.double() * scale) < 6e-3
+    if ld > d:
+        assert dx[:, d:].float().abs().max().item() == 0.0 and dxd[:, d:].float().abs().max().item() == 0.0
+    for k in range(groups):
+        sl = slice(k * rg, (k + 1) * rg)
+        assert rel(dg[k, :d], (dyd[sl] * xh[sl]).sum(0)) < 1e-3 and rel(db[k, :d], dyd[sl].sum(0)) < 1e-3
+        if gstride > d:
+            assert dg[k, d:].abs().max().item() == 0.0 and db[k, d:].abs().max().item() == 0.0
+
+
 def test_pack_and_patch_permutations(dev):
     from transfusion_amd import ops
     from oracle import fusion_oracle as O

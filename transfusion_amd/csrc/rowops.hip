@@ -220,6 +220,164 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
   }
 }
 
+// LayerNorm backward, form 2 (the encoder's per-layer launches: bf16 tensors, no lo planes, identity row maps, equal parameter
+// groups).  The kernel is a dependent load -> reduce -> store chain per row, so its rate is set by the bytes a CU keeps in flight.
+// Against the form above: (a) a row's x and dy stay PACKED (bf16) across its two wave reductions and xhat / g are recomputed for the
+// output pass -- 16 live registers per row instead of 32; (b) a wave keeps ROWS rows in flight at once (all their loads issued before
+// the first use); (c) ACC = 1: the dgamma / dbeta column partials of a wave live in a private LDS image (one 16-byte read-modify-write
+// per 4 columns and iteration, lane-contiguous: conflict-free) instead of 32 registers per lane (ds_add_f32 into a shared image was
+// measured 5x slower than the whole former kernel); (d) gamma comes from LDS (staged once per workgroup), not from four more vector
+// loads per row in front of the row's own data; (e) no row-map divisions.
+__device__ __forceinline__ void ld_gam(const float* gam, int i, int lane, float (&gm)[8]) {
+  const f32x4 lo = *(const f32x4*)(gam + (((i * 2) * 64 + lane) << 2)), hi = *(const f32x4*)(gam + (((i * 2 + 1) * 64 + lane) << 2));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { gm[k] = lo[k]; gm[4 + k] = hi[k]; }
+}
+template <int MAXC, int WAVES, int ROWS, int ACC, int OCC>      // OCC: waves per SIMD the register allocation must leave room for
+__global__ __launch_bounds__(64 * WAVES, OCC) void ln_bwd2_kernel(const TfLnArgs a) {
+  constexpr int W = 64 * MAXC * 8;                       // columns a lane set covers
+  const unsigned drop_key = tf_salted(a.drop_key);
+  // column partials [wave][dgamma | dbeta][(i * 2 + half) * 64 + lane][4]  (ACC = 0: written once, at the end)
+  extern __shared__ __attribute__((aligned(16))) float lds2[];
+  float* gam = lds2;                                     // [(i * 2 + half) * 64 + lane][4]
+  float* part = lds2 + W;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* mine = part + wave * 2 * W;
+  const int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g, row_hi = row_lo + rows_g;
+  const long long poff = (long long)blockIdx.y * a.p_gstride;
+  const float* gamma_g = (const float*)((const unsigned char*)a.gamma + poff);
+  for (int c = threadIdx.x; c < W; c += 64 * WAVES)
+    gam[((((c >> 9) * 2 + ((c >> 2) & 1)) * 64 + ((c >> 3) & 63)) << 2) + (c & 3)] = c < a.d ? gamma_g[c] : 0.f;
+  if constexpr (ACC == 1) {
+#pragma unroll
+    for (int k = 0; k < 4 * MAXC; ++k) *(f32x4*)(mine + ((k * 64 + lane) << 2)) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const u16* __restrict__ X = (const u16*)a.x;
+  const u16* __restrict__ DY = (const u16*)a.dy;
+  const float inv_d = 1.0f / (float)a.d;
+  bool act[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) act[i] = (lane + 64 * i) * 8 < a.d;
+  float dg[MAXC][8], db[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  const int stride = gridDim.x * WAVES * ROWS;
+  for (int row0 = row_lo + (blockIdx.x * WAVES + wave) * ROWS; row0 < row_hi; row0 += stride) {
+    u32x4 rx[ROWS][MAXC], rdy[ROWS][MAXC];
+    float mean[ROWS], rstd[ROWS];
+    int rw[ROWS];
+    bool ok[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      ok[r] = row0 + r < row_hi;                           // wave-uniform
+      rw[r] = ok[r] ? row0 + r : row_hi - 1;               // identity row maps (checked by the launcher)
+      mean[r] = a.mean[rw[r]]; rstd[r] = a.rstd[rw[r]];
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        rx[r][i] = u32x4{0, 0, 0, 0}; rdy[r][i] = u32x4{0, 0, 0, 0};
+        if (act[i]) {
+          rx[r][i] = *(const u32x4*)(X + (size_t)rw[r] * a.ldx + c);
+          rdy[r][i] = *(const u32x4*)(DY + (size_t)rw[r] * a.lddy + c);
+        }
+      }
+    }
+    float s1[ROWS], s2[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      s1[r] = 0.f; s2[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        if (act[i] && ok[r]) {
+          float xv[8], dy[8], gm[8];
+          unpack8(rx[r][i], xv);
+          unpack8(rdy[r][i], dy);
+          ld_gam(gam, i, lane, gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - mean[r]) * rstd[r], g = dy[e] * gm[e];
+            s1[r] += g;
+            s2[r] += g * xh;
+            if constexpr (ACC == 1) xv[e] = dy[e] * xh;                 // the row's dgamma terms (dbeta terms: dy)
+            else { dg[i][e] += dy[e] * xh; db[i][e] += dy[e]; }
+          }
+          if constexpr (ACC == 1) {                                      // fold them into the wave's LDS image
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float* pg = mine + (((i * 2 + h) * 64 + lane) << 2);
+              float* pb = pg + W;
+              f32x4 vg = *(f32x4*)pg, vb = *(f32x4*)pb;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { vg[k] += xv[4 * h + k]; vb[k] += dy[4 * h + k]; }
+              *(f32x4*)pg = vg; *(f32x4*)pb = vb;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+    }
+    asm volatile("" ::: "memory");                         // gamma is re-read from LDS for the output pass, not kept in 16 registers
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (!ok[r]) continue;
+      const float c1 = s1[r] * inv_d, c2 = s2[r] * inv_d;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (act[i]) {
+          float xv[8], dy[8], gm[8], o[8];
+          unpack8(rx[r][i], xv);
+          unpack8(rdy[r][i], dy);
+          ld_gam(gam, i, lane, gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rstd[r] * (dy[e] * gm[e] - c1 - (xv[e] - mean[r]) * rstd[r] * c2);
+          *(u32x4*)((u16*)a.dx + (size_t)rw[r] * a.lddx + c) = pack8(o);
+          if (a.dx_drop != nullptr) {
+            if (a.drop_thr) {
+              const unsigned km = tf_keep8((unsigned)rw[r] * (unsigned)a.drop_ld + (unsigned)c, drop_key, a.drop_thr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = ((km >> e) & 1u) ? o[e] * a.drop_scale : 0.f;
+            }
+            *(u32x4*)((u16*)a.dx_drop + (size_t)rw[r] * a.lddxd + c) = pack8(o);
+          }
+        } else {
+          if (c < a.lddx) *(u32x4*)((u16*)a.dx + (size_t)rw[r] * a.lddx + c) = u32x4{0, 0, 0, 0};
+          if (a.dx_drop != nullptr && c < a.lddxd) *(u32x4*)((u16*)a.dx_drop + (size_t)rw[r] * a.lddxd + c) = u32x4{0, 0, 0, 0};
+        }
+      }
+    }
+  }
+  if constexpr (ACC == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float* pg = mine + (((i * 2 + h) * 64 + lane) << 2);
+        *(f32x4*)pg = f32x4{dg[i][4 * h], dg[i][4 * h + 1], dg[i][4 * h + 2], dg[i][4 * h + 3]};
+        *(f32x4*)(pg + W) = f32x4{db[i][4 * h], db[i][4 * h + 1], db[i][4 * h + 2], db[i][4 * h + 3]};
+      }
+  }
+  __syncthreads();
+  float* dgam = (float*)((unsigned char*)a.dgamma + poff);
+  float* dbet = (float*)((unsigned char*)a.dbeta + poff);
+  for (int c = threadIdx.x; c < a.d; c += 64 * WAVES) {
+    const int idx = ((((c >> 9) * 2 + ((c >> 2) & 1)) * 64 + ((c >> 3) & 63)) << 2) + (c & 3);
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { tg += part[w * 2 * W + idx]; tb += part[w * 2 * W + W + idx]; }
+    atomicAdd(dgam + c, tg);
+    atomicAdd(dbet + c, tb);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Token assemble (K2): out[b, s] = s < Nv ? dropout(vis[b,s] + pe[s] + kind_v) : lang[b,s-Nv] + kind_l
 // ------------------------------------------------------------------------------------------------
@@ -1151,6 +1309,14 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const u16* __restri
   }
 }
 
+inline int cu_count_rows() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
 inline int grid_for(long long n, int per_block, int cap = 2048) {
   long long g = (n + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -1413,6 +1579,11 @@ __global__ void lm_pool_affine_kernel(const float* __restrict__ scratch, float* 
 
 }  // namespace
 
+template <int C, int W, int R, int A, int O> void lnb2_launch(dim3 g, dim3 b, unsigned lds, hipStream_t st, const TfLnArgs& a) {
+  static const hipError_t once = hipFuncSetAttribute((const void*)ln_bwd2_kernel<C, W, R, A, O>, hipFuncAttributeMaxDynamicSharedMemorySize, (1 + 2 * W) * 64 * C * 8 * 4);
+  (void)once;
+  hipLaunchKernelGGL((ln_bwd2_kernel<C, W, R, A, O>), g, b, lds, st, a);
+}
 extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   if (a->rows <= 0) return 0;
   if (a->d > 64 * MAXC_MAX * 8 || (a->d % 8) || (a->ldx % 8) || (a->ldy % 8)) return -2;
@@ -1450,6 +1621,32 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   TfTraceScope tr("ln_bwd_kernel", st, 0.0, (split ? 2.0 : 1.0) * (a->dx_drop ? 8.0 : 6.0) * a->rows * a->d);
   const dim3 block(64 * nw);
   const bool ragged = (pg > 1 && a->group_rows[0] > 0) || a->x_row_map != nullptr;
+  // form 2 (ln_bwd2_kernel): the encoder's per-layer launches
+  static const int v2 = TF_ENV_INT("TF_LNB_V", 1), cfg_env = TF_ENV_INT("TF_LNB_CFG", -1), v2_grid = TF_ENV_INT("TF_LNB_GRID2", 0);
+  const bool ident = a->x_group_row0 == nullptr && a->rows_per_group >= a->rows;      // x row = dy row = row
+  if (v2 && !split && !ragged && ident && !a->dy_is_f32 && a->dres == nullptr && width <= 1024) {
+    const int Wc = width <= 512 ? 512 : 1024;
+    // (waves per workgroup, rows in flight per wave, column partials in LDS, waves per SIMD)
+    static const int cfgs[][4] = {{8, 1, 0, 4}, {8, 2, 1, 4}, {4, 2, 0, 3}, {4, 3, 1, 3}, {4, 4, 1, 2}, {4, 1, 1, 5}, {4, 2, 1, 3}, {4, 2, 1, 4}, {4, 1, 0, 4}, {16, 1, 0, 4}, {16, 2, 1, 4}};
+    // many rows: one row per wave and iteration, partials in registers (28.7 us at 16 640 rows against 30.6; the former kernel: 32.6);
+    // few rows: two rows in flight, partials in LDS (11.5 us at 2 080 rows against 13.9; the former kernel: 14.9)
+    const int v2_cfg = cfg_env >= 0 && cfg_env < 11 ? cfg_env : (rows_g >= 8192 ? 0 : 1);
+    const int* cf = cfgs[v2_cfg];
+    const int waves = cf[0], rows_it = cf[1], occ = cf[3];
+    const int resident = cu_count_rows() * (occ * 4 / waves);
+    const unsigned lds = (unsigned)((1 + 2 * waves) * Wc * 4);
+    const dim3 g2(grid_for(rows_g, waves * rows_it, max(1, (v2_grid > 0 ? v2_grid : resident) / pg)), pg), b2(64 * waves);
+#define TF_LNB2(C, W, R, A, O) lnb2_launch<C, W, R, A, O>(g2, b2, lds, st, *a)
+#ifdef TF_EXPERIMENTS
+#define TF_LNB2R(C) do { switch (v2_cfg) { case 0: TF_LNB2(C, 8, 1, 0, 4); break; case 2: TF_LNB2(C, 4, 2, 0, 3); break; case 3: TF_LNB2(C, 4, 3, 1, 3); break; \
+      case 4: TF_LNB2(C, 4, 4, 1, 2); break; case 5: TF_LNB2(C, 4, 1, 1, 5); break; case 6: TF_LNB2(C, 4, 2, 1, 3); break; case 7: TF_LNB2(C, 4, 2, 1, 4); break; \
+      case 8: TF_LNB2(C, 4, 1, 0, 4); break; case 9: TF_LNB2(C, 16, 1, 0, 4); break; case 10: TF_LNB2(C, 16, 2, 1, 4); break; default: TF_LNB2(C, 8, 2, 1, 4); } } while (0)
+#else
+#define TF_LNB2R(C) do { if (v2_cfg == 0) TF_LNB2(C, 8, 1, 0, 4); else TF_LNB2(C, 8, 2, 1, 4); } while (0)
+#endif
+    if (width <= 512) TF_LNB2R(1); else TF_LNB2R(2);
+    return (int)hipGetLastError();
+  }
 #define TF_LNB(C, W) do { if (split && ragged) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true, true>), grid, block, 0, st, *a); \
                           else if (split) hipLaunchKernelGGL((ln_bwd_kernel<C, W, true>), grid, block, 0, st, *a); \
                           else if (ragged) hipLaunchKernelGGL((ln_bwd_kernel<C, W, false, true>), grid, block, 0, st, *a); \
