@@ -12,6 +12,15 @@
 #include <mutex>
 #include <vector>
 
+// Flags of the events that order the chain and its side stream.  They are waited for by streams of the SAME device only
+// (hipStreamWaitEvent; never hipEventSynchronize / hipEventQuery followed by a host read), so the system-scope fence a default event
+// adds when it is recorded -- the write-back that makes device memory visible to the host and to other devices -- buys nothing: every
+// kernel still ends with its own device-scope release (which is what makes its stores visible to the other XCDs' L2s, same stream or
+// not).  Same box, three runs each (tools/experiments/event_flags_ab.sh): 4.002 -> 3.979 ms at B = 32, 1.367 -> 1.348 at B = 4;
+// hipEventReleaseToDevice alone: 3.992 / 1.363.
+#ifndef TF_EVENT_FLAGS
+#define TF_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
 namespace {
 
 thread_local char g_err[512] = "";
@@ -407,7 +416,7 @@ int tf_overlap_create(TfOverlap* o) {
   tf_trace_mark_side(st);
   for (int i = 0; i < 8; ++i) {
     hipEvent_t ev = nullptr;
-    TF_TRY((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming), "tf_overlap_create(event)");
+    TF_TRY((int)hipEventCreateWithFlags(&ev, TF_EVENT_FLAGS), "tf_overlap_create(event)");
     o->ev[i] = ev;
   }
   return 0;

@@ -193,6 +193,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
       for (int kb = 0; kb < KB; ++kb) bfr[kb] = join_tr64(Xv[kb][0], Xv[kb][1]);
       sfor<NB * KB>([&](auto I) {
         constexpr int i = decltype(I)::value, nb = i / KB, kb = i % KB;
+        if constexpr ((TF_ABL_WGM & 32) != 0) {       // timing only: the same matrix cycles as two 16x16x32 instructions (wrong values)
+          f32x4 t0 = {acc[nb][kb][4 * ms], acc[nb][kb][4 * ms + 1], acc[nb][kb][4 * ms + 2], acc[nb][kb][4 * ms + 3]};
+          f32x4 t1 = {acc[nb][kb][8 + 4 * ms], acc[nb][kb][9 + 4 * ms], acc[nb][kb][10 + 4 * ms], acc[nb][kb][11 + 4 * ms]};
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], bfr[kb], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], bfr[kb], t1, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { acc[nb][kb][4 * ms + q] = t0[q]; acc[nb][kb][8 + 4 * ms + q] = t1[q]; }
+        } else
         if constexpr (!(TF_ABL_WGM & 2) || i == 0) acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
         else asm volatile("" :: "v"(af[nb]), "v"(bfr[kb]));
         if constexpr (INTL == 1) {

@@ -503,6 +503,14 @@ class FusionTrainStep:
     def zero_grad(self):
         self.flat.grad.zero_()
 
+    def _root_grad(self, loss, value):
+        cache = self.__dict__.setdefault("_root_grads", {})
+        key = (loss.device, loss.dtype, tuple(loss.shape), float(value))
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.full(tuple(loss.shape), float(value), dtype=loss.dtype, device=loss.device)
+        return t
+
     def step(self, micro_batches: List, loss_fn, on_clock: bool = False):
         """``loss_fn(module, batch) -> scalar``; returns the last loss (detached).  ``on_clock``: see FusedRAdam.step."""
         self.check_errors(sync=False)                  # deferred device-side findings of EARLIER steps that have reached the host
@@ -516,7 +524,10 @@ class FusionTrainStep:
                 # (Lightning's no_sync on the others, run_experiment.py:444-446)
                 self.layerwise.active = i == len(micro_batches) - 1
             loss = loss_fn(self.module, mb)
-            (loss / len(micro_batches)).backward()
+            # d(loss / n) handed to autograd as the root gradient 1 / n (a cached device scalar): no division kernel, no ones-fill and
+            # no multiply in front of the backward (three launches of ~5 us each per micro-batch; Lightning divides the loss,
+            # run_experiment.py:444-446 -- the gradients are the same numbers)
+            loss.backward(gradient=self._root_grad(loss, 1.0 / len(micro_batches)))
         if self.flat.grad.is_cuda:
             # streams whose backward added into the flat gradient buffer without handing autograd a gradient (ops.note_grad_writer): the
             # exchange, the norm and the optimiser below are ordered behind them explicitly
