@@ -64,7 +64,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 #endif
 }
 // INTL: 0 = the step's transfers in front of its MFMAs (the form of wgrad_tn2_kernel), 1 = one transfer after every second MFMA
-template <bool SPLIT, int NS, int INTL>
+// MF16: the products as v_mfma_f32_16x16x32_bf16 (8 x 4 blocks of 16 x 16 per wave, one instruction spans the step's 32 rows) instead of
+// v_mfma_f32_32x32x16_bf16 (4 x 2 blocks of 32 x 32, two 16-row substeps): the same matrix cycles, fragment bytes and accumulator
+// registers -- the 16 x 16 shape holds a higher clock under load (MI355X_MICROARCH.md, DVFS give-back (7); timing ablation with the
+// reads unchanged: 170 -> 164 us alone, step -0.9 %).  Its A / B fragments put the step's four row OCTETS on the four 16-lane groups
+// (the 32 x 32 shape: two octets x two column halves), so the tile swizzle also folds row bit 3 into the chunk index (conflict-free
+// for both read patterns).
+template <bool SPLIT, int NS, int INTL, bool MF16>
 __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
   constexpr int WN = 2, WK = 2, NB = 4, KB = 2;
   constexpr int NWV = WN * WK, TN = WN * NB * 32, TK = WK * KB * 32;
@@ -106,14 +112,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
   for (int i = 0; i < NPY; ++i) {
     const int j = i * NWV + wave;
     const int r = j * (1024 / YROW) + lane / YLPR;
-    const int c = (lane % YLPR) ^ ((r & 3) << 2);
+    const int c = (lane % YLPR) ^ ((r & 3) << 2) ^ (MF16 ? ((r >> 3) & 1) << 1 : 0);
     vy[i] = r * ldy * 2 + min(n0 + c * 8, N - 8) * 2;
   }
 #pragma unroll
   for (int i = 0; i < NPX; ++i) {
     const int j = i * NWV + wave;
     const int r = j * (1024 / XROW) + lane / XLPR;
-    const int c = (lane % XLPR) ^ ((r & 3) << 2);
+    const int c = (lane % XLPR) ^ ((r & 3) << 2) ^ (MF16 ? ((r >> 3) & 1) << 1 : 0);
     vx[i] = r * ldx * 2 + min(k0 + c * 8, K - 8) * 2;
   }
   const int step_y = STEP * ldy * 2, step_x = STEP * ldx * 2;
@@ -137,6 +143,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
   };
   auto stage = [&](int slot, int step) { sfor<NPW>([&](auto Q) { piece(Q, slot, step); }); };
 
+  const bool has_bias = P.db != nullptr;
+  const int bias_mod = WK * tiles_k;                           // k-tile blocks x wave columns share one n-range: take turns
+  int bias_cnt = WK * (tile % tiles_k) + wc;
+  const int grp = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  const unsigned lds_base = lds_addr_of(smem);
+  float* __restrict__ dW = P.dW;
+  const int lddw = P.lddw, rg = P.rg, rgp = P.rgp, n_src = P.n_src, cg = P.cg, cgp = P.cgp, k_src = P.k_src;
+  stage(0, 0);
+  if constexpr (NS >= 3) stage(1, 1);
+  if constexpr (NS >= 4) stage(2, 2);
+  int slot = 0;
+  if constexpr (MF16) {
+    f32x4 acc4[32];                                            // block (nb, kb), nb = 0 .. 7 (16 n each), kb = 0 .. 3: acc4[nb * 4 + kb]
+    f32x4 accb4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane = 16 g + 4 q4 + p4 supplies row 8 g + q4 (+ 4: second read), columns 4 p4 .. 4 p4 + 3 of a block's 16; it receives column
+    // (lane & 15), rows 8 g .. 8 g + 7 = the A (or B) fragment of v_mfma_f32_16x16x32_bf16
+    const int sw = (q4 << 2) | ((grp & 1) << 1), o8 = (p4 & 1) * 8;
+    const int yoff = (8 * grp + q4) * YROW + ((((wr * 16) | (p4 >> 1)) ^ sw) << 4) + o8;              // n-block nb (16 columns): ^ (nb * 32)
+    const int xoff = YB + (8 * grp + q4) * XROW + ((((wc * 8) | (p4 >> 1)) ^ sw) << 4) + o8;          // k-block kb: ^ (kb * 32)
+    for (int st = 0; st < nsteps; ++st) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * NPW) : "memory");
+      const unsigned sl = lds_base + slot * SLOT;
+      u64 xb[4][2], ya[8][2];
+#define TF_RDX(kb) xb[kb][0] = tr_read_asm<0>(sl + (xoff ^ ((kb) * 32))); xb[kb][1] = tr_read_asm<4 * XROW>(sl + (xoff ^ ((kb) * 32)));
+#define TF_RDY(nb) ya[nb][0] = tr_read_asm<0>(sl + (yoff ^ ((nb) * 32))); ya[nb][1] = tr_read_asm<4 * YROW>(sl + (yoff ^ ((nb) * 32)));
+      TF_RDX(0) TF_RDX(1) TF_RDX(2) TF_RDX(3)
+      TF_RDY(0) TF_RDY(1) TF_RDY(2) TF_RDY(3)
+      TF_RDY(4) TF_RDY(5) TF_RDY(6) TF_RDY(7)
+#undef TF_RDX
+#undef TF_RDY
+      const int nslot = slot == 0 ? NS - 1 : slot - 1;
+      const int nstep = st + NS - 1;
+      slot = slot == NS - 1 ? 0 : slot + 1;
+      if constexpr (INTL == 0) stage(nslot, nstep);
+      bf16x8 bfr[4], af[8];
+      auto half = [&](auto H) {
+        constexpr int h = decltype(H)::value;
+        sfor<16>([&](auto I) {
+          constexpr int i = decltype(I)::value, nb = 4 * h + i / 4, kb = i % 4;
+          acc4[nb * 4 + kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], bfr[kb], acc4[nb * 4 + kb], 0, 0, 0);
+          if constexpr (INTL == 1) {
+            constexpr int done = h * 16 + i + 1;                 // one transfer behind every fourth MFMA of the step (64 matrix cycles apart)
+            if constexpr (done % 4 == 0 && done / 4 - 1 < NPW) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece(std::integral_constant<int, done / 4 - 1>{}, nslot, nstep);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        });
+      };
+      // the first 16 products need the four X fragments and dY blocks 0 - 3 (16 reads; the 8 of blocks 4 - 7 still in flight)
+      asm volatile("s_waitcnt lgkmcnt(8)"
+                   : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[2][0]), "+v"(xb[2][1]), "+v"(xb[3][0]), "+v"(xb[3][1]),
+                     "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(ya[1][0]), "+v"(ya[1][1]), "+v"(ya[2][0]), "+v"(ya[2][1]), "+v"(ya[3][0]), "+v"(ya[3][1]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) bfr[kb] = join_tr64(xb[kb][0], xb[kb][1]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) af[nb] = join_tr64(ya[nb][0], ya[nb][1]);
+      half(std::integral_constant<int, 0>{});
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ya[4][0]), "+v"(ya[4][1]), "+v"(ya[5][0]), "+v"(ya[5][1]), "+v"(ya[6][0]), "+v"(ya[6][1]), "+v"(ya[7][0]), "+v"(ya[7][1]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 4; nb < 8; ++nb) af[nb] = join_tr64(ya[nb][0], ya[nb][1]);
+      half(std::integral_constant<int, 1>{});
+      // bias gradient: D[i][j] += sum_m SEL[i][m] dY[m][16 nb + j], SEL row i = ones iff i == nb: row nb of the one extra accumulator
+      // collects block nb's column sums; a wave takes every (2 tiles_k)-th STEP of the chunk (the waves that share its n-range the others)
+      const bool my_turn = has_bias && bias_cnt == 0 && (!SPLIT || st < 2 * nsteps0);          // wave-uniform
+      bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
+      if (my_turn) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          const unsigned w = li == nb ? 0x3F803F80u : 0u;          // two bf16 ones
+          const u32x4 sv = {w, w, w, w};
+          accb4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(sv), af[nb], accb4, 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the workgroup retires
+    // ---- flush: register r of block (nb, kb) holds rows 4 (lane >> 4) + r, column lane & 15: four 64-B row segments per instruction ----
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int np = n0 + wr * 128 + nb * 16 + 4 * grp + r;
+        const int ng = np / rgp, ne = np - ng * rgp;
+        const int ns = ng * rg + ne;
+        const bool nok = (np < N) && (ne < rg) && (ns < n_src);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const int kp = k0 + wc * 64 + kb * 16 + li;
+          const int kg = kp / cgp, ke = kp - kg * cgp;
+          const int ks = kg * cg + ke;
+          if (nok && kp < K && ke < cg && ks < k_src) atomicAdd(dW + (size_t)ns * lddw + ks, acc4[nb * 4 + kb][r]);
+        }
+      }
+      if (has_bias && grp == (nb >> 2)) {                        // row nb of the bias accumulator: lanes 16 (nb >> 2) + j, register nb & 3
+        const int np = n0 + wr * 128 + nb * 16 + li;
+        const int ng = np / rgp, ne = np - ng * rgp;
+        const int ns = ng * rg + ne;
+        if (np < N && ne < rg && ns < n_src) atomicAdd(P.db + ns, accb4[nb & 3]);
+      }
+    }
+  } else {
   f32x16 acc[NB][KB], accb;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -146,22 +259,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
 #pragma unroll
       for (int k = 0; k < KB; ++k) acc[i][k][r] = 0.f;
   }
-  const bool has_bias = P.db != nullptr;
-  const int bias_mod = WK * tiles_k;                           // k-tile blocks x wave columns share one n-range: take turns
-  int bias_cnt = WK * (tile % tiles_k) + wc;
   const int sel_nb = (lane & 31) / (32 / NB);
-
-  const int grp = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
   const int h = grp >> 1, cb = grp & 1;
   const int sw = q4 << 2, o8 = (p4 & 1) * 8;
   const int yoff = (8 * h + q4) * YROW + (((wr * NB * 4 + cb * 2 + (p4 >> 1)) ^ sw) << 4) + o8;         // n-block nb: ^ (nb * 64)
   const int xoff = YB + (8 * h + q4) * XROW + (((wc * KB * 4 + cb * 2 + (p4 >> 1)) ^ sw) << 4) + o8;    // k-block kb: ^ (kb * 64)
-
-  const unsigned lds_base = lds_addr_of(smem);
-  stage(0, 0);
-  if constexpr (NS >= 3) stage(1, 1);
-  if constexpr (NS >= 4) stage(2, 2);
-  int slot = 0;
   for (int st = 0; st < nsteps; ++st) {
     // retire step st's transfers (issued NS - 1 steps ago), make them visible, recycle slot (st + NS - 1) % NS
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * NPW) : "memory");
@@ -237,10 +339,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
     substep(y1, x1, std::integral_constant<int, 1>{});
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers land before the workgroup retires
-
   // ---- flush: fp32 atomics into the (unpadded) parameter-layout gradient; a register of a 32x32 accumulator is two 128-B row segments ----
-  float* __restrict__ dW = P.dW;
-  const int lddw = P.lddw, rg = P.rg, rgp = P.rgp, n_src = P.n_src, cg = P.cg, cgp = P.cgp, k_src = P.k_src;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -264,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
       const int ns = ng * rg + ne;
       if (np < N && ne < rg && ns < n_src) atomicAdd(P.db + ns, accb[(16 / NB) * nb]);
     }
-  }
+  }  }
 }
 
 int cu_count() {
@@ -351,15 +450,15 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
   m.count = n; m.chunks = chunks; m.tiles_total = tiles;
   (void)max_steps;
   constexpr int NS = 3, LDS = NS * (32 * 512 + 32 * 256);
-  static const int intl = TF_ENV_INT("TF_WGM_INTL", 1);
+  static const int intl = TF_ENV_INT("TF_WGM_INTL", 1), mf16 = TF_ENV_INT("TF_WGM_MF16", 1);
   dim3 grid((unsigned)tiles * (unsigned)chunks), block(256);
   TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops, abytes);
-  static const hipError_t o0 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  static const hipError_t o1 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<false, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  static const hipError_t o2 = hipFuncSetAttribute((const void*)wgrad_multi_kernel<true, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  (void)o0; (void)o1; (void)o2;
-  if (split) hipLaunchKernelGGL((wgrad_multi_kernel<true, NS, 1>), grid, block, LDS, stream, m);
-  else if (intl == 0) hipLaunchKernelGGL((wgrad_multi_kernel<false, NS, 0>), grid, block, LDS, stream, m);
-  else hipLaunchKernelGGL((wgrad_multi_kernel<false, NS, 1>), grid, block, LDS, stream, m);
+#define TF_WGM_LAUNCH(S, I, F) do { \
+    static const hipError_t once = hipFuncSetAttribute((const void*)wgrad_multi_kernel<S, NS, I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    (void)once; hipLaunchKernelGGL((wgrad_multi_kernel<S, NS, I, F>), grid, block, LDS, stream, m); } while (0)
+  if (split) { if (mf16) TF_WGM_LAUNCH(true, 1, true); else TF_WGM_LAUNCH(true, 1, false); }
+  else if (intl == 0) { if (mf16) TF_WGM_LAUNCH(false, 0, true); else TF_WGM_LAUNCH(false, 0, false); }
+  else { if (mf16) TF_WGM_LAUNCH(false, 1, true); else TF_WGM_LAUNCH(false, 1, false); }
+#undef TF_WGM_LAUNCH
   return (int)hipGetLastError();
 }
