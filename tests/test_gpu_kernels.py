@@ -322,14 +322,20 @@ def test_layernorm_fwd_bwd(dev, guard, rows, d, ld):
 
 
 @pytest.mark.parametrize("rows,d,ld,groups", [(2 * 4500, 768, 768, 2), (16640, 768, 768, 1), (3 * 333, 712, 768, 3), (130, 72, 128, 1),
-                                              (2 * 257, 1024, 1024, 2)])
+                                              (2 * 257, 1024, 1024, 2), (1450, 768, 768, (700, 300, 450)), (12000, 768, 768, (9000, 3000))])
 def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld, groups):
     """The per-layer form of the LayerNorm backward (ln_bwd2_kernel, both of its shipped configurations: >= 8192 rows per group and
     fewer): dx, the dropout-masked copy dx_drop = dx * keep / (1 - p) with the mask tf_dropout_mask replays, zeroed pad columns, and
     dgamma / dbeta per parameter group (equal row ranges, parameters p_gstride bytes apart) -- against fp64 torch, operands at guard pages."""
     from transfusion_amd import _lib as L, ops
     g = torch.Generator().manual_seed(rows + d)
-    rg = rows // groups
+    ranges = None
+    if isinstance(groups, tuple):                           # ragged parameter groups (TfLnArgs.group_rows): the wrapper's unequal levels
+        ranges, groups = groups, len(groups)
+        assert sum(ranges) == rows
+    bounds = [0]
+    for k in range(groups):
+        bounds.append(bounds[-1] + (ranges[k] if ranges else rows // groups))
     x = torch.zeros(rows, ld)
     x[:, :d] = torch.randn(rows, d, generator=g) * 1.5 - 0.3
     xb = guard(bf(x))
@@ -350,9 +356,12 @@ def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld
                    x_group_stride=rows, y_group_stride=rows, eps=1e-5, dy=L.ptr(dy), lddy=ld, dy_is_f32=0, dx=L.ptr(dx), lddx=ld,
                    dx_drop=L.ptr(dxd), lddxd=ld, drop_thr=thr, drop_key=key, drop_scale=scale, drop_ld=ld, dgamma=L.ptr(dg), dbeta=L.ptr(db),
                    pgroups=groups, p_gstride=gstride * 4)
+    if ranges:
+        for k, n in enumerate(ranges):
+            a.group_rows[k] = n
     L.call("tf_layernorm_bwd", a, ops._stream())
     torch.cuda.synchronize()
-    gam = gamma.double().cpu()[:, :d].repeat_interleave(rg, 0)
+    gam = torch.cat([gamma.double().cpu()[k:k + 1, :d].expand(bounds[k + 1] - bounds[k], d) for k in range(groups)])
     dyd = dy.double().cpu()[:, :d]
     xh = (xd - mean[:, None]) * rstd[:, None]
     gg = dyd * gam
@@ -365,7 +374,7 @@ def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld
     if ld > d:
         assert dx[:, d:].float().abs().max().item() == 0.0 and dxd[:, d:].float().abs().max().item() == 0.0
     for k in range(groups):
-        sl = slice(k * rg, (k + 1) * rg)
+        sl = slice(bounds[k], bounds[k + 1])
         assert rel(dg[k, :d], (dyd[sl] * xh[sl]).sum(0)) < 1e-3 and rel(db[k, :d], dyd[sl].sum(0)) < 1e-3
         if gstride > d:
             assert dg[k, d:].abs().max().item() == 0.0 and db[k, d:].abs().max().item() == 0.0

@@ -220,8 +220,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
   }
 }
 
-// LayerNorm backward, form 2 (the encoder's per-layer launches: bf16 tensors, no lo planes, identity row maps, equal parameter
-// groups).  The kernel is a dependent load -> reduce -> store chain per row, so its rate is set by the bytes a CU keeps in flight.
+// LayerNorm backward, form 2 (the encoder's per-layer launches: bf16 tensors, no lo planes, identity row maps; parameter groups
+// equal or ragged).  The kernel is a dependent load -> reduce -> store chain per row, so its rate is set by the bytes a CU keeps in flight.
 // Against the form above: (a) a row's x and dy stay PACKED (bf16) across its two wave reductions and xhat / g are recomputed for the
 // output pass -- 16 live registers per row instead of 32; (b) a wave keeps ROWS rows in flight at once (all their loads issued before
 // the first use); (c) ACC = 1: the dgamma / dbeta column partials of a wave live in a private LDS image (one 16-byte read-modify-write
@@ -244,7 +244,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void ln_bwd2_kernel(const TfLnArgs
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* mine = part + wave * 2 * W;
-  const int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g, row_hi = row_lo + rows_g;
+  int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g;
+  if (a.pgroups > 1 && a.group_rows[0] > 0) {              // ragged parameter groups (TfLnArgs.group_rows): scalar table walk, once
+    const TfRange rg = tf_range_of_group(a.group_rows, (int)blockIdx.y);
+    rows_g = rg.n; row_lo = rg.lo;
+  }
+  const int row_hi = row_lo + rows_g;
   const long long poff = (long long)blockIdx.y * a.p_gstride;
   const float* gamma_g = (const float*)((const unsigned char*)a.gamma + poff);
   for (int c = threadIdx.x; c < W; c += 64 * WAVES)
@@ -1624,7 +1629,7 @@ extern "C" int tf_launch_ln_bwd(const TfLnArgs* a, hipStream_t st) {
   // form 2 (ln_bwd2_kernel): the encoder's per-layer launches
   static const int v2 = TF_ENV_INT("TF_LNB_V", 1), cfg_env = TF_ENV_INT("TF_LNB_CFG", -1), v2_grid = TF_ENV_INT("TF_LNB_GRID2", 0);
   const bool ident = a->x_group_row0 == nullptr && a->rows_per_group >= a->rows;      // x row = dy row = row
-  if (v2 && !split && !ragged && ident && !a->dy_is_f32 && a->dres == nullptr && width <= 1024) {
+  if (v2 && !split && a->x_row_map == nullptr && ident && !a->dy_is_f32 && a->dres == nullptr && width <= 1024) {
     const int Wc = width <= 512 ? 512 : 1024;
     // (waves per workgroup, rows in flight per wave, column partials in LDS, waves per SIMD)
     static const int cfgs[][4] = {{8, 1, 0, 4}, {8, 2, 1, 4}, {4, 2, 0, 3}, {4, 3, 1, 3}, {4, 4, 1, 2}, {4, 1, 1, 5}, {4, 2, 1, 3}, {4, 2, 1, 4}, {4, 1, 0, 4}, {16, 1, 0, 4}, {16, 2, 1, 4}};
