@@ -46,7 +46,8 @@ def test_library_holds_the_expected_kernels(table):
     assert len(table) > 150
     for must in ("gemm_nt_big_kernel<1, 9, false, false, 2>", "wgrad_tn2_kernel<false, 3>", "attn_fwd_kernel<192, false>",
                  "attn_bwd_dkv16_kernel<192, false, 64, true, 2>", "attn_bwd_dq_ds_kernel<192>", "attn_delta_kernel", "row_map_kernel",
-                 "ln_bwd_kernel<2, 8, false, false>", "radam_kernel", "wgrad_multi_kernel<false, 3, 1>", "wgrad_multi_kernel<true, 3, 1>",
+                 "ln_bwd_kernel<2, 8, false, false>", "ln_bwd2_kernel<2, 8, 1, 0, 4>", "ln_bwd2_kernel<2, 8, 2, 1, 4>", "radam_kernel",
+                 "wgrad_multi_kernel<false, 3, 1, true>", "wgrad_multi_kernel<true, 3, 1, true>",
                  "attn_bwd_dkv_pair_kernel<192, false>", "attn_bwd_dkv_pair_kernel<192, true>"):
         assert must in table, must
     # every kernel was compiled for wave64 workgroups of at most 1024 threads and declares its registers
@@ -62,7 +63,7 @@ def test_default_paths_are_spill_free(table):
     """Explicitly, whatever the allow-list says: head dims <= 192, and every kernel with hand-placed DMA rings / asm LDS reads."""
     for k, v in table.items():
         hd = _head_dim(k)
-        critical = (hd is not None and hd <= 192) or k.startswith(("wgrad_tn", "wgrad_multi", "gemm_nt_big", "gemm_nt_kernel"))
+        critical = (hd is not None and hd <= 192) or k.startswith(("wgrad_tn", "wgrad_multi", "gemm_nt_big", "gemm_nt_kernel", "ln_bwd"))
         if critical:
             assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
             assert k not in ALLOWED_SPILLS, k
@@ -97,8 +98,9 @@ def test_occupancy_assumptions(table):
     assert alloc("attn_bwd_dq_ds_kernel<192>") <= 256
     assert alloc("attn_bwd_dkv16_kernel<192, false, 64, true, 2>") <= 256    # 8 waves = two per SIMD
     assert alloc("wgrad_tn2_kernel<false, 3>") <= 256                # leaves half of every SIMD's file to the backward chain
-    assert alloc("wgrad_multi_kernel<false, 3, 1>") <= 256           # two 4-wave workgroups per CU
-    assert alloc("wgrad_multi_kernel<true, 3, 1>") <= 256
+    assert alloc("wgrad_multi_kernel<false, 3, 1, true>") <= 256     # two 4-wave workgroups per CU
+    assert alloc("wgrad_multi_kernel<true, 3, 1, true>") <= 256
     assert alloc("attn_bwd_dkv_pair_kernel<192, false>") <= 256      # the wave pair of a SIMD
     assert alloc("ln_bwd_kernel<2, 8, false, false>") <= 128                # four waves per SIMD at d <= 1024
+    assert alloc("ln_bwd2_kernel<2, 8, 1, 0, 4>") <= 128 and alloc("ln_bwd2_kernel<2, 8, 2, 1, 4>") <= 128
     assert alloc("gemm_nt_big_kernel<1, 9, false, false, 1>") <= 256 # the two-workgroups-per-CU form
