@@ -278,9 +278,22 @@ def wgrad_alone(B, device, reps=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     fl = sum(2.0 * M * a.shape[1] * b.shape[1] for a, b in pairs)
+    # the same products as the library sizes a launch that HAS the chip to itself (blocks = 0: 128 tiles of 192 x 192 at two row chunks,
+    # one 8-wave workgroup per CU, the two row halves reduced in LDS before one atomic pass -- what the last launch of a backward runs)
+    fn0 = lambda: ops.wgrad_multi(probs, 0)
+    fn0()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn0()
+    e1.record()
+    torch.cuda.synchronize()
+    us0 = e0.elapsed_time(e1) * 1e3 / reps
     return dict(avg_launch_us=round(us, 1), achieved=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4),
                 flops_per_launch=fl, rows=M, workgroups=blocks,
-                note="one layer's four products as one launch, the encoder runtime's sizing, alone back to back")
+                note="one layer's four products as one launch, the encoder runtime's sizing, alone back to back",
+                chip_to_itself=dict(avg_launch_us=round(us0, 1), achieved=round(fl / us0 / 1e6, 1), frac=round(fl / us0 / 1e6 / PEAK_BF16_TFLOPS, 4),
+                                    note="the same launch sized by the library for a launch with the chip to itself (blocks = 0: the 192 x 192 two-quad form)"))
 
 
 def cpu_baseline(seconds_budget=12.0):

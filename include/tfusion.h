@@ -393,7 +393,9 @@ void tf_set_gemm_concurrency(int n);
 int tf_gemm_fwd(const TfGemmArgs* a, tf_stream_t s);
 int tf_gemm_wgrad(const TfWgradArgs* a, tf_stream_t s);
 /* probs[0 .. count): see TF_WGRAD_MULTI_MAX.  blocks > 0: that many workgroups (256 x 128 output tiles x row chunks) in flight;
- * 0 = sized by the library for a launch that has the chip to itself; -1 = sized for a launch that runs beside other kernels */
+ * 0 = sized by the library for a launch that has the chip to itself; -1 = sized for a launch that runs beside other kernels (0 / -1:
+ * where the products make one well-filled round of 192 x 192 tiles, the two-quad form with its in-workgroup reduction is taken);
+ * -2 = that form wherever the row count allows it (tests) */
 int tf_gemm_wgrad_multi(const TfWgradArgs* probs, int count, int blocks, tf_stream_t s);
 int tf_attn_fwd(const TfAttnArgs* a, tf_stream_t s);
 int tf_attn_bwd(const TfAttnArgs* a, tf_stream_t s);       /* dQ (which also fills `delta`), then dK, dV */

@@ -31,7 +31,7 @@ def _problem(g, M, N, K, dev, scale=1.0, guard=None):
     return dY, X, dY.double().cpu().t() @ X.double().cpu(), dY.double().cpu().sum(0)
 
 
-@pytest.mark.parametrize("blocks", [0, -1, 1, 40, 97, 512])
+@pytest.mark.parametrize("blocks", [0, -1, 1, 40, 97, 512, -2])          # -2: the 192 x 192 two-quad form
 def test_layer_shaped_problems(dev, guard, blocks):
     """four problems with a layer's operand relations (shared rows, different N / K, one without a bias) at a small width"""
     from transfusion_amd import ops
@@ -92,7 +92,7 @@ def test_different_row_counts_and_tile_tails(dev):
         probs.append(ops.wgrad_args(dY, N, X, K, dW, db))
         outs.append((dW, db, ref, refb))
         keep += [dY, X]
-    for blocks in (0, 64, -1):
+    for blocks in (0, 64, -1, -2):
         for dW, db, _, _ in outs:
             dW.zero_(); db.zero_()
         ops.wgrad_multi(probs, blocks)
@@ -117,12 +117,35 @@ def test_padded_groups_and_leading_dimensions(dev):
     dW2 = torch.zeros(K, n_src, device=dev)
     probs = [ops.wgrad_args(dY, N, X, K, dW, db, rg=rg, rgp=rgp, n_src=n_src),
              ops.wgrad_args(X, K, dY, N, dW2, None, cg=rg, cgp=rgp, k_src=n_src)]
-    for blocks in (48, -1):
+    for blocks in (48, -1, -2):
         dW.zero_(); db.zero_(); dW2.zero_()
         ops.wgrad_multi(probs, blocks)
         assert rel(dW, ref[idx]) < 1e-4
         assert rel(db, refb[idx]) < 1e-4
         assert rel(dW2, ref[idx].t()) < 1e-4
+
+
+def test_layer_at_the_benchmark_size_takes_the_two_quad_form(dev):
+    """a d = 768 layer's four products at a packed row count (ragged last step, odd step count): 128 tiles of 192 x 192 at two row chunks
+    -- the launcher's own rule (blocks = -1) picks the two-quad form here; against the 256 x 128 form (blocks = 432) and fp64"""
+    from transfusion_amd import ops
+    g = torch.Generator().manual_seed(77)
+    M, d = 16637, 768
+    probs, outs, keep = [], [], []
+    for N, K in [(3 * d, d), (d, d), (2 * d, d), (d, 2 * d)]:
+        dY = bf(torch.randn(M, N, generator=g) * 0.1).to(dev)
+        X = bf(torch.randn(M, K, generator=g)).to(dev)
+        dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        dW2, db2 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        probs.append((ops.wgrad_args(dY, N, X, K, dW, db), ops.wgrad_args(dY, N, X, K, dW2, db2)))
+        outs.append((dW, db, dW2, db2, dY, X))
+    ops.wgrad_multi([p[0] for p in probs], -1)
+    ops.wgrad_multi([p[1] for p in probs], 432)
+    for dW, db, dW2, db2, dY, X in outs:
+        ref = dY.double().t() @ X.double()
+        assert rel(dW, ref) < 1e-4 and rel(dW2, ref) < 1e-4
+        assert rel(db, dY.double().sum(0)) < 1e-4 and rel(db2, dY.double().sum(0)) < 1e-4
+        assert rel(dW, dW2) < 2e-6                                         # same products, different summation orders
 
 
 def test_groups_expand(dev):
@@ -137,7 +160,9 @@ def test_groups_expand(dev):
     p = ops.wgrad_args(dy, N, x, K, store[: N * K].view(N, K), store[N * K: N * K + N], groups=G, dw_gstride=blk * 4)
     ops.wgrad_multi([p], 30)
     ops.wgrad_multi([p], -1)                                               # the launcher's own sizing adds the same again
-    store *= 0.5
+    ops.wgrad_multi([p], -2)                                               # ... and the 192 x 192 form a third time
+    ops.wgrad_multi([p], 0)
+    store *= 0.25
     for k in range(G):
         dW = store[k * blk: k * blk + N * K].view(N, K)
         db = store[k * blk + N * K: k * blk + N * K + N]
@@ -162,7 +187,7 @@ def test_split_mode(dev):
         Y64, X64 = joined(Yh, Yl).cpu()[:, :N], joined(Xh, Xl).cpu()[:, :K]
         outs.append((dW, db, Y64.t() @ X64, Y64.sum(0)))
         keep += [Yh, Yl, Xh, Xl]
-    for blocks in (24, -1):
+    for blocks in (24, -1, -2):
         for dW, db, _, _ in outs:
             dW.zero_(); db.zero_()
         ops.wgrad_multi(probs, blocks)

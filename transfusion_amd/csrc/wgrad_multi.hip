@@ -366,6 +366,210 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti a) {
   }  }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Form 2: 192 x 192 output tiles, EIGHT waves = two quads.  A d = 768 layer's four products are 48 + 16 + 32 + 32 = 128 such tiles: at two
+// row chunks 256 workgroups, one per CU, every CU the same work (the 256 x 128 form: 144 tiles x 3 chunks = 432 workgroups, 176 CUs with
+// two and 80 with one).  The two quads of a workgroup take the two HALVES of its row chunk with a 3-slot ring each, and their partial
+// tiles meet in LDS before ONE atomic pass: 256 x 147 KB = 37.7 MB of fp32 atomics per layer launch instead of 432 x 128 KB = 56.6 MB.
+// Quad = 2 x 2 waves of 96 x 96 = 6 x 6 blocks of v_mfma_f32_16x16x32_bf16 (144 accumulator registers); a step stages 2 x [32][192]
+// = 24 KB per quad for 2.36 MFLOP (96 FLOP per staged byte; the 256 x 128 form: 85), and a wave reads 24 transposed fragments halves
+// for 36 instructions (the other form: 24 for 32).
+// LDS rows are 384 B (24 chunks of 16 B): row r holds source chunk c at position c ^ (s(r) << 1), s(r) = ((r >> 1) & 1) | ((r >> 3) & 1) << 1,
+// i.e. 16-column block b of row r sits at block b ^ s(r) of its aligned group of four -- the eight rows a transposed read touches per
+// 32-lane half (r = 8 g + q, g = 0 / 1, q = 0 .. 3) then fall on eight different 32-byte bank groups (rows of odd r start 32 banks on).
+// A wave's six blocks per operand are blocks 2 w, 2 w + 1 (w = its row / column in the quad) of each of the three aligned groups, so a
+// lane needs two base addresses per operand and the group is an instruction offset.
+template <bool SPLIT, int NS>
+__global__ __launch_bounds__(512, 2) void wgrad_multi192_kernel(const WgMulti a) {
+  constexpr int T = 192, STEP = 32, ROWB = T * 2, OPB = STEP * ROWB, SLOT = 2 * OPB;        // 384 B rows, 12 KB per operand, 24 KB per slot
+  constexpr int NPO = OPB / 1024 / 4, NPW = 2 * NPO;                                         // 1-KiB transfers per wave, operand and step: 3 (+ 3)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave8 >> 2, wave = wave8 & 3;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = logical / a.tiles_total, gt = logical - chunk * a.tiles_total;
+  int pi = 0;
+  for (int i = 1; i < a.count; ++i) pi = gt >= a.p[i].tile0 ? i : pi;
+  const WgProb& P = a.p[pi];
+  const int tiles_k = P.tiles_k, tile = gt - P.tile0;
+  const int n0 = (tile / tiles_k) * T, k0 = (tile % tiles_k) * T;
+  const int m_begin = chunk * P.m_chunk;                           // m_chunk: a multiple of 64 rows
+  if (m_begin >= P.M) return;
+  const int half = P.m_chunk >> 1;
+  const int rows_wg = min(P.M, m_begin + P.m_chunk) - m_begin;
+  const int nsteps0 = (min(rows_wg, half) + STEP - 1) / STEP;       // quad 0 has the longer half: both quads walk its step count
+  const int nsteps = SPLIT ? 3 * nsteps0 : nsteps0;
+  const int qbeg = m_begin + quad * half;
+  const int qrows = max(0, min(P.M, qbeg + half) - qbeg);           // 0: every transfer of this quad reads zeros
+  const int ldy = P.ldy, ldx = P.ldx, N = P.N, K = P.K;
+  const size_t qoff = (size_t)min(qbeg, P.M - 1);
+  const __amdgpu_buffer_rsrc_t rYh = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY + qoff * ldy * 2), 0, qrows * ldy * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rXh = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X + qoff * ldx * 2), 0, qrows * ldx * 2, 0x00020000);
+  __amdgpu_buffer_rsrc_t rYl = rYh, rXl = rXh;
+  if constexpr (SPLIT) {
+    rYl = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY_lo + qoff * ldy * 2), 0, qrows * ldy * 2, 0x00020000);
+    rXl = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X_lo + qoff * ldx * 2), 0, qrows * ldx * 2, 0x00020000);
+  }
+  // transfer j (0 .. 11) of an operand fills LDS bytes [1024 j, 1024 j + 1024) of its [32][384 B] image; wave w issues j = w, w + 4, w + 8
+  int vy[NPO], vx[NPO];
+#pragma unroll
+  for (int i = 0; i < NPO; ++i) {
+    const int off = (i * 4 + wave) * 1024 + lane * 16;
+    const int r = off / ROWB, cp = (off - r * ROWB) >> 4;
+    const int c = cp ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+    vy[i] = r * ldy * 2 + min(n0 + c * 8, N - 8) * 2;
+    vx[i] = r * ldx * 2 + min(k0 + c * 8, K - 8) * 2;
+  }
+  const int step_y = STEP * ldy * 2, step_x = STEP * ldx * 2;
+  unsigned char* ring = smem + quad * NS * SLOT;
+  auto piece = [&](auto Q, int slot, int step) {
+    constexpr int q = decltype(Q)::value;
+    int st = step;
+    bool ylo = false, xlo = false;
+    if constexpr (SPLIT) {
+      const int seg = step >= 2 * nsteps0 ? 2 : (step >= nsteps0 ? 1 : 0);
+      st = step - seg * nsteps0;
+      ylo = seg == 1; xlo = seg == 2;
+    }
+    unsigned char* base = ring + slot * SLOT;
+    if constexpr (q < NPO) dma16(SPLIT && ylo ? rYl : rYh, base + (q * 4 + wave) * 1024, vy[q], st * step_y);
+    else dma16(SPLIT && xlo ? rXl : rXh, base + OPB + ((q - NPO) * 4 + wave) * 1024, vx[q - NPO], st * step_x);
+  };
+  auto stage = [&](int slot, int step) { sfor<NPW>([&](auto Q) { piece(Q, slot, step); }); };
+
+  const bool has_bias = P.db != nullptr;
+  const int bias_mod = 2 * tiles_k;                            // k-tile workgroups x wave columns share one n-range (per quad): take turns
+  int bias_cnt = 2 * (tile % tiles_k) + wc;
+  const int grp = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  float* __restrict__ dW = P.dW;
+  const int lddw = P.lddw, rg = P.rg, rgp = P.rgp, n_src = P.n_src, cg = P.cg, cgp = P.cgp, k_src = P.k_src;
+  // fragment addresses: lane = 16 g + 4 q4 + p4 supplies row 8 g + q4 (+ 4), columns 4 p4 .. 4 p4 + 3 of a 16-column block
+  const int sw = ((q4 >> 1) & 1) | ((grp & 1) << 1);
+  const int rowb = (8 * grp + q4) * ROWB + (p4 >> 1) * 16 + (p4 & 1) * 8;
+  const unsigned lds_q = lds_addr_of(ring);
+  const unsigned ya0 = rowb + 32 * ((2 * wr) ^ sw), ya1 = rowb + 32 * ((2 * wr + 1) ^ sw);             // block i: (i & 1 ? ya1 : ya0) + 128 (i >> 1)
+  const unsigned xa0 = OPB + rowb + 32 * ((2 * wc) ^ sw), xa1 = OPB + rowb + 32 * ((2 * wc + 1) ^ sw);
+
+  f32x4 acc4[36];                                              // block (i, k): acc4[i * 6 + k]
+  f32x4 accb4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage(0, 0);
+  if constexpr (NS >= 3) stage(1, 1);
+  int slot = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * NPW) : "memory");
+    const unsigned sl = lds_q + slot * SLOT;
+    u64 xb[6][2], ya[6][2];
+#define TF_RDX(k) xb[k][0] = tr_read_asm<128 * ((k) >> 1)>(sl + (((k) & 1) ? xa1 : xa0)); xb[k][1] = tr_read_asm<128 * ((k) >> 1) + 4 * ROWB>(sl + (((k) & 1) ? xa1 : xa0));
+#define TF_RDY(i) ya[i][0] = tr_read_asm<128 * ((i) >> 1)>(sl + (((i) & 1) ? ya1 : ya0)); ya[i][1] = tr_read_asm<128 * ((i) >> 1) + 4 * ROWB>(sl + (((i) & 1) ? ya1 : ya0));
+    TF_RDX(0) TF_RDX(1) TF_RDX(2) TF_RDX(3) TF_RDX(4) TF_RDX(5)
+    TF_RDY(0) TF_RDY(1) TF_RDY(2)
+    TF_RDY(3) TF_RDY(4) TF_RDY(5)
+#undef TF_RDX
+#undef TF_RDY
+    const int nslot = slot == 0 ? NS - 1 : slot - 1;
+    const int nstep = st + NS - 1;
+    slot = slot == NS - 1 ? 0 : slot + 1;
+    bf16x8 bfr[6], af[6];
+    auto part = [&](auto H) {
+      constexpr int h = decltype(H)::value;
+      sfor<18>([&](auto I) {
+        constexpr int j = decltype(I)::value, i = 3 * h + j / 6, k = j % 6;
+        acc4[i * 6 + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[k], acc4[i * 6 + k], 0, 0, 0);
+        constexpr int done = h * 18 + j + 1;                   // one transfer behind every sixth MFMA of the step
+        if constexpr (done % 6 == 0 && done / 6 - 1 < NPW) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(std::integral_constant<int, done / 6 - 1>{}, nslot, nstep);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    };
+    asm volatile("s_waitcnt lgkmcnt(6)"
+                 : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[2][0]), "+v"(xb[2][1]), "+v"(xb[3][0]), "+v"(xb[3][1]),
+                   "+v"(xb[4][0]), "+v"(xb[4][1]), "+v"(xb[5][0]), "+v"(xb[5][1]),
+                   "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(ya[1][0]), "+v"(ya[1][1]), "+v"(ya[2][0]), "+v"(ya[2][1]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bfr[k] = join_tr64(xb[k][0], xb[k][1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) af[i] = join_tr64(ya[i][0], ya[i][1]);
+    part(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[3][0]), "+v"(ya[3][1]), "+v"(ya[4][0]), "+v"(ya[4][1]), "+v"(ya[5][0]), "+v"(ya[5][1]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 3; i < 6; ++i) af[i] = join_tr64(ya[i][0], ya[i][1]);
+    part(std::integral_constant<int, 1>{});
+    const bool my_turn = has_bias && bias_cnt == 0 && (!SPLIT || st < 2 * nsteps0);          // wave-uniform
+    bias_cnt = bias_cnt == 0 ? bias_mod - 1 : bias_cnt - 1;
+    if (my_turn) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const unsigned w = li == i ? 0x3F803F80u : 0u;             // row i of the bias accumulator collects block i's column sums
+        const u32x4 sv = {w, w, w, w};
+        accb4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(sv), af[i], accb4, 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // surplus transfers have landed, every wave is past its last fragment read
+  // ---- the two quads' partial tiles meet in LDS: a wave hands the partner wave of the other quad the 18 blocks that one flushes (quad 0:
+  // i = 0 .. 2, quad 1: i = 3 .. 5) and adds what it receives; image [wave][quad][block][lane] of 16 B, lane-contiguous ----
+  {
+    float* xch = (float*)smem;
+    const int give0 = quad == 0 ? 18 : 0;                      // first of the 18 accumulators handed over
+    float* mine = xch + (((wave * 2 + quad) * 18) * 64 + lane) * 4;
+#pragma unroll
+    for (int b = 0; b < 18; ++b) {
+      const f32x4 v = quad == 0 ? acc4[18 + b] : acc4[b];
+      *(f32x4*)(mine + b * 256) = v;
+    }
+    (void)give0;
+    __syncthreads();
+    const float* theirs = xch + (((wave * 2 + (quad ^ 1)) * 18) * 64 + lane) * 4;
+#pragma unroll
+    for (int b = 0; b < 18; ++b) {
+      const f32x4 v = *(const f32x4*)(theirs + b * 256);
+      if (quad == 0) acc4[b] += v; else acc4[18 + b] += v;
+    }
+  }
+  // ---- flush: this quad's 3 x 6 blocks; register r of a block holds rows 4 (lane >> 4) + r, column lane & 15 ----
+#pragma unroll
+  for (int ii = 0; ii < 3; ++ii) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+          if (qd != quad) continue;                              // (wave-uniform; keeps the accumulator indices compile-time)
+          const int i = 3 * qd + ii;
+          const int np = n0 + 16 * (4 * (i >> 1) + 2 * wr + (i & 1)) + 4 * grp + r;
+          const int ng = np / rgp, ne = np - ng * rgp;
+          const int ns = ng * rg + ne;
+          const int kp = k0 + 16 * (4 * (k >> 1) + 2 * wc + (k & 1)) + li;
+          const int kg = kp / cgp, ke = kp - kg * cgp;
+          const int ks = kg * cg + ke;
+          if (np < N && ne < rg && ns < n_src && kp < K && ke < cg && ks < k_src) atomicAdd(dW + (size_t)ns * lddw + ks, acc4[i * 6 + k][r]);
+        }
+      }
+    }
+  }
+  if (has_bias) {                                                // each quad adds the column sums of its own rows
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (grp == (i >> 2)) {
+        const int np = n0 + 16 * (4 * (i >> 1) + 2 * wr + (i & 1)) + li;
+        const int ng = np / rgp, ne = np - ng * rgp;
+        const int ns = ng * rg + ne;
+        if (np < N && ne < rg && ns < n_src) atomicAdd(P.db + ns, accb4[i & 3]);
+      }
+    }
+  }
+}
+
 int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 256;
@@ -423,6 +627,52 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
     }
   }
   if (n == 0) return 0;
+  // Form 2 (192 x 192 tiles, two quads per workgroup, one workgroup per CU) where it makes ONE well-filled round of workgroups that keep
+  // a few dozen steps per quad: a d = 768 layer's four products (128 tiles x 2 chunks = 256), its FFN pair (64 x 4), its in-proj (48 x 5)
+  // It is taken by launches that have the chip to themselves (blocks = 0: the last launch of a backward).  Beside the chain (-1) its
+  // full-CU workgroups leave the chain's row kernels no half-free CUs: 156 against 161 us alone, and the STEP +0.3 % (3.909 against
+  // 3.899 ms, tools/experiments/wgm192_ab.sh) -- the 256 x 128 form stays there.
+  static const int f192 = TF_ENV_INT("TF_WGM_192", -1);       // experiments: 0 never, 1 whenever the shapes allow, 2 the rule for -1 launches too
+  const bool force192 = blocks == -2;                         // tf_gemm_wgrad_multi(blocks = -2): form 2 wherever a quad gets two steps (tests)
+  if (force192) blocks = -1;
+  if (f192 != 0 && (blocks == 0 || force192 || f192 > 0)) {
+    int t192 = 0;
+    for (int i = 0; i < n; ++i) t192 += ((m.p[i].N + 191) / 192) * ((m.p[i].K + 191) / 192);
+    const int cus = cu_count();
+    const int G = t192 >= cus ? 1 : (cus + t192 / 2) / t192;
+    const long wgs = (long)t192 * G;
+    const int per_quad = ((min_steps + G - 1) / G + 1) / 2;
+    const bool fits = wgs <= cus && wgs * 100 >= 85L * cus && per_quad >= 24;
+    if ((f192 == 1 || force192) ? per_quad >= 2 : fits) {
+      WgMulti m2 = m;
+      int tl = 0;
+      bool ok32 = true;
+      for (int i = 0; i < n; ++i) {
+        WgProb& q = m2.p[i];
+        q.tiles_k = (q.K + 191) / 192;
+        q.tile0 = tl;
+        tl += q.tiles_k * ((q.N + 191) / 192);
+        int cs = ((q.M + 31) / 32 + G - 1) / G;
+        cs += cs & 1;
+        q.m_chunk = cs * 32;
+        const int ld = q.ldy > q.ldx ? q.ldy : q.ldx;
+        if ((long long)q.m_chunk * ld * 2 >= (1ll << 31)) ok32 = false;
+      }
+      if (ok32) {
+        m2.count = n; m2.chunks = G; m2.tiles_total = tl;
+        constexpr int NS2 = 3, LDS2 = 2 * NS2 * 2 * 32 * 384;
+        TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops, abytes);
+        if (split) {
+          static const hipError_t o = hipFuncSetAttribute((const void*)wgrad_multi192_kernel<true, NS2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+          (void)o; hipLaunchKernelGGL((wgrad_multi192_kernel<true, NS2>), dim3((unsigned)(tl * G)), dim3(512), LDS2, stream, m2);
+        } else {
+          static const hipError_t o = hipFuncSetAttribute((const void*)wgrad_multi192_kernel<false, NS2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+          (void)o; hipLaunchKernelGGL((wgrad_multi192_kernel<false, NS2>), dim3((unsigned)(tl * G)), dim3(512), LDS2, stream, m2);
+        }
+        return (int)hipGetLastError();
+      }
+    }
+  }
   if (blocks == 0) blocks = 2 * cu_count();
   int chunks;
   if (blocks > 0) chunks = (blocks + tiles / 2) / tiles;
