@@ -112,6 +112,115 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TfLnArgs a) {
   }
 }
 
+__device__ __forceinline__ void ld_gam(const float* gam, int i, int lane, float (&gm)[8]) {
+  const f32x4 lo = *(const f32x4*)(gam + (((i * 2) * 64 + lane) << 2)), hi = *(const f32x4*)(gam + (((i * 2 + 1) * 64 + lane) << 2));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { gm[k] = lo[k]; gm[4 + k] = hi[k]; }
+}
+// LayerNorm forward, form 2 (the encoder's per-layer launches: bf16 in and out, no lo planes, identity row maps, equal or ragged parameter
+// groups): a resident grid whose waves walk the rows ROWS at a time (all their loads issued before the first use), gamma and beta
+// staged once per workgroup in LDS in a lane-contiguous image -- the one-row-per-wave form re-reads 6 KB of parameters per 1.5-KB row
+// and resolves two row maps with integer divisions.
+template <int MAXC, int WAVES, int ROWS>
+__global__ __launch_bounds__(64 * WAVES) void ln_fwd2_kernel(const TfLnArgs a) {
+  constexpr int W = 64 * MAXC * 8;
+  __shared__ __attribute__((aligned(16))) float par[2][W];       // [gamma | beta][(i * 2 + half) * 64 + lane][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int rows_g = a.pgroups > 1 ? a.rows / a.pgroups : a.rows, row_lo = (int)blockIdx.y * rows_g;
+  if (a.pgroups > 1 && a.group_rows[0] > 0) {
+    const TfRange rg = tf_range_of_group(a.group_rows, (int)blockIdx.y);
+    rows_g = rg.n; row_lo = rg.lo;
+  }
+  const int row_hi = row_lo + rows_g;
+  const long long poff = (long long)blockIdx.y * a.p_gstride;
+  const float* gamma_g = (const float*)((const unsigned char*)a.gamma + poff);
+  const float* beta_g = (const float*)((const unsigned char*)a.beta + poff);
+  for (int c = threadIdx.x; c < W; c += 64 * WAVES) {
+    const int pos = ((((c >> 9) * 2 + ((c >> 2) & 1)) * 64 + ((c >> 3) & 63)) << 2) + (c & 3);
+    par[0][pos] = c < a.d ? gamma_g[c] : 0.f;
+    par[1][pos] = c < a.d ? beta_g[c] : 0.f;
+  }
+  __syncthreads();
+  const u16* __restrict__ X = (const u16*)a.x;
+  u16* __restrict__ Y = (u16*)a.y;
+  const float inv_d = 1.0f / (float)a.d;
+  bool act[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) act[i] = (lane + 64 * i) * 8 < a.d;
+  const int stride = gridDim.x * WAVES * ROWS;
+  for (int row0 = row_lo + (blockIdx.x * WAVES + wave) * ROWS; row0 < row_hi; row0 += stride) {
+    u32x4 rx[ROWS][MAXC];
+    bool ok[ROWS];
+    int rw[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      ok[r] = row0 + r < row_hi;
+      rw[r] = ok[r] ? row0 + r : row_hi - 1;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        rx[r][i] = u32x4{0, 0, 0, 0};
+        if (act[i]) rx[r][i] = *(const u32x4*)(X + (size_t)rw[r] * a.ldx + (lane + 64 * i) * 8);
+      }
+    }
+    float s[ROWS], q[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      s[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        float v[8];
+        unpack8(rx[r][i], v);                                  // (inactive chunks hold zeros)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[r] += v[e];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) s[r] += __shfl_xor(s[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      s[r] *= inv_d;                                           // mean
+      q[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        if (act[i]) {
+          float v[8];
+          unpack8(rx[r][i], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float t = v[e] - s[r]; q[r] += t * t; }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) q[r] += __shfl_xor(q[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (!ok[r]) continue;
+      const float mean = s[r], rstd = rsqrtf(q[r] * inv_d + a.eps);
+      if (lane == 0 && a.mean != nullptr) { a.mean[rw[r]] = mean; a.rstd[rw[r]] = rstd; }
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (act[i]) {
+          float v[8], g[8], b[8], o[8];
+          unpack8(rx[r][i], v);
+          ld_gam(par[0], i, lane, g);
+          ld_gam(par[1], i, lane, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * g[e] + b[e];
+          *(u32x4*)(Y + (size_t)rw[r] * a.ldy + c) = pack8(o);
+        } else if (c < a.ldy) {
+          *(u32x4*)(Y + (size_t)rw[r] * a.ldy + c) = u32x4{0, 0, 0, 0};
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  g = (dy [+ dres]) * gamma ; xhat = (x - mean) * rstd
 //   dx = rstd * (g - mean_d(g) - xhat * mean_d(g * xhat));  dgamma += dy * xhat;  dbeta += dy
@@ -228,11 +337,6 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const TfLnArgs a
 // per 4 columns and iteration, lane-contiguous: conflict-free) instead of 32 registers per lane (ds_add_f32 into a shared image was
 // measured 5x slower than the whole former kernel); (d) gamma comes from LDS (staged once per workgroup), not from four more vector
 // loads per row in front of the row's own data; (e) no row-map divisions.
-__device__ __forceinline__ void ld_gam(const float* gam, int i, int lane, float (&gm)[8]) {
-  const f32x4 lo = *(const f32x4*)(gam + (((i * 2) * 64 + lane) << 2)), hi = *(const f32x4*)(gam + (((i * 2 + 1) * 64 + lane) << 2));
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { gm[k] = lo[k]; gm[4 + k] = hi[k]; }
-}
 template <int MAXC, int WAVES, int ROWS, int ACC, int OCC>      // OCC: waves per SIMD the register allocation must leave room for
 __global__ __launch_bounds__(64 * WAVES, OCC) void ln_bwd2_kernel(const TfLnArgs a) {
   constexpr int W = 64 * MAXC * 8;                       // columns a lane set covers
@@ -1599,6 +1703,30 @@ extern "C" int tf_launch_ln_fwd(const TfLnArgs* a, hipStream_t st) {
   // fp32-accuracy mode: every bf16 tensor of the call carries its lo plane (x always; y unless it is fp32)
   const bool split = a->x_lo != nullptr || a->y_lo != nullptr;
   TfTraceScope tr("ln_fwd_kernel", st, 0.0, (split ? 8.0 : 4.0) * a->rows * a->d);
+  // form 2 (ln_fwd2_kernel): the encoder's per-layer launches
+  static const int f2 = TF_ENV_INT("TF_LNF_V", 1), f2_rows = TF_ENV_INT("TF_LNF_ROWS", 1), f2_grid = TF_ENV_INT("TF_LNF_GRID", 0);
+  const bool ident = a->x_group_row0 == nullptr && a->x_row_map == nullptr && a->rows_per_group >= a->rows;
+  static const int f2_min = TF_ENV_INT("TF_LNF_MIN_ROWS", 8192);
+  // (many rows only: at 2 080 rows it is 0.6 us shorter alone and the B = 4 step came out 1.8 % LONGER, 1.337 against 1.313 ms)
+  if (f2 && !split && ident && !a->y_is_f32 && width <= 1024 && a->rows >= f2_min) {
+    const int pg = a->pgroups > 1 ? a->pgroups : 1;
+    int rows_g = a->rows / pg;
+    if (pg > 1 && a->group_rows[0] > 0) for (int g = 0; g < pg; ++g) rows_g = max(rows_g, a->group_rows[g]);
+    else if (a->rows % pg) return -2;
+    const int resident = cu_count_rows() * 4;                                   // 8-wave workgroups, <= 64 registers: four per CU
+    const dim3 g2(grid_for(rows_g, 8 * f2_rows, max(1, (f2_grid > 0 ? f2_grid : resident) / pg)), pg);
+#define TF_LNF2(C, R) hipLaunchKernelGGL((ln_fwd2_kernel<C, 8, R>), g2, dim3(512), 0, st, *a)
+    // one row per wave and iteration at 1 024 workgroups: 12.3 us at 16 640 rows (two rows: 13.0, four: 15.6; the former kernel: 14.8),
+    // 4.6 - 4.9 at 2 080 (5.4)   (tools/experiments/lnf2_sweep.sh)
+#ifdef TF_EXPERIMENTS
+    if (width <= 512) { if (f2_rows == 2) TF_LNF2(1, 2); else if (f2_rows == 4) TF_LNF2(1, 4); else TF_LNF2(1, 1); }
+    else { if (f2_rows == 2) TF_LNF2(2, 2); else if (f2_rows == 4) TF_LNF2(2, 4); else TF_LNF2(2, 1); }
+#else
+    if (width <= 512) TF_LNF2(1, 1); else TF_LNF2(2, 1);
+#endif
+#undef TF_LNF2
+    return (int)hipGetLastError();
+  }
 #define TF_LNF(C) do { if (split) hipLaunchKernelGGL((ln_fwd_kernel<C, true>), grid, dim3(256), 0, st, *a); \
                        else hipLaunchKernelGGL((ln_fwd_kernel<C, false>), grid, dim3(256), 0, st, *a); } while (0)
   if (width <= 512) TF_LNF(1);
