@@ -268,27 +268,25 @@ def wgrad_alone(B, device, reps=20):
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     blocks = max(1, (cus * 17 // 10 + tiles // 2) // tiles) * tiles
     fn = lambda: ops.wgrad_multi(probs, blocks)
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    fl = sum(2.0 * M * a.shape[1] * b.shape[1] for a, b in pairs)
-    # the same products as the library sizes a launch that HAS the chip to itself (blocks = 0: 128 tiles of 192 x 192 at two row chunks,
-    # one 8-wave workgroup per CU, the two row halves reduced in LDS before one atomic pass -- what the last launch of a backward runs)
+    # ... and the same products as the library sizes a launch that HAS the chip to itself (blocks = 0: 128 tiles of 192 x 192 at two row
+    # chunks, one 8-wave workgroup per CU, the two row halves reduced in LDS before one atomic pass -- what the last launch of a backward
+    # runs).  The two sizings are timed in ALTERNATING blocks of launches: back to back, whichever comes second runs on the clock the
+    # first left behind (the same launch measured 7 % longer in second place).
     fn0 = lambda: ops.wgrad_multi(probs, 0)
-    fn0()
+    fn(); fn0()
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        fn0()
-    e1.record()
-    torch.cuda.synchronize()
-    us0 = e0.elapsed_time(e1) * 1e3 / reps
+    tot, per = [0.0, 0.0], max(1, reps // 4)
+    for _ in range(4):
+        for k, f in enumerate((fn, fn0)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            tot[k] += e0.elapsed_time(e1) * 1e3
+    us, us0 = tot[0] / (4 * per), tot[1] / (4 * per)
+    fl = sum(2.0 * M * a.shape[1] * b.shape[1] for a, b in pairs)
     return dict(avg_launch_us=round(us, 1), achieved=round(fl / us / 1e6, 1), frac=round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4),
                 flops_per_launch=fl, rows=M, workgroups=blocks,
                 note="one layer's four products as one launch, the encoder runtime's sizing, alone back to back",
