@@ -661,7 +661,7 @@ extern "C" int tf_launch_wgrad_multi(const TfWgradArgs* probs, int count, int bl
       if (ok32) {
         m2.count = n; m2.chunks = G; m2.tiles_total = tl;
         constexpr int NS2 = 3, LDS2 = 2 * NS2 * 2 * 32 * 384;
-        TfTraceScope tr(split ? "wgrad_multi_kernel<x3>" : "wgrad_multi_kernel", stream, flops, abytes);
+        TfTraceScope tr(split ? "wgrad_multi192_kernel<x3>" : "wgrad_multi192_kernel", stream, flops, abytes);
         if (split) {
           static const hipError_t o = hipFuncSetAttribute((const void*)wgrad_multi192_kernel<true, NS2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
           (void)o; hipLaunchKernelGGL((wgrad_multi192_kernel<true, NS2>), dim3((unsigned)(tl * G)), dim3(512), LDS2, stream, m2);
