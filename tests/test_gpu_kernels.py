@@ -310,6 +310,14 @@ def test_layernorm_fwd_bwd(dev, guard, rows, d, ld):
     assert rel(y[:, :d], yr.detach()) < 4e-3
     if ld > d:
         assert y[:, d:].float().abs().max().item() == 0.0
+    if rows >= 8192:
+        # the launch above took the resident-grid form (>= 8 192 rows), a short launch takes the one-row-per-wave form: the same bits
+        # (the encoder's batch-independence property rests on it: test_gpu_encoder.py::test_full_size_properties)
+        y2, m2, r2 = guard(torch.zeros(1000, ld, dtype=torch.bfloat16)), guard(torch.zeros(1000)), guard(torch.zeros(1000))
+        a2 = L.TfLnArgs(x=L.ptr(xb), ldx=ld, y=L.ptr(y2), ldy=ld, y_is_f32=0, gamma=L.ptr(gamma), beta=L.ptr(beta), mean=L.ptr(m2),
+                        rstd=L.ptr(r2), rows=1000, d=d, rows_per_group=1000, x_group_stride=1000, y_group_stride=1000, eps=1e-5)
+        L.call("tf_layernorm_fwd", a2, ops._stream())
+        assert torch.equal(y2, y[:1000]) and torch.equal(m2, mean[:1000]) and torch.equal(r2, rstd[:1000])
     dy = guard(bf(torch.randn(rows, ld, generator=g)))
     dx = guard(torch.zeros(rows, ld, dtype=torch.bfloat16))
     dg = guard(torch.zeros(d))

@@ -144,7 +144,6 @@ __global__ __launch_bounds__(64 * WAVES) void ln_fwd2_kernel(const TfLnArgs a) {
   __syncthreads();
   const u16* __restrict__ X = (const u16*)a.x;
   u16* __restrict__ Y = (u16*)a.y;
-  const float inv_d = 1.0f / (float)a.d;
   bool act[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) act[i] = (lane + 64 * i) * 8 < a.d;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES) void ln_fwd2_kernel(const TfLnArgs a) {
       for (int r = 0; r < ROWS; ++r) s[r] += __shfl_xor(s[r], o, 64);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      s[r] *= inv_d;                                           // mean
+      s[r] = s[r] / (float)a.d;                                // mean (a division, as in ln_fwd_kernel: the two forms give the same bits)
       q[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(64 * WAVES) void ln_fwd2_kernel(const TfLnArgs a) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (!ok[r]) continue;
-      const float mean = s[r], rstd = rsqrtf(q[r] * inv_d + a.eps);
+      const float mean = s[r], rstd = rsqrtf(q[r] / (float)a.d + a.eps);
       if (lane == 0 && a.mean != nullptr) { a.mean[rw[r]] = mean; a.rstd[rw[r]] = rstd; }
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
@@ -365,7 +364,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void ln_bwd2_kernel(const TfLnArgs
   __syncthreads();
   const u16* __restrict__ X = (const u16*)a.x;
   const u16* __restrict__ DY = (const u16*)a.dy;
-  const float inv_d = 1.0f / (float)a.d;
   bool act[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) act[i] = (lane + 64 * i) * 8 < a.d;
@@ -437,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void ln_bwd2_kernel(const TfLnArgs
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (!ok[r]) continue;
-      const float c1 = s1[r] * inv_d, c2 = s2[r] * inv_d;
+      const float c1 = s1[r] / (float)a.d, c2 = s2[r] / (float)a.d;       // (divisions, as in ln_bwd_kernel)
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
         const int c = (lane + 64 * i) * 8;
