@@ -329,6 +329,46 @@ def test_layernorm_fwd_bwd(dev, guard, rows, d, ld):
     assert rel(dg, gr.grad) < 1e-3 and rel(db, br.grad) < 1e-3
 
 
+@pytest.mark.parametrize("rows,d,ld,groups", [(2 * 4500, 768, 768, 2), (12000, 768, 768, (9000, 3000)), (9000, 712, 768, (8000, 600, 400)),
+                                              (1450, 768, 768, (700, 300, 450))])
+def test_layernorm_fwd_parameter_groups(dev, guard, rows, d, ld, groups):
+    """LayerNorm forward with parameter groups (equal and ragged row ranges, gamma / beta p_gstride bytes apart) in both kernel forms
+    (>= 8 192 rows: the resident-grid form): y, mean, rstd against fp64, pad columns zeroed; operands at guard pages."""
+    from transfusion_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + d)
+    ranges = None
+    if isinstance(groups, tuple):
+        ranges, groups = groups, len(groups)
+        assert sum(ranges) == rows
+    bounds = [0]
+    for k in range(groups):
+        bounds.append(bounds[-1] + (ranges[k] if ranges else rows // groups))
+    x = torch.zeros(rows, ld)
+    x[:, :d] = torch.randn(rows, d, generator=g) * 1.7 + 0.4
+    xb = guard(bf(x))
+    gstride = ((d + 63) // 64) * 64
+    gamma = guard((1 + 0.1 * torch.randn(groups, gstride, generator=g)).contiguous())
+    beta = guard((0.1 * torch.randn(groups, gstride, generator=g)).contiguous())
+    y = guard(torch.full((rows, ld), 5.0, dtype=torch.bfloat16))
+    mean, rstd = guard(torch.zeros(rows)), guard(torch.zeros(rows))
+    a = L.TfLnArgs(x=L.ptr(xb), ldx=ld, y=L.ptr(y), ldy=ld, y_is_f32=0, gamma=L.ptr(gamma), beta=L.ptr(beta), mean=L.ptr(mean), rstd=L.ptr(rstd),
+                   rows=rows, d=d, rows_per_group=rows, x_group_stride=rows, y_group_stride=rows, eps=1e-5, pgroups=groups, p_gstride=gstride * 4)
+    if ranges:
+        for k, n in enumerate(ranges):
+            a.group_rows[k] = n
+    L.call("tf_layernorm_fwd", a, ops._stream())
+    torch.cuda.synchronize()
+    xd = xb.double().cpu()[:, :d]
+    mu, var = xd.mean(1), xd.var(1, unbiased=False)
+    gam = torch.cat([gamma.double().cpu()[k:k + 1, :d].expand(bounds[k + 1] - bounds[k], d) for k in range(groups)])
+    bet = torch.cat([beta.double().cpu()[k:k + 1, :d].expand(bounds[k + 1] - bounds[k], d) for k in range(groups)])
+    ref = (xd - mu[:, None]) / torch.sqrt(var[:, None] + 1e-5) * gam + bet
+    assert rel(y[:, :d], ref) < 4e-3
+    assert rel(mean, mu) < 1e-5 and rel(rstd, 1.0 / torch.sqrt(var + 1e-5)) < 1e-5
+    if ld > d:
+        assert y[:, d:].float().abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("rows,d,ld,groups", [(2 * 4500, 768, 768, 2), (16640, 768, 768, 1), (3 * 333, 712, 768, 3), (130, 72, 128, 1),
                                               (2 * 257, 1024, 1024, 2), (1450, 768, 768, (700, 300, 450)), (12000, 768, 768, (9000, 3000))])
 def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld, groups):
