@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 typedef void* tf_stream_t;   /* hipStream_t */
-#define TF_ABI_VERSION 9
+#define TF_ABI_VERSION 10
 #define TF_MAX_LAYERS 16
 #define TF_MAX_GROUPS 8     /* ragged groups (ABI v8): at most this many row ranges of unequal size in one grouped launch */
 
@@ -420,6 +420,9 @@ const uint32_t* tf_clock_ptr(void);
 int tf_clock_advance(uint32_t by, tf_stream_t s);
 int tf_clock_set(uint32_t value, tf_stream_t s);
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s);
+/* ABI v10.  out[0] = sum(x^2) -- tf_sumsq without the accumulation: the global gradient norm of a step over ONE flat gradient buffer is
+ * then a single launch (no zero fill in front, no launch per parameter range).  Same deterministic block sum. */
+int tf_sumsq_set(const float* x, long long n, float* out, tf_stream_t s);
 /* ABI v9.  One term of the synthetic training loss of the benchmark (mean(vis^2) + mean(lang[valid]^2); the reference
  * has no counterpart -- its losses sit behind the detector, losses.py:98-135) and its gradient, so that a timed step holds no
  * framework elementwise kernel.  x: contiguous fp32 [rows, d], d % 4 == 0, 16-B aligned; row_w: optional [rows] weights (the 0 / 1

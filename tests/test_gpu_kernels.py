@@ -428,6 +428,24 @@ def test_layernorm_bwd_dropout_copy_and_parameter_groups(dev, guard, rows, d, ld
             assert dg[k, d:].abs().max().item() == 0.0 and db[k, d:].abs().max().item() == 0.0
 
 
+def test_sumsq_set_overwrites_and_equals_the_accumulating_form(dev, guard):
+    """tf_sumsq_set (ABI v10): out = sum(x^2) whatever out held, the same bits as tf_sumsq into a zeroed scalar; an odd length (scalar
+    tail) and the flat gradient buffer's size; operand at a guard page."""
+    from transfusion_amd import _lib as L, ops
+    lib = L.load()
+    for n in (18_912_000, 1_000_003, 5):
+        x = guard(torch.randn(n, generator=torch.Generator().manual_seed(n)))
+        a, b = torch.full((1,), 123.0, device=dev), torch.zeros(1, device=dev)
+        L.check(lib.tf_sumsq_set(L.ptr(x), n, L.ptr(a), ops._stream()), "tf_sumsq_set")
+        L.check(lib.tf_sumsq(L.ptr(x), n, L.ptr(b), ops._stream()), "tf_sumsq")
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert abs(a.item() / x.double().pow(2).sum().item() - 1.0) < 1e-5
+        L.check(lib.tf_sumsq_set(L.ptr(x), n, L.ptr(a), ops._stream()), "tf_sumsq_set")      # again: overwritten, not doubled
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+
+
 def test_pack_and_patch_permutations(dev):
     from transfusion_amd import ops
     from oracle import fusion_oracle as O

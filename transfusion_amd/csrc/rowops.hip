@@ -1952,15 +1952,17 @@ extern "C" int tf_launch_radam(const TfRadamArgs* a, hipStream_t st) {
   hipLaunchKernelGGL(radam_kernel, dim3(grid_for(a->n, 256 * 16)), dim3(256), 0, st, *a);
   return (int)hipGetLastError();
 }
-extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) {
-  if (n <= 0) return 0;
+extern "C" int tf_launch_sumsq_ex(const float* x, long long n, float* out, int accumulate, hipStream_t st) {
+  if (n <= 0) return accumulate ? 0 : (int)hipMemsetAsync(out, 0, sizeof(float), st);
   if (((size_t)x & 15) != 0) return -2;
   TfTraceScope tr("sumsq_kernel", st);
   static std::atomic<unsigned> next_slot{0};
   const int slot = (int)(next_slot.fetch_add(1u) % SUMSQ_SLOTS);
-  hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS)), dim3(256), 0, st, x, n, out, slot, (const float*)nullptr, 1, 1.0f, 1);
+  hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid_for(n, 256 * 32, SUMSQ_MAX_BLOCKS)), dim3(256), 0, st, x, n, out, slot, (const float*)nullptr, 1, 1.0f,
+                     accumulate ? 1 : 0);
   return (int)hipGetLastError();
 }
+extern "C" int tf_launch_sumsq(const float* x, long long n, float* out, hipStream_t st) { return tf_launch_sumsq_ex(x, n, out, 1, st); }
 // The synthetic training loss of SURVEY.md 8(d) -- mean(vis^2) + mean(lang[valid]^2) -- as library kernels, so that a benchmark step holds
 // no framework elementwise kernel: fwd: out[0] (+)= scale * sum_r row_w[r]^2 |x[r, :]|^2 (deterministic: tf_sumsq's last-arriver sum);
 // bwd: dx[r, :] = g[0] * 2 * scale * row_w[r]^2 * x[r, :].

@@ -550,6 +550,7 @@ int tf_pool_norm_bwd(const TfPoolNormArgs* a, tf_stream_t s) { TF_WRAP("tf_pool_
 int tf_lm_pool_fwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_fwd(a, (hipStream_t)s), "tf_lm_pool_fwd"); return 0; }
 int tf_lm_pool_bwd(const TfLmPoolArgs* a, tf_stream_t s) { TF_TRY(tf_launch_lm_pool_bwd(a, (hipStream_t)s), "tf_lm_pool_bwd"); return 0; }
 int tf_sumsq(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq(x, n, out, (hipStream_t)s), "tf_sumsq"); return 0; }
+int tf_sumsq_set(const float* x, long long n, float* out, tf_stream_t s) { TF_TRY(tf_launch_sumsq_ex(x, n, out, 0, (hipStream_t)s), "tf_sumsq_set"); return 0; }
 int tf_sq_loss_fwd(const TfSqLossArgs* a, tf_stream_t s) {
   if (a == nullptr) return fail(-1, "tf_sq_loss_fwd");
   TF_TRY(tf_launch_sq_loss(a, 0, (hipStream_t)s), "tf_sq_loss_fwd");

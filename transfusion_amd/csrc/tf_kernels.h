@@ -50,6 +50,7 @@ int tf_launch_pool_norm_bwd(const TfPoolNormArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_fwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_lm_pool_bwd(const TfLmPoolArgs* a, hipStream_t stream);
 int tf_launch_sumsq(const float* x, long long n, float* out /* atomically accumulated */, hipStream_t stream);
+int tf_launch_sumsq_ex(const float* x, long long n, float* out, int accumulate /* 0: out is overwritten */, hipStream_t stream);
 int tf_launch_sq_loss(const TfSqLossArgs* a, int backward, hipStream_t stream);
 int tf_launch_clock_advance(unsigned* clock, unsigned by, hipStream_t stream);
 int tf_tu_set_clock_gemm(const unsigned* clock);                       // per translation unit: where its kernels find the step clock

@@ -544,8 +544,16 @@ class FusionTrainStep:
         if self.zero_in_opt:
             extra["zero_grad"] = True
         if self.grad_clip:
-            self._norm.zero_()
-            self.opt.grad_sumsq(self._norm)                        # stays on the device: no host sync in the step
+            g = self.flat.grad
+            if g.is_cuda:
+                # the optimiser's parameters tile the flat buffer (one tensor, or contiguous ranges whose pad floats have zero gradients):
+                # its norm is ONE launch that overwrites the scalar (tf_sumsq_set) -- no zero fill, no launch per range; stays on the
+                # device: no host sync in the step
+                from transfusion_amd import _lib as L, ops
+                L.check(L.load().tf_sumsq_set(L.ptr(g), g.numel(), L.ptr(self._norm), ops._stream()), "tf_sumsq_set")
+            else:
+                self._norm.zero_()
+                self.opt.grad_sumsq(self._norm)
             self.opt.step(grad_scale=scale, sumsq=self._norm, clip=self.grad_clip, **extra)
         else:
             self.opt.step(grad_scale=scale, **extra)
