@@ -695,6 +695,9 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   // layers >= 3 share an event: a wait on it then covers every later record too (correct, less overlap); ev[1]: layer 0's re-pack alone
   auto evi = [](int l) { return 4 + (l < 3 ? l : 3); };
   bool side_work[TF_MAX_LAYERS] = {};
+  static const int one_wait_sel = TF_ENV_INT("TF_FWD_ONE_WAIT", 1);
+  const bool one_wait = one_wait_sel != 0 && c.D.G == 1 && c.D.L >= 3;
+  bool side_later = false;                                 // layers >= 1 have side-stream work
   if (side != nullptr && e->overlap->pending != 0u) TF_TRY(tf_overlap_join(e->overlap, s), "fwd join");   // events are about to be reused
   // the row map (packed batches) comes BEFORE the fork: the side stream's attention dropout masks are generated for the rows and key
   // tiles the samples really have (tf_launch_attn_dropmask_packed reads cu), so they wait for it through the fork event
@@ -718,8 +721,12 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
       const Drop dr = drop_for(e, e->p_token, site_of(l, SITE_ATTN));
       if (e->repack && l >= 1) { TF_TRY(pack_layer(c, l, side), "pack layer"); side_work[l] = true; }
       if (dr.thr) { TF_TRY(tf_launch_attn_dropmask_packed(c.LB(l) + c.A.dbits, c.D.B, c.D.H, c.D.S, c.cu(), dr.key, dr.thr, side), "attn_dropmask"); side_work[l] = true; }
-      if (side_work[l]) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
+      // one encoder (G = 1): ONE event behind the side work of ALL layers >= 1, waited for once at the top of layer 1 (the side stream is
+      // through with it ~150 us before the chain gets there); grouped calls keep an event per layer (their re-packs take longer)
+      if (side_work[l] && (!one_wait || l == 0)) TF_TRY((int)hipEventRecord(ev[evi(l)], side), "side event");
+      if (l >= 1 && side_work[l]) side_later = true;
     }
+    if (one_wait && side_later) TF_TRY((int)hipEventRecord(ev[evi(1)], side), "side event (layers >= 1)");
   } else if (e->repack) {
     for (int l = 0; l < c.D.L; ++l) TF_TRY(pack_layer(c, l, c.st), "pack layer");
   }
@@ -742,7 +749,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   const float scale = 1.0f / sqrtf((float)D.hd);
   for (int l = 0; l < D.L; ++l) {
     // layer 0 needs only its mask (before the attention); later layers wait once, at the top, for pack + mask
-    if (side != nullptr && side_work[l] && l >= 1) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(l)], 0), "side wait");
+    if (side != nullptr && l >= 1 && (one_wait ? (l == 1 && side_later) : side_work[l])) TF_TRY((int)hipStreamWaitEvent(c.st, ev[evi(l)], 0), "side wait");
     unsigned char* w = c.WB(l); unsigned char* b = c.LB(l);
     const TfLayerParams& p = e->p[l];
     const Drop none{0u, 0u, 1.f};
