@@ -555,6 +555,10 @@ typedef struct TfEncoderDesc {
                                  * (every group drops the same tokens).  vis / vis_out / d_vis_out / d_vis are then the CONCATENATION
                                  * [sum_g (B / groups) group_nv[g], d], group-major; pe is read by its first group_nv[g] rows (the tables
                                  * of the levels must agree on their common prefix: the sin1d tables do).  All zero: every group has Nv. */
+  int* packed_error_host;       /* ABI v10, optional: a device-accessible word of PINNED HOST memory (hipHostMalloc / torch pin_memory).  The
+                                 * row-map kernel of a packed forward stores this forward's verdict there too (0, or the row count the mask
+                                 * gave): the host presets the word to -1 and polls it later -- no device-to-host copy and no event on the
+                                 * forward's stream (tf_encoder_packed_error costs the chain a 4-us copy and a barrier packet per step). */
 } TfEncoderDesc;
 
 int tf_encoder_plan(int B, int Nv, int Nl, int d, int H, int L, int ff, TfEncoderPlan* out);   /* precision 0 */

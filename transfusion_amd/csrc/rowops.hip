@@ -772,7 +772,7 @@ __global__ void key_mask_kernel(const uint8_t* __restrict__ lm, uint8_t* __restr
 __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict__ lm, int B, int Nv, int Nl, int* __restrict__ cu,
                                                        int* __restrict__ start_of, int* __restrict__ dense_of, int* __restrict__ packed_of_lang,
                                                        int expected, int* __restrict__ err, int groups, const TfGroupTab gnv,
-                                                       int* __restrict__ vis_rows) {
+                                                       int* __restrict__ vis_rows, int* __restrict__ err_host) {
   extern __shared__ int sh[];                                     // cnt[B] | pos_of[B] | start[B + 1] (by position) | total
   int* cnt = sh; int* pos_of = sh + B; int* start = sh + 2 * B;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -844,6 +844,8 @@ __global__ __launch_bounds__(1024) void row_map_kernel(const uint8_t* __restrict
     }
     start[B] = run; cu[B] = min(run, expected);
     err[0] = (run != expected || bad) ? run : 0;                    // (this forward's verdict: the word does not accumulate)
+    // ... and into the caller's word of pinned host memory (TfEncoderDesc.packed_error_host: preset to -1, polled by the host -- no copy)
+    if (err_host != nullptr) __hip_atomic_store(err_host, (run != expected || bad) ? run : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   const int total = start[B];
@@ -1852,7 +1854,7 @@ extern "C" int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang,
-                                 int expected, int* err, int groups, const int* group_nv, int* vis_rows, hipStream_t st) {
+                                 int expected, int* err, int groups, const int* group_nv, int* vis_rows, int* err_host, hipStream_t st) {
   if (groups < 1 || B % groups) return -2;
   if (B <= 0 || Nv < 0 || Nl < 0 || cu == nullptr || start_of == nullptr || dense_of == nullptr || packed_of_lang == nullptr || err == nullptr) return -2;
   TfGroupTab gnv{};
@@ -1869,7 +1871,7 @@ extern "C" int tf_launch_row_map(const uint8_t* lm, int B, int Nv, int Nl, int* 
   if (lds > 60000) return -2;          // the per-sample tables live in LDS
   TfTraceScope tr("row_map_kernel", st);
   hipLaunchKernelGGL(row_map_kernel, dim3(1), dim3(1024), lds, st, lm, B, Nv, Nl, cu, start_of, dense_of, packed_of_lang, expected, err, groups, gnv,
-                     vis_rows);
+                     vis_rows, err_host);
   return (int)hipGetLastError();
 }
 extern "C" int tf_launch_key_mask(const uint8_t* lm, uint8_t* km, int B, int Nv, int Nl, hipStream_t st) {

@@ -705,7 +705,7 @@ int tf_encoder_fwd(const TfEncoderDesc* e, tf_stream_t s) {
   if (c.packed()) {
     // packed batches: the masked language tokens are never gathered, so every row that exists is a real token -- no key mask
     TF_TRY(tf_launch_row_map(e->lang_pad_mask, D.B, D.Nv, D.Nl, (int*)(c.wk + c.A.cu), (int*)(c.wk + c.A.starts), (int*)(c.wk + c.A.dense_of), (int*)(c.wk + c.A.pol),
-                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, D.ragged ? D.nv : nullptr, (int*)(c.wk + c.A.visrows), c.st), "row_map");
+                             e->packed_rows, (int*)(c.wk + c.A.perr), D.G, D.ragged ? D.nv : nullptr, (int*)(c.wk + c.A.visrows), e->packed_error_host, c.st), "row_map");
     km = nullptr;
   } else {
     TF_TRY(tf_launch_key_mask(e->lang_pad_mask, km, D.B, D.Nv, D.Nl, c.st), "key_mask");

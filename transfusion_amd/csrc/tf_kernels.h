@@ -30,7 +30,7 @@ int tf_launch_copy_rows(const TfCopyRowsArgs* a, hipStream_t stream);
 // ragged groups: group_nv [TF_MAX_GROUPS] host ints (visual tokens per sample of group g; null / [0] == 0: Nv everywhere) and vis_rows
 // [sum_g (B / groups) group_nv[g]] (packed row of every token of the concatenated visual tokens; null unless ragged)
 int tf_launch_row_map(const uint8_t* lang_pad_mask, int B, int Nv, int Nl, int* cu, int* start_of, int* dense_of, int* packed_of_lang, int expected,
-                      int* err, int groups, const int* group_nv, int* vis_rows, hipStream_t stream);
+                      int* err, int groups, const int* group_nv, int* vis_rows, int* err_host /* pinned host word or null */, hipStream_t stream);
 int tf_launch_key_mask(const uint8_t* lang_pad_mask, uint8_t* key_mask, int B, int Nv, int Nl, hipStream_t stream);
 int tf_launch_dropout_apply(const void* x, void* y, long long n, unsigned key, unsigned thr, float scale, hipStream_t stream);
 int tf_launch_attn_dropmask(void* bits, int B, int H, int S, unsigned key, unsigned thr, hipStream_t stream);

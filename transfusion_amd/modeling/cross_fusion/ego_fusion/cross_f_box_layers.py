@@ -100,10 +100,13 @@ class _EncoderFn(torch.autograd.Function):
         if desc.packed_rows > 0:
             check_packed_row_errors(sync=False)          # an earlier call whose lang_valid_rows disagreed with its mask raises here
         desc.repack = 1 if mod._wpack_dirty() else 0     # bf16 weight shadows are refreshed inside the forward call
+        watch = desc.packed_rows > 0 and not torch.cuda.is_current_stream_capturing()
+        slot = _claim_packed_slot(desc) if watch else None
         L.call("tf_encoder_fwd", desc, st)
         desc.repack = 0
-        if desc.packed_rows > 0 and not torch.cuda.is_current_stream_capturing():
-            _watch_packed_rows(desc, st, x.device)
+        desc.packed_error_host = None        # (the descriptor lives on for the backward: the word belongs to THIS forward's row map)
+        if watch:
+            _watch_packed_rows(desc, slot, x.device)
         ctx.mod, ctx.desc, ctx.keep, ctx.gen = mod, desc, keep, keep["gen"]
         ctx.group_mods = list(mod._group_mods) if mod._group_mods else None
         mod._last_desc = desc               # debug / test hooks (packed_row_error, peek)
@@ -168,30 +171,47 @@ class _EncoderFn(torch.autograd.Function):
 # host sized, and the step computes garbage for the truncated samples).  The error word travels to pinned host memory behind the
 # forward, on its stream, with an event -- no host synchronisation in the step -- and the NEXT packed forward whose copy has landed
 # raises (``check_packed_row_errors(sync=True)`` waits for all of them: end of an epoch, tests).
-_packed_flags = []
+_packed_flags = []          # (slot, packed_rows the host claimed, device) of forwards whose word has not been looked at yet
+_PACKED_SLOTS = 256
+_packed_pin = None          # pinned int32 ring: the row-map kernel of a forward stores its verdict into the forward's word
+_packed_next = 0
 
 
-def _watch_packed_rows(desc, stream, device):
-    host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-    L.check(L.load().tf_encoder_packed_error(C.byref(desc), C.c_void_p(host.data_ptr()), C.c_void_p(stream)), "tf_encoder_packed_error")
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    _packed_flags.append((host, ev, int(desc.packed_rows)))
+def _claim_packed_slot(desc):
+    """A word of pinned host memory for this forward's verdict, preset to -1 (not landed), handed to the runtime through the descriptor:
+    the row-map kernel stores 0 or the mask's row count into it -- no device-to-host copy, no event on the forward's stream."""
+    global _packed_pin, _packed_next
+    if _packed_pin is None:
+        _packed_pin = torch.full((_PACKED_SLOTS,), -1, dtype=torch.int32).pin_memory()
+    if len(_packed_flags) >= _PACKED_SLOTS - 1:        # the ring is full of words nobody looked at: look (and WAIT for the oldest ones)
+        check_packed_row_errors(sync=False)
+        while len(_packed_flags) >= _PACKED_SLOTS - 1:
+            _check_one_packed_flag(sync=True)
+    slot = _packed_next
+    _packed_next = (_packed_next + 1) % _PACKED_SLOTS
+    _packed_pin[slot] = -1
+    desc.packed_error_host = _packed_pin.data_ptr() + 4 * slot
+    return slot
+
+
+def _watch_packed_rows(desc, slot, device):
+    _packed_flags.append((slot, int(desc.packed_rows), device))
     if len(_packed_flags) > 64:
         check_packed_row_errors(sync=False)
-        while len(_packed_flags) > 64:                 # still too many in flight: WAIT for the oldest rather than dropping one unseen
-            _check_one_packed_flag(sync=True)
 
 
 def _check_one_packed_flag(sync: bool) -> bool:
     """Looks at the oldest pending error word; False when its copy has not landed yet (and ``sync`` is off)."""
-    host, ev, want = _packed_flags[0]
-    if not sync and not ev.query():
-        return False
-    if sync:
-        ev.synchronize()
+    slot, want, device = _packed_flags[0]
+    got = int(_packed_pin[slot])
+    if got < 0:                          # the row-map kernel of that forward has not run (or its store has not landed) yet
+        if not sync:
+            return False
+        torch.cuda.synchronize(device)
+        got = int(_packed_pin[slot])
+        if got < 0:
+            raise L.TfError("lang_valid_rows: a forward's row-map verdict never reached the host (packed_error_host)")
     _packed_flags.pop(0)
-    got = int(host[0])
     if got != 0:
         _packed_flags.clear()
         if got == want:                  # the total agrees, the split over the groups does not (row_map_kernel's `bad`)
