@@ -706,7 +706,7 @@ def run_wrapper_leg(device, rank, comm, batch=4, steps=10, warmup=4, real=False,
         comm.sync()
         # TWO timed regions of `steps` steps, both reported (`ms_per_step_runs`), the lower one quoted: the step is within 1.5x of the
         # host's enqueue time, and on the shared boxes of the pool single regions came out 2x long now and then (host enqueue 6.8 ms
-        # against 2.9: profiles/r06_v5_bench.json, first take) -- a host stall is then visible as the difference, not hidden
+        # against 2.9 in one take of the closing set; profiles/r06_v6_bench.json: 9.88 against 4.41 ms) -- a host stall is then visible as the difference, not hidden
         runs = []
         with _QuietGC():
             for _ in range(2):
